@@ -1,0 +1,161 @@
+/* nksr_hip.h -- C-ABI of the MI355X-native NKSR solve-time hot path.
+ *
+ * Drop-in boundary.  The reference's native boundary is the
+ * compiled `_C` module inside the un-vendored `nksr` wheel (README.md:46), reached
+ * through the Python surface evidenced at examples/recons_simple.py:25-27,
+ * models/nksr_net.py:57-62,91-112 and models/loss.py:189-198.  Each entry point
+ * below names the reference-side call it serves.  Conventions:
+ *   - plain device pointers + sizes; the caller (Python/torch) owns every buffer
+ *   - `stream` is a hipStream_t passed as void*
+ *   - return 0 on success, negative on error; nksr_last_error() gives the message
+ *   - no hidden host synchronisation unless the doc comment says "syncs"
+ */
+#ifndef NKSR_HIP_H
+#define NKSR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NKSR_MAX_DEPTH 6
+#define NKSR_OK 0
+#define NKSR_ERR_ARG (-1)
+#define NKSR_ERR_HIP (-2)
+#define NKSR_ERR_CAPACITY (-3)
+
+const char* nksr_last_error(void);
+int nksr_version(void);
+
+/* ---- one level of the sparse voxel hierarchy (SparseFeatureHierarchy.grids[d],
+ *      models/nksr_net.py:57-62, models/loss.py:33-46) ------------------------------- */
+typedef struct {
+    int32_t n;                 /* active voxels, canonical order = ascending Morton key */
+    int32_t offset;            /* first unknown index of this level in alpha            */
+    const int64_t* keys;       /* [n] sorted Morton keys                                */
+    const int32_t* ijk;        /* [n,3]                                                 */
+    const int32_t* nbr;        /* [n,27] neighbour voxel index or -1                    */
+    const int64_t* hkeys;      /* open-addressing hash: keys (-1 = empty)               */
+    const int32_t* hvals;      /*                      values                           */
+    int32_t hcap;              /* capacity (power of two)                               */
+    const float* feat;         /* [n,K] basis features                                  */
+    const float* psi;          /* [n,K] phi_d(c_j)                                      */
+    const float* mlp;          /* interpolator weights W1[H,K] b1[H] W2[H,H] b2[H] W3[K,H] b3[K] */
+} nksr_level_t;
+
+typedef struct {
+    int32_t depth, kdim, hidden;
+    float inv_w0;              /* fp32 reciprocal of the finest voxel size              */
+    nksr_level_t lv[NKSR_MAX_DEPTH];
+} nksr_hier_t;
+
+/* ---- device primitives (rocPRIM-backed; tmp==NULL -> size query) --------------------- */
+int nksr_sort_keys_u64(void* tmp, size_t* tmp_bytes, const uint64_t* in, uint64_t* out, int64_t n,
+                       int begin_bit, int end_bit, void* stream);
+int nksr_sort_pairs_u64_u32(void* tmp, size_t* tmp_bytes, const uint64_t* kin, uint64_t* kout,
+                            const uint32_t* vin, uint32_t* vout, int64_t n, int begin_bit, int end_bit, void* stream);
+int nksr_unique_u64(void* tmp, size_t* tmp_bytes, const uint64_t* in, uint64_t* out, int64_t* d_count,
+                    int64_t n, void* stream);
+int nksr_exclusive_sum_i32(void* tmp, size_t* tmp_bytes, const int32_t* in, int32_t* out, int64_t n, void* stream);
+int nksr_exclusive_sum_i64(void* tmp, size_t* tmp_bytes, const int64_t* in, int64_t* out, int64_t n, void* stream);
+
+/* ---- hierarchy build/query (SparseFeatureHierarchy.build_point_splatting,
+ *      models/nksr_net.py:62; grids[d].active_grid_coords models/loss.py:36) ------------ */
+/* mode 0: 8 nearest voxel centres per point (encoder hierarchy); mode 1: containing
+ * cell + 26 neighbours (decoder structure rule).  keys_out has n*8 / n*27 entries. */
+int nksr_splat_keys(const float* xyz, int64_t n, float inv_w0, int level, int mode, int64_t* keys_out, void* stream);
+/* Morton key of the level-0 cell containing each point. */
+int nksr_point_keys(const float* xyz, int64_t n, float inv_w0, int64_t* keys_out, void* stream);
+int nksr_decode_keys(const int64_t* keys, int64_t n, int level, int32_t* ijk_out, void* stream);
+int nksr_encode_keys(const int32_t* ijk, int64_t n, int level, int64_t* keys_out, void* stream);
+/* hkeys must be pre-filled with 0xFF bytes. */
+int nksr_hash_build(const int64_t* keys, int32_t n, int64_t* hkeys, int32_t* hvals, int32_t hcap, void* stream);
+int nksr_hash_query(const int64_t* q, int64_t nq, const int64_t* hkeys, const int32_t* hvals, int32_t hcap,
+                    int32_t* idx_out, void* stream);
+int nksr_build_nbr(const int32_t* ijk, int32_t n, int level, const int64_t* hkeys, const int32_t* hvals,
+                   int32_t hcap, int32_t* nbr_out, void* stream);
+/* start/end of the sites (sorted level-0 Morton keys) that fall inside each level-d voxel */
+int nksr_site_ranges(const int64_t* site_keys, int64_t ns, const int64_t* vox_keys, int32_t n, int level,
+                     int32_t* start_out, int32_t* end_out, void* stream);
+
+/* Trilinear splat (weighted sum + weight sum) of per-point features onto the voxels of one
+ * level; points must be Morton-sorted with start/end = nksr_site_ranges of that level.
+ * Point encoder skip path (network.encoder, models/nksr_net.py:73). */
+int nksr_splat_trilinear(const float* xyz_sorted, const float* feat_sorted, int C, const int32_t* start,
+                         const int32_t* end, const int32_t* nbr, const int32_t* ijk, int32_t n, float inv_w,
+                         float* out, float* wsum_out, void* stream);
+
+/* ---- neural kernel (KernelField, models/nksr_net.py:91-96) --------------------------- */
+int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden, const float* mlp, float* psi_out, void* stream);
+/* Dense-slot kernel rows at arbitrary sites.  val [n, L, 27]; dval [n, 3, L, 27] (may be
+ * NULL).  approx!=0 drops the d(phi)/dx term (approx_kernel_grad, recons_waymo.py:33). */
+int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float* val, float* dval, void* stream);
+/* f(x) (and gradient if grad_out != NULL): field.evaluate_f, models/loss.py:189-198. */
+int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx,
+                    float* f_out, float* grad_out, void* stream);
+
+/* ---- normal-equation assembly (KernelField.solve_non_fused, models/nksr_net.py:105-112) */
+typedef struct {
+    int64_t n;                 /* sites                                                */
+    int32_t ncomp;             /* 1 (position rows, G) or 3 (gradient rows, Q)         */
+    float weight;              /* pos_weight or normal_weight                          */
+    const float* val;          /* [n, ncomp, L, 27] dense-slot rows                    */
+    const float* target;       /* [n, ncomp] right-hand side values or NULL (zero)     */
+    const int32_t* start[NKSR_MAX_DEPTH]; /* per level: [n_d] site range per voxel     */
+    const int32_t* end[NKSR_MAX_DEPTH];
+} nksr_siteset_t;
+
+/* Upper bound of the number of (row,col) pairs nksr_assemble will append. */
+int nksr_assemble_count(const nksr_hier_t* h, int64_t* d_count, void* stream);
+/* Appends the symmetric COO of  sum_s w_s R_s^T R_s + reg I  (keys = row<<col_bits | col, 2^col_bits >= M) and
+ * writes b = sum_s w_s R_s^T t_s.  d_count must be zeroed by the caller. */
+int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, int nsets, float reg, int col_bits,
+                  uint64_t* coo_keys, float* coo_vals, int64_t capacity, int64_t* d_count, float* b_out, void* stream);
+/* Sorted COO -> CSR (rowptr int32 [M+1], cols int32 [nnz]) + diagonal. */
+int nksr_coo_to_csr(const uint64_t* keys_sorted, const float* vals, int64_t nnz, int32_t M, int col_bits,
+                    int32_t* rowptr, int32_t* cols, float* diag, void* stream);
+
+/* ---- PCG (the CG SpMV is the roofline kernel) -------------------- */
+int nksr_spmv_csr(const int32_t* rowptr, const int32_t* cols, const float* vals, int32_t M,
+                  const float* x, float* y, void* stream);
+/* Scratch bytes required by nksr_pcg_solve for a system of M unknowns. */
+size_t nksr_pcg_workspace_bytes(int32_t M);
+/* Jacobi-PCG, x0 = 0.  info_out (host, may be NULL): [0]=iterations [1]=relative residual.
+ * Checks convergence every `check_every` iterations (one stream sync each) -- syncs. */
+int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t M,
+                   const float* b, float* x, float tol, int max_iter, int check_every, void* workspace,
+                   double* info_out, void* stream);
+
+/* ---- dual marching cubes (field.extract_dual_mesh, examples/recons_simple.py:27) ------- */
+/* flags[i]=1 where voxel i and its +x,+y,+z,... 7 partners are all active */
+int nksr_base_cell_flags(const int32_t* nbr, int32_t n, int32_t* flags, void* stream);
+/* expand selected base voxels into U^3 lattice cell keys */
+int nksr_base_cell_keys(const int32_t* ijk, const int32_t* sel, int64_t nsel, int upsample, int64_t* cell_keys, void* stream);
+/* 8 corner lattice keys per cell */
+int nksr_cell_corner_keys(const int64_t* cell_keys, int64_t ncell, int64_t* corner_keys, void* stream);
+/* lattice key -> position x = g*h + half_w0 */
+int nksr_lattice_positions(const int64_t* vkeys, int64_t n, float h, float half_w0, float* xyz_out, void* stream);
+/* sorted-key lower-bound lookup (exact match required; -1 otherwise) */
+int nksr_sorted_lookup(const int64_t* sorted, int64_t n, const int64_t* q, int64_t nq, int32_t* idx_out, void* stream);
+/* per cell: 8-bit sign configuration (bit c set iff f[corner c] > 0) and triangle count */
+int nksr_cell_config(const int32_t* corner_idx, const float* f, int64_t ncell, int32_t* config, int32_t* ntri, void* stream);
+/* flags[i]=1 where the cell's corners do not share a sign (MISE candidates) */
+int nksr_cell_active_flags(const int32_t* config, int64_t ncell, int32_t* flags, void* stream);
+/* ordered stream compaction: per-256-block counts, then (after an exclusive scan of the
+ * counts) ordered scatter of the flagged indices -- wave ballot + popcount prefix */
+int nksr_compact_block_counts(const int32_t* flags, int64_t n, int32_t* block_counts, void* stream);
+int nksr_compact_scatter(const int32_t* flags, int64_t n, const int32_t* block_offsets, int32_t* sel, void* stream);
+/* children of the flagged cells: out has 8 keys per selected cell */
+int nksr_cell_children(const int64_t* cell_keys, const int32_t* sel, int64_t nsel, int64_t* child_keys, void* stream);
+/* triangle emission: edge keys (lower vertex index*3+axis) [ntri_total,3] */
+int nksr_mc_emit(const int32_t* corner_idx, const int32_t* config, const int32_t* tri_offset, int64_t ncell,
+                 int64_t* edge_keys, void* stream);
+/* mesh vertices from unique edge keys */
+int nksr_mc_vertices(const int64_t* edge_keys, int64_t nedge, const int64_t* vkeys, int64_t nv, const float* vpos,
+                     const float* f, float h, float* verts_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,136 @@
+"""ctypes binding of the C-ABI declared in include/nksr_hip.h.
+
+The product path has NO CPU fallback: if libnksr_hip.so is missing (and cannot be built)
+importing this module raises, and every op raises RuntimeError on a non-GPU tensor.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import build as _build
+
+MAX_DEPTH = 6
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class LevelT(C.Structure):
+    _fields_ = [('n', _i32), ('offset', _i32), ('keys', _vp), ('ijk', _vp), ('nbr', _vp), ('hkeys', _vp),
+                ('hvals', _vp), ('hcap', _i32), ('feat', _vp), ('psi', _vp), ('mlp', _vp)]
+
+
+class HierT(C.Structure):
+    _fields_ = [('depth', _i32), ('kdim', _i32), ('hidden', _i32), ('inv_w0', _f32), ('lv', LevelT * MAX_DEPTH)]
+
+
+class SiteSetT(C.Structure):
+    _fields_ = [('n', _i64), ('ncomp', _i32), ('weight', _f32), ('val', _vp), ('target', _vp),
+                ('start', _vp * MAX_DEPTH), ('end', _vp * MAX_DEPTH)]
+
+
+def _load():
+    path = _build.LIB
+    if _build.needs_build():
+        try:
+            _build.build_library()
+        except Exception as e:  # stale/missing library and no compiler: fail loudly
+            if not os.path.exists(path):
+                raise RuntimeError('libnksr_hip.so is missing and could not be built: %s' % e)
+    return C.CDLL(path)
+
+
+lib = _load()
+lib.nksr_last_error.restype = C.c_char_p
+lib.nksr_pcg_workspace_bytes.restype = _sz
+lib.nksr_pcg_workspace_bytes.argtypes = [_i32]
+
+_P = C.POINTER
+_PROTOS = {
+    'nksr_sort_keys_u64': [_vp, _P(_sz), _vp, _vp, _i64, C.c_int, C.c_int, _vp],
+    'nksr_sort_pairs_u64_u32': [_vp, _P(_sz), _vp, _vp, _vp, _vp, _i64, C.c_int, C.c_int, _vp],
+    'nksr_unique_u64': [_vp, _P(_sz), _vp, _vp, _vp, _i64, _vp],
+    'nksr_exclusive_sum_i32': [_vp, _P(_sz), _vp, _vp, _i64, _vp],
+    'nksr_exclusive_sum_i64': [_vp, _P(_sz), _vp, _vp, _i64, _vp],
+    'nksr_splat_keys': [_vp, _i64, _f32, C.c_int, C.c_int, _vp, _vp],
+    'nksr_point_keys': [_vp, _i64, _f32, _vp, _vp],
+    'nksr_decode_keys': [_vp, _i64, C.c_int, _vp, _vp],
+    'nksr_encode_keys': [_vp, _i64, C.c_int, _vp, _vp],
+    'nksr_hash_build': [_vp, _i32, _vp, _vp, _i32, _vp],
+    'nksr_hash_query': [_vp, _i64, _vp, _vp, _i32, _vp, _vp],
+    'nksr_build_nbr': [_vp, _i32, C.c_int, _vp, _vp, _i32, _vp, _vp],
+    'nksr_site_ranges': [_vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp],
+    'nksr_sorted_lookup': [_vp, _i64, _vp, _i64, _vp, _vp],
+    'nksr_splat_trilinear': [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp],
+    'nksr_voxel_psi': [_vp, _i32, C.c_int, C.c_int, _vp, _vp, _vp],
+    'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _vp, _vp, _vp],
+    'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, _vp, _vp, _vp],
+    'nksr_assemble_count': [_P(HierT), _vp, _vp],
+    'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp],
+    'nksr_coo_to_csr': [_vp, _vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _vp],
+    'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _vp, _vp, _vp],
+    'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
+    'nksr_base_cell_flags': [_vp, _i32, _vp, _vp],
+    'nksr_base_cell_keys': [_vp, _vp, _i64, C.c_int, _vp, _vp],
+    'nksr_cell_corner_keys': [_vp, _i64, _vp, _vp],
+    'nksr_lattice_positions': [_vp, _i64, _f32, _f32, _vp, _vp],
+    'nksr_cell_config': [_vp, _vp, _i64, _vp, _vp, _vp],
+    'nksr_cell_active_flags': [_vp, _i64, _vp, _vp],
+    'nksr_compact_block_counts': [_vp, _i64, _vp, _vp],
+    'nksr_compact_scatter': [_vp, _i64, _vp, _vp, _vp],
+    'nksr_cell_children': [_vp, _vp, _i64, _vp, _vp],
+    'nksr_mc_emit': [_vp, _vp, _vp, _i64, _vp, _vp],
+    'nksr_mc_vertices': [_vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _vp],
+}
+for _name, _args in _PROTOS.items():
+    _fn = getattr(lib, _name)
+    _fn.argtypes = _args
+    _fn.restype = C.c_int
+
+EXPORTED = ['nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes'] + sorted(_PROTOS)
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib.nksr_last_error().decode(errors='replace')
+        if 'out of memory' in msg.lower():
+            raise MemoryError(msg)
+        raise RuntimeError('nksr_hip: %s (code %d)' % (msg, rc))
+
+
+def ptr(t):
+    """Device pointer of a contiguous GPU tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('nksr_amd is MI355X-only: expected a GPU tensor, got device %s' % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError('expected a contiguous tensor')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(device):
+    device = torch.device(device)
+    if device.type != 'cuda':
+        raise RuntimeError("nksr_amd is MI355X-native: device must be 'cuda' (got %s). The CPU restatement of "
+                           "this path lives in oracle/ and is test infrastructure only." % device)
+    if not torch.cuda.is_available():
+        raise RuntimeError('no GPU visible to PyTorch-ROCm')
+    return device
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args))
+
+
+def with_tmp(name, device, *args_after_tmp):
+    """Run a rocPRIM-backed primitive: size query, allocate, run."""
+    nbytes = _sz(0)
+    fn = getattr(lib, name)
+    check(fn(None, C.byref(nbytes), *args_after_tmp))
+    tmp = torch.empty(max(int(nbytes.value), 16), dtype=torch.uint8, device=device)
+    check(fn(tmp.data_ptr(), C.byref(nbytes), *args_after_tmp))
+    return tmp

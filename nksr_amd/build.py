@@ -1,0 +1,64 @@
+"""In-tree build of the HIP extension (libnksr_hip.so) for gfx950.
+
+No torch types cross the boundary, so the library is built with plain hipcc and loaded
+through ctypes (nksr_amd/_lib.py).  The .so stays in-tree (git-ignored) so it travels to
+the GPU box with the snapshot.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libnksr_hip.so')
+SOURCES = ['prims.hip', 'hierarchy.hip', 'kfield.hip', 'assemble.hip', 'pcg.hip', 'meshing.hip']
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+
+
+def _deps():
+    files = [os.path.join(CSRC, s) for s in SOURCES]
+    files += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    files.append(os.path.join(os.path.dirname(HERE), 'include', 'nksr_hip.h'))
+    return files
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(f) > t for f in _deps())
+
+
+def _compile(src):
+    obj = os.path.join(CSRC, src.replace('.hip', '.o'))
+    hdr_t = max(os.path.getmtime(f) for f in _deps() if f.endswith('.h'))
+    if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(os.path.join(CSRC, src)), hdr_t):
+        return obj
+    cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+    return obj
+
+
+def build_library(force=False, verbose=False):
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if not force and not needs_build():
+        return LIB
+    if not os.path.exists(HIPCC):
+        raise RuntimeError('hipcc not found at %s and %s is missing/stale' % (HIPCC, LIB))
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = list(ex.map(_compile, srcs))
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    if verbose:
+        print('built', LIB, file=sys.stderr)
+    return LIB
+
+
+if __name__ == '__main__':
+    build_library(force='--force' in sys.argv, verbose=True)

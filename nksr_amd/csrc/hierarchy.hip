@@ -1,0 +1,205 @@
+// Sparse voxel hierarchy: key generation, hash build/query, 27-neighbour tables, site ranges.
+// Serves SparseFeatureHierarchy.build_point_splatting / grids[d] (reference call sites
+// models/nksr_net.py:57-62, models/loss.py:33-46).  All kernels are HBM-bound integer work:
+// one thread per element, coalesced key streams, hash probes served from L2.
+#include "common.h"
+
+__global__ void k_splat_keys(const float* __restrict__ xyz, int64_t n, float inv_w0, int level, int mode,
+                             int64_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float p;
+    int H[3];
+    for (int a = 0; a < 3; ++a) H[a] = half_index(xyz[i * 3 + a], inv_w0, p) >> level;
+    int bias = NKSR_BIAS0 >> level;
+    if (mode == 0) {
+        int bx = (H[0] - 1) >> 1, by = (H[1] - 1) >> 1, bz = (H[2] - 1) >> 1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            out[i * 8 + c] = morton_biased(bx + (c >> 2), by + ((c >> 1) & 1), bz + (c & 1), bias);
+    } else {
+        int cx = H[0] >> 1, cy = H[1] >> 1, cz = H[2] >> 1;
+        for (int s = 0; s < 27; ++s)
+            out[i * 27 + s] = morton_biased(cx + s / 9 - 1, cy + (s / 3) % 3 - 1, cz + s % 3 - 1, bias);
+    }
+}
+
+__global__ void k_point_keys(const float* __restrict__ xyz, int64_t n, float inv_w0, int64_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float p;
+    int cx = half_index(xyz[i * 3 + 0], inv_w0, p) >> 1;
+    int cy = half_index(xyz[i * 3 + 1], inv_w0, p) >> 1;
+    int cz = half_index(xyz[i * 3 + 2], inv_w0, p) >> 1;
+    out[i] = morton_biased(cx, cy, cz, NKSR_BIAS0);
+}
+
+__global__ void k_decode_keys(const int64_t* __restrict__ keys, int64_t n, int bias, int32_t* __restrict__ ijk) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x, y, z;
+    morton_decode_biased(keys[i], bias, x, y, z);
+    ijk[i * 3 + 0] = x;
+    ijk[i * 3 + 1] = y;
+    ijk[i * 3 + 2] = z;
+}
+
+__global__ void k_encode_keys(const int32_t* __restrict__ ijk, int64_t n, int bias, int64_t* __restrict__ keys) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = morton_biased(ijk[i * 3], ijk[i * 3 + 1], ijk[i * 3 + 2], bias);
+}
+
+__global__ void k_hash_build(const int64_t* __restrict__ keys, int n, int64_t* hkeys, int32_t* hvals, int hcap) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t key = keys[i];
+    uint32_t slot = hash_mix(key) & (uint32_t)(hcap - 1);
+    for (int probe = 0; probe < hcap; ++probe) {
+        unsigned long long prev = atomicCAS((unsigned long long*)&hkeys[slot], 0xFFFFFFFFFFFFFFFFull,
+                                            (unsigned long long)key);
+        if (prev == 0xFFFFFFFFFFFFFFFFull || prev == (unsigned long long)key) {
+            hvals[slot] = i;  // keys are unique: exactly one writer per slot
+            return;
+        }
+        slot = (slot + 1) & (uint32_t)(hcap - 1);
+    }
+}
+
+__global__ void k_hash_query(const int64_t* __restrict__ q, int64_t nq, const int64_t* __restrict__ hkeys,
+                             const int32_t* __restrict__ hvals, int hcap, int32_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    out[i] = hash_find(hkeys, hvals, hcap, q[i]);
+}
+
+// one thread per (voxel, slot): consecutive lanes write consecutive nbr entries
+__global__ void k_build_nbr(const int32_t* __restrict__ ijk, int n, int bias, const int64_t* __restrict__ hkeys,
+                            const int32_t* __restrict__ hvals, int hcap, int32_t* __restrict__ nbr) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * 27) return;
+    int i = (int)(t / 27), s = (int)(t % 27);
+    int x = ijk[i * 3] + s / 9 - 1, y = ijk[i * 3 + 1] + (s / 3) % 3 - 1, z = ijk[i * 3 + 2] + s % 3 - 1;
+    nbr[t] = (s == 13) ? i : hash_find(hkeys, hvals, hcap, morton_biased(x, y, z, bias));
+}
+
+__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t v) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_site_ranges(const int64_t* __restrict__ site_keys, int64_t ns, const int64_t* __restrict__ vkeys,
+                              int n, int shift, int32_t* __restrict__ start, int32_t* __restrict__ end) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t k = vkeys[i];
+    start[i] = (int32_t)lower_bound_i64(site_keys, ns, k << shift);
+    end[i] = (int32_t)lower_bound_i64(site_keys, ns, (k + 1) << shift);
+}
+
+__global__ void k_sorted_lookup(const int64_t* __restrict__ sorted, int64_t n, const int64_t* __restrict__ q,
+                                int64_t nq, int32_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int64_t v = q[i];
+    int64_t pos = lower_bound_i64(sorted, n, v);
+    out[i] = (pos < n && sorted[pos] == v) ? (int32_t)pos : -1;
+}
+
+#define LAUNCH1D(kern, n, stream, ...)                                                              \
+    do {                                                                                            \
+        if ((n) > 0) {                                                                              \
+            hipLaunchKernelGGL(kern, dim3(nksr_blocks((n), 256)), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__); \
+            NKSR_CHECK_LAUNCH();                                                                    \
+        }                                                                                           \
+    } while (0)
+
+extern "C" int nksr_splat_keys(const float* xyz, int64_t n, float inv_w0, int level, int mode, int64_t* keys_out,
+                               void* stream) {
+    if (level < 0 || level >= NKSR_MAX_DEPTH || (mode != 0 && mode != 1)) return nksr_set_error(NKSR_ERR_ARG, "bad level/mode");
+    LAUNCH1D(k_splat_keys, n, stream, xyz, n, inv_w0, level, mode, keys_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_point_keys(const float* xyz, int64_t n, float inv_w0, int64_t* keys_out, void* stream) {
+    LAUNCH1D(k_point_keys, n, stream, xyz, n, inv_w0, keys_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_decode_keys(const int64_t* keys, int64_t n, int level, int32_t* ijk_out, void* stream) {
+    int bias = level < 0 ? NKSR_BIAS0 : (NKSR_BIAS0 >> level);
+    LAUNCH1D(k_decode_keys, n, stream, keys, n, bias, ijk_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_encode_keys(const int32_t* ijk, int64_t n, int level, int64_t* keys_out, void* stream) {
+    int bias = level < 0 ? NKSR_BIAS0 : (NKSR_BIAS0 >> level);
+    LAUNCH1D(k_encode_keys, n, stream, ijk, n, bias, keys_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_hash_build(const int64_t* keys, int32_t n, int64_t* hkeys, int32_t* hvals, int32_t hcap, void* stream) {
+    if (hcap <= 0 || (hcap & (hcap - 1)) || hcap < 2 * n) return nksr_set_error(NKSR_ERR_ARG, "hash capacity must be a power of two >= 2n");
+    LAUNCH1D(k_hash_build, n, stream, keys, n, hkeys, hvals, hcap);
+    return NKSR_OK;
+}
+extern "C" int nksr_hash_query(const int64_t* q, int64_t nq, const int64_t* hkeys, const int32_t* hvals, int32_t hcap,
+                               int32_t* idx_out, void* stream) {
+    LAUNCH1D(k_hash_query, nq, stream, q, nq, hkeys, hvals, hcap, idx_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_build_nbr(const int32_t* ijk, int32_t n, int level, const int64_t* hkeys, const int32_t* hvals,
+                              int32_t hcap, int32_t* nbr_out, void* stream) {
+    LAUNCH1D(k_build_nbr, (int64_t)n * 27, stream, ijk, n, NKSR_BIAS0 >> level, hkeys, hvals, hcap, nbr_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_site_ranges(const int64_t* site_keys, int64_t ns, const int64_t* vox_keys, int32_t n, int level,
+                                int32_t* start_out, int32_t* end_out, void* stream) {
+    LAUNCH1D(k_site_ranges, n, stream, site_keys, ns, vox_keys, n, 3 * level, start_out, end_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_sorted_lookup(const int64_t* sorted, int64_t n, const int64_t* q, int64_t nq, int32_t* idx_out,
+                                  void* stream) {
+    LAUNCH1D(k_sorted_lookup, nq, stream, sorted, n, q, nq, idx_out);
+    return NKSR_OK;
+}
+
+// ---- trilinear splat-mean of per-point features onto the voxels of one level ------------------
+// Gather form (deterministic, no float atomics): voxel j visits the points of its 27 neighbour
+// cells (contiguous ranges of the Morton-sorted cloud) and weights them with the hat function
+// prod_a max(0, 1 - |x_a/w - (j_a + 1/2)|).  Used by the point encoder (network.encoder,
+// reference call site models/nksr_net.py:73) for the input-normal skip path.
+__global__ void k_splat_trilinear(const float* __restrict__ xyz, const float* __restrict__ feat, int C,
+                                  const int32_t* __restrict__ start, const int32_t* __restrict__ end,
+                                  const int32_t* __restrict__ nbr, const int32_t* __restrict__ ijk, int n, float inv_w,
+                                  float* __restrict__ out, float* __restrict__ wsum_out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float acc[8];
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    float wsum = 0.f;
+    const float cx = (float)ijk[j * 3] + 0.5f, cy = (float)ijk[j * 3 + 1] + 0.5f, cz = (float)ijk[j * 3 + 2] + 0.5f;
+    for (int s = 0; s < 27; ++s) {
+        int c = nbr[(int64_t)j * 27 + s];
+        if (c < 0) continue;
+        for (int k = start[c]; k < end[c]; ++k) {
+            float wx = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3], inv_w) - cx);
+            float wy = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 1], inv_w) - cy);
+            float wz = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 2], inv_w) - cz);
+            if (wx <= 0.f || wy <= 0.f || wz <= 0.f) continue;
+            float w = wx * wy * wz;
+            wsum += w;
+            for (int c2 = 0; c2 < C; ++c2) acc[c2] = fmaf(w, feat[(int64_t)k * C + c2], acc[c2]);
+        }
+    }
+    for (int c = 0; c < C; ++c) out[(int64_t)j * C + c] = acc[c];
+    wsum_out[j] = wsum;
+}
+
+extern "C" int nksr_splat_trilinear(const float* xyz_sorted, const float* feat_sorted, int C, const int32_t* start,
+                                    const int32_t* end, const int32_t* nbr, const int32_t* ijk, int32_t n, float inv_w,
+                                    float* out, float* wsum_out, void* stream) {
+    if (C < 1 || C > 8) return nksr_set_error(NKSR_ERR_ARG, "splat supports 1..8 channels");
+    LAUNCH1D(k_splat_trilinear, (int64_t)n, stream, xyz_sorted, feat_sorted, C, start, end, nbr, ijk, n, inv_w, out, wsum_out);
+    return NKSR_OK;
+}

@@ -1,0 +1,301 @@
+// Neural-kernel evaluation on the sparse voxel hierarchy:
+//   K_d(x, c_j) = <phi_d(x), psi_j> * B((x - c_j)/w_d),  phi_d = t + MLP_d(t), t = trilerp(feat_d)(x)
+// Serves KernelField(...) / evaluate_f (reference call sites models/nksr_net.py:91-96,
+// models/loss.py:189-198).  Gather-bound: per (site, level) 8 feature gathers for the
+// trilinear stencil and 27 psi gathers through the neighbour table; the interpolator MLP
+// weights live in LDS.
+#include "common.h"
+
+template <int K, int H>
+struct MlpView {
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    __device__ explicit MlpView(const float* w) {
+        W1 = w; b1 = W1 + H * K; W2 = b1 + H; b2 = W2 + H * H; W3 = b2 + H; b3 = W3 + K * H;
+    }
+    static constexpr int SIZE = H * K + H + H * H + H + K * H + K;
+};
+
+// phi = t + W3 relu(W2 relu(W1 t + b1) + b2) + b3 ; optional forward-mode tangents J[K][3]
+template <int K, int H, bool JAC>
+__device__ __forceinline__ void mlp_residual(const MlpView<K, H>& m, const float t[K], const float Jt[K][3],
+                                             float phi[K], float J[K][3]) {
+    float h1[H], h2[H];
+    float d1[JAC ? H : 1][3], d2[JAC ? H : 1][3];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float a = m.b1[h];
+        float da[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float w = m.W1[h * K + k];
+            a = fmaf(w, t[k], a);
+            if (JAC) { da[0] = fmaf(w, Jt[k][0], da[0]); da[1] = fmaf(w, Jt[k][1], da[1]); da[2] = fmaf(w, Jt[k][2], da[2]); }
+        }
+        bool on = a > 0.f;
+        h1[h] = on ? a : 0.f;
+        if (JAC) { d1[h][0] = on ? da[0] : 0.f; d1[h][1] = on ? da[1] : 0.f; d1[h][2] = on ? da[2] : 0.f; }
+    }
+#pragma unroll
+    for (int g = 0; g < H; ++g) {
+        float a = m.b2[g];
+        float da[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float w = m.W2[g * H + h];
+            a = fmaf(w, h1[h], a);
+            if (JAC) { da[0] = fmaf(w, d1[h][0], da[0]); da[1] = fmaf(w, d1[h][1], da[1]); da[2] = fmaf(w, d1[h][2], da[2]); }
+        }
+        bool on = a > 0.f;
+        h2[g] = on ? a : 0.f;
+        if (JAC) { d2[g][0] = on ? da[0] : 0.f; d2[g][1] = on ? da[1] : 0.f; d2[g][2] = on ? da[2] : 0.f; }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float a = m.b3[k];
+        float da[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < H; ++g) {
+            float w = m.W3[k * H + g];
+            a = fmaf(w, h2[g], a);
+            if (JAC) { da[0] = fmaf(w, d2[g][0], da[0]); da[1] = fmaf(w, d2[g][1], da[1]); da[2] = fmaf(w, d2[g][2], da[2]); }
+        }
+        phi[k] = t[k] + a;
+        if (JAC) { J[k][0] = Jt[k][0] + da[0]; J[k][1] = Jt[k][1] + da[1]; J[k][2] = Jt[k][2] + da[2]; }
+    }
+}
+
+struct SiteCell {
+    int cell;      // voxel index of the containing cell or -1
+    int hb[3];     // half bits
+    float u[3];    // local coordinate in [0,1)
+};
+
+__device__ __forceinline__ SiteCell locate_site(const nksr_level_t& lv, int level, float inv_w0, const float x[3]) {
+    SiteCell sc;
+    int I[3];
+    float scale = __int_as_float((127 - level) << 23);  // 2^-level
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float p;
+        int Hd = half_index(x[a], inv_w0, p) >> level;
+        I[a] = Hd >> 1;
+        sc.hb[a] = Hd & 1;
+        sc.u[a] = p * scale - (float)I[a];
+    }
+    sc.cell = hash_find(lv.hkeys, lv.hvals, lv.hcap, morton_biased(I[0], I[1], I[2], NKSR_BIAS0 >> level));
+    return sc;
+}
+
+// trilinear interpolation of the level's basis features (+ spatial tangents in world units)
+template <int K, bool JAC>
+__device__ __forceinline__ void trilerp_feat(const nksr_level_t& lv, const SiteCell& sc, float inv_w, float t[K],
+                                             float Jt[K][3]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t[k] = 0.f; if (JAC) { Jt[k][0] = Jt[k][1] = Jt[k][2] = 0.f; } }
+    float v[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v[a] = sc.u[a] + 0.5f - (float)sc.hb[a];
+    const int32_t* nb = lv.nbr + (int64_t)sc.cell * 27;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        int cx = c >> 2, cy = (c >> 1) & 1, cz = c & 1;
+        int s = (sc.hb[0] + cx) * 9 + (sc.hb[1] + cy) * 3 + (sc.hb[2] + cz);  // (hb-1+c)+1
+        int j = nb[s];
+        if (j < 0) continue;
+        float wx = cx ? v[0] : 1.f - v[0], wy = cy ? v[1] : 1.f - v[1], wz = cz ? v[2] : 1.f - v[2];
+        float w = wx * wy * wz;
+        float gx = (cx ? 1.f : -1.f) * wy * wz * inv_w, gy = wx * (cy ? 1.f : -1.f) * wz * inv_w,
+              gz = wx * wy * (cz ? 1.f : -1.f) * inv_w;
+        const float* f = lv.feat + (int64_t)j * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float fk = f[k];
+            t[k] = fmaf(fk, w, t[k]);
+            if (JAC) { Jt[k][0] = fmaf(fk, gx, Jt[k][0]); Jt[k][1] = fmaf(fk, gy, Jt[k][1]); Jt[k][2] = fmaf(fk, gz, Jt[k][2]); }
+        }
+    }
+}
+
+// ---- psi_j = feat_j + MLP(feat_j) -----------------------------------------------------------
+template <int K, int H>
+__global__ void k_voxel_psi(const float* __restrict__ feat, int n, const float* __restrict__ mlp, float* __restrict__ psi) {
+    __shared__ float w[MlpView<K, H>::SIZE];
+    for (int i = threadIdx.x; i < MlpView<K, H>::SIZE; i += blockDim.x) w[i] = mlp[i];
+    __syncthreads();
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    MlpView<K, H> m(w);
+    float t[K], phi[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) t[k] = feat[(int64_t)i * K + k];
+    mlp_residual<K, H, false>(m, t, nullptr, phi, nullptr);
+#pragma unroll
+    for (int k = 0; k < K; ++k) psi[(int64_t)i * K + k] = phi[k];
+}
+
+// ---- dense-slot kernel rows -------------------------------------------------------------------
+// grid.y = level; one thread per site.
+template <int K, int H, bool GRAD, bool JAC>
+__global__ void k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float* __restrict__ val,
+                              float* __restrict__ dval) {
+    const int d = blockIdx.y, L = hier.depth;
+    const nksr_level_t& lv = hier.lv[d];
+    __shared__ float w[MlpView<K, H>::SIZE];
+    for (int i = threadIdx.x; i < MlpView<K, H>::SIZE; i += blockDim.x) w[i] = lv.mlp[i];
+    __syncthreads();
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
+    float* vrow = val + (i * L + d) * 27;
+    if (sc.cell < 0) {
+        for (int s = 0; s < 27; ++s) vrow[s] = 0.f;
+        if (GRAD)
+            for (int a = 0; a < 3; ++a)
+                for (int s = 0; s < 27; ++s) dval[((i * 3 + a) * L + d) * 27 + s] = 0.f;
+        return;
+    }
+    float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
+    float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
+    trilerp_feat<K, JAC>(lv, sc, inv_w, t, Jt);
+    MlpView<K, H> m(w);
+    mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
+    float bw[3][3], bd[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
+    const int32_t* nb = lv.nbr + (int64_t)sc.cell * 27;
+    for (int s = 0; s < 27; ++s) {
+        int j = nb[s];
+        int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
+        float v = 0.f, g[3] = {0.f, 0.f, 0.f};
+        if (j >= 0) {
+            const float* ps = lv.psi + (int64_t)j * K;
+            float dot = 0.f, jd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float pk = ps[k];
+                dot = fmaf(phi[k], pk, dot);
+                if (JAC) { jd[0] = fmaf(J[k][0], pk, jd[0]); jd[1] = fmaf(J[k][1], pk, jd[1]); jd[2] = fmaf(J[k][2], pk, jd[2]); }
+            }
+            float bx = bw[0][ox], by = bw[1][oy], bz = bw[2][oz];
+            float B = bx * by * bz;
+            v = dot * B;
+            if (GRAD) {
+                g[0] = dot * (bd[0][ox] * by * bz * inv_w);
+                g[1] = dot * (bx * bd[1][oy] * bz * inv_w);
+                g[2] = dot * (bx * by * bd[2][oz] * inv_w);
+                if (JAC) { g[0] = fmaf(jd[0], B, g[0]); g[1] = fmaf(jd[1], B, g[1]); g[2] = fmaf(jd[2], B, g[2]); }
+            }
+        }
+        vrow[s] = v;
+        if (GRAD) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) dval[((i * 3 + a) * L + d) * 27 + s] = g[a];
+        }
+    }
+}
+
+// ---- f(x) = sum_d sum_s alpha_j K_d(x, c_j) ---------------------------------------------------
+template <int K, int H, bool GRAD, bool JAC>
+__global__ void k_evaluate_f(nksr_hier_t hier, const float* __restrict__ alpha, const float* __restrict__ xyz,
+                             int64_t n, float* __restrict__ fout, float* __restrict__ gout) {
+    extern __shared__ __attribute__((aligned(16))) float wall[];
+    const int L = hier.depth;
+    for (int d = 0; d < L; ++d)
+        for (int i = threadIdx.x; i < MlpView<K, H>::SIZE; i += blockDim.x)
+            wall[d * MlpView<K, H>::SIZE + i] = hier.lv[d].mlp[i];
+    __syncthreads();
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    float f = 0.f, gr[3] = {0.f, 0.f, 0.f};
+    for (int d = 0; d < L; ++d) {
+        const nksr_level_t& lv = hier.lv[d];
+        SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
+        if (sc.cell < 0) continue;
+        float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
+        float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
+        trilerp_feat<K, JAC>(lv, sc, inv_w, t, Jt);
+        MlpView<K, H> m(wall + d * MlpView<K, H>::SIZE);
+        mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
+        float bw[3][3], bd[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
+        const int32_t* nb = lv.nbr + (int64_t)sc.cell * 27;
+        float fl = 0.f, gl[3] = {0.f, 0.f, 0.f};
+        for (int s = 0; s < 27; ++s) {
+            int j = nb[s];
+            if (j < 0) continue;
+            int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
+            const float* ps = lv.psi + (int64_t)j * K;
+            float dot = 0.f, jd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float pk = ps[k];
+                dot = fmaf(phi[k], pk, dot);
+                if (JAC) { jd[0] = fmaf(J[k][0], pk, jd[0]); jd[1] = fmaf(J[k][1], pk, jd[1]); jd[2] = fmaf(J[k][2], pk, jd[2]); }
+            }
+            float a = alpha[lv.offset + j];
+            float bx = bw[0][ox], by = bw[1][oy], bz = bw[2][oz];
+            float B = bx * by * bz;
+            fl = fmaf(a, dot * B, fl);
+            if (GRAD) {
+                float g0 = dot * (bd[0][ox] * by * bz * inv_w), g1 = dot * (bx * bd[1][oy] * bz * inv_w),
+                      g2 = dot * (bx * by * bd[2][oz] * inv_w);
+                if (JAC) { g0 = fmaf(jd[0], B, g0); g1 = fmaf(jd[1], B, g1); g2 = fmaf(jd[2], B, g2); }
+                gl[0] = fmaf(a, g0, gl[0]); gl[1] = fmaf(a, g1, gl[1]); gl[2] = fmaf(a, g2, gl[2]);
+            }
+        }
+        f += fl;
+        if (GRAD) { gr[0] += gl[0]; gr[1] += gl[1]; gr[2] += gl[2]; }
+    }
+    fout[i] = f;
+    if (GRAD) { gout[i * 3] = gr[0]; gout[i * 3 + 1] = gr[1]; gout[i * 3 + 2] = gr[2]; }
+}
+
+// ---- dispatch on (K, H) ------------------------------------------------------------------------
+#define DISPATCH_KH(K_, H_, ...)                                  \
+    if (K_ == 4 && H_ == 16) { constexpr int K = 4, H = 16; __VA_ARGS__ } \
+    else if (K_ == 16 && H_ == 32) { constexpr int K = 16, H = 32; __VA_ARGS__ } \
+    else if (K_ == 4 && H_ == 32) { constexpr int K = 4, H = 32; __VA_ARGS__ } \
+    else if (K_ == 16 && H_ == 16) { constexpr int K = 16, H = 16; __VA_ARGS__ } \
+    else return nksr_set_error(NKSR_ERR_ARG, "unsupported (kernel_dim, hidden_dim) = (%d, %d)", K_, H_);
+
+extern "C" int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden, const float* mlp, float* psi_out,
+                              void* stream) {
+    if (n <= 0) return NKSR_OK;
+    DISPATCH_KH(kdim, hidden, {
+        hipLaunchKernelGGL((k_voxel_psi<K, H>), dim3(nksr_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, feat, n, mlp, psi_out);
+    })
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float* val, float* dval,
+                                void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
+    dim3 grid(nksr_blocks(n, 128), h->depth), block(128);
+    DISPATCH_KH(h->kdim, h->hidden, {
+        if (!dval) hipLaunchKernelGGL((k_kernel_rows<K, H, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, val, dval);
+        else if (approx) hipLaunchKernelGGL((k_kernel_rows<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, val, dval);
+        else hipLaunchKernelGGL((k_kernel_rows<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, val, dval);
+    })
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+extern "C" int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx,
+                               float* f_out, float* grad_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
+    dim3 grid(nksr_blocks(n, 128)), block(128);
+    DISPATCH_KH(h->kdim, h->hidden, {
+        size_t lds = (size_t)h->depth * MlpView<K, H>::SIZE * sizeof(float);
+        if (!grad_out) hipLaunchKernelGGL((k_evaluate_f<K, H, false, false>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out);
+        else if (approx) hipLaunchKernelGGL((k_evaluate_f<K, H, true, false>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out);
+        else hipLaunchKernelGGL((k_evaluate_f<K, H, true, true>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out);
+    })
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}

@@ -1,0 +1,213 @@
+// Dual marching cubes on the finest level of the hierarchy + MISE refinement
+// (field.extract_dual_mesh; reference call sites examples/recons_simple.py:27,
+// recons_scannet.py:29, models/nksr_net.py:214,284).  All integer/topology work; the field
+// values come from nksr_evaluate_f.  Lattice convention:
+//   x = g*h + w0/2,  h = w0/(U 2^m),  lattice keys = Morton(g + 2^20).
+// Compaction is ordered (deterministic): per-wave ballot + popcount prefix inside a block,
+// block offsets from an exclusive scan.
+#include "common.h"
+#include "mc_table.h"
+
+#define CMP_BLOCK 256
+
+// ---- ordered stream compaction ----------------------------------------------------------------
+__global__ void __launch_bounds__(CMP_BLOCK) k_flag_block_count(const int32_t* __restrict__ flags, int64_t n,
+                                                                 int32_t* __restrict__ block_counts) {
+    __shared__ int wsum[CMP_BLOCK / 64];
+    int64_t i = (int64_t)blockIdx.x * CMP_BLOCK + threadIdx.x;
+    bool f = i < n && flags[i] != 0;
+    unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < CMP_BLOCK / 64; ++w) t += wsum[w];
+        block_counts[blockIdx.x] = t;
+    }
+}
+
+__global__ void __launch_bounds__(CMP_BLOCK) k_flag_block_scatter(const int32_t* __restrict__ flags, int64_t n,
+                                                                   const int32_t* __restrict__ block_offsets,
+                                                                   int32_t* __restrict__ sel) {
+    __shared__ int wsum[CMP_BLOCK / 64];
+    int64_t i = (int64_t)blockIdx.x * CMP_BLOCK + threadIdx.x;
+    bool f = i < n && flags[i] != 0;
+    unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wsum[wave] = __popcll(m);
+    __syncthreads();
+    int base = block_offsets[blockIdx.x];
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    if (f) sel[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)i;
+}
+
+extern "C" int nksr_compact_block_counts(const int32_t* flags, int64_t n, int32_t* block_counts, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    hipLaunchKernelGGL(k_flag_block_count, dim3(nksr_blocks(n, CMP_BLOCK)), dim3(CMP_BLOCK), 0, (hipStream_t)stream, flags, n, block_counts);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+extern "C" int nksr_compact_scatter(const int32_t* flags, int64_t n, const int32_t* block_offsets, int32_t* sel, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    hipLaunchKernelGGL(k_flag_block_scatter, dim3(nksr_blocks(n, CMP_BLOCK)), dim3(CMP_BLOCK), 0, (hipStream_t)stream, flags, n, block_offsets, sel);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+// ---- dual cells ---------------------------------------------------------------------------------
+__global__ void k_base_cell_flags(const int32_t* __restrict__ nbr, int n, int32_t* __restrict__ flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t* nb = nbr + (int64_t)i * 27;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ok = ok && nb[(1 + (c >> 2)) * 9 + (1 + ((c >> 1) & 1)) * 3 + (1 + (c & 1))] >= 0;
+    flags[i] = ok ? 1 : 0;
+}
+
+__global__ void k_base_cell_keys(const int32_t* __restrict__ ijk, const int32_t* __restrict__ sel, int64_t nsel, int U,
+                                 int64_t* __restrict__ keys) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int U3 = U * U * U;
+    if (t >= nsel * U3) return;
+    int64_t c = t / U3;
+    int r = (int)(t % U3);
+    int i = sel[c];
+    int x = ijk[i * 3] * U + r / (U * U), y = ijk[i * 3 + 1] * U + (r / U) % U, z = ijk[i * 3 + 2] * U + r % U;
+    keys[t] = morton_biased(x, y, z, NKSR_BIAS0);
+}
+
+__global__ void k_cell_corner_keys(const int64_t* __restrict__ cell_keys, int64_t ncell, int64_t* __restrict__ ck) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncell * 8) return;
+    int x, y, z;
+    morton_decode_biased(cell_keys[t >> 3], NKSR_BIAS0, x, y, z);
+    int c = (int)(t & 7);
+    ck[t] = morton_biased(x + (c >> 2), y + ((c >> 1) & 1), z + (c & 1), NKSR_BIAS0);
+}
+
+__global__ void k_cell_children(const int64_t* __restrict__ cell_keys, const int32_t* __restrict__ sel, int64_t nsel,
+                                int64_t* __restrict__ child) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nsel * 8) return;
+    int x, y, z;
+    morton_decode_biased(cell_keys[sel[t >> 3]], NKSR_BIAS0, x, y, z);
+    int c = (int)(t & 7);
+    child[t] = morton_biased(2 * x + (c >> 2), 2 * y + ((c >> 1) & 1), 2 * z + (c & 1), NKSR_BIAS0);
+}
+
+__global__ void k_lattice_positions(const int64_t* __restrict__ vkeys, int64_t n, float h, float half_w0,
+                                    float* __restrict__ xyz) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x, y, z;
+    morton_decode_biased(vkeys[i], NKSR_BIAS0, x, y, z);
+    xyz[i * 3] = __fadd_rn(__fmul_rn((float)x, h), half_w0);
+    xyz[i * 3 + 1] = __fadd_rn(__fmul_rn((float)y, h), half_w0);
+    xyz[i * 3 + 2] = __fadd_rn(__fmul_rn((float)z, h), half_w0);
+}
+
+__global__ void k_cell_config(const int32_t* __restrict__ corner_idx, const float* __restrict__ f, int64_t ncell,
+                              int32_t* __restrict__ config, int32_t* __restrict__ ntri) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncell) return;
+    int cfg = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cfg |= (f[corner_idx[i * 8 + c]] > 0.f) ? (1 << c) : 0;
+    config[i] = cfg;
+    ntri[i] = MC_NTRI[cfg];
+}
+
+__global__ void k_cell_active_flags(const int32_t* __restrict__ config, int64_t ncell, int32_t* __restrict__ flags) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncell) return;
+    int c = config[i];
+    flags[i] = (c != 0 && c != 255) ? 1 : 0;
+}
+
+__global__ void k_mc_emit(const int32_t* __restrict__ corner_idx, const int32_t* __restrict__ config,
+                          const int32_t* __restrict__ tri_offset, int64_t ncell, int64_t* __restrict__ edge_keys) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncell) return;
+    const int cfg = config[i];
+    const int nt = MC_NTRI[cfg];
+    int64_t o = (int64_t)tri_offset[i] * 3;
+    for (int t = 0; t < nt * 3; ++t) {
+        int e = MC_TRI[cfg][t];
+        edge_keys[o + t] = (int64_t)corner_idx[i * 8 + MC_EDGE_LO[e]] * 3 + MC_EDGE_AXIS[e];
+    }
+}
+
+__global__ void k_mc_vertices(const int64_t* __restrict__ edge_keys, int64_t nedge, const int64_t* __restrict__ vkeys,
+                              int64_t nv, const float* __restrict__ vpos, const float* __restrict__ f, float h,
+                              float* __restrict__ verts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nedge) return;
+    int64_t ek = edge_keys[i];
+    int64_t v0 = ek / 3;
+    int axis = (int)(ek % 3);
+    int g[3];
+    morton_decode_biased(vkeys[v0], NKSR_BIAS0, g[0], g[1], g[2]);
+    g[axis] += 1;
+    int64_t k1 = morton_biased(g[0], g[1], g[2], NKSR_BIAS0);
+    int64_t lo = 0, hi = nv;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (vkeys[mid] < k1) lo = mid + 1; else hi = mid;
+    }
+    float f0 = f[v0], f1 = f[lo];
+    float t = __fdiv_rn(f0, __fsub_rn(f0, f1));
+    float p[3] = {vpos[v0 * 3], vpos[v0 * 3 + 1], vpos[v0 * 3 + 2]};
+    p[axis] = __fadd_rn(p[axis], __fmul_rn(t, h));
+    verts[i * 3] = p[0];
+    verts[i * 3 + 1] = p[1];
+    verts[i * 3 + 2] = p[2];
+}
+
+#define LAUNCH1D(kern, n, stream, ...)                                                              \
+    do {                                                                                            \
+        if ((n) > 0) {                                                                              \
+            hipLaunchKernelGGL(kern, dim3(nksr_blocks((n), 256)), dim3(256), 0, (hipStream_t)(stream), __VA_ARGS__); \
+            NKSR_CHECK_LAUNCH();                                                                    \
+        }                                                                                           \
+    } while (0)
+
+extern "C" int nksr_base_cell_flags(const int32_t* nbr, int32_t n, int32_t* flags, void* stream) {
+    LAUNCH1D(k_base_cell_flags, (int64_t)n, stream, nbr, n, flags);
+    return NKSR_OK;
+}
+extern "C" int nksr_base_cell_keys(const int32_t* ijk, const int32_t* sel, int64_t nsel, int upsample, int64_t* cell_keys, void* stream) {
+    if (upsample < 1 || upsample > 8) return nksr_set_error(NKSR_ERR_ARG, "grid_upsample must be in [1,8]");
+    LAUNCH1D(k_base_cell_keys, nsel * upsample * upsample * upsample, stream, ijk, sel, nsel, upsample, cell_keys);
+    return NKSR_OK;
+}
+extern "C" int nksr_cell_corner_keys(const int64_t* cell_keys, int64_t ncell, int64_t* corner_keys, void* stream) {
+    LAUNCH1D(k_cell_corner_keys, ncell * 8, stream, cell_keys, ncell, corner_keys);
+    return NKSR_OK;
+}
+extern "C" int nksr_cell_children(const int64_t* cell_keys, const int32_t* sel, int64_t nsel, int64_t* child_keys, void* stream) {
+    LAUNCH1D(k_cell_children, nsel * 8, stream, cell_keys, sel, nsel, child_keys);
+    return NKSR_OK;
+}
+extern "C" int nksr_lattice_positions(const int64_t* vkeys, int64_t n, float h, float half_w0, float* xyz_out, void* stream) {
+    LAUNCH1D(k_lattice_positions, n, stream, vkeys, n, h, half_w0, xyz_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_cell_config(const int32_t* corner_idx, const float* f, int64_t ncell, int32_t* config, int32_t* ntri, void* stream) {
+    LAUNCH1D(k_cell_config, ncell, stream, corner_idx, f, ncell, config, ntri);
+    return NKSR_OK;
+}
+extern "C" int nksr_cell_active_flags(const int32_t* config, int64_t ncell, int32_t* flags, void* stream) {
+    LAUNCH1D(k_cell_active_flags, ncell, stream, config, ncell, flags);
+    return NKSR_OK;
+}
+extern "C" int nksr_mc_emit(const int32_t* corner_idx, const int32_t* config, const int32_t* tri_offset, int64_t ncell,
+                            int64_t* edge_keys, void* stream) {
+    LAUNCH1D(k_mc_emit, ncell, stream, corner_idx, config, tri_offset, ncell, edge_keys);
+    return NKSR_OK;
+}
+extern "C" int nksr_mc_vertices(const int64_t* edge_keys, int64_t nedge, const int64_t* vkeys, int64_t nv, const float* vpos,
+                                const float* f, float h, float* verts_out, void* stream) {
+    LAUNCH1D(k_mc_vertices, nedge, stream, edge_keys, nedge, vkeys, nv, vpos, f, h, verts_out);
+    return NKSR_OK;
+}

@@ -1,0 +1,97 @@
+"""Dual marching cubes + MISE -- host orchestration of csrc/meshing.hip.
+
+Mirrors ``field.extract_dual_mesh(mise_iter=0, grid_upsample=1, max_points=-1)`` of the
+reference (call sites examples/recons_simple.py:27, recons_scannet.py:29,
+recons_colored_mesh.py:30, models/nksr_net.py:214,284) returning ``.v [V,3] f32``,
+``.f [T,3] int``, ``.c [V,3]`` (NKSR-USAGE.md:52,79).  Steps:
+base dual cells -> (lattice vertices, f) -> MISE split of sign-changing cells -> 256-case
+table -> edge-keyed vertex dedup (radix sort + unique) -> mask trim -> world units.
+Host syncs happen only where a size (cells, vertices, triangles) must reach the host.
+"""
+import torch
+
+from . import ops
+from ._lib import call, ptr, stream
+from .fields.base_field import MeshingResult
+
+
+def _cell_vertices(cell_keys_raw):
+    """sorted-unique cells, their sorted-unique lattice vertices, and the [ncell,8] corner table"""
+    dev = cell_keys_raw.device
+    cells = ops.sort_unique(cell_keys_raw)
+    nc = cells.numel()
+    ck = torch.empty(nc * 8, dtype=torch.int64, device=dev)
+    call('nksr_cell_corner_keys', ptr(cells), nc, ptr(ck), stream())
+    vkeys = ops.sort_unique(ck)
+    cidx = ops.sorted_lookup(vkeys, ck).view(nc, 8)
+    return cells, vkeys, cidx
+
+
+def extract_dual_mesh(field, mise_iter=0, grid_upsample=1, max_points=-1):
+    svh = field.svh
+    dev = svh.device
+    g0 = svh.level(0)
+    w0 = svh.voxel_size
+    U = int(grid_upsample)
+    empty = MeshingResult(torch.zeros((0, 3), dtype=torch.float32, device=dev), torch.zeros((0, 3), dtype=torch.int64, device=dev))
+    if g0.num_voxels == 0:
+        return empty
+    batch = max_points if (max_points is not None and max_points > 0) else (1 << 22)
+
+    flags = torch.empty(g0.num_voxels, dtype=torch.int32, device=dev)
+    call('nksr_base_cell_flags', ptr(g0.nbr), g0.num_voxels, ptr(flags), stream())
+    sel = ops.compact(flags)
+    if sel.numel() == 0:
+        return empty
+    raw = torch.empty(sel.numel() * U ** 3, dtype=torch.int64, device=dev)
+    call('nksr_base_cell_keys', ptr(g0.ijk), ptr(sel), sel.numel(), U, ptr(raw), stream())
+
+    h = w0 / U
+    for m in range(mise_iter + 1):
+        cells, vkeys, cidx = _cell_vertices(raw)
+        nv, nc = vkeys.numel(), cells.numel()
+        pos = torch.empty((nv, 3), dtype=torch.float32, device=dev)
+        call('nksr_lattice_positions', ptr(vkeys), nv, float(h), float(0.5 * w0), ptr(pos), stream())
+        f = field._evaluate_f_model(pos, False, max_points=batch).value
+        config = torch.empty(nc, dtype=torch.int32, device=dev)
+        ntri = torch.empty(nc + 1, dtype=torch.int32, device=dev)
+        ntri[nc] = 0
+        call('nksr_cell_config', ptr(cidx), ptr(f), nc, ptr(config), ptr(ntri), stream())
+        if m < mise_iter:
+            act = torch.empty(nc, dtype=torch.int32, device=dev)
+            call('nksr_cell_active_flags', ptr(config), nc, ptr(act), stream())
+            asel = ops.compact(act)
+            if asel.numel() == 0:
+                return empty
+            raw = torch.empty(asel.numel() * 8, dtype=torch.int64, device=dev)
+            call('nksr_cell_children', ptr(cells), ptr(asel), asel.numel(), ptr(raw), stream())
+            h = h / 2
+
+    tri_off = ops.exclusive_sum_i32(ntri)
+    T = int(tri_off[nc].item())
+    if T == 0:
+        return empty
+    ekeys = torch.empty(T * 3, dtype=torch.int64, device=dev)
+    call('nksr_mc_emit', ptr(cidx), ptr(config), ptr(tri_off), nc, ptr(ekeys), stream())
+    uek = ops.sort_unique(ekeys)
+    faces = ops.sorted_lookup(uek, ekeys).view(T, 3)
+    ne = uek.numel()
+    verts = torch.empty((ne, 3), dtype=torch.float32, device=dev)
+    call('nksr_mc_vertices', ptr(uek), ne, ptr(vkeys), nv, ptr(pos), ptr(f), float(h), ptr(verts), stream())
+
+    keep_v = field.mask_vertices(verts)
+    if keep_v is not None and not bool(keep_v.all()):
+        keep_f = keep_v[faces.long()].all(1)
+        faces = faces[keep_f]
+        used = torch.zeros(ne, dtype=torch.int32, device=dev)
+        used[faces.reshape(-1).long()] = 1
+        remap = ops.exclusive_sum_i32(used)
+        vsel = ops.compact(used)
+        verts = verts[vsel.long()]
+        faces = remap[faces.long()]
+
+    v_world = verts / field.scale if field.scale != 1.0 else verts
+    colors = None
+    if field.texture_field is not None:
+        colors = field.texture_field.evaluate_color(v_world)
+    return MeshingResult(v_world, faces.long(), colors)

@@ -1,0 +1,99 @@
+"""Thin tensor-level wrappers over the C-ABI primitives (sort / unique / scan / compaction /
+hash).  PyTorch supplies device memory and the stream only."""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream, with_tmp
+
+
+def _bits(n):
+    b = 1
+    while (1 << b) < max(int(n), 1):
+        b += 1
+    return b
+
+
+def sort_keys(keys, end_bit=63):
+    """Ascending radix sort of non-negative int64 keys."""
+    n = keys.numel()
+    out = torch.empty_like(keys)
+    if n:
+        with_tmp('nksr_sort_keys_u64', keys.device, ptr(keys), ptr(out), n, 0, int(end_bit), stream())
+    return out
+
+
+def sort_pairs(keys, vals32, end_bit=63):
+    """Sort (int64 key, 32-bit payload) pairs by key."""
+    n = keys.numel()
+    ko, vo = torch.empty_like(keys), torch.empty_like(vals32)
+    if n:
+        with_tmp('nksr_sort_pairs_u64_u32', keys.device, ptr(keys), ptr(ko), ptr(vals32), ptr(vo), n, 0, int(end_bit), stream())
+    return ko, vo
+
+
+def unique_sorted(keys_sorted):
+    """Unique of an already sorted key stream (syncs to read the count)."""
+    n = keys_sorted.numel()
+    if n == 0:
+        return keys_sorted
+    out = torch.empty_like(keys_sorted)
+    cnt = torch.zeros(1, dtype=torch.int64, device=keys_sorted.device)
+    with_tmp('nksr_unique_u64', keys_sorted.device, ptr(keys_sorted), ptr(out), ptr(cnt), n, stream())
+    return out[:int(cnt.item())].clone()
+
+
+def sort_unique(keys):
+    return unique_sorted(sort_keys(keys))
+
+
+def exclusive_sum_i32(x):
+    out = torch.empty_like(x)
+    if x.numel():
+        with_tmp('nksr_exclusive_sum_i32', x.device, ptr(x), ptr(out), x.numel(), stream())
+    return out
+
+
+def compact(flags):
+    """Ordered indices (int32) of the non-zero int32 flags (syncs to read the count)."""
+    n = flags.numel()
+    if n == 0:
+        return torch.empty(0, dtype=torch.int32, device=flags.device)
+    nb = (n + 255) // 256
+    counts = torch.empty(nb + 1, dtype=torch.int32, device=flags.device)
+    counts[nb] = 0
+    call('nksr_compact_block_counts', ptr(flags), n, ptr(counts), stream())
+    offs = exclusive_sum_i32(counts)
+    total = int(offs[nb].item())
+    sel = torch.empty(total, dtype=torch.int32, device=flags.device)
+    if total:
+        call('nksr_compact_scatter', ptr(flags), n, ptr(offs), ptr(sel), stream())
+    return sel
+
+
+def sorted_lookup(sorted_keys, q):
+    out = torch.empty(q.numel(), dtype=torch.int32, device=q.device)
+    if q.numel():
+        call('nksr_sorted_lookup', ptr(sorted_keys), sorted_keys.numel(), ptr(q), q.numel(), ptr(out), stream())
+    return out
+
+
+class HashTable:
+    """Open-addressing hash  Morton key -> canonical voxel index."""
+
+    def __init__(self, keys_sorted_unique):
+        n = keys_sorted_unique.numel()
+        cap = 16
+        while cap < 2 * n:
+            cap *= 2
+        dev = keys_sorted_unique.device
+        self.cap = cap
+        self.hkeys = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+        self.hvals = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+        if n:
+            call('nksr_hash_build', ptr(keys_sorted_unique), n, ptr(self.hkeys), ptr(self.hvals), cap, stream())
+
+    def query(self, q):
+        out = torch.empty(q.numel(), dtype=torch.int32, device=q.device)
+        if q.numel():
+            call('nksr_hash_query', ptr(q), q.numel(), ptr(self.hkeys), ptr(self.hvals), self.cap, ptr(out), stream())
+        return out

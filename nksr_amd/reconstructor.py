@@ -1,0 +1,90 @@
+"""Reconstructor -- host-side mirror of ``nksr.Reconstructor``.
+
+Reference interface (call sites): ``nksr.Reconstructor(device)`` examples/recons_simple.py:25;
+attributes ``network`` / ``chunk_tmp_device`` recons_by_chunk.py:26-27, NKSR-USAGE.md:164;
+``reconstruct(xyz, normal=None, sensor=None, detail_level=, voxel_size=, chunk_size=,
+preprocess_fn=, approx_kernel_grad=, solver_tol=, fused_mode=)`` recons_simple.py:26,
+recons_by_chunk.py:29, recons_scannet.py:28, recons_waymo.py:30-37, gis_app.py:38-42;
+semantics of detail_level / voxel_size NKSR-USAGE.md:129-137.  Solver weights follow
+models/nksr_net.py:103-112.
+"""
+import time
+
+import torch
+
+from . import _lib, configs
+from .fields import KernelField, LayerField
+from .nn.network import NKSRNetwork
+from .svh import SparseFeatureHierarchy
+
+
+class Reconstructor:
+    def __init__(self, device, config='ks', hparams=None):
+        self.device = _lib.require_gpu(device)
+        self.hparams = hparams if hparams is not None else configs.get_hparams(config)
+        self.network = NKSRNetwork(self.hparams).to(self.device)
+        self.network.eval()
+        self.chunk_tmp_device = self.device
+        self.timing = {}
+
+    # ---- scale selection (NKSR-USAGE.md:129-137) ---------------------------------------------------
+    def _global_scale(self, xyz, detail_level, voxel_size):
+        if voxel_size is not None:
+            return self.hparams.voxel_size / float(voxel_size)
+        if detail_level is None:
+            return 1.0
+        from .density import scale_for_detail_level
+        return scale_for_detail_level(xyz, float(detail_level), self.hparams.voxel_size)
+
+    # ---- one chunk: hierarchy -> features -> kernel solve -> mask -------------------------------------
+    def _reconstruct_single(self, xyz, normal, approx_kernel_grad, solver_max_iter, solver_tol, fused_mode):
+        hp = self.hparams
+        t = {}
+        tic = time.perf_counter()
+        enc_svh = SparseFeatureHierarchy(hp.voxel_size, hp.tree_depth, self.device).build_point_splatting(xyz)
+        enc = self.network.encoder(xyz, normal, enc_svh, 0)
+        feat, dec_svh, udf_svh = self.network.unet(enc, enc_svh, adaptive_depth=hp.adaptive_depth)
+        if all(dec_svh.grids[d] is None for d in range(hp.adaptive_depth)):
+            raise RuntimeError('empty decoder hierarchy')
+        field = KernelField(svh=dec_svh, interpolator=self.network.interpolators, features=feat.basis_features,
+                            approx_kernel_grad=approx_kernel_grad)
+        field.solver_config.update({'max_iter': int(solver_max_iter), 'tol': float(solver_tol)})
+        normal_xyz = torch.cat([dec_svh.get_voxel_centers(d) for d in range(hp.adaptive_depth)])
+        normal_value = torch.cat([feat.normal_features[d] for d in range(hp.adaptive_depth)])
+        t['network'] = time.perf_counter() - tic
+        field.solve(pos_xyz=enc.xyz, normal_xyz=normal_xyz, normal_value=-normal_value,
+                    pos_weight=hp.solver.pos_weight / xyz.shape[0],
+                    normal_weight=hp.solver.normal_weight / normal_xyz.shape[0] * hp.voxel_size ** 2,
+                    reg_weight=1.0, fused_mode=fused_mode)
+        field.set_mask_field(LayerField(dec_svh, hp.adaptive_depth))
+        t.update({k: v for k, v in field.solve_info.items() if k.startswith('t_')})
+        self.timing = t
+        return field
+
+    def reconstruct(self, xyz, normal=None, sensor=None, detail_level=0.0, voxel_size=None, chunk_size=-1.0,
+                    overlap_ratio=0.05, approx_kernel_grad=False, solver_max_iter=2000, solver_tol=1e-5,
+                    fused_mode=True, preprocess_fn=None):
+        if xyz.dtype != torch.float32 or xyz.dim() != 2 or xyz.shape[1] != 3:
+            raise RuntimeError('xyz must be a float32 [N,3] tensor')
+        xyz = xyz.to(self.device)
+        normal = normal.to(self.device) if normal is not None else None
+        sensor = sensor.to(self.device) if sensor is not None else None
+        chunked = chunk_size is not None and chunk_size > 0
+        if chunked and (voxel_size is not None or detail_level not in (None, 0.0)):
+            raise RuntimeError('detail_level / voxel_size are not supported together with chunk_size: scale the '
+                               'cloud by 0.1/voxel_size beforehand (NKSR-USAGE.md:137)')
+        if chunked:
+            from .chunking import reconstruct_by_chunk
+            return reconstruct_by_chunk(self, xyz, normal, sensor, float(chunk_size), float(overlap_ratio),
+                                        approx_kernel_grad, solver_max_iter, solver_tol, fused_mode, preprocess_fn)
+        if preprocess_fn is not None:
+            xyz, normal, sensor = preprocess_fn(xyz, normal, sensor)
+        if normal is None:
+            raise RuntimeError('oriented input required: pass normal=, or sensor= together with '
+                               'preprocess_fn=nksr.get_estimate_normal_preprocess_fn(...)')
+        scale = self._global_scale(xyz, detail_level, voxel_size)
+        xs = (xyz * scale).contiguous() if scale != 1.0 else xyz.contiguous()
+        field = self._reconstruct_single(xs, normal.to(torch.float32).contiguous(), approx_kernel_grad, solver_max_iter,
+                                         solver_tol, fused_mode)
+        field.set_scale(scale)
+        return field

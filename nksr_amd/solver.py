@@ -1,0 +1,28 @@
+"""CSR SpMV + Jacobi-PCG wrappers (csrc/pcg.hip).  The solve behind
+``KernelField.solve*`` (reference call site models/nksr_net.py:105-112; ``solver_tol``
+examples/recons_waymo.py:33)."""
+import ctypes as C
+
+import torch
+
+from ._lib import call, lib, ptr, stream
+
+
+def spmv(rowptr, cols, vals, x):
+    M = rowptr.numel() - 1
+    y = torch.empty(M, dtype=torch.float32, device=x.device)
+    call('nksr_spmv_csr', ptr(rowptr), ptr(cols), ptr(vals), M, ptr(x), ptr(y), stream())
+    return y
+
+
+def pcg_solve(rowptr, cols, vals, diag, b, tol=1e-5, max_iter=2000, check_every=16, workspace=None):
+    """Returns (x, iterations, relative residual).  x0 = 0, stop on ||r|| <= tol ||b||."""
+    M = b.numel()
+    x = torch.empty(M, dtype=torch.float32, device=b.device)
+    nbytes = int(lib.nksr_pcg_workspace_bytes(M))
+    if workspace is None or workspace.numel() < nbytes:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+    info = (C.c_double * 2)()
+    call('nksr_pcg_solve', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), M, ptr(b), ptr(x), float(tol), int(max_iter),
+         int(check_every), ptr(workspace), info, stream())
+    return x, int(info[0]), float(info[1])

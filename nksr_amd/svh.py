@@ -1,0 +1,193 @@
+"""Sparse voxel hierarchy -- host-side mirror of ``nksr.svh.SparseFeatureHierarchy``.
+
+Reference interface (call sites; the implementation ships in the absent wheel):
+  * ``SparseFeatureHierarchy(voxel_size=, depth=, device=)`` + ``build_point_splatting(xyz)``
+    -- models/nksr_net.py:57-62
+  * ``grids[d]`` (``None`` when a level is empty) with ``active_grid_coords()``,
+    ``grid_to_world(ijk.float())``, ``voxel_size`` -- models/loss.py:33-46
+  * ``get_voxel_centers(d)`` -- models/nksr_net.py:100; ``depth`` / ``device`` -- models/loss.py:33,39
+  * ``evaluate_voxel_status(grid, d)`` -> {0 non-exist, 1 exist-stop, 2 exist-continue}
+    -- models/loss.py:155-160
+Level d has voxel width voxel_size * 2**d; the canonical order of a level's voxels is the
+ascending Morton key order produced by the device radix sort, so topology is index-exact and
+independent of atomics.  All heavy lifting happens in nksr_amd/csrc/hierarchy.hip.
+"""
+import enum
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import call, ptr, stream
+
+
+class VoxelStatus(enum.IntEnum):
+    VS_NON_EXIST = 0
+    VS_EXIST_STOP = 1
+    VS_EXIST_CONTINUE = 2
+
+
+def inv_w0_f32(voxel_size):
+    return float(np.float32(1.0 / float(voxel_size)))
+
+
+class SparseGrid:
+    """One level: sorted Morton keys, ijk, hash table and the 27-neighbour table."""
+
+    def __init__(self, keys, level, base_voxel_size):
+        self.level = level
+        self.voxel_size = float(base_voxel_size) * (1 << level)
+        self.keys = keys
+        self.device = keys.device
+        self.num_voxels = n = int(keys.numel())
+        self.ijk = torch.empty((n, 3), dtype=torch.int32, device=self.device)
+        call('nksr_decode_keys', ptr(keys), n, level, ptr(self.ijk), stream())
+        self.hash = ops.HashTable(keys)
+        self.nbr = torch.empty((n, 27), dtype=torch.int32, device=self.device)
+        call('nksr_build_nbr', ptr(self.ijk), n, level, ptr(self.hash.hkeys), ptr(self.hash.hvals), self.hash.cap,
+             ptr(self.nbr), stream())
+
+    def active_grid_coords(self):
+        return self.ijk
+
+    def grid_to_world(self, ijk):
+        return (ijk.to(torch.float32) + 0.5) * self.voxel_size
+
+    def world_to_grid(self, xyz):
+        return xyz / self.voxel_size - 0.5
+
+    def ijk_to_index(self, ijk):
+        """Canonical voxel index of integer coordinates (-1 where inactive)."""
+        ijk = ijk.to(torch.int32).contiguous()
+        keys = torch.empty(ijk.shape[0], dtype=torch.int64, device=self.device)
+        call('nksr_encode_keys', ptr(ijk), ijk.shape[0], self.level, ptr(keys), stream())
+        return self.hash.query(keys)
+
+    def to(self, device):
+        g = object.__new__(SparseGrid)
+        g.__dict__.update(self.__dict__)
+        for k in ('keys', 'ijk', 'nbr'):
+            setattr(g, k, getattr(self, k).to(device))
+        g.hash = object.__new__(ops.HashTable)
+        g.hash.cap = self.hash.cap
+        g.hash.hkeys, g.hash.hvals = self.hash.hkeys.to(device), self.hash.hvals.to(device)
+        g.device = torch.device(device)
+        return g
+
+
+class SparseFeatureHierarchy:
+    def __init__(self, voxel_size, depth, device):
+        self.device = _lib.require_gpu(device)
+        if not (1 <= depth <= _lib.MAX_DEPTH):
+            raise RuntimeError('depth must be in [1, %d]' % _lib.MAX_DEPTH)
+        self.voxel_size = float(voxel_size)
+        self.depth = int(depth)
+        self._levels = [None] * self.depth
+        self.inv_w0 = inv_w0_f32(voxel_size)
+
+    # ---- builders ---------------------------------------------------------------------------
+    def _check_xyz(self, xyz):
+        if xyz.dtype != torch.float32 or xyz.dim() != 2 or xyz.shape[1] != 3:
+            raise RuntimeError('xyz must be a float32 [N,3] tensor')
+        _lib.require_gpu(xyz.device)
+        return xyz.contiguous()
+
+    def _build_from_points(self, xyz, mode):
+        xyz = self._check_xyz(xyz)
+        n = xyz.shape[0]
+        per = 8 if mode == 0 else 27
+        for d in range(self.depth):
+            raw = torch.empty(n * per, dtype=torch.int64, device=self.device)
+            call('nksr_splat_keys', ptr(xyz), n, self.inv_w0, d, mode, ptr(raw), stream())
+            keys = ops.sort_unique(raw)
+            self._levels[d] = SparseGrid(keys, d, self.voxel_size)
+        return self
+
+    def build_point_splatting(self, xyz):
+        """Activate the 8 voxel centres nearest to every point at every level
+        (reference: models/nksr_net.py:62)."""
+        return self._build_from_points(xyz, 0)
+
+    def build_point_neighborhood(self, xyz):
+        """Activate the containing cell and its 26 neighbours at every level: the analytic
+        structure rule of the decoder hierarchy."""
+        return self._build_from_points(xyz, 1)
+
+    def build_from_keys(self, keys_per_level):
+        for d in range(self.depth):
+            k = keys_per_level[d]
+            if k is None:
+                k = torch.empty(0, dtype=torch.int64, device=self.device)
+            self._levels[d] = SparseGrid(ops.sort_unique(k.to(self.device).contiguous()), d, self.voxel_size)
+        return self
+
+    def build_from_grid_coords(self, depth, ijk):
+        ijk = ijk.to(device=self.device, dtype=torch.int32).contiguous()
+        keys = torch.empty(ijk.shape[0], dtype=torch.int64, device=self.device)
+        call('nksr_encode_keys', ptr(ijk), ijk.shape[0], depth, ptr(keys), stream())
+        self._levels[depth] = SparseGrid(ops.sort_unique(keys), depth, self.voxel_size)
+        return self
+
+    # ---- queries ------------------------------------------------------------------------------
+    @property
+    def grids(self):
+        """Per level: the grid, or ``None`` when the level holds no voxel (reference
+        convention, models/nksr_net.py:80, models/loss.py:34)."""
+        return [g if (g is not None and g.num_voxels > 0) else None for g in self._levels]
+
+    def level(self, d):
+        """Level d as a (possibly empty) SparseGrid."""
+        if self._levels[d] is None:
+            self._levels[d] = SparseGrid(torch.empty(0, dtype=torch.int64, device=self.device), d, self.voxel_size)
+        return self._levels[d]
+
+    def num_voxels(self, d):
+        return 0 if self._levels[d] is None else self._levels[d].num_voxels
+
+    @property
+    def offsets(self):
+        off, o = [], 0
+        for d in range(self.depth):
+            off.append(o)
+            o += self.num_voxels(d)
+        return off
+
+    @property
+    def num_unknowns(self):
+        return sum(self.num_voxels(d) for d in range(self.depth))
+
+    def get_voxel_centers(self, d):
+        g = self.grids[d]
+        if g is None:
+            return torch.zeros((0, 3), dtype=torch.float32, device=self.device)
+        return g.grid_to_world(g.ijk)
+
+    def evaluate_voxel_status(self, grid, depth):
+        """Class id of every voxel of ``grid`` (a level-``depth`` grid) w.r.t. this hierarchy."""
+        n = grid.num_voxels
+        status = torch.zeros(n, dtype=torch.long, device=self.device)
+        mine = self.grids[depth]
+        if mine is None or n == 0:
+            return status
+        exist = mine.hash.query(grid.keys) >= 0
+        status[exist] = int(VoxelStatus.VS_EXIST_STOP)
+        if depth > 0 and self.grids[depth - 1] is not None:
+            child_parent = ops.sort_unique(self.grids[depth - 1].keys >> 3)
+            has_child = ops.sorted_lookup(child_parent, grid.keys.contiguous()) >= 0
+            status[exist & has_child] = int(VoxelStatus.VS_EXIST_CONTINUE)
+        return status
+
+    def get_visualization(self):
+        """Wireframe-free stand-in for the reference's pycg visualisation: list of
+        (voxel centres, voxel size) per level."""
+        return [(self.get_voxel_centers(d).cpu().numpy(), self.voxel_size * (1 << d)) for d in range(self.depth)]
+
+    def to_(self, device):
+        device = torch.device(device)
+        self._levels = [None if g is None else g.to(device) for g in self._levels]
+        self.device = device
+        return self
+
+    def __repr__(self):
+        return 'SparseFeatureHierarchy(voxel_size=%g, depth=%d, voxels=%s)' % (
+            self.voxel_size, self.depth, [self.num_voxels(d) for d in range(self.depth)])

@@ -1,0 +1,211 @@
+"""GPU parity: every HIP stage against the CPU oracle on the same seeded inputs.
+Bar: index-exact for voxel sets / neighbour tables / mesh topology,
+fp32 tolerances (stated per test) for kernel rows, the matrix, PCG and field values."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+def _setup(kind='sphere', n=3000, vs=0.05, K=4, H=16, depth=4, init_scale=0.5, seed=0, random_feats=True):
+    """Same hierarchy / features / interpolators on both sides."""
+    import nksr_amd
+    from nksr_amd import configs
+    from nksr_amd.nn.network import NKSRNetwork
+    from oracle import hierarchy, kernel
+    xyz, nrm = make_cloud(kind, n, 0.005, seed)
+    scale = 0.1 / vs
+    xyz = (xyz * np.float32(scale)).astype(np.float32)
+    hp = configs.get_hparams('ks', kernel_dim=K, interpolator={'n_hidden': 2, 'hidden_dim': H}, tree_depth=depth,
+                             interpolator_init_scale=init_scale)
+    net = NKSRNetwork(hp)
+    rs = np.random.RandomState(seed + 1)
+    for it in net.interpolators:  # non-trivial biases so every MLP branch is exercised
+        it.b1.data = torch.from_numpy(rs.randn(H).astype(np.float32) * 0.2)
+        it.b2.data = torch.from_numpy(rs.randn(H).astype(np.float32) * 0.2)
+        it.b3.data = torch.from_numpy(rs.randn(K).astype(np.float32) * 0.05)
+    oh = hierarchy.Hierarchy(0.1, depth).build_point_neighborhood(xyz)
+    svh = nksr_amd.SparseFeatureHierarchy(0.1, depth, _dev()).build_point_neighborhood(torch.from_numpy(xyz).to(_dev()))
+    feats = []
+    for L in oh.levels:
+        f = np.zeros((L.n, K), np.float32)
+        f[:, 0] = 1
+        if random_feats:
+            f += rs.randn(L.n, K).astype(np.float32) * 0.3
+        feats.append(f)
+    ointerps = [kernel.Interpolator(*[p.detach().numpy() for p in (i.W1, i.b1, i.W2, i.b2, i.W3, i.b3)]) for i in net.interpolators]
+    return xyz, nrm, oh, svh, feats, ointerps, net
+
+
+def test_hierarchy_exact():
+    import nksr_amd
+    from oracle import hierarchy
+    xyz, nrm = make_cloud('torus', 5000, 0.005, 3)
+    xyz = xyz * np.float32(2.0)
+    for builder in ('build_point_splatting', 'build_point_neighborhood'):
+        oh = getattr(hierarchy.Hierarchy(0.1, 4), builder)(xyz)
+        svh = getattr(nksr_amd.SparseFeatureHierarchy(0.1, 4, _dev()), builder)(torch.from_numpy(xyz).to(_dev()))
+        for d in range(4):
+            g = svh.level(d)
+            assert g.num_voxels == oh.levels[d].n
+            assert np.array_equal(g.keys.cpu().numpy(), oh.levels[d].keys)
+            assert np.array_equal(g.ijk.cpu().numpy(), oh.levels[d].ijk)
+            assert np.array_equal(g.nbr.cpu().numpy(), oh.levels[d].nbr)
+            np.testing.assert_array_equal(svh.get_voxel_centers(d).cpu().numpy(), oh.levels[d].centers())
+
+
+def test_empty_and_tiny_inputs():
+    import nksr_amd
+    svh = nksr_amd.SparseFeatureHierarchy(0.1, 3, _dev()).build_point_splatting(torch.zeros((0, 3), device=_dev()))
+    assert svh.grids == [None, None, None] and svh.num_unknowns == 0
+    one = torch.tensor([[0.01, -0.02, 0.03]], device=_dev())
+    svh = nksr_amd.SparseFeatureHierarchy(0.1, 3, _dev()).build_point_splatting(one)
+    assert [svh.num_voxels(d) for d in range(3)] == [8, 8, 8]
+    svh = nksr_amd.SparseFeatureHierarchy(0.1, 3, _dev()).build_point_neighborhood(one)
+    assert [svh.num_voxels(d) for d in range(3)] == [27, 27, 27]
+
+
+@pytest.mark.parametrize('K,H', [(4, 16), (16, 32)])
+@pytest.mark.parametrize('approx', [False, True])
+def test_kernel_rows(K, H, approx):
+    from nksr_amd.fields import KernelField
+    from oracle import kernel
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=1500, K=K, H=H)
+    fld = KernelField(svh, net.interpolators, [torch.from_numpy(f) for f in feats], approx_kernel_grad=approx)
+    psis = [kernel.voxel_psi(feats[d], ointerps[d]) for d in range(4)]
+    for d in range(4):
+        np.testing.assert_allclose(fld._psi[d].cpu().numpy(), psis[d], rtol=2e-5, atol=2e-6)
+    q = np.concatenate([xyz[:700], oh.levels[0].centers()[:300]])
+    cols, val, dval = kernel.kernel_rows(oh, feats, ointerps, psis, q, True, approx)
+    gv, gd = fld.kernel_rows(torch.from_numpy(q).to(_dev()), grad=True)
+    np.testing.assert_allclose(gv.cpu().numpy(), val, rtol=1e-4, atol=2e-6)
+    # gradients carry a 1/w factor (up to 10 in model units): tolerance scaled accordingly
+    np.testing.assert_allclose(gd.cpu().numpy(), dval, rtol=1e-4, atol=5e-5)
+
+
+def test_assembly_and_spmv():
+    import scipy.sparse as sp
+    from nksr_amd import solver
+    from nksr_amd.fields import KernelField
+    from oracle import solve
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=3000)
+    fld = KernelField(svh, net.interpolators, [torch.from_numpy(f) for f in feats])
+    nxyz = oh.levels[0].centers()
+    nval = np.random.RandomState(5).randn(len(nxyz), 3).astype(np.float32)
+    wp, wn = 1e4 / len(xyz), 1e4 / len(nxyz) * 0.01
+    A, b, G, Q, psis = solve.assemble(oh, feats, ointerps, xyz, nxyz, nval, wp, wn, 1.0)
+    t = lambda a: torch.from_numpy(a).to(_dev())
+    rowptr, cols, vals, diag, gb = fld.assemble(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
+    M = A.shape[0]
+    Ag = sp.csr_matrix((vals.cpu().numpy(), cols.cpu().numpy(), rowptr.cpu().numpy()), shape=(M, M))
+    # exactly symmetric, sorted columns, SPD diagonal
+    assert abs(Ag - Ag.T).max() == 0.0
+    assert Ag.has_sorted_indices
+    D = (Ag - A).tocoo()
+    scale = abs(A).max()
+    assert abs(D.data).max() <= 2e-5 * scale, abs(D.data).max() / scale
+    # structural zeros dropped on the GPU side only where the oracle value is ~0 as well
+    np.testing.assert_allclose(gb.cpu().numpy(), b, rtol=1e-4, atol=1e-5 * abs(b).max())
+    np.testing.assert_allclose(diag.cpu().numpy(), A.diagonal(), rtol=1e-4)
+    x = np.random.RandomState(1).randn(M).astype(np.float32)
+    y = solver.spmv(rowptr, cols, vals, t(x)).cpu().numpy()
+    yo = solve.csr_spmv(Ag.indptr, Ag.indices, Ag.data, x)
+    # same matrix, fp32: |dy| <= 1e-5 * |A||x|  (rel-tol 1e-5 on SpMV)
+    bound = 1e-5 * (abs(Ag) @ abs(x))
+    assert (abs(y - yo) <= bound + 1e-30).all()
+
+
+def test_pcg_matches_oracle_and_scipy():
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sla
+    from nksr_amd import solver
+    from nksr_amd.fields import KernelField
+    from oracle import solve
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=3000, random_feats=False, init_scale=0.0)
+    fld = KernelField(svh, net.interpolators, [torch.from_numpy(f) for f in feats])
+    t = lambda a: torch.from_numpy(a).to(_dev())
+    nxyz = oh.levels[0].centers()
+    nval = np.random.RandomState(5).randn(len(nxyz), 3).astype(np.float32)
+    rowptr, cols, vals, diag, b = fld.assemble(t(xyz), t(nxyz), t(nval), 1e4 / len(xyz), 1e4 / len(nxyz) * 0.01, 1.0)
+    M = b.numel()
+    Ag = sp.csr_matrix((vals.cpu().numpy(), cols.cpu().numpy(), rowptr.cpu().numpy()), shape=(M, M))
+    bn = b.cpu().numpy()
+    # (1) few fixed iterations: iterates agree tightly (same matrix, same algorithm)
+    x5, it5, _ = solver.pcg_solve(rowptr, cols, vals, diag, b, tol=0.0, max_iter=6, check_every=2)
+    o5, _, _ = solve.pcg_jacobi(Ag, bn, fixed_iters=6)
+    assert it5 == 6
+    np.testing.assert_allclose(x5.cpu().numpy(), o5, rtol=0, atol=1e-4 * abs(o5).max())
+    # (2) converged: residual below tol, solution matches fp64 scipy CG
+    x, it, rel = solver.pcg_solve(rowptr, cols, vals, diag, b, tol=1e-6, max_iter=2000, check_every=7)
+    xo, ito, relo = solve.pcg_jacobi(Ag, bn, tol=1e-6)
+    assert rel <= 1e-6 and abs(it - ito) <= max(3, ito // 10), (it, ito)
+    r = bn - Ag.astype(np.float64) @ x.cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(r) / np.linalg.norm(bn) <= 2e-6
+    xs, info = sla.cg(Ag.astype(np.float64), bn.astype(np.float64), rtol=1e-12, maxiter=20000)
+    assert info == 0
+    assert abs(x.cpu().numpy() - xs).max() <= 1e-3 * abs(xs).max()
+    # zero right-hand side: zero iterations, zero solution
+    x0, it0, _ = solver.pcg_solve(rowptr, cols, vals, diag, torch.zeros_like(b))
+    assert it0 == 0 and float(x0.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('approx', [False, True])
+def test_evaluate_f(approx):
+    from nksr_amd.fields import KernelField
+    from oracle import field, kernel
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=2000)
+    fld = KernelField(svh, net.interpolators, [torch.from_numpy(f) for f in feats], approx_kernel_grad=approx)
+    alpha = np.random.RandomState(2).randn(oh.num_unknowns).astype(np.float32)
+    fld.alpha = torch.from_numpy(alpha).to(_dev())
+    psis = [kernel.voxel_psi(feats[d], ointerps[d]) for d in range(4)]
+    rs = np.random.RandomState(4)
+    q = np.concatenate([xyz[:800] + rs.randn(800, 3).astype(np.float32) * 0.03, (rs.rand(200, 3).astype(np.float32) - 0.5) * 3])
+    fo, go = field.evaluate_f(oh, feats, ointerps, psis, alpha, q, True, approx)
+    res = fld.evaluate_f(torch.from_numpy(q).to(_dev()), grad=True)
+    mag = abs(fo).max()
+    np.testing.assert_allclose(res.value.cpu().numpy(), fo, rtol=0, atol=1e-4 * mag)
+    np.testing.assert_allclose(res.gradient.cpu().numpy(), go, rtol=0, atol=1e-4 * abs(go).max())
+
+
+@pytest.mark.parametrize('kind,vs', [('sphere', 0.05), ('torus', 0.04)])
+def test_end_to_end_mesh(kind, vs):
+    """Full reconstruct -> extract_dual_mesh against the oracle pipeline; topology index-exact
+    wherever |f| at the lattice vertices is away from the sign threshold."""
+    import nksr_amd
+    from oracle import pipeline
+    xyz, nrm = make_cloud(kind, 3000, 0.005, 0)
+    rec = nksr_amd.Reconstructor(_dev())
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(_dev()), torch.from_numpy(nrm).to(_dev()), voxel_size=vs, solver_tol=1e-6)
+    scale = 0.1 / vs
+    ofl = pipeline.reconstruct((xyz * np.float32(scale)).astype(np.float32), nrm, tol=1e-6)
+    assert fld.solve_info['M'] == ofl['A'].shape[0]
+    # field values at the input points agree (both solved to 1e-6)
+    fo, _ = pipeline.evaluate(ofl, (xyz * np.float32(scale)).astype(np.float32))
+    fg = fld.evaluate_f(torch.from_numpy(xyz).to(_dev())).value.cpu().numpy()
+    ref = np.abs(ofl['alpha']).max()
+    assert abs(fg - fo).max() <= 2e-3 * ref
+    for mise in (0, 1):
+        mesh = fld.extract_dual_mesh(mise_iter=mise)
+        ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=mise)
+        gv, gf = mesh.v.cpu().numpy() * scale, mesh.f.cpu().numpy()
+        if gf.shape == of.shape and np.array_equal(gf, of):
+            np.testing.assert_allclose(gv, ov, rtol=0, atol=1e-3 * 0.1)   # <= 1e-3 voxel
+        else:
+            # near-threshold sign flips change local topology; then require near-identical size + geometry
+            assert abs(len(gf) - len(of)) <= 0.01 * len(of)
+            from scipy.spatial import cKDTree
+            d, _ = cKDTree(ov).query(gv)
+            assert d.max() <= 0.02 * 0.1
+        if mise == 0:
+            e = np.sort(np.concatenate([gf[:, [0, 1]], gf[:, [1, 2]], gf[:, [2, 0]]]), 1)
+            _, cnt = np.unique(e, axis=0, return_counts=True)
+            assert (cnt == 2).all(), 'mesh is not closed'
+            V, E, F = len(gv), len(cnt), len(gf)
+            assert V - E + F == (2 if kind == 'sphere' else 0)
