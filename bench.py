@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""Headline benchmark (driver contract):  python bench.py --gpus N --steps K --warmup W
+
+metric  : reconstructed points/sec (solve + mesh), BASELINE.json
+workload: BASELINE.json configs[2] -- synthetic 1M-point oriented cloud per GPU,
+          detail_level=1.0, reconstruct() + extract_dual_mesh(mise_iter=1).  One "step" = one
+          full pass of the hot path over the rank's resident cloud.  Weak scaling: every rank
+          owns one 40x40x10 tile of the scene (tiles adjacent along x).
+roofline: the CG SpMV (csrc/pcg.hip k_spmv), algorithmic bytes 8*nnz + 12*M + 4 per launch
+          divided by the average launch duration measured live with HIP events on the solve
+          stream inside the timed region (nksr_pcg_profile).
+cpu_baseline: the CPU oracle ("port" -- the reference's own CPU path is the absent wheel) on a
+          bounded spatial crop of the same workload, timed on rank 0 at N=1.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
+
+
+def load_traffic():
+    """HBM bytes per SpMV launch from the committed rocprofv3 --pmc pass (or None)."""
+    best = None
+    pdir = os.path.join(ROOT, 'profiles')
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith('_spmv_pmc.json'):
+                try:
+                    best = json.load(open(os.path.join(pdir, f))).get('hbm_bytes_per_launch')
+                except Exception:
+                    pass
+    return best
+
+
+def cpu_baseline(xyz, nrm, scale, n_sample, mise_iter):
+    """Oracle pipeline on a spatial crop holding ~n_sample points (same density as the GPU run)."""
+    from oracle import pipeline
+    c = xyz[0]
+    d = np.abs(xyz - c).max(1)
+    idx = np.argsort(d)[:n_sample]
+    xs = (xyz[idx] * np.float32(scale)).astype(np.float32)
+    ns = nrm[idx]
+    t0 = time.perf_counter()
+    timing = {}
+    fld = pipeline.reconstruct(xs, ns, tol=1e-5, timing=timing)
+    v, f = pipeline.extract_dual_mesh(fld, mise_iter=mise_iter)
+    dt = time.perf_counter() - t0
+    return {'value': len(idx) / dt, 'unit': 'points/s', 'cores': 1, 'kind': 'port',
+            'sample': 'oracle.pipeline reconstruct+extract_dual_mesh(mise_iter=%d) on a %d-point spatial crop of the '
+                      'same cloud at the same scale: %.1fs (M=%d nnz=%d iters=%d)' % (
+                          mise_iter, len(idx), dt, timing.get('M', 0), timing.get('nnz', 0), timing.get('iters', 0))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--points', type=int, default=1_000_000, help='points per GPU')
+    ap.add_argument('--mise-iter', type=int, default=1)
+    ap.add_argument('--detail-level', type=float, default=1.0)
+    ap.add_argument('--cpu-sample', type=int, default=20000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    import nksr_amd
+    from nksr_amd import solver, utils
+
+    extent = (40.0, 40.0, 10.0)
+    xyz_np, nrm_np = utils.synth_scene(args.points, seed=rank, extent=extent, noise=0.01, origin=(rank * extent[0], 0.0, 0.0))
+    xyz = torch.from_numpy(xyz_np).to(dev)
+    nrm = torch.from_numpy(nrm_np).to(dev)
+    rec = nksr_amd.Reconstructor(dev)
+    rec.sync_timing = True
+    stage_acc = {}
+
+    def step():
+        field = rec.reconstruct(xyz, nrm, detail_level=args.detail_level)
+        t0 = time.perf_counter()
+        mesh = field.extract_dual_mesh(mise_iter=args.mise_iter)
+        torch.cuda.synchronize()
+        tm = time.perf_counter() - t0
+        for k, v in list(rec.timing.items()) + [('t_mesh', tm)]:
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+        return field, mesh
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    stage_acc.clear()
+    solver.profile_spmv(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        field, mesh = step()
+    fence()
+    dt = time.perf_counter() - t0
+    spmv_ms, spmv_launches = solver.profile_spmv(False)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    info = field.solve_info
+    M, nnz = info['M'], info['nnz']
+    b_spmv = 8.0 * nnz + 12.0 * M + 4.0
+    avg_s = (spmv_ms / max(spmv_launches, 1)) * 1e-3
+    achieved = b_spmv / avg_s if avg_s > 0 else 0.0
+    total_points = args.points * world * args.steps
+    out = {
+        'metric': 'reconstructed points/sec (solve+mesh)', 'value': total_points / dt, 'unit': 'points/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[2]: synthetic %d-point oriented cloud per GPU (8 spheres/tori in a 40x40x10 tile, '
+                               'sigma=0.01), detail_level=%.1f, reconstruct()+extract_dual_mesh(mise_iter=%d)' % (
+                                   args.points, args.detail_level, args.mise_iter),
+                   'points_per_gpu': args.points, 'tree_depth': rec.hparams.tree_depth, 'kernel_dim': rec.hparams.kernel_dim,
+                   'unknowns_M': M, 'nnz_A': nnz, 'pcg_iters': info['iters'], 'pcg_rel_residual': info['rel_residual'],
+                   'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]),
+                   'global_scale': field.scale},
+        'roofline': {'bound': 'hbm', 'kernel': 'k_spmv<true> (CSR SpMV + fused p.Ap partial dot)',
+                     'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
+                     'traffic': load_traffic(), 'bytes_per_launch': b_spmv, 'avg_launch_us': avg_s * 1e6,
+                     'launches_timed': spmv_launches},
+        'stages_s_per_step': {k: v / args.steps for k, v in sorted(stage_acc.items())},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(xyz_np, nrm_np, field.scale, args.cpu_sample, args.mise_iter)
+    elif rank == 0:
+        out['cpu_baseline'] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

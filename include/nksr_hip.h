@@ -127,6 +127,10 @@ int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const float* vals
                    const float* b, float* x, float tol, int max_iter, int check_every, void* workspace,
                    double* info_out, void* stream);
 
+/* Live profiling of the SpMV launches inside nksr_pcg_solve (HIP events on the solve's stream).
+ * Returns and resets the accumulated milliseconds / launch count, then sets the enable flag. */
+int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out);
+
 /* ---- dual marching cubes (field.extract_dual_mesh, examples/recons_simple.py:27) ------- */
 /* flags[i]=1 where voxel i and its +x,+y,+z,... 7 partners are all active */
 int nksr_base_cell_flags(const int32_t* nbr, int32_t n, int32_t* flags, void* stream);

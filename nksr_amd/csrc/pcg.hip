@@ -208,6 +208,22 @@ extern "C" int nksr_spmv_csr(const int32_t* rowptr, const int32_t* cols, const f
     return NKSR_OK;
 }
 
+// ---- optional live profiling of the SpMV launches (bench.py's roofline leg) ---------------------
+#include <vector>
+static int g_prof_enable = 0;
+static double g_prof_ms = 0.0;
+static long long g_prof_launches = 0;
+static std::vector<hipEvent_t> g_prof_events;
+
+extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out) {
+    if (ms_out) *ms_out = g_prof_ms;
+    if (launches_out) *launches_out = g_prof_launches;
+    g_prof_ms = 0.0;
+    g_prof_launches = 0;
+    g_prof_enable = enable;
+    return NKSR_OK;
+}
+
 extern "C" int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t M,
                               const float* b, float* x, float tol, int max_iter, int check_every, void* workspace,
                               double* info_out, void* stream) {
@@ -224,19 +240,38 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const 
     PcgScalars host;
     memset(&host, 0, sizeof(host));
     int launched = 0;
+    const bool prof = g_prof_enable != 0;
+    if (prof)
+        while ((int)g_prof_events.size() < 2 * check_every) {
+            hipEvent_t e;
+            NKSR_CHECK_HIP(hipEventCreate(&e));
+            g_prof_events.push_back(e);
+        }
     while (launched < max_iter) {
         int chunk = check_every < (max_iter - launched) ? check_every : (max_iter - launched);
         for (int c = 0; c < chunk; ++c) {
             const int parity = (launched + c) & 1;
+            if (prof) hipEventRecord(g_prof_events[2 * c], st);
             hipLaunchKernelGGL((k_spmv<true>), dim3(nbs), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, w.p, w.y, w.part1,
                                &w.sc->done);
+            if (prof) hipEventRecord(g_prof_events[2 * c + 1], st);
             hipLaunchKernelGGL(k_pcg_update, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, diag, w, x, nbs, parity);
             hipLaunchKernelGGL(k_pcg_pupdate, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w, nbv, parity, tol);
         }
         NKSR_CHECK_LAUNCH();
-        launched += chunk;
         NKSR_CHECK_HIP(hipMemcpyAsync(&host, w.sc, sizeof(host), hipMemcpyDeviceToHost, st));
         NKSR_CHECK_HIP(hipStreamSynchronize(st));
+        if (prof) {
+            // only launches that did real work (the done flag turns later ones into no-ops)
+            for (int c = 0; c < chunk && launched + c < host.iter; ++c) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, g_prof_events[2 * c], g_prof_events[2 * c + 1]) == hipSuccess) {
+                    g_prof_ms += ms;
+                    g_prof_launches += 1;
+                }
+            }
+        }
+        launched += chunk;
         if (host.done) break;
     }
     if (info_out) {

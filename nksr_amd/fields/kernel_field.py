@@ -30,7 +30,7 @@ class KernelField(BaseField):
     def __init__(self, svh, interpolator, features, approx_kernel_grad=False):
         super().__init__(svh)
         self.approx_kernel_grad = bool(approx_kernel_grad)
-        self.solver_config = {'verbose': False, 'max_iter': 2000, 'tol': 1e-5, 'check_every': 16}
+        self.solver_config = {'verbose': False, 'max_iter': 2000, 'tol': 1e-5, 'check_every': 16, 'sync_timing': False}
         self.solve_info = {}
         self.kdim = int(interpolator[0].kernel_dim)
         self.hidden = int(interpolator[0].hidden_dim)
@@ -154,7 +154,7 @@ class KernelField(BaseField):
         from .. import solver
         t0 = time.perf_counter()
         rowptr, cols, vals, diag, b = self.assemble(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight)
-        if self.solver_config.get('verbose'):
+        if self.solver_config.get('verbose') or self.solver_config.get('sync_timing'):
             torch.cuda.synchronize()
         t1 = time.perf_counter()
         x, iters, rel = solver.pcg_solve(rowptr, cols, vals, diag, b, tol=self.solver_config['tol'],

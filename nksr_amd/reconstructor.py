@@ -26,6 +26,7 @@ class Reconstructor:
         self.network.eval()
         self.chunk_tmp_device = self.device
         self.timing = {}
+        self.sync_timing = False   # insert device syncs so that per-stage wall times are exact
 
     # ---- scale selection (NKSR-USAGE.md:129-137) ---------------------------------------------------
     def _global_scale(self, xyz, detail_level, voxel_size):
@@ -48,10 +49,12 @@ class Reconstructor:
             raise RuntimeError('empty decoder hierarchy')
         field = KernelField(svh=dec_svh, interpolator=self.network.interpolators, features=feat.basis_features,
                             approx_kernel_grad=approx_kernel_grad)
-        field.solver_config.update({'max_iter': int(solver_max_iter), 'tol': float(solver_tol)})
+        field.solver_config.update({'max_iter': int(solver_max_iter), 'tol': float(solver_tol), 'sync_timing': self.sync_timing})
         normal_xyz = torch.cat([dec_svh.get_voxel_centers(d) for d in range(hp.adaptive_depth)])
         normal_value = torch.cat([feat.normal_features[d] for d in range(hp.adaptive_depth)])
-        t['network'] = time.perf_counter() - tic
+        if self.sync_timing:
+            torch.cuda.synchronize()
+        t['t_network'] = time.perf_counter() - tic
         field.solve(pos_xyz=enc.xyz, normal_xyz=normal_xyz, normal_value=-normal_value,
                     pos_weight=hp.solver.pos_weight / xyz.shape[0],
                     normal_weight=hp.solver.normal_weight / normal_xyz.shape[0] * hp.voxel_size ** 2,

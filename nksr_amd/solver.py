@@ -26,3 +26,11 @@ def pcg_solve(rowptr, cols, vals, diag, b, tol=1e-5, max_iter=2000, check_every=
     call('nksr_pcg_solve', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), M, ptr(b), ptr(x), float(tol), int(max_iter),
          int(check_every), ptr(workspace), info, stream())
     return x, int(info[0]), float(info[1])
+
+
+def profile_spmv(enable):
+    """Toggle live HIP-event timing of the SpMV launches inside pcg_solve; returns the
+    (milliseconds, launches) accumulated since the previous call."""
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    call('nksr_pcg_profile', int(bool(enable)), C.byref(ms), C.byref(n))
+    return float(ms.value), int(n.value)
