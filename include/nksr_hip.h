@@ -106,27 +106,40 @@ typedef struct {
     const int32_t* end[NKSR_MAX_DEPTH];
 } nksr_siteset_t;
 
-/* Upper bound of the number of (row,col) pairs nksr_assemble will append. */
-int nksr_assemble_count(const nksr_hier_t* h, int64_t* d_count, void* stream);
-/* Appends the symmetric COO of  sum_s w_s R_s^T R_s + reg I  (keys = row<<col_bits | col, 2^col_bits >= M) and
- * writes b = sum_s w_s R_s^T t_s.  d_count must be zeroed by the caller. */
+/* rowcount[row] = number of COO entries row `row` emits (2 per structural upper entry + the
+ * diagonal).  A slot is structural iff the column voxel exists and the B-spline supports overlap. */
+int nksr_assemble_count(const nksr_hier_t* h, int32_t* rowcount, void* stream);
+/* Bytes of scratch for the per-cell blocks of nksr_assemble. */
+size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h);
+/* Two-phase assembly (per-cell dense blocks, then per-row gather; csrc/assemble.hip).  Writes the
+ * symmetric COO of  sum_s w_s R_s^T R_s + reg I  (keys = row<<col_bits | col, 2^col_bits >= M) at
+ * rowoff = exclusive scan of rowcount, and b = sum_s w_s R_s^T t_s. */
 int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, int nsets, float reg, int col_bits,
-                  uint64_t* coo_keys, float* coo_vals, int64_t capacity, int64_t* d_count, float* b_out, void* stream);
-/* Sorted COO -> CSR (rowptr int32 [M+1], cols int32 [nnz]) + diagonal. */
+                  void* workspace, const int32_t* rowoff, uint64_t* coo_keys, float* coo_vals, float* b_out, void* stream);
+/* Sorted COO -> CSR (rowptr int32 [M+1]) + diagonal.  cols / vals_out are written in the SpMV's
+ * physical layout: 256-entry tiles, logical entry m of a tile at 4*(m%64) + m/64; both arrays must
+ * be zero-initialised and sized to nnz rounded up to a multiple of 4096. */
 int nksr_coo_to_csr(const uint64_t* keys_sorted, const float* vals, int64_t nnz, int32_t M, int col_bits,
-                    int32_t* rowptr, int32_t* cols, float* diag, void* stream);
+                    int32_t* rowptr, int32_t* cols, float* vals_out, float* diag, void* stream);
 
 /* ---- PCG (the CG SpMV is the roofline kernel) -------------------- */
-int nksr_spmv_csr(const int32_t* rowptr, const int32_t* cols, const float* vals, int32_t M,
-                  const float* x, float* y, void* stream);
-/* Scratch bytes required by nksr_pcg_solve for a system of M unknowns. */
-size_t nksr_pcg_workspace_bytes(int32_t M);
+/* nnz-chunked streaming CSR SpMV (csrc/pcg.hip).  cols/vals in the tile-interleaved physical layout
+ * produced by nksr_coo_to_csr (zero-padded to a multiple of 4096 entries).  The plan (row
+ * of every 4096-entry chunk) lives in `workspace` (nksr_spmv_workspace_bytes) and must be built
+ * once per matrix with nksr_spmv_plan. */
+size_t nksr_spmv_workspace_bytes(int64_t nnz);
+int nksr_spmv_plan(const int32_t* rowptr, int32_t M, int64_t nnz, void* workspace, void* stream);
+int nksr_spmv_csr(const int32_t* rowptr, const int32_t* cols, const float* vals, int32_t M, int64_t nnz,
+                  const float* x, float* y, void* workspace, void* stream);
+/* Experimental kernel variants for tools/spmv_probe.py (0 = default). */
+int nksr_spmv_set_variant(int v);
+/* Scratch bytes required by nksr_pcg_solve. */
+size_t nksr_pcg_workspace_bytes(int32_t M, int64_t nnz);
 /* Jacobi-PCG, x0 = 0.  info_out (host, may be NULL): [0]=iterations [1]=relative residual.
  * Checks convergence every `check_every` iterations (one stream sync each) -- syncs. */
 int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t M,
-                   const float* b, float* x, float tol, int max_iter, int check_every, void* workspace,
+                   int64_t nnz, const float* b, float* x, float tol, int max_iter, int check_every, void* workspace,
                    double* info_out, void* stream);
-
 /* Live profiling of the SpMV launches inside nksr_pcg_solve (HIP events on the solve's stream).
  * Returns and resets the accumulated milliseconds / launch count, then sets the enable flag. */
 int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out);

@@ -42,7 +42,11 @@ def _load():
 lib = _load()
 lib.nksr_last_error.restype = C.c_char_p
 lib.nksr_pcg_workspace_bytes.restype = _sz
-lib.nksr_pcg_workspace_bytes.argtypes = [_i32]
+lib.nksr_pcg_workspace_bytes.argtypes = [_i32, _i64]
+lib.nksr_assemble_workspace_bytes.restype = _sz
+lib.nksr_assemble_workspace_bytes.argtypes = [C.POINTER(HierT)]
+lib.nksr_spmv_workspace_bytes.restype = _sz
+lib.nksr_spmv_workspace_bytes.argtypes = [_i64]
 
 _P = C.POINTER
 _PROTOS = {
@@ -65,10 +69,12 @@ _PROTOS = {
     'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _vp, _vp, _vp],
     'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, _vp, _vp, _vp],
     'nksr_assemble_count': [_P(HierT), _vp, _vp],
-    'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _i64, _vp, _vp, _vp],
-    'nksr_coo_to_csr': [_vp, _vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _vp],
-    'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _vp, _vp, _vp],
-    'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
+    'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    'nksr_coo_to_csr': [_vp, _vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _vp, _vp],
+    'nksr_spmv_set_variant': [C.c_int],
+    'nksr_spmv_plan': [_vp, _i32, _i64, _vp, _vp],
+    'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
+    'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
     'nksr_base_cell_flags': [_vp, _i32, _vp, _vp],
     'nksr_base_cell_keys': [_vp, _vp, _i64, C.c_int, _vp, _vp],
@@ -87,7 +93,7 @@ for _name, _args in _PROTOS.items():
     _fn.argtypes = _args
     _fn.restype = C.c_int
 
-EXPORTED = ['nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes'] + sorted(_PROTOS)
+EXPORTED = ['nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes'] + sorted(_PROTOS)
 
 
 def check(rc):

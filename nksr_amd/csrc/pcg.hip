@@ -9,7 +9,7 @@
 #include "common.h"
 
 #define PCG_BLOCK 256
-#define PCG_MAX_BLOCKS 1024
+#define PCG_MAX_BLOCKS 2048
 
 struct PcgScalars {
     double rz[2];
@@ -28,9 +28,13 @@ struct PcgWork {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-extern "C" size_t nksr_pcg_workspace_bytes(int32_t M) {
+static size_t pcg_vector_bytes(int32_t M) {
     size_t vec = align_up((size_t)M * sizeof(float), 256);
     return 4 * vec + 3 * PCG_MAX_BLOCKS * sizeof(double) + 256;
+}
+extern "C" size_t nksr_spmv_workspace_bytes(int64_t nnz);
+extern "C" size_t nksr_pcg_workspace_bytes(int32_t M, int64_t nnz) {
+    return pcg_vector_bytes(M) + nksr_spmv_workspace_bytes(nnz);
 }
 
 static PcgWork carve(void* ws, int M) {
@@ -82,32 +86,111 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
     return bc;
 }
 
-// ---- SpMV: one wavefront per row, lanes stride the row's (col,val) stream -------------------
-template <bool DOT>
+// ---- SpMV ---------------------------------------------------------------------------------------
+// nnz-balanced streaming CSR SpMV.  The (col,val) stream is cut into chunks of SPMV_CHUNK
+// entries regardless of row boundaries (rows range from ~30 to several thousand entries: a
+// coarse voxel couples to every fine voxel under its support), so every workgroup moves the same
+// number of bytes with perfectly coalesced 16-byte loads: 16 entries = 128 B in flight per lane,
+// 32 KiB per workgroup, ~8 workgroups per CU.  Products go to LDS; each wavefront then reduces
+// whole row segments from LDS (butterfly), writing y for rows that START in the chunk and one
+// carry per chunk for the row that started earlier.  A tiny fix-up kernel adds the carries in
+// chunk order, so the result is deterministic.  x gathers hit L2 (Morton-ordered unknowns).
+// cols/vals must be readable (cols valid, vals zero) up to the next multiple of 4 past nnz.
+#define SPMV_CHUNK 4096
+#define SPMV_QUADS (SPMV_CHUNK / (PCG_BLOCK * 4))
+
+__global__ void k_spmv_plan(const int32_t* __restrict__ rowptr, int M, int64_t nnz, int nchunks,
+                            int32_t* __restrict__ chunk_row) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nchunks) return;
+    if (b == nchunks) { chunk_row[b] = M; return; }
+    // row containing entry b*CHUNK: last r with rowptr[r] <= k
+    const int64_t k = (int64_t)b * SPMV_CHUNK;
+    int lo = 0, hi = M;  // invariant: rowptr[lo] <= k < rowptr[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if ((int64_t)rowptr[mid] <= k) lo = mid; else hi = mid;
+    }
+    chunk_row[b] = lo;
+}
+
+template <bool DOT, int VARIANT>
 __global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                                    const float* __restrict__ vals, int M, const float* __restrict__ x,
-                                                    float* __restrict__ y, double* __restrict__ part,
+                                                    const float* __restrict__ vals, int M, int nnz, int nchunks,
+                                                    const int32_t* __restrict__ chunk_row, const float* __restrict__ x,
+                                                    float* __restrict__ y, float* __restrict__ carry,
+                                                    int32_t* __restrict__ carry_row, double* __restrict__ part,
                                                     const int* __restrict__ done) {
     if (DOT && *done) return;
+    __shared__ __attribute__((aligned(16))) float prod[SPMV_CHUNK];
     __shared__ double sm[PCG_BLOCK / 64];
-    const int lane = threadIdx.x & 63;
-    const int wave_global = (blockIdx.x * PCG_BLOCK + threadIdx.x) >> 6;
-    const int nwaves = (gridDim.x * PCG_BLOCK) >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double dot = 0.0;
-    for (int row = wave_global; row < M; row += nwaves) {
-        const int k0 = rowptr[row], k1 = rowptr[row + 1];
-        float acc = 0.f;
-        for (int k = k0 + lane; k < k1; k += 64) acc = fmaf(vals[k], x[cols[k]], acc);
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            y[row] = acc;
-            if (DOT) dot += (double)acc * (double)x[row];
+    for (int b = blockIdx.x; b < nchunks; b += gridDim.x) {
+        const int base = b * SPMV_CHUNK;
+        const int end = (base + SPMV_CHUNK < nnz) ? base + SPMV_CHUNK : nnz;
+        // cols/vals are stored in 256-entry interleaved tiles (see k_coo_cols): component j of the
+        // 16-byte load of lane l is logical entry 64 j + l of the tile -> every gather instruction
+        // below covers 64 consecutive entries of the stream.  Storage is zero-padded to a multiple
+        // of SPMV_CHUNK, so no bounds checks are needed.
+        int4 c[SPMV_QUADS];
+        float4 v[SPMV_QUADS];
+#pragma unroll
+        for (int q = 0; q < SPMV_QUADS; ++q) {
+            const int k = base + q * (PCG_BLOCK * 4) + tid * 4;
+            c[q] = *reinterpret_cast<const int4*>(cols + k);
+            v[q] = *reinterpret_cast<const float4*>(vals + k);
         }
+#pragma unroll
+        for (int q = 0; q < SPMV_QUADS; ++q) {
+            float* pt = prod + q * (PCG_BLOCK * 4) + wave * 256 + lane;
+            if (VARIANT == 1) {   // probe only: no gather (streaming ceiling)
+                pt[0] = v[q].x * (float)c[q].x; pt[64] = v[q].y * (float)c[q].y; pt[128] = v[q].z * (float)c[q].z; pt[192] = v[q].w * (float)c[q].w;
+            } else {
+                pt[0] = v[q].x * x[c[q].x];
+                pt[64] = v[q].y * x[c[q].y];
+                pt[128] = v[q].z * x[c[q].z];
+                pt[192] = v[q].w * x[c[q].w];
+            }
+        }
+        __syncthreads();
+        const int r_first = chunk_row[b];
+        int r_last = chunk_row[b + 1];                    // row holding entry `end` (or M)
+        if (r_last >= M || rowptr[r_last] >= end) r_last -= 1;
+        if (tid == 0 && rowptr[r_first] >= base) carry_row[b] = -1;   // no row continues into this chunk
+        for (int r = r_first + wave; r <= r_last; r += PCG_BLOCK / 64) {
+            const int p0 = rowptr[r], p1 = rowptr[r + 1];
+            const int k0 = p0 > base ? p0 : base, k1 = p1 < end ? p1 : end;
+            float s = 0.f;
+            for (int k = k0 + lane; k < k1; k += 64) s += prod[k - base];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) {
+                if (p0 >= base) y[r] = s;
+                else { carry[b] = s; carry_row[b] = r; }
+                if (DOT) dot += (double)s * (double)x[r];
+            }
+        }
+        __syncthreads();
     }
     if (DOT) {
         double t = block_sum(dot, sm);
-        if (threadIdx.x == 0) part[blockIdx.x] = t;
+        if (tid == 0) part[blockIdx.x] = t;
     }
+}
+
+// adds the per-chunk carries to y in chunk order (one thread per run of equal rows)
+__global__ void k_spmv_fixup(int nchunks, const float* __restrict__ carry, const int32_t* __restrict__ carry_row,
+                             float* __restrict__ y, const int* __restrict__ done) {
+    if (done && *done) return;
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nchunks) return;
+    const int r = carry_row[b];
+    if (r < 0) return;
+    if (b > 0 && carry_row[b - 1] == r) return;   // not the head of the run
+    float s = 0.f;
+    for (int j = b; j < nchunks && carry_row[j] == r; ++j) s += carry[j];
+    y[r] += s;
 }
 
 __global__ void __launch_bounds__(PCG_BLOCK) k_pcg_init(int M, const float* __restrict__ b, const float* __restrict__ diag,
@@ -193,17 +276,64 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_pcg_pupdate(int M, PcgWork w, int
     }
 }
 
-static int spmv_grid(int M) {
-    int rows_per_block = PCG_BLOCK / 64;
-    int nb = (M + rows_per_block - 1) / rows_per_block;
-    return nb < 1 ? 1 : (nb > PCG_MAX_BLOCKS ? PCG_MAX_BLOCKS : nb);
+// ---- SpMV plan / workspace ------------------------------------------------------------------------
+struct SpmvPlan {
+    int nchunks;
+    int32_t* chunk_row;   // [nchunks + 1]
+    float* carry;         // [nchunks]
+    int32_t* carry_row;   // [nchunks]
+};
+
+static int spmv_nchunks(int64_t nnz) { return (int)((nnz + SPMV_CHUNK - 1) / SPMV_CHUNK); }
+
+extern "C" size_t nksr_spmv_workspace_bytes(int64_t nnz) {
+    size_t nc = (size_t)spmv_nchunks(nnz);
+    return align_up((nc + 1) * sizeof(int32_t), 256) + 2 * align_up(nc * sizeof(float), 256) + 256;
 }
 
-extern "C" int nksr_spmv_csr(const int32_t* rowptr, const int32_t* cols, const float* vals, int32_t M, const float* x,
-                             float* y, void* stream) {
+static SpmvPlan carve_spmv(void* ws, int64_t nnz) {
+    SpmvPlan p;
+    p.nchunks = spmv_nchunks(nnz);
+    char* c = (char*)ws;
+    p.chunk_row = (int32_t*)c; c += align_up(((size_t)p.nchunks + 1) * sizeof(int32_t), 256);
+    p.carry = (float*)c; c += align_up((size_t)p.nchunks * sizeof(float), 256);
+    p.carry_row = (int32_t*)c;
+    return p;
+}
+
+static int spmv_grid(int nchunks) {
+    return nchunks < 1 ? 1 : (nchunks > PCG_MAX_BLOCKS ? PCG_MAX_BLOCKS : nchunks);
+}
+
+extern "C" int nksr_spmv_plan(const int32_t* rowptr, int32_t M, int64_t nnz, void* workspace, void* stream) {
+    if (M <= 0 || nnz <= 0) return NKSR_OK;
+    if (nnz >= ((int64_t)1 << 31)) return nksr_set_error(NKSR_ERR_CAPACITY, "nnz exceeds int32");
+    SpmvPlan p = carve_spmv(workspace, nnz);
+    hipLaunchKernelGGL(k_spmv_plan, dim3(nksr_blocks(p.nchunks + 1, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, M, nnz,
+                       p.nchunks, p.chunk_row);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+static int g_spmv_variant = 0;
+extern "C" int nksr_spmv_set_variant(int v) { g_spmv_variant = v; return NKSR_OK; }
+
+template <bool DOT>
+static int launch_spmv(const int32_t* rowptr, const int32_t* cols, const float* vals, int M, int64_t nnz, const SpmvPlan& p,
+                       const float* x, float* y, double* part, const int* done, hipStream_t st) {
+#define SPMV_LAUNCH(V) hipLaunchKernelGGL((k_spmv<DOT, V>), dim3(spmv_grid(p.nchunks)), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, (int)nnz, \
+                       p.nchunks, p.chunk_row, x, y, p.carry, p.carry_row, part, done)
+    if (g_spmv_variant == 1) SPMV_LAUNCH(1); else SPMV_LAUNCH(0);
+    hipLaunchKernelGGL(k_spmv_fixup, dim3(nksr_blocks(p.nchunks, 256)), dim3(256), 0, st, p.nchunks, p.carry, p.carry_row, y, done);
+    return 0;
+}
+
+extern "C" int nksr_spmv_csr(const int32_t* rowptr, const int32_t* cols, const float* vals, int32_t M, int64_t nnz,
+                             const float* x, float* y, void* workspace, void* stream) {
     if (M <= 0) return NKSR_OK;
-    hipLaunchKernelGGL((k_spmv<false>), dim3(spmv_grid(M)), dim3(PCG_BLOCK), 0, (hipStream_t)stream, rowptr, cols, vals,
-                       M, x, y, (double*)nullptr, (const int*)nullptr);
+    if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL (run nksr_spmv_plan first)");
+    SpmvPlan p = carve_spmv(workspace, nnz);
+    launch_spmv<false>(rowptr, cols, vals, M, nnz, p, x, y, nullptr, nullptr, (hipStream_t)stream);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -225,15 +355,19 @@ extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_ou
 }
 
 extern "C" int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t M,
-                              const float* b, float* x, float tol, int max_iter, int check_every, void* workspace,
-                              double* info_out, void* stream) {
+                              int64_t nnz, const float* b, float* x, float tol, int max_iter, int check_every,
+                              void* workspace, double* info_out, void* stream) {
     if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
     if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     if (check_every < 1) check_every = 1;
     hipStream_t st = (hipStream_t)stream;
     PcgWork w = carve(workspace, M);
+    void* spmv_ws = (char*)workspace + pcg_vector_bytes(M);
+    int rc = nksr_spmv_plan(rowptr, M, nnz, spmv_ws, stream);
+    if (rc) return rc;
+    SpmvPlan plan = carve_spmv(spmv_ws, nnz);
     const int nbv = nksr_blocks(M, PCG_BLOCK) > PCG_MAX_BLOCKS ? PCG_MAX_BLOCKS : nksr_blocks(M, PCG_BLOCK);
-    const int nbs = spmv_grid(M);
+    const int nbs = spmv_grid(plan.nchunks);
     hipLaunchKernelGGL(k_pcg_init, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, b, diag, w, x);
     hipLaunchKernelGGL(k_pcg_init_finish, dim3(1), dim3(PCG_BLOCK), 0, st, w, nbv);
     NKSR_CHECK_LAUNCH();
@@ -252,8 +386,7 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const 
         for (int c = 0; c < chunk; ++c) {
             const int parity = (launched + c) & 1;
             if (prof) hipEventRecord(g_prof_events[2 * c], st);
-            hipLaunchKernelGGL((k_spmv<true>), dim3(nbs), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, w.p, w.y, w.part1,
-                               &w.sc->done);
+            launch_spmv<true>(rowptr, cols, vals, M, nnz, plan, w.p, w.y, w.part1, &w.sc->done, st);
             if (prof) hipEventRecord(g_prof_events[2 * c + 1], st);
             hipLaunchKernelGGL(k_pcg_update, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, diag, w, x, nbs, parity);
             hipLaunchKernelGGL(k_pcg_pupdate, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w, nbv, parity, tol);

@@ -125,26 +125,31 @@ class KernelField(BaseField):
                 S.start[d], S.end[d] = ptr(st[d]), ptr(en[d])
             keep += [xs, rows, st, en, tgt, ks]
             nsets += 1
-        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-        call('nksr_assemble_count', C.byref(self._hier), ptr(cnt), stream())
-        cap = int(cnt.item())
+        # per-row structural counts -> exclusive scan -> COO offsets (no atomics, deterministic)
+        rowcount = torch.zeros(M + 1, dtype=torch.int32, device=dev)
+        call('nksr_assemble_count', C.byref(self._hier), ptr(rowcount), stream())
+        rowoff = ops.exclusive_sum_i32(rowcount)
+        nnz = int(rowoff[M].item())
+        if nnz <= 0 or nnz >= 2 ** 31 - 8:
+            raise RuntimeError('matrix too large for int32 indexing (nnz=%d): use chunk_size' % nnz)
         col_bits = ops._bits(M)
-        coo_k = torch.empty(cap, dtype=torch.int64, device=dev)
-        coo_v = torch.empty(cap, dtype=torch.float32, device=dev)
+        coo_k = torch.empty(nnz, dtype=torch.int64, device=dev)
+        coo_v = torch.empty(nnz, dtype=torch.float32, device=dev)
         b = torch.empty(M, dtype=torch.float32, device=dev)
-        cnt.zero_()
-        call('nksr_assemble', C.byref(self._hier), sets, nsets, float(reg_weight), col_bits, ptr(coo_k), ptr(coo_v), cap,
-             ptr(cnt), ptr(b), stream())
-        nnz = int(cnt.item())
-        if nnz > cap:
-            raise RuntimeError('assembly overflow: %d > %d' % (nnz, cap))
-        ks, vs = ops.sort_pairs(coo_k[:nnz].contiguous(), coo_v[:nnz].contiguous().view(torch.int32), end_bit=2 * col_bits)
-        del coo_k, coo_v
-        vals = vs.view(torch.float32)
+        ws = torch.empty(int(_lib.lib.nksr_assemble_workspace_bytes(C.byref(self._hier))), dtype=torch.uint8, device=dev)
+        call('nksr_assemble', C.byref(self._hier), sets, nsets, float(reg_weight), col_bits, ptr(ws), ptr(rowoff), ptr(coo_k),
+             ptr(coo_v), ptr(b), stream())
+        ks, vs = ops.sort_pairs(coo_k, coo_v.view(torch.int32), end_bit=2 * col_bits)
+        del coo_k, coo_v, ws
+        # physical (tile-interleaved, zero-padded) CSR arrays for the streaming SpMV
+        npad = (nnz + 4095) // 4096 * 4096
         rowptr = torch.empty(M + 1, dtype=torch.int32, device=dev)
-        cols = torch.empty(nnz, dtype=torch.int32, device=dev)
+        cols = torch.zeros(npad, dtype=torch.int32, device=dev)
+        vals = torch.zeros(npad, dtype=torch.float32, device=dev)
         diag = torch.empty(M, dtype=torch.float32, device=dev)
-        call('nksr_coo_to_csr', ptr(ks), ptr(vals), nnz, M, col_bits, ptr(rowptr), ptr(cols), ptr(diag), stream())
+        call('nksr_coo_to_csr', ptr(ks), ptr(vs.view(torch.float32)), nnz, M, col_bits, ptr(rowptr), ptr(cols), ptr(vals),
+             ptr(diag), stream())
+        self.nnz = nnz
         del keep
         return rowptr, cols, vals, diag, b
 
@@ -163,11 +168,11 @@ class KernelField(BaseField):
         self.alpha = x
         self.matrix = (rowptr, cols, vals, diag)
         self.rhs = b
-        self.solve_info = {'iters': iters, 'rel_residual': rel, 'M': int(b.numel()), 'nnz': int(cols.numel()),
+        self.solve_info = {'iters': iters, 'rel_residual': rel, 'M': int(b.numel()), 'nnz': int(self.nnz),
                            't_assemble': t1 - t0, 't_pcg': t2 - t1}
         if self.solver_config.get('verbose'):
             print('[KernelField] M=%d nnz=%d iters=%d rel=%.3e assemble=%.3fs pcg=%.3fs' % (
-                b.numel(), cols.numel(), iters, rel, t1 - t0, t2 - t1))
+                b.numel(), self.nnz, iters, rel, t1 - t0, t2 - t1))
         return self
 
     def solve(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0, fused_mode=True):

@@ -22,10 +22,12 @@ def sort_keys(keys, end_bit=63):
     return out
 
 
-def sort_pairs(keys, vals32, end_bit=63):
-    """Sort (int64 key, 32-bit payload) pairs by key."""
+def sort_pairs(keys, vals32, end_bit=63, pad=0):
+    """Sort (int64 key, 32-bit payload) pairs by key.  ``pad`` extra (zeroed) elements are kept
+    behind the returned views so that 16-byte loads may run past the end."""
     n = keys.numel()
-    ko, vo = torch.empty_like(keys), torch.empty_like(vals32)
+    ko = torch.empty_like(keys)
+    vo = torch.zeros(n + pad, dtype=vals32.dtype, device=vals32.device)[:n] if pad else torch.empty_like(vals32)
     if n:
         with_tmp('nksr_sort_pairs_u64_u32', keys.device, ptr(keys), ptr(ko), ptr(vals32), ptr(vo), n, 0, int(end_bit), stream())
     return ko, vo

@@ -104,7 +104,8 @@ def test_assembly_and_spmv():
     t = lambda a: torch.from_numpy(a).to(_dev())
     rowptr, cols, vals, diag, gb = fld.assemble(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
     M = A.shape[0]
-    Ag = sp.csr_matrix((vals.cpu().numpy(), cols.cpu().numpy(), rowptr.cpu().numpy()), shape=(M, M))
+    lc, lv = solver.csr_logical(rowptr, cols, vals)
+    Ag = sp.csr_matrix((lv.cpu().numpy(), lc.cpu().numpy(), rowptr.cpu().numpy()), shape=(M, M))
     # exactly symmetric, sorted columns, SPD diagonal
     assert abs(Ag - Ag.T).max() == 0.0
     assert Ag.has_sorted_indices
@@ -135,7 +136,8 @@ def test_pcg_matches_oracle_and_scipy():
     nval = np.random.RandomState(5).randn(len(nxyz), 3).astype(np.float32)
     rowptr, cols, vals, diag, b = fld.assemble(t(xyz), t(nxyz), t(nval), 1e4 / len(xyz), 1e4 / len(nxyz) * 0.01, 1.0)
     M = b.numel()
-    Ag = sp.csr_matrix((vals.cpu().numpy(), cols.cpu().numpy(), rowptr.cpu().numpy()), shape=(M, M))
+    lc, lv = solver.csr_logical(rowptr, cols, vals)
+    Ag = sp.csr_matrix((lv.cpu().numpy(), lc.cpu().numpy(), rowptr.cpu().numpy()), shape=(M, M))
     bn = b.cpu().numpy()
     # (1) few fixed iterations: iterates agree tightly (same matrix, same algorithm)
     x5, it5, _ = solver.pcg_solve(rowptr, cols, vals, diag, b, tol=0.0, max_iter=6, check_every=2)
