@@ -108,8 +108,8 @@ typedef struct {
 
 /* rowcount[row] = number of COO entries row `row` emits (2 per structural upper entry + the
  * diagonal).  A slot is structural iff the column voxel exists and the B-spline supports overlap. */
-int nksr_assemble_count(const nksr_hier_t* h, int32_t* rowcount, void* stream);
-/* Bytes of scratch for the per-cell blocks of nksr_assemble. */
+int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, void* stream);
+/* Bytes of scratch (per-cell blocks + per-row column map) shared by nksr_assemble_count / nksr_assemble. */
 size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h);
 /* Two-phase assembly (per-cell dense blocks, then per-row gather; csrc/assemble.hip).  Writes the
  * symmetric COO of  sum_s w_s R_s^T R_s + reg I  (keys = row<<col_bits | col, 2^col_bits >= M) at

@@ -13,8 +13,9 @@
 //     block row B[d][c][slot of i in c's stencil] into a structured (L-d) x 5^3 slot frame in
 //     LDS, then emits the upper triangle (coarser level, or same level and col > row) mirrored
 //     into a COO list at offsets obtained from an exclusive scan of per-row counts.  The
-//     (row,col) keys are unique, so the following radix sort yields a deterministic, exactly
-//     symmetric CSR.  A slot is structural iff the column voxel exists and the two B-spline
+//     Keys are (col << col_bits | row); a STABLE radix sort on the row bits only (3 passes instead
+//     of 6) then yields CSR rows = [mirrored entries, ascending source row = ascending column]
+//     [own upper entries in slot order][diagonal]: deterministic and exactly symmetric.  A slot is structural iff the column voxel exists and the two B-spline
 //     supports overlap (integer test), so count and fill agree without looking at values.
 #include "common.h"
 
@@ -30,6 +31,7 @@ struct AsmArgs {
     float* blocks[NKSR_MAX_DEPTH];   // [n_d, 27, T_d]
     float* bvec[NKSR_MAX_DEPTH];     // [n_d, 27]
     int32_t* nsites[NKSR_MAX_DEPTH]; // [n_d]
+    int32_t* colmap[NKSR_MAX_DEPTH]; // [n_d, (L-d) 125] column of every structural upper slot or -1
 };
 
 __device__ __forceinline__ int row_level(const nksr_hier_t& h, int row) {
@@ -46,7 +48,9 @@ __device__ __forceinline__ int rel_slot(int cx, int cy, int cz, int ix, int iy, 
 }
 
 // ---- phase 1: one wavefront per (level, cell) -------------------------------------------------------
-template <bool TWO_COLS>
+// NC = columns per lane (T <= 64 NC).  Products are accumulated unweighted and symmetric
+// (fmaf(r_s, r_t, acc)); the set weight is applied once per set at the end.
+template <int NC>
 __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const nksr_level_t& lv = A.hier.lv[d];
@@ -54,42 +58,56 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
     if (c >= lv.n) return;
     const int L = A.hier.depth;
     const int T = (L - d) * 27;
-    float acc0[27], acc1[TWO_COLS ? 27 : 1];
+    float tot[NC][27];
 #pragma unroll
-    for (int s = 0; s < 27; ++s) { acc0[s] = 0.f; if (TWO_COLS) acc1[s] = 0.f; }
-    float bacc = 0.f;
+    for (int q = 0; q < NC; ++q)
+#pragma unroll
+        for (int s = 0; s < 27; ++s) tot[q][s] = 0.f;
+    float btot = 0.f;
     int total = 0;
-    const bool has0 = lane < T, has1 = TWO_COLS && (lane + 64 < T);
     for (int si = 0; si < A.nsets; ++si) {
         const nksr_siteset_t& S = A.sets[si];
         const int k0 = S.start[d][c], k1 = S.end[d][c];
+        if (k0 >= k1) continue;
         const int ncomp = S.ncomp;
-        const float w = S.weight;
         total += k1 - k0;
+        float acc[NC][27];
+#pragma unroll
+        for (int q = 0; q < NC; ++q)
+#pragma unroll
+            for (int s = 0; s < 27; ++s) acc[q][s] = 0.f;
+        float bacc = 0.f;
         for (int k = k0; k < k1; ++k) {
             for (int a = 0; a < ncomp; ++a) {
                 const float* ra = S.val + (((int64_t)k * ncomp + a) * L + d) * 27;
-                const float v0 = has0 ? ra[lane] : 0.f;
-                const float v1 = has1 ? ra[lane + 64] : 0.f;
-                if (S.target && lane < 27) bacc = fmaf(w * v0, S.target[(int64_t)k * ncomp + a], bacc);
+                float v[NC];
+#pragma unroll
+                for (int q = 0; q < NC; ++q) v[q] = (lane + 64 * q < T) ? ra[lane + 64 * q] : 0.f;
+                if (S.target && lane < 27) bacc = fmaf(v[0], S.target[(int64_t)k * ncomp + a], bacc);
 #pragma unroll
                 for (int s = 0; s < 27; ++s) {
-                    const float gs = w * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v0), s));
-                    acc0[s] = fmaf(gs, v0, acc0[s]);
-                    if (TWO_COLS) acc1[s] = fmaf(gs, v1, acc1[s]);
+                    const float gs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[0]), s));
+#pragma unroll
+                    for (int q = 0; q < NC; ++q) acc[q][s] = fmaf(gs, v[q], acc[q][s]);
                 }
             }
         }
+        const float w = S.weight;
+#pragma unroll
+        for (int q = 0; q < NC; ++q)
+#pragma unroll
+            for (int s = 0; s < 27; ++s) tot[q][s] = fmaf(w, acc[q][s], tot[q][s]);
+        btot = fmaf(w, bacc, btot);
     }
     if (lane == 0) A.nsites[d][c] = total;
     if (total == 0) return;
     float* out = A.blocks[d] + (int64_t)c * 27 * T;
 #pragma unroll
-    for (int s = 0; s < 27; ++s) {
-        if (has0) out[s * T + lane] = acc0[s];
-        if (has1) out[s * T + lane + 64] = acc1[s];
-    }
-    if (lane < 27) A.bvec[d][(int64_t)c * 27 + lane] = bacc;
+    for (int s = 0; s < 27; ++s)
+#pragma unroll
+        for (int q = 0; q < NC; ++q)
+            if (lane + 64 * q < T) out[s * T + lane + 64 * q] = tot[q][s];
+    if (lane < 27) A.bvec[d][(int64_t)c * 27 + lane] = btot;
 }
 
 // ---- structural test shared by count and fill -----------------------------------------------------
@@ -107,16 +125,38 @@ __device__ __forceinline__ int slot_column(const nksr_hier_t& h, int d, int ix, 
     return j < 0 ? -1 : lc.offset + j;
 }
 
-// ---- phase 2: one wavefront per row -----------------------------------------------------------------
-template <bool COUNT_ONLY>
-__global__ void __launch_bounds__(ASM_WAVES * 64) k_row_gather(AsmArgs A, int32_t* __restrict__ rowcount,
-                                                               const int32_t* __restrict__ rowoff,
-                                                               uint64_t* __restrict__ coo_keys, float* __restrict__ coo_vals,
-                                                               float* __restrict__ b_out) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+// ---- phase 2a: structure.  colmap[row slot] = column (> row) of every structural upper slot ------
+__global__ void __launch_bounds__(ASM_WAVES * 64) k_row_count(AsmArgs A, int32_t* __restrict__ rowcount) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * ASM_WAVES + wave;
     if (row >= A.M) return;
+    const nksr_hier_t& h = A.hier;
+    const int d = row_level(h, row);
+    const nksr_level_t& lv = h.lv[d];
+    const int i = row - lv.offset;
+    const int ix = lv.ijk[i * 3], iy = lv.ijk[i * 3 + 1], iz = lv.ijk[i * 3 + 2];
+    const int nslots = (h.depth - d) * 125;
+    int32_t* cm = A.colmap[d] + (int64_t)i * nslots;
+    int cnt = 0;
+    for (int t0 = 0; t0 < nslots; t0 += 64) {
+        const int t = t0 + lane;
+        int col = (t < nslots) ? slot_column(h, d, ix, iy, iz, t) : -1;
+        if (col <= row) col = -1;
+        if (t < nslots) cm[t] = col;
+        cnt += __popcll(__ballot(col >= 0));
+    }
+    if (lane == 0) rowcount[row] = 2 * cnt + 1;
+}
+
+// ---- phase 2b: one wavefront per row: gather block rows into the slot frame, emit COO ----------------
+template <int NQ>
+__global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const int32_t* __restrict__ rowoff,
+                                                             uint64_t* __restrict__ coo_keys, float* __restrict__ coo_vals,
+                                                             float* __restrict__ b_out, int row_begin, int row_end) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = row_begin + blockIdx.x * ASM_WAVES + wave;
+    if (row >= row_end) return;
     const nksr_hier_t& h = A.hier;
     const int L = h.depth;
     const int d = row_level(h, row);
@@ -124,52 +164,86 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_gather(AsmArgs A, int32_
     const int i = row - lv.offset;
     const int ix = lv.ijk[i * 3], iy = lv.ijk[i * 3 + 1], iz = lv.ijk[i * 3 + 2];
     const int nslots = (L - d) * 125;
+    const int T = (L - d) * 27;
     float* acc = lds + wave * (NKSR_MAX_DEPTH * 125);
+    for (int t = lane; t < nslots; t += 64) acc[t] = 0.f;
 
-    if (!COUNT_ONLY) {
-        for (int t = lane; t < nslots; t += 64) acc[t] = 0.f;
-        const int T = (L - d) * 27;
-        float bsum = 0.f;
-        for (int sp = 0; sp < 27; ++sp) {
-            const int c = lv.nbr[(int64_t)i * 27 + sp];
-            if (c < 0 || A.nsites[d][c] == 0) continue;
-            const int s_i = 26 - sp;
-            const int cx = ix + sp / 9 - 1, cy = iy + (sp / 3) % 3 - 1, cz = iz + sp % 3 - 1;
-            const float* brow = A.blocks[d] + ((int64_t)c * 27 + s_i) * T;
-            for (int t = lane; t < T; t += 64) {
-                const int sl = rel_slot(cx, cy, cz, ix, iy, iz, t / 27, t % 27);
-                acc[sl] += brow[t];
-            }
-            bsum += A.bvec[d][(int64_t)c * 27 + s_i];
+    // neighbour cells and their site counts, one per lane
+    const int cme = (lane < 27) ? lv.nbr[(int64_t)i * 27 + lane] : -1;
+    const int nse = (cme >= 0) ? A.nsites[d][cme] : 0;
+    unsigned long long act = __ballot(nse > 0);
+    float bl = (nse > 0) ? A.bvec[d][(int64_t)cme * 27 + (26 - lane)] : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bl += __shfl_xor(bl, o);
+    if (lane == 0) b_out[row] = bl;
+
+    // per-lane entry decomposition (independent of the neighbour cell)
+    int edd[NQ], esx[NQ], esy[NQ], esz[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int t = lane + 64 * q, s = t % 27;
+        edd[q] = t / 27;
+        esx[q] = s / 9 - 1; esy[q] = (s / 3) % 3 - 1; esz[q] = s % 3 - 1;
+    }
+    // software pipeline over the active neighbour cells: next block row is in flight while the
+    // current one is accumulated in LDS
+    float vcur[NQ], vnext[NQ];
+    int spc = -1;
+    if (act) {
+        spc = __ffsll((long long)act) - 1;
+        act &= act - 1;
+        const int c = __builtin_amdgcn_readlane(cme, spc);
+        const float* brow = A.blocks[d] + ((int64_t)c * 27 + (26 - spc)) * T;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) vcur[q] = (lane + 64 * q < T) ? brow[lane + 64 * q] : 0.f;
+    }
+    while (spc >= 0) {
+        int spn = -1;
+        if (act) {
+            spn = __ffsll((long long)act) - 1;
+            act &= act - 1;
+            const int c = __builtin_amdgcn_readlane(cme, spn);
+            const float* brow = A.blocks[d] + ((int64_t)c * 27 + (26 - spn)) * T;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) vnext[q] = (lane + 64 * q < T) ? brow[lane + 64 * q] : 0.f;
         }
-        if (lane == 0) b_out[row] = bsum;
+        const int cx = ix + spc / 9 - 1, cy = iy + (spc / 3) % 3 - 1, cz = iz + spc % 3 - 1;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (lane + 64 * q < T) {
+                const int dd = edd[q];
+                const int rx = ((cx >> dd) + esx[q]) - (ix >> dd) + 2, ry = ((cy >> dd) + esy[q]) - (iy >> dd) + 2,
+                          rz = ((cz >> dd) + esz[q]) - (iz >> dd) + 2;
+                const int sl = dd * 125 + (rx * 5 + ry) * 5 + rz;
+                acc[sl] += vcur[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) vcur[q] = vnext[q];
+        spc = spn;
     }
 
-    int64_t wpos = COUNT_ONLY ? 0 : (int64_t)rowoff[row];
-    int cnt = 0;
+    // emission: structure comes from the count pass (no hashing here)
+    const int32_t* cm = A.colmap[d] + (int64_t)i * nslots;
+    int64_t wpos = (int64_t)rowoff[row];
     for (int t0 = 0; t0 < nslots; t0 += 64) {
         const int t = t0 + lane;
-        const int col = (t < nslots) ? slot_column(h, d, ix, iy, iz, t) : -1;
-        const bool keep = col > row;
+        const int col = (t < nslots) ? cm[t] : -1;
+        const bool keep = col >= 0;
         const unsigned long long mask = __ballot(keep);
-        if (!COUNT_ONLY && keep) {
+        if (keep) {
             const int64_t pos = wpos + 2 * __popcll(mask & ((1ull << lane) - 1ull));
             const float v = acc[t];
-            coo_keys[pos] = ((uint64_t)row << A.col_bits) | (uint64_t)col;
+            coo_keys[pos] = ((uint64_t)col << A.col_bits) | (uint64_t)row;
             coo_vals[pos] = v;
-            coo_keys[pos + 1] = ((uint64_t)col << A.col_bits) | (uint64_t)row;
+            coo_keys[pos + 1] = ((uint64_t)row << A.col_bits) | (uint64_t)col;
             coo_vals[pos + 1] = v;
         }
-        const int n = __popcll(mask);
-        wpos += 2 * n;
-        cnt += n;
+        wpos += 2 * __popcll(mask);
     }
     if (lane == 0) {
-        if (COUNT_ONLY) rowcount[row] = 2 * cnt + 1;
-        else {
-            coo_keys[wpos] = ((uint64_t)row << A.col_bits) | (uint64_t)row;
-            coo_vals[wpos] = acc[62] + A.reg;  // slot (dd=0, rel=(2,2,2))
-        }
+        coo_keys[wpos] = ((uint64_t)row << A.col_bits) | (uint64_t)row;
+        coo_vals[wpos] = acc[62] + A.reg;  // slot (dd=0, rel=(2,2,2))
     }
 }
 
@@ -191,6 +265,7 @@ static int fill_args(AsmArgs& A, const nksr_hier_t* h, const nksr_siteset_t* set
         A.blocks[d] = (float*)p; p += (n * 27 * T * sizeof(float) + 255) / 256 * 256;
         A.bvec[d] = (float*)p; p += (n * 27 * sizeof(float) + 255) / 256 * 256;
         A.nsites[d] = (int32_t*)p; p += (n * sizeof(int32_t) + 255) / 256 * 256;
+        A.colmap[d] = (int32_t*)p; p += (n * (size_t)(h->depth - d) * 125 * sizeof(int32_t) + 255) / 256 * 256;
     }
     return NKSR_OK;
 }
@@ -200,21 +275,20 @@ extern "C" size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h) {
     for (int d = 0; d < h->depth; ++d) {
         const size_t n = (size_t)h->lv[d].n, T = (size_t)(h->depth - d) * 27;
         tot += (n * 27 * T * sizeof(float) + 255) / 256 * 256 + (n * 27 * sizeof(float) + 255) / 256 * 256 +
-               (n * sizeof(int32_t) + 255) / 256 * 256;
+               (n * sizeof(int32_t) + 255) / 256 * 256 + (n * (size_t)(h->depth - d) * 125 * sizeof(int32_t) + 255) / 256 * 256;
     }
     return tot;
 }
 
-extern "C" int nksr_assemble_count(const nksr_hier_t* h, int32_t* rowcount, void* stream) {
+extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, void* stream) {
     AsmArgs A;
     int M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
     int cb = 1;
     while (((int64_t)1 << cb) < M) ++cb;
-    int rc = fill_args(A, h, nullptr, 0, 0.f, cb, nullptr);
+    int rc = fill_args(A, h, nullptr, 0, 0.f, cb, workspace);
     if (rc) return rc;
     if (A.M <= 0) return NKSR_OK;
-    hipLaunchKernelGGL((k_row_gather<true>), dim3(nksr_blocks(A.M, ASM_WAVES)), dim3(ASM_WAVES * 64), 0, (hipStream_t)stream, A,
-                       rowcount, (const int32_t*)nullptr, (uint64_t*)nullptr, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL(k_row_count, dim3(nksr_blocks(A.M, ASM_WAVES)), dim3(ASM_WAVES * 64), 0, (hipStream_t)stream, A, rowcount);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -227,19 +301,29 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
     if (rc) return rc;
     if (A.M <= 0) return NKSR_OK;
     hipStream_t st = (hipStream_t)stream;
+    const dim3 blk(ASM_WAVES * 64);
+    const size_t lds = (size_t)ASM_WAVES * NKSR_MAX_DEPTH * 125 * sizeof(float);
     for (int d = 0; d < h->depth; ++d) {
         const int n = h->lv[d].n;
         if (n <= 0) continue;
         const int T = (h->depth - d) * 27;
-        if (T > 128) return nksr_set_error(NKSR_ERR_ARG, "tree_depth - level > 4 not supported by the block kernel");
-        if (T > 64) hipLaunchKernelGGL((k_cell_blocks<true>), dim3(nksr_blocks(n, ASM_WAVES)), dim3(ASM_WAVES * 64), 0, st, A, d);
-        else hipLaunchKernelGGL((k_cell_blocks<false>), dim3(nksr_blocks(n, ASM_WAVES)), dim3(ASM_WAVES * 64), 0, st, A, d);
+        const dim3 grid(nksr_blocks(n, ASM_WAVES));
+        if (T > 128) hipLaunchKernelGGL((k_cell_blocks<3>), grid, blk, 0, st, A, d);
+        else if (T > 64) hipLaunchKernelGGL((k_cell_blocks<2>), grid, blk, 0, st, A, d);
+        else hipLaunchKernelGGL((k_cell_blocks<1>), grid, blk, 0, st, A, d);
         NKSR_CHECK_LAUNCH();
     }
-    size_t lds = (size_t)ASM_WAVES * NKSR_MAX_DEPTH * 125 * sizeof(float);
-    hipLaunchKernelGGL((k_row_gather<false>), dim3(nksr_blocks(A.M, ASM_WAVES)), dim3(ASM_WAVES * 64), lds, st, A,
-                       (int32_t*)nullptr, rowoff, coo_keys, coo_vals, b_out);
-    NKSR_CHECK_LAUNCH();
+    for (int d = 0; d < h->depth; ++d) {
+        const int n = h->lv[d].n;
+        if (n <= 0) continue;
+        const int T = (h->depth - d) * 27;
+        const int r0 = h->lv[d].offset, r1 = r0 + n;
+        const dim3 grid(nksr_blocks(n, ASM_WAVES));
+        if (T > 128) hipLaunchKernelGGL((k_row_fill<3>), grid, blk, lds, st, A, rowoff, coo_keys, coo_vals, b_out, r0, r1);
+        else if (T > 64) hipLaunchKernelGGL((k_row_fill<2>), grid, blk, lds, st, A, rowoff, coo_keys, coo_vals, b_out, r0, r1);
+        else hipLaunchKernelGGL((k_row_fill<1>), grid, blk, lds, st, A, rowoff, coo_keys, coo_vals, b_out, r0, r1);
+        NKSR_CHECK_LAUNCH();
+    }
     return NKSR_OK;
 }
 
@@ -247,11 +331,11 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
 __global__ void k_coo_rowptr(const uint64_t* __restrict__ keys, int64_t nnz, int M, int col_bits, int32_t* __restrict__ rowptr) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r > M) return;
-    uint64_t target = (uint64_t)r << col_bits;
+    const uint64_t target = (uint64_t)r, rmask = ((uint64_t)1 << col_bits) - 1;
     int64_t lo = 0, hi = nnz;
     while (lo < hi) {
         int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+        if ((keys[mid] & rmask) < target) lo = mid + 1; else hi = mid;
     }
     rowptr[r] = (int32_t)lo;
 }
@@ -261,8 +345,8 @@ __global__ void k_coo_cols(const uint64_t* __restrict__ keys, const float* __res
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nnz) return;
     uint64_t key = keys[k];
-    int col = (int)(key & (((uint64_t)1 << col_bits) - 1));
-    int row = (int)(key >> col_bits);
+    int row = (int)(key & (((uint64_t)1 << col_bits) - 1));
+    int col = (int)(key >> col_bits);
     // physical layout: 256-entry tiles, logical entry m of a tile is stored at 4*(m%64) + m/64, so a
     // wavefront's 16-byte loads deliver 64 CONSECUTIVE logical entries per vector component
     // (csrc/pcg.hip: x-gather instructions then touch few cache lines)

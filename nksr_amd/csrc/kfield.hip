@@ -15,52 +15,60 @@ struct MlpView {
     static constexpr int SIZE = H * K + H + H * H + H + K * H + K;
 };
 
-// phi = t + W3 relu(W2 relu(W1 t + b1) + b2) + b3 ; optional forward-mode tangents J[K][3]
+// phi = t + W3 relu(W2 relu(W1 t + b1) + b2) + b3 ; optional forward-mode tangents J[K][3].
+// The tangents are pushed through one spatial axis at a time (activation masks are kept), so only
+// 2 H extra registers are live instead of 6 H.
 template <int K, int H, bool JAC>
 __device__ __forceinline__ void mlp_residual(const MlpView<K, H>& m, const float t[K], const float Jt[K][3],
                                              float phi[K], float J[K][3]) {
     float h1[H], h2[H];
-    float d1[JAC ? H : 1][3], d2[JAC ? H : 1][3];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         float a = m.b1[h];
-        float da[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            float w = m.W1[h * K + k];
-            a = fmaf(w, t[k], a);
-            if (JAC) { da[0] = fmaf(w, Jt[k][0], da[0]); da[1] = fmaf(w, Jt[k][1], da[1]); da[2] = fmaf(w, Jt[k][2], da[2]); }
-        }
-        bool on = a > 0.f;
-        h1[h] = on ? a : 0.f;
-        if (JAC) { d1[h][0] = on ? da[0] : 0.f; d1[h][1] = on ? da[1] : 0.f; d1[h][2] = on ? da[2] : 0.f; }
+        for (int k = 0; k < K; ++k) a = fmaf(m.W1[h * K + k], t[k], a);
+        h1[h] = a > 0.f ? a : 0.f;
     }
 #pragma unroll
     for (int g = 0; g < H; ++g) {
         float a = m.b2[g];
-        float da[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int h = 0; h < H; ++h) {
-            float w = m.W2[g * H + h];
-            a = fmaf(w, h1[h], a);
-            if (JAC) { da[0] = fmaf(w, d1[h][0], da[0]); da[1] = fmaf(w, d1[h][1], da[1]); da[2] = fmaf(w, d1[h][2], da[2]); }
-        }
-        bool on = a > 0.f;
-        h2[g] = on ? a : 0.f;
-        if (JAC) { d2[g][0] = on ? da[0] : 0.f; d2[g][1] = on ? da[1] : 0.f; d2[g][2] = on ? da[2] : 0.f; }
+        for (int h = 0; h < H; ++h) a = fmaf(m.W2[g * H + h], h1[h], a);
+        h2[g] = a > 0.f ? a : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float a = m.b3[k];
-        float da[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < H; ++g) {
-            float w = m.W3[k * H + g];
-            a = fmaf(w, h2[g], a);
-            if (JAC) { da[0] = fmaf(w, d2[g][0], da[0]); da[1] = fmaf(w, d2[g][1], da[1]); da[2] = fmaf(w, d2[g][2], da[2]); }
-        }
+        for (int g = 0; g < H; ++g) a = fmaf(m.W3[k * H + g], h2[g], a);
         phi[k] = t[k] + a;
-        if (JAC) { J[k][0] = Jt[k][0] + da[0]; J[k][1] = Jt[k][1] + da[1]; J[k][2] = Jt[k][2] + da[2]; }
+    }
+    if (JAC) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            float d1[H], d2[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < K; ++k) a = fmaf(m.W1[h * K + k], Jt[k][ax], a);
+                d1[h] = h1[h] > 0.f ? a : 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < H; ++g) {
+                float a = 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) a = fmaf(m.W2[g * H + h], d1[h], a);
+                d2[g] = h2[g] > 0.f ? a : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float a = 0.f;
+#pragma unroll
+                for (int g = 0; g < H; ++g) a = fmaf(m.W3[k * H + g], d2[g], a);
+                J[k][ax] = Jt[k][ax] + a;
+            }
+        }
     }
 }
 

@@ -17,7 +17,10 @@ def occupied_voxels(xyz, voxel_size):
     return int(ops.sort_unique(keys).numel())
 
 
-def scale_for_detail_level(xyz, detail_level, model_voxel_size, iters=18):
+def scale_for_detail_level(xyz, detail_level, model_voxel_size, refine_iters=3):
+    """One radix sort at a fine probe resolution gives the occupied-voxel count at every
+    power-of-two multiple of it (Morton keys: coarser cell = key >> 3k); the target size is
+    bracketed, log-interpolated and sharpened by a few bisection steps."""
     detail_level = min(max(detail_level, 0.0), 1.0)
     target = 32.0 * (4.0 / 32.0) ** detail_level
     n = xyz.shape[0]
@@ -26,11 +29,26 @@ def scale_for_detail_level(xyz, detail_level, model_voxel_size, iters=18):
         return 1.0
     center = xyz.mean(0, keepdim=True)
     xc = (xyz - center).contiguous()     # keep |x / vs| small while probing tiny voxels
-    lo, hi = ext / 2048.0, ext / 2.0      # voxel-size bracket: ppv is monotone in the voxel size
-    for _ in range(iters):
+    vs0 = ext / 4096.0
+    keys = torch.empty(n, dtype=torch.int64, device=xyz.device)
+    call('nksr_point_keys', ptr(xc), n, inv_w0_f32(vs0), ptr(keys), stream())
+    ks = ops.sort_keys(keys)
+    counts = []
+    for k in range(12):
+        sh = ks >> (3 * k)
+        counts.append(1 + int((sh[1:] != sh[:-1]).sum().item()))
+    ppv = [n / c for c in counts]        # monotone non-decreasing in k
+    lo, hi = vs0, vs0 * 2 ** 11
+    for k in range(11):
+        if ppv[k] < target <= ppv[k + 1]:
+            lo, hi = vs0 * 2 ** k, vs0 * 2 ** (k + 1)
+            break
+    else:
+        if target <= ppv[0]:
+            return float(model_voxel_size) / vs0
+    for _ in range(refine_iters):
         mid = (lo * hi) ** 0.5
-        ppv = n / max(occupied_voxels(xc, mid), 1)
-        if ppv < target:
+        if n / max(occupied_voxels(xc, mid), 1) < target:
             lo = mid
         else:
             hi = mid

@@ -127,7 +127,8 @@ class KernelField(BaseField):
             nsets += 1
         # per-row structural counts -> exclusive scan -> COO offsets (no atomics, deterministic)
         rowcount = torch.zeros(M + 1, dtype=torch.int32, device=dev)
-        call('nksr_assemble_count', C.byref(self._hier), ptr(rowcount), stream())
+        ws = torch.empty(int(_lib.lib.nksr_assemble_workspace_bytes(C.byref(self._hier))), dtype=torch.uint8, device=dev)
+        call('nksr_assemble_count', C.byref(self._hier), ptr(ws), ptr(rowcount), stream())
         rowoff = ops.exclusive_sum_i32(rowcount)
         nnz = int(rowoff[M].item())
         if nnz <= 0 or nnz >= 2 ** 31 - 8:
@@ -136,10 +137,9 @@ class KernelField(BaseField):
         coo_k = torch.empty(nnz, dtype=torch.int64, device=dev)
         coo_v = torch.empty(nnz, dtype=torch.float32, device=dev)
         b = torch.empty(M, dtype=torch.float32, device=dev)
-        ws = torch.empty(int(_lib.lib.nksr_assemble_workspace_bytes(C.byref(self._hier))), dtype=torch.uint8, device=dev)
         call('nksr_assemble', C.byref(self._hier), sets, nsets, float(reg_weight), col_bits, ptr(ws), ptr(rowoff), ptr(coo_k),
              ptr(coo_v), ptr(b), stream())
-        ks, vs = ops.sort_pairs(coo_k, coo_v.view(torch.int32), end_bit=2 * col_bits)
+        ks, vs = ops.sort_pairs(coo_k, coo_v.view(torch.int32), end_bit=col_bits)   # stable, row bits only
         del coo_k, coo_v, ws
         # physical (tile-interleaved, zero-padded) CSR arrays for the streaming SpMV
         npad = (nnz + 4095) // 4096 * 4096
