@@ -13,7 +13,9 @@ the topology rule is explicit and checkable:
     agree on every shared face and the extracted surface is watertight.
   * segments are directed (entry edge -> exit edge of the run) which orients every
     loop so that triangle normals point from inside (f>0) to outside.
-  * each loop is rotated to start at its smallest edge id and fan-triangulated.
+  * each loop is fan-triangulated from the smallest edge id whose fan has no diagonal joining
+    two edges of one cube face (such a diagonal would lie IN that face and be shared with the
+    neighbouring cell's triangles: a non-manifold edge); such a start always exists.
 """
 import numpy as np
 
@@ -96,12 +98,28 @@ def case_loops(config):
     return loops
 
 
+def edge_faces(e):
+    axis, r = divmod(e, 4)
+    others = [a for a in range(3) if a != axis]
+    return {(others[0], r >> 1), (others[1], r & 1)}
+
+
+def fan_start(loop):
+    """Rotation (as index into loop) of the canonical fan start."""
+    n = len(loop)
+    for start in sorted(range(n), key=lambda i: loop[i]):
+        l = loop[start:] + loop[:start]
+        if not any(edge_faces(l[0]) & edge_faces(l[i]) for i in range(2, n - 1)):
+            return start
+    raise AssertionError('no manifold fan for loop %s' % (loop,))
+
+
 def build_tables():
     tris = []
     for config in range(256):
         t = []
         for loop in case_loops(config):
-            k = loop.index(min(loop))
+            k = fan_start(loop)
             loop = loop[k:] + loop[:k]
             for i in range(1, len(loop) - 1):
                 t.append((loop[0], loop[i], loop[i + 1]))

@@ -211,3 +211,38 @@ def test_end_to_end_mesh(kind, vs):
             assert (cnt == 2).all(), 'mesh is not closed'
             V, E, F = len(gv), len(cnt), len(gf)
             assert V - E + F == (2 if kind == 'sphere' else 0)
+
+
+@pytest.mark.parametrize('name', ['bunny_2k', 'sphere_3k'])
+def test_against_committed_golden(name):
+    """HIP path vs the committed oracle fixtures (tests/golden, oracle/make_golden.py)."""
+    import os
+    import nksr_amd
+    from nksr_amd import utils
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    g = np.load(os.path.join(gold, name + '_golden.npz'))
+    if name == 'bunny_2k':
+        d = np.load(os.path.join(gold, 'bunny_2k.npz'))
+        xyz, nrm = d['xyz'], d['normal']
+    else:
+        xyz, nrm = utils.synth_sphere(3000, 0.45, 0.005, seed=0)
+    vs = float(g['voxel_size'])
+    rec = nksr_amd.Reconstructor(_dev())
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(_dev()), torch.from_numpy(nrm).to(_dev()), voxel_size=vs, solver_tol=1e-6)
+    for d in range(4):
+        assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), g['keys_%d' % d])      # voxel sets: exact
+    amax = abs(g['alpha']).max()
+    np.testing.assert_allclose(fld.alpha.cpu().numpy(), g['alpha'], rtol=0, atol=2e-3 * amax)
+    np.testing.assert_allclose(fld.rhs.cpu().numpy(), g['b'], rtol=1e-4, atol=1e-5 * abs(g['b']).max())
+    np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), g['A_diag'], rtol=1e-4)
+    res = fld.evaluate_f(torch.from_numpy(xyz).to(_dev()), grad=True)
+    np.testing.assert_allclose(res.value.cpu().numpy(), g['f_at_points'], rtol=0, atol=2e-3 * amax)
+    scale = 0.1 / vs
+    np.testing.assert_allclose(res.gradient.cpu().numpy() / scale, g['grad_at_points'], rtol=0,
+                               atol=2e-3 * abs(g['grad_at_points']).max())
+    mesh = fld.extract_dual_mesh(mise_iter=0)
+    gf, gv = mesh.f.cpu().numpy(), mesh.v.cpu().numpy() * scale
+    if gf.shape == g['mesh_f_0'].shape and np.array_equal(gf, g['mesh_f_0']):                # topology: exact
+        np.testing.assert_allclose(gv, g['mesh_v_0'], rtol=0, atol=1e-3 * 0.1)
+    else:
+        assert abs(len(gf) - len(g['mesh_f_0'])) <= 0.01 * len(g['mesh_f_0'])
