@@ -15,62 +15,56 @@ struct MlpView {
     static constexpr int SIZE = H * K + H + H * H + H + K * H + K;
 };
 
-// phi = t + W3 relu(W2 relu(W1 t + b1) + b2) + b3 ; optional forward-mode tangents J[K][3].
-// The tangents are pushed through one spatial axis at a time (activation masks are kept), so only
-// 2 H extra registers are live instead of 6 H.
+// phi = t + W3 relu(W2 relu(W1 t + b1) + b2) + b3 ; optional forward-mode tangents J[K][3]
 template <int K, int H, bool JAC>
 __device__ __forceinline__ void mlp_residual(const MlpView<K, H>& m, const float t[K], const float Jt[K][3],
                                              float phi[K], float J[K][3]) {
     float h1[H], h2[H];
+    float d1[JAC ? H : 1][3], d2[JAC ? H : 1][3];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         float a = m.b1[h];
+        float da[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < K; ++k) a = fmaf(m.W1[h * K + k], t[k], a);
-        h1[h] = a > 0.f ? a : 0.f;
+        for (int k = 0; k < K; ++k) {
+            float w = m.W1[h * K + k];
+            a = fmaf(w, t[k], a);
+            if (JAC) { da[0] = fmaf(w, Jt[k][0], da[0]); da[1] = fmaf(w, Jt[k][1], da[1]); da[2] = fmaf(w, Jt[k][2], da[2]); }
+        }
+        bool on = a > 0.f;
+        h1[h] = on ? a : 0.f;
+        if (JAC) { d1[h][0] = on ? da[0] : 0.f; d1[h][1] = on ? da[1] : 0.f; d1[h][2] = on ? da[2] : 0.f; }
     }
 #pragma unroll
     for (int g = 0; g < H; ++g) {
         float a = m.b2[g];
+        float da[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int h = 0; h < H; ++h) a = fmaf(m.W2[g * H + h], h1[h], a);
-        h2[g] = a > 0.f ? a : 0.f;
+        for (int h = 0; h < H; ++h) {
+            float w = m.W2[g * H + h];
+            a = fmaf(w, h1[h], a);
+            if (JAC) { da[0] = fmaf(w, d1[h][0], da[0]); da[1] = fmaf(w, d1[h][1], da[1]); da[2] = fmaf(w, d1[h][2], da[2]); }
+        }
+        bool on = a > 0.f;
+        h2[g] = on ? a : 0.f;
+        if (JAC) { d2[g][0] = on ? da[0] : 0.f; d2[g][1] = on ? da[1] : 0.f; d2[g][2] = on ? da[2] : 0.f; }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         float a = m.b3[k];
+        float da[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int g = 0; g < H; ++g) a = fmaf(m.W3[k * H + g], h2[g], a);
-        phi[k] = t[k] + a;
-    }
-    if (JAC) {
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) {
-            float d1[H], d2[H];
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                float a = 0.f;
-#pragma unroll
-                for (int k = 0; k < K; ++k) a = fmaf(m.W1[h * K + k], Jt[k][ax], a);
-                d1[h] = h1[h] > 0.f ? a : 0.f;
-            }
-#pragma unroll
-            for (int g = 0; g < H; ++g) {
-                float a = 0.f;
-#pragma unroll
-                for (int h = 0; h < H; ++h) a = fmaf(m.W2[g * H + h], d1[h], a);
-                d2[g] = h2[g] > 0.f ? a : 0.f;
-            }
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float a = 0.f;
-#pragma unroll
-                for (int g = 0; g < H; ++g) a = fmaf(m.W3[k * H + g], d2[g], a);
-                J[k][ax] = Jt[k][ax] + a;
-            }
+        for (int g = 0; g < H; ++g) {
+            float w = m.W3[k * H + g];
+            a = fmaf(w, h2[g], a);
+            if (JAC) { da[0] = fmaf(w, d2[g][0], da[0]); da[1] = fmaf(w, d2[g][1], da[1]); da[2] = fmaf(w, d2[g][2], da[2]); }
         }
+        phi[k] = t[k] + a;
+        if (JAC) { J[k][0] = Jt[k][0] + da[0]; J[k][1] = Jt[k][1] + da[1]; J[k][2] = Jt[k][2] + da[2]; }
     }
 }
+
+__device__ __forceinline__ float sel3(const float w[3], int i) { return i == 0 ? w[0] : (i == 1 ? w[1] : w[2]); }
 
 struct SiteCell {
     int cell;      // voxel index of the containing cell or -1
@@ -144,7 +138,7 @@ __global__ void k_voxel_psi(const float* __restrict__ feat, int n, const float* 
 // ---- dense-slot kernel rows -------------------------------------------------------------------
 // grid.y = level; one thread per site.
 template <int K, int H, bool GRAD, bool JAC>
-__global__ void k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float* __restrict__ val,
+__global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float* __restrict__ val,
                               float* __restrict__ dval) {
     const int d = blockIdx.y, L = hier.depth;
     const nksr_level_t& lv = hier.lv[d];
@@ -172,9 +166,9 @@ __global__ void k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, i
 #pragma unroll
     for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
     const int32_t* nb = lv.nbr + (int64_t)sc.cell * 27;
-    for (int s = 0; s < 27; ++s) {
+    for (int s = 0; s < 27; ++s) {   // rolled: weights picked with selects (runtime array indexing would go to scratch)
         int j = nb[s];
-        int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
+        const int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
         float v = 0.f, g[3] = {0.f, 0.f, 0.f};
         if (j >= 0) {
             const float* ps = lv.psi + (int64_t)j * K;
@@ -185,13 +179,13 @@ __global__ void k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, i
                 dot = fmaf(phi[k], pk, dot);
                 if (JAC) { jd[0] = fmaf(J[k][0], pk, jd[0]); jd[1] = fmaf(J[k][1], pk, jd[1]); jd[2] = fmaf(J[k][2], pk, jd[2]); }
             }
-            float bx = bw[0][ox], by = bw[1][oy], bz = bw[2][oz];
+            float bx = sel3(bw[0], ox), by = sel3(bw[1], oy), bz = sel3(bw[2], oz);
             float B = bx * by * bz;
             v = dot * B;
             if (GRAD) {
-                g[0] = dot * (bd[0][ox] * by * bz * inv_w);
-                g[1] = dot * (bx * bd[1][oy] * bz * inv_w);
-                g[2] = dot * (bx * by * bd[2][oz] * inv_w);
+                g[0] = dot * (sel3(bd[0], ox) * by * bz * inv_w);
+                g[1] = dot * (bx * sel3(bd[1], oy) * bz * inv_w);
+                g[2] = dot * (bx * by * sel3(bd[2], oz) * inv_w);
                 if (JAC) { g[0] = fmaf(jd[0], B, g[0]); g[1] = fmaf(jd[1], B, g[1]); g[2] = fmaf(jd[2], B, g[2]); }
             }
         }
@@ -205,7 +199,7 @@ __global__ void k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, i
 
 // ---- f(x) = sum_d sum_s alpha_j K_d(x, c_j) ---------------------------------------------------
 template <int K, int H, bool GRAD, bool JAC>
-__global__ void k_evaluate_f(nksr_hier_t hier, const float* __restrict__ alpha, const float* __restrict__ xyz,
+__global__ void __launch_bounds__(128) k_evaluate_f(nksr_hier_t hier, const float* __restrict__ alpha, const float* __restrict__ xyz,
                              int64_t n, float* __restrict__ fout, float* __restrict__ gout) {
     extern __shared__ __attribute__((aligned(16))) float wall[];
     const int L = hier.depth;
@@ -234,7 +228,7 @@ __global__ void k_evaluate_f(nksr_hier_t hier, const float* __restrict__ alpha, 
         for (int s = 0; s < 27; ++s) {
             int j = nb[s];
             if (j < 0) continue;
-            int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
+            const int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
             const float* ps = lv.psi + (int64_t)j * K;
             float dot = 0.f, jd[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -244,12 +238,12 @@ __global__ void k_evaluate_f(nksr_hier_t hier, const float* __restrict__ alpha, 
                 if (JAC) { jd[0] = fmaf(J[k][0], pk, jd[0]); jd[1] = fmaf(J[k][1], pk, jd[1]); jd[2] = fmaf(J[k][2], pk, jd[2]); }
             }
             float a = alpha[lv.offset + j];
-            float bx = bw[0][ox], by = bw[1][oy], bz = bw[2][oz];
+            float bx = sel3(bw[0], ox), by = sel3(bw[1], oy), bz = sel3(bw[2], oz);
             float B = bx * by * bz;
             fl = fmaf(a, dot * B, fl);
             if (GRAD) {
-                float g0 = dot * (bd[0][ox] * by * bz * inv_w), g1 = dot * (bx * bd[1][oy] * bz * inv_w),
-                      g2 = dot * (bx * by * bd[2][oz] * inv_w);
+                float g0 = dot * (sel3(bd[0], ox) * by * bz * inv_w), g1 = dot * (bx * sel3(bd[1], oy) * bz * inv_w),
+                      g2 = dot * (bx * by * sel3(bd[2], oz) * inv_w);
                 if (JAC) { g0 = fmaf(jd[0], B, g0); g1 = fmaf(jd[1], B, g1); g2 = fmaf(jd[2], B, g2); }
                 gl[0] = fmaf(a, g0, gl[0]); gl[1] = fmaf(a, g1, gl[1]); gl[2] = fmaf(a, g2, gl[2]);
             }
