@@ -88,15 +88,35 @@ def main():
     from nksr_amd import solver, utils
 
     extent = (40.0, 40.0, 10.0)
-    xyz_np, nrm_np = utils.synth_scene(args.points, seed=rank, extent=extent, noise=0.01, origin=(rank * extent[0], 0.0, 0.0))
-    xyz = torch.from_numpy(xyz_np).to(dev)
-    nrm = torch.from_numpy(nrm_np).to(dev)
     rec = nksr_amd.Reconstructor(dev)
     rec.sync_timing = True
     stage_acc = {}
+    if world == 1:
+        xyz_np, nrm_np = utils.synth_scene(args.points, seed=0, extent=extent, noise=0.01)
+        xyz = torch.from_numpy(xyz_np).to(dev)
+        nrm = torch.from_numpy(nrm_np).to(dev)
+        chunk_size = None
+    else:
+        # N tiles side by side along x, every rank holds the full cloud (reference semantics: one
+        # reconstruct() call over the scene); chunk_size = tile width => one chunk per rank.  The
+        # detail_level scale of the N=1 run is applied up front because chunk mode takes a pre-scaled
+        # cloud (NKSR-USAGE.md:137).
+        tiles = [utils.synth_scene(args.points, seed=r, extent=extent, noise=0.01, origin=(r * extent[0], 0.0, 0.0))
+                 for r in range(world)]
+        from nksr_amd.density import scale_for_detail_level
+        scale = scale_for_detail_level(torch.from_numpy(tiles[0][0]).to(dev), args.detail_level, rec.hparams.voxel_size)
+        xyz_np = np.concatenate([t[0] for t in tiles]) * np.float32(scale)
+        xyz_np[:, 0] -= xyz_np[:, 0].min()
+        nrm_np = np.concatenate([t[1] for t in tiles])
+        xyz = torch.from_numpy(xyz_np.astype(np.float32)).to(dev)
+        nrm = torch.from_numpy(nrm_np).to(dev)
+        chunk_size = float(xyz_np[:, 0].max()) / world + 1e-3
 
     def step():
-        field = rec.reconstruct(xyz, nrm, detail_level=args.detail_level)
+        if chunk_size is None:
+            field = rec.reconstruct(xyz, nrm, detail_level=args.detail_level)
+        else:
+            field = rec.reconstruct(xyz, nrm, detail_level=None, chunk_size=chunk_size)
         t0 = time.perf_counter()
         mesh = field.extract_dual_mesh(mise_iter=args.mise_iter)
         torch.cuda.synchronize()
@@ -127,7 +147,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    info = field.solve_info
+    info = field.solve_info if world == 1 else [f for f in field.fields.values() if f.solve_info][0].solve_info
     M, nnz = info['M'], info['nnz']
     b_spmv = 8.0 * nnz + 12.0 * M + 4.0
     avg_s = (spmv_ms / max(spmv_launches, 1)) * 1e-3
@@ -143,7 +163,8 @@ def main():
                    'points_per_gpu': args.points, 'tree_depth': rec.hparams.tree_depth, 'kernel_dim': rec.hparams.kernel_dim,
                    'unknowns_M': M, 'nnz_A': nnz, 'pcg_iters': info['iters'], 'pcg_rel_residual': info['rel_residual'],
                    'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]),
-                   'global_scale': field.scale},
+                   'global_scale': field.scale if world == 1 else scale,
+                   'parallelism': 'none' if world == 1 else 'chunks sharded 1/rank, all_gather of solved fields before meshing, mesh gather'},
         'roofline': {'bound': 'hbm', 'kernel': 'k_spmv<true> (CSR SpMV + fused p.Ap partial dot)',
                      'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
                      'traffic': load_traffic(), 'bytes_per_launch': b_spmv, 'avg_launch_us': avg_s * 1e6,

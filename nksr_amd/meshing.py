@@ -28,18 +28,29 @@ def _cell_vertices(cell_keys_raw):
 
 
 def extract_dual_mesh(field, mise_iter=0, grid_upsample=1, max_points=-1):
+    res = _extract(field, mise_iter, grid_upsample, max_points)
+    if hasattr(field, 'finalize_mesh'):       # distributed fields gather + stitch the pieces (collective)
+        res = field.finalize_mesh(res)
+    return res
+
+
+def _extract(field, mise_iter, grid_upsample, max_points):
     svh = field.svh
     dev = svh.device
     g0 = svh.level(0)
     w0 = svh.voxel_size
     U = int(grid_upsample)
     empty = MeshingResult(torch.zeros((0, 3), dtype=torch.float32, device=dev), torch.zeros((0, 3), dtype=torch.int64, device=dev))
+    empty.edge_vkey = torch.zeros(0, dtype=torch.int64, device=dev)
+    empty.edge_axis = torch.zeros(0, dtype=torch.int8, device=dev)
     if g0.num_voxels == 0:
         return empty
     batch = max_points if (max_points is not None and max_points > 0) else (1 << 22)
 
     flags = torch.empty(g0.num_voxels, dtype=torch.int32, device=dev)
     call('nksr_base_cell_flags', ptr(g0.nbr), g0.num_voxels, ptr(flags), stream())
+    if hasattr(field, 'base_cell_mask'):      # chunked / distributed fields: only cells this rank owns
+        flags = (flags * field.base_cell_mask(g0.ijk).to(torch.int32)).contiguous()
     sel = ops.compact(flags)
     if sel.numel() == 0:
         return empty
@@ -79,6 +90,9 @@ def extract_dual_mesh(field, mise_iter=0, grid_upsample=1, max_points=-1):
     verts = torch.empty((ne, 3), dtype=torch.float32, device=dev)
     call('nksr_mc_vertices', ptr(uek), ne, ptr(vkeys), nv, ptr(pos), ptr(f), float(h), ptr(verts), stream())
 
+    # canonical identity of every mesh vertex: (lattice key of the lower end point, axis)
+    ev = torch.div(uek, 3, rounding_mode='floor')
+    edge_vkey, edge_axis = vkeys[ev], (uek - ev * 3).to(torch.int8)
     keep_v = field.mask_vertices(verts)
     if keep_v is not None and not bool(keep_v.all()):
         keep_f = keep_v[faces.long()].all(1)
@@ -88,10 +102,13 @@ def extract_dual_mesh(field, mise_iter=0, grid_upsample=1, max_points=-1):
         remap = ops.exclusive_sum_i32(used)
         vsel = ops.compact(used)
         verts = verts[vsel.long()]
+        edge_vkey, edge_axis = edge_vkey[vsel.long()], edge_axis[vsel.long()]
         faces = remap[faces.long()]
 
     v_world = verts / field.scale if field.scale != 1.0 else verts
     colors = None
     if field.texture_field is not None:
         colors = field.texture_field.evaluate_color(v_world)
-    return MeshingResult(v_world, faces.long(), colors)
+    res = MeshingResult(v_world, faces.long(), colors)
+    res.edge_vkey, res.edge_axis, res.lattice_h = edge_vkey, edge_axis, h
+    return res

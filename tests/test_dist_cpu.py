@@ -1,0 +1,88 @@
+"""world_size-2 gloo tests (CPU) of the multi-rank protocol: chunk partition, payload exchange,
+mesh gather + seam merge (nksr_amd/dist.py).  The HIP kernels are not involved -- the GPU side of
+the chunked path is covered by tests/test_gpu_chunking.py."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nksr_amd import dist as D
+    try:
+        assert D.world() == (rank, world)
+        # --- payload exchange: every rank ends up with every chunk, contents intact
+        owner = D.partition_chunks(5, world, [50, 10, 40, 30, 20])
+        local = {}
+        for c in range(5):
+            if owner[c] == rank:
+                g = torch.Generator().manual_seed(c)
+                local[c] = (torch.randint(0, 1 << 40, (100 + 7 * c,), generator=g, dtype=torch.int64),
+                            torch.randn(33 * (c + 1), generator=g))
+        got = D.exchange_payloads(local, list(range(5)))
+        for c in range(5):
+            g = torch.Generator().manual_seed(c)
+            assert torch.equal(got[c][0], torch.randint(0, 1 << 40, (100 + 7 * c,), generator=g, dtype=torch.int64))
+            assert torch.equal(got[c][1], torch.randn(33 * (c + 1), generator=g))
+        # --- mesh gather + seam merge: two quads sharing an edge, one per rank
+        if rank == 0:
+            v = torch.tensor([[0., 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])
+            key = torch.tensor([10, 11, 12, 13])
+        else:
+            v = torch.tensor([[1., 0, 0], [2, 0, 0], [2, 1, 0], [1, 1, 0]])
+            key = torch.tensor([11, 21, 22, 12])
+        f = torch.tensor([[0, 1, 2], [0, 2, 3]])
+        ax = torch.zeros(4, dtype=torch.int8)
+        mv, mf = D.gather_meshes(v, f, key, ax)
+        assert mv.shape[0] == 6 and mf.shape[0] == 4
+        mfn = mf.numpy()
+        e = np.sort(np.concatenate([mfn[:, [0, 1]], mfn[:, [1, 2]], mfn[:, [2, 0]]]), 1)
+        _, cnt = np.unique(e, axis=0, return_counts=True)
+        assert (cnt == 2).sum() == 3          # two diagonals + the stitched seam edge
+        # --- empty contribution from a rank still completes the collective
+        z = D.all_gather_variable(torch.arange(3 * rank, dtype=torch.int64))
+        assert [t.numel() for t in z] == [0, 3]
+        q.put((rank, 'ok'))
+    except Exception as e:  # surface the failure in the parent
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_protocol_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def test_partition_is_balanced_and_deterministic():
+    from nksr_amd import dist as D
+    w = [100, 90, 80, 10, 10, 10, 5, 5]
+    o = D.partition_chunks(len(w), 4, w)
+    assert o == D.partition_chunks(len(w), 4, w)
+    load = [sum(w[c] for c in range(len(w)) if o[c] == r) for r in range(4)]
+    assert max(load) <= 100 and min(load) >= 30
+    assert D.partition_chunks(3, 8) == [0, 1, 2]          # more ranks than chunks: idle ranks
+    assert D.merge_meshes([(torch.zeros((0, 3)), torch.zeros((0, 3), dtype=torch.int64), torch.zeros(0, dtype=torch.int64),
+                            torch.zeros(0, dtype=torch.int8))])[0].shape[0] == 0
