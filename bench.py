@@ -42,7 +42,7 @@ def load_traffic():
     return best
 
 
-def cpu_baseline(xyz, nrm, scale, n_sample, mise_iter):
+def cpu_baseline(xyz, nrm, scale, n_sample, mise_iter, net_params=None):
     """Oracle pipeline on a spatial crop holding ~n_sample points (same density as the GPU run)."""
     from oracle import pipeline
     c = xyz[0]
@@ -52,7 +52,7 @@ def cpu_baseline(xyz, nrm, scale, n_sample, mise_iter):
     ns = nrm[idx]
     t0 = time.perf_counter()
     timing = {}
-    fld = pipeline.reconstruct(xs, ns, tol=1e-5, timing=timing)
+    fld = pipeline.reconstruct(xs, ns, tol=1e-5, timing=timing, net_params=net_params)
     v, f = pipeline.extract_dual_mesh(fld, mise_iter=mise_iter)
     dt = time.perf_counter() - t0
     return {'value': len(idx) / dt, 'unit': 'points/s', 'cores': 1, 'kind': 'port',
@@ -80,7 +80,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        # backend "nccl" is RCCL on ROCm; NKSR_DIST_BACKEND=gloo lets two ranks share one GPU in tests
+        dist.init_process_group(os.environ.get('NKSR_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
@@ -172,7 +174,9 @@ def main():
         'stages_s_per_step': {k: v / args.steps for k, v in sorted(stage_acc.items())},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(xyz_np, nrm_np, field.scale, args.cpu_sample, args.mise_iter)
+        from oracle import network as onet
+        out['cpu_baseline'] = cpu_baseline(xyz_np, nrm_np, field.scale, args.cpu_sample, args.mise_iter,
+                                           onet.export_params(rec.network))
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:

@@ -86,6 +86,27 @@ int nksr_splat_trilinear(const float* xyz_sorted, const float* feat_sorted, int 
                          const int32_t* end, const int32_t* nbr, const int32_t* ijk, int32_t n, float inv_w,
                          float* out, float* wsum_out, void* stream);
 
+/* ---- sparse feature-hierarchy network (network.encoder / network.unet, models/nksr_net.py:73-78;
+ *      csrc/nn.hip).  C = unet.f_maps = 32 (configs/default/train.yaml:17-18). --------------------- */
+/* per-point MLP on [local cell coordinate - 1/2 (3), orientation feature (3)]:  W1 [C,6], W2 [C,C] */
+int nksr_point_mlp(const float* xyz, const float* feat, int64_t n, float inv_w0, int C, const float* W1,
+                   const float* b1, const float* W2, const float* b2, float* out, void* stream);
+/* trilinear splat-MEAN of C-channel point features onto one level (points Morton-sorted) */
+int nksr_splat_mean(const float* xyz_sorted, const float* feat_sorted, int C, const int32_t* start,
+                    const int32_t* end, const int32_t* nbr, const int32_t* ijk, int32_t n, float inv_w, float* out,
+                    void* stream);
+/* 3x3x3 submanifold sparse convolution on the fp32 matrix cores: out = act(b + sum_s W[s]^T in[nbr[:,s]]
+ * (+ residual)),  W [27, C, C] */
+int nksr_sparse_conv3(const float* in, const int32_t* nbr, int32_t n, int C, const float* W, const float* bias,
+                      const float* residual, int relu, float* out, void* stream);
+/* mean over the children (contiguous Morton range start/end in the finer level) of every voxel */
+int nksr_pool_children(const float* child_feat, const int32_t* start, const int32_t* end, int32_t n_parent, int C,
+                       float* out, void* stream);
+/* out[i] = (idx[i] >= 0 ? src[idx[i]] : 0) (+ add[i]) -- hierarchy transfer / parent->child up-sampling */
+int nksr_gather_rows(const float* src, const int32_t* idx, int64_t n, int C, const float* add, float* out, void* stream);
+/* per-voxel linear head: out [n, Cout] = in [n, 32] W^T + b */
+int nksr_linear(const float* in, int64_t n, int Cin, const float* W, const float* b, int Cout, float* out, void* stream);
+
 /* ---- neural kernel (KernelField, models/nksr_net.py:91-96) --------------------------- */
 int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden, const float* mlp, float* psi_out, void* stream);
 /* Dense-slot kernel rows at arbitrary sites.  val [n, L, 27]; dval [n, 3, L, 27] (may be

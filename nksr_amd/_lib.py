@@ -65,6 +65,12 @@ _PROTOS = {
     'nksr_site_ranges': [_vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp],
     'nksr_sorted_lookup': [_vp, _i64, _vp, _i64, _vp, _vp],
     'nksr_splat_trilinear': [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp],
+    'nksr_point_mlp': [_vp, _vp, _i64, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
+    'nksr_splat_mean': [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp],
+    'nksr_sparse_conv3': [_vp, _vp, _i32, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp],
+    'nksr_pool_children': [_vp, _vp, _vp, _i32, C.c_int, _vp, _vp],
+    'nksr_gather_rows': [_vp, _vp, _i64, C.c_int, _vp, _vp, _vp],
+    'nksr_linear': [_vp, _i64, C.c_int, _vp, _vp, C.c_int, _vp, _vp],
     'nksr_voxel_psi': [_vp, _i32, C.c_int, C.c_int, _vp, _vp, _vp],
     'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _vp, _vp, _vp],
     'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, _vp, _vp, _vp],

@@ -37,7 +37,7 @@ _DEFAULT = {
     'adaptive_depth': 1, 'unet': {'f_maps': 32}, 'udf': {'enabled': False},
     'interpolator': {'n_hidden': 2, 'hidden_dim': 16},
     'solver': {'pos_weight': 10000.0, 'normal_weight': 10000.0},
-    'seed': 0, 'interpolator_init_scale': 0.0,
+    'seed': 0, 'interpolator_init_scale': 0.0, 'head_init_scale': 0.0,
 }
 
 _PRESETS = {

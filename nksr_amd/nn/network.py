@@ -6,25 +6,29 @@ Reference interface (call sites): ``NKSRNetwork(hparams)`` is an ``nn.Module`` w
 ``unet(feat, enc_svh, adaptive_depth=, gt_decoder_svh=) -> (feat, dec_svh, udf_svh)`` :74-78
 with ``feat.basis_features[d]``, ``feat.normal_features[d]``, ``feat.structure_features``,
 ``feat.udf_features`` (:94,101,118,128,136-138).  Hyper-parameters by name:
-configs/default/train.yaml:9-29.
+configs/default/train.yaml:9-29 (unet.f_maps 32, kernel_dim, tree_depth, adaptive_depth).
 
-The pretrained weights are fetched from the network at run time by the reference
-(models/nksr_net.py:36-38) and are unavailable offline, so the default initialisation here is
-*analytic + seeded*: heads are residual around quantities that make an untrained network a
-sound (non-learned) kernel solver --
-  * basis features   = e_0 + unet head         (pure quadratic B-spline kernel when head = 0)
-  * normal features  = normalize(splat(input normals) + unet head)
-  * structure        = the containing cell + 26 neighbours of every point exist
-A user-supplied ``state_dict`` replaces the seeded part.
+Architecture (the reference's layer list lives in the absent wheel):
+  encoder   per-point MLP on (local cell coordinate, orientation) -> trilinear splat-mean onto
+            the finest level of the encoder hierarchy                        [C = f_maps channels]
+  down      x_0 = relu(conv3(e_0)),  x_d = relu(conv3(mean-pool of children of x_{d-1}))
+  up        top-down over the decoder hierarchy: y_d = relu(conv3(parent(y_{d+1}) + transfer(x_d)));
+            a 3-way structure head (0 not-exist / 1 exist-stop / 2 exist-continue, the classes of
+            models/loss.py:155-160) decides which candidate voxels exist and which are subdivided
+  heads     basis = e_0 + W_b y,  normal = normalize(splat(input normals) + W_n y),  udf = W_u y
+All convolutions are 3x3x3 submanifold sparse convolutions on the fp32 matrix cores
+(csrc/nn.hip).  The pretrained weights are fetched from the network at run time by the reference
+(models/nksr_net.py:36-38) and are unavailable offline: the default initialisation is analytic +
+seeded -- trunk weights are He-random (seeded), the residual heads are zero and the structure head
+is biased to "exist-continue", which makes an untrained network a sound non-learned kernel solver.
+A user-supplied ``state_dict`` replaces all of it.
 """
-import ctypes as C
-
 import torch
 import torch.nn as nn
 
 from .. import ops
 from .._lib import call, ptr, stream
-from ..svh import SparseFeatureHierarchy
+from ..svh import SparseFeatureHierarchy, SparseGrid
 
 
 class Interpolator(nn.Module):
@@ -36,7 +40,6 @@ class Interpolator(nn.Module):
             raise RuntimeError('interpolator.n_hidden must be 2 (configs/default/train.yaml:24)')
         self.kernel_dim, self.hidden_dim = int(kernel_dim), int(hidden_dim)
         K, H = self.kernel_dim, self.hidden_dim
-
         self.W1 = nn.Parameter(torch.randn(H, K, generator=generator) / K ** 0.5)
         self.b1 = nn.Parameter(torch.zeros(H))
         self.W2 = nn.Parameter(torch.randn(H, H, generator=generator) / H ** 0.5)
@@ -62,21 +65,17 @@ class FeatureSet:
         self.normal_features = [None] * depth
         self.structure_features = {}
         self.udf_features = [None] * depth
-        self.encoder_features = None
+        self.trunk_features = [None] * depth
 
 
 class EncodedCloud:
-    """Output of ``network.encoder``: Morton-sorted cloud + per-level site ranges + the
-    trilinear splat of the input feature onto the encoder hierarchy's finest level."""
+    """Output of ``network.encoder``: Morton-sorted cloud + the encoded finest-level features."""
 
     def __init__(self):
-        self.xyz = None
-        self.feat = None
-        self.keys = None
-        self.splat = None
-        self.wsum = None
+        self.xyz = self.feat = self.keys = self.voxel_feat = None
 
 
+# ---- thin wrappers over csrc/nn.hip ---------------------------------------------------------------------
 def sort_cloud(xyz, feat, inv_w0):
     n = xyz.shape[0]
     keys = torch.empty(n, dtype=torch.int64, device=xyz.device)
@@ -86,61 +85,171 @@ def sort_cloud(xyz, feat, inv_w0):
     return ks, xyz[perm].contiguous(), (feat[perm].contiguous() if feat is not None else None)
 
 
-def splat_trilinear(svh, d, site_keys, xyz_sorted, feat_sorted):
-    """Weighted sum and weight sum of ``feat`` splatted onto level d of ``svh``."""
-    g = svh.level(d)
-    n, C_ = g.num_voxels, feat_sorted.shape[1]
-    st = torch.empty(n, dtype=torch.int32, device=svh.device)
-    en = torch.empty(n, dtype=torch.int32, device=svh.device)
-    call('nksr_site_ranges', ptr(site_keys), site_keys.numel(), ptr(g.keys), n, d, ptr(st), ptr(en), stream())
-    out = torch.empty((n, C_), dtype=torch.float32, device=svh.device)
-    ws = torch.empty(n, dtype=torch.float32, device=svh.device)
-    inv_w = svh.inv_w0 * (2.0 ** (-d))
-    call('nksr_splat_trilinear', ptr(xyz_sorted), ptr(feat_sorted), C_, ptr(st), ptr(en), ptr(g.nbr), ptr(g.ijk), n,
-         float(inv_w), ptr(out), ptr(ws), stream())
+def site_ranges(site_keys, grid, shift_level):
+    n = grid.num_voxels
+    st = torch.empty(n, dtype=torch.int32, device=grid.device)
+    en = torch.empty(n, dtype=torch.int32, device=grid.device)
+    call('nksr_site_ranges', ptr(site_keys), site_keys.numel(), ptr(grid.keys), n, shift_level, ptr(st), ptr(en), stream())
+    return st, en
+
+
+def splat_trilinear(grid, d, inv_w0, site_keys, xyz_sorted, feat_sorted):
+    """Weighted SUM (and weight sum) of <= 8-channel features splatted onto level-d ``grid``."""
+    n, C_ = grid.num_voxels, feat_sorted.shape[1]
+    st, en = site_ranges(site_keys, grid, d)
+    out = torch.empty((n, C_), dtype=torch.float32, device=grid.device)
+    ws = torch.empty(n, dtype=torch.float32, device=grid.device)
+    call('nksr_splat_trilinear', ptr(xyz_sorted), ptr(feat_sorted), C_, ptr(st), ptr(en), ptr(grid.nbr), ptr(grid.ijk), n,
+         float(inv_w0 * 2.0 ** (-d)), ptr(out), ptr(ws), stream())
     return out, ws
 
 
+def splat_mean(grid, d, inv_w0, site_keys, xyz_sorted, feat_sorted):
+    n, C_ = grid.num_voxels, feat_sorted.shape[1]
+    st, en = site_ranges(site_keys, grid, d)
+    out = torch.empty((n, C_), dtype=torch.float32, device=grid.device)
+    call('nksr_splat_mean', ptr(xyz_sorted), ptr(feat_sorted), C_, ptr(st), ptr(en), ptr(grid.nbr), ptr(grid.ijk), n,
+         float(inv_w0 * 2.0 ** (-d)), ptr(out), stream())
+    return out
+
+
+def gather_rows(src, idx, add=None):
+    n, C_ = idx.numel(), src.shape[1]
+    out = torch.empty((n, C_), dtype=torch.float32, device=idx.device)
+    call('nksr_gather_rows', ptr(src), ptr(idx), n, C_, ptr(add), ptr(out), stream())
+    return out
+
+
+class SparseConv3(nn.Module):
+    """3x3x3 submanifold sparse convolution, weight [27, C_in, C_out]."""
+
+    def __init__(self, channels, generator=None):
+        super().__init__()
+        self.channels = channels
+        self.weight = nn.Parameter(torch.randn(27, channels, channels, generator=generator) * (2.0 / (27 * channels)) ** 0.5)
+        self.bias = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x, nbr, relu=True, residual=None):
+        n = x.shape[0]
+        out = torch.empty_like(x)
+        call('nksr_sparse_conv3', ptr(x.contiguous()), ptr(nbr), n, self.channels, ptr(self.weight.detach().contiguous()),
+             ptr(self.bias.detach().contiguous()), ptr(residual), int(relu), ptr(out), stream())
+        return out
+
+
+class Head(nn.Module):
+    def __init__(self, cin, cout, scale, generator=None, bias=None):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.weight = nn.Parameter(float(scale) * torch.randn(cout, cin, generator=generator) / cin ** 0.5)
+        self.bias = nn.Parameter(torch.zeros(cout) if bias is None else torch.tensor(bias, dtype=torch.float32))
+
+    def forward(self, x):
+        out = torch.empty((x.shape[0], self.cout), dtype=torch.float32, device=x.device)
+        call('nksr_linear', ptr(x.contiguous()), x.shape[0], self.cin, ptr(self.weight.detach().contiguous()),
+             ptr(self.bias.detach().contiguous()), self.cout, ptr(out), stream())
+        return out
+
+
 class PointEncoder(nn.Module):
-    def __init__(self, hparams):
+    def __init__(self, hparams, generator=None):
         super().__init__()
         self.hparams = hparams
+        C_ = int(hparams.unet.f_maps)
+        self.channels = C_
+        self.W1 = nn.Parameter(torch.randn(C_, 6, generator=generator) / 6 ** 0.5)
+        self.b1 = nn.Parameter(torch.zeros(C_))
+        self.W2 = nn.Parameter(torch.randn(C_, C_, generator=generator) / C_ ** 0.5)
+        self.b2 = nn.Parameter(torch.zeros(C_))
 
     def forward(self, xyz, feat, svh, depth=0):
-        enc = EncodedCloud()
         if feat is None:
             raise RuntimeError("this network needs an orientation feature (hparams.feature='normal')")
+        enc = EncodedCloud()
         enc.keys, enc.xyz, enc.feat = sort_cloud(xyz.contiguous(), feat.to(torch.float32).contiguous(), svh.inv_w0)
+        n = enc.xyz.shape[0]
+        g = torch.empty((n, self.channels), dtype=torch.float32, device=xyz.device)
+        call('nksr_point_mlp', ptr(enc.xyz), ptr(enc.feat), n, svh.inv_w0, self.channels, ptr(self.W1.detach().contiguous()),
+             ptr(self.b1.detach().contiguous()), ptr(self.W2.detach().contiguous()), ptr(self.b2.detach().contiguous()), ptr(g), stream())
+        enc.voxel_feat = splat_mean(svh.level(depth), depth, svh.inv_w0, enc.keys, enc.xyz, g)
         return enc
 
 
 class StructureUNet(nn.Module):
-    """Decoder-side structure + heads.  Round-1 scope: the analytic branch (see module doc);
-    the sparse-convolution trunk plugs in as residual heads."""
-
-    def __init__(self, hparams):
+    def __init__(self, hparams, generator=None):
         super().__init__()
         self.hparams = hparams
+        C_, D, K = int(hparams.unet.f_maps), int(hparams.tree_depth), int(hparams.kernel_dim)
+        hs = float(getattr(hparams, 'head_init_scale', 0.0))
+        self.down = nn.ModuleList([SparseConv3(C_, generator) for _ in range(D)])
+        self.up = nn.ModuleList([SparseConv3(C_, generator) for _ in range(D)])
+        self.structure_heads = nn.ModuleList([Head(C_, 3, hs, generator, bias=[-1.0, 0.0, 1.0]) for _ in range(D)])
+        self.basis_heads = nn.ModuleList([Head(C_, K, hs, generator) for _ in range(D)])
+        self.normal_heads = nn.ModuleList([Head(C_, 3, hs, generator) for _ in range(D)])
+        self.udf_heads = nn.ModuleList([Head(C_, 8, hs, generator) for _ in range(D)])
 
     def forward(self, enc, enc_svh, adaptive_depth=1, gt_decoder_svh=None):
         hp = self.hparams
-        depth = enc_svh.depth
+        D = enc_svh.depth
         dev = enc_svh.device
-        if gt_decoder_svh is not None:
-            dec_svh = gt_decoder_svh
-        else:
-            dec_svh = SparseFeatureHierarchy(enc_svh.voxel_size, depth, dev).build_point_neighborhood(enc.xyz)
-        feat = FeatureSet(depth)
         K = int(hp.kernel_dim)
-        for d in range(depth):
-            n = dec_svh.num_voxels(d)
-            b = torch.zeros((n, K), dtype=torch.float32, device=dev)
-            b[:, 0] = 1.0
-            feat.basis_features[d] = b
-            feat.structure_features[d] = torch.zeros((n, 3), dtype=torch.float32, device=dev)
+        # ---- down path on the encoder hierarchy ----------------------------------------------------
+        x = [None] * D
+        g = enc_svh.level(0)
+        x[0] = self.down[0](enc.voxel_feat, g.nbr)
+        for d in range(1, D):
+            g, gc = enc_svh.level(d), enc_svh.level(d - 1)
+            st, en = site_ranges(gc.keys, g, 1)      # children = contiguous Morton range one level down
+            p = torch.empty((g.num_voxels, x[d - 1].shape[1]), dtype=torch.float32, device=dev)
+            call('nksr_pool_children', ptr(x[d - 1]), ptr(st), ptr(en), g.num_voxels, p.shape[1], ptr(p), stream())
+            x[d] = self.down[d](p, g.nbr)
+        # ---- candidate decoder structure ------------------------------------------------------------
+        cand = gt_decoder_svh if gt_decoder_svh is not None else \
+            SparseFeatureHierarchy(enc_svh.voxel_size, D, dev).build_point_neighborhood(enc.xyz)
+        feat = FeatureSet(D)
+        dec_levels = [None] * D
+        y_up, keep_up = None, None           # trunk features / "continue" flags of the level above
+        for d in range(D - 1, -1, -1):
+            gc = cand.level(d)
+            keys = gc.keys
+            if d < D - 1:
+                par = dec_levels[d + 1].hash.query((keys >> 3).contiguous())
+                ok = (par >= 0) & keep_up[par.clamp_min(0).long()]
+                if not bool(ok.all()):
+                    keys = keys[ok].contiguous()
+                    gc = SparseGrid(keys, d, enc_svh.voxel_size)
+                    par = dec_levels[d + 1].hash.query((keys >> 3).contiguous())
+            t = gather_rows(x[d], enc_svh.level(d).hash.query(keys))
+            if d < D - 1:
+                t = gather_rows(y_up, par, add=t)
+            y = self.up[d](t, gc.nbr)
+            s = self.structure_heads[d](y)
+            status = s.argmax(1)
+            exist = status != 0
+            if not bool(exist.all()):          # prune "not-exist" voxels (needs a re-indexed grid)
+                y, s, status = y[exist].contiguous(), s[exist].contiguous(), status[exist]
+                gc = SparseGrid(keys[exist].contiguous(), d, enc_svh.voxel_size)
+            dec_levels[d] = gc
+            feat.structure_features[d] = s
+            feat.trunk_features[d] = y
+            y_up, keep_up = y, status == 2
+        dec_svh = SparseFeatureHierarchy(enc_svh.voxel_size, D, dev)
+        dec_svh._levels = dec_levels
+        # ---- heads -----------------------------------------------------------------------------------
+        e0 = torch.zeros(K, dtype=torch.float32, device=dev)
+        e0[0] = 1.0
+        for d in range(D):
+            y = feat.trunk_features[d]
+            feat.basis_features[d] = self.basis_heads[d](y) + e0
+            feat.udf_features[d] = self.udf_heads[d](y)
             if d < adaptive_depth:
-                s, _ = splat_trilinear(dec_svh, d, enc.keys, enc.xyz, enc.feat)
-                feat.normal_features[d] = s / s.norm(dim=1, keepdim=True).clamp_min(1e-8)
+                # splat on the CANDIDATE grid (it holds every cell that contains a point; the gather
+                # form of the splat walks neighbour voxels), then keep the rows of surviving voxels
+                s, _ = splat_trilinear(cand.level(d), d, enc_svh.inv_w0, enc.keys, enc.xyz, enc.feat)
+                if dec_levels[d] is not cand.level(d):
+                    s = gather_rows(s, cand.level(d).hash.query(dec_levels[d].keys))
+                nv = s + self.normal_heads[d](y)
+                feat.normal_features[d] = nv / nv.norm(dim=1, keepdim=True).clamp_min(1e-8)
         return feat, dec_svh, dec_svh
 
 
@@ -149,11 +258,11 @@ class NKSRNetwork(nn.Module):
         super().__init__()
         self.hparams = hparams
         gen = torch.Generator().manual_seed(int(getattr(hparams, 'seed', 0)))
-        self.encoder = PointEncoder(hparams)
-        self.unet = StructureUNet(hparams)
         self.interpolators = nn.ModuleList([
             Interpolator(hparams.kernel_dim, hparams.interpolator.hidden_dim, hparams.interpolator.n_hidden,
                          init_scale=float(getattr(hparams, 'interpolator_init_scale', 0.0)), generator=gen)
             for _ in range(hparams.tree_depth)])
+        self.encoder = PointEncoder(hparams, gen)
+        self.unet = StructureUNet(hparams, gen)
         self.sdf_decoder = None
         self.udf_decoder = None

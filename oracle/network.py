@@ -1,0 +1,105 @@
+"""Oracle: the sparse feature-hierarchy network (restates nksr_amd.nn.network, which mirrors
+``nksr.NKSRNetwork``: encoder / unet call sites models/nksr_net.py:73-78, hyper-parameters
+configs/default/train.yaml:9-29).  numpy only; weights are passed in as a dict of arrays exported
+from the torch module's ``state_dict`` so both sides run the same parameters."""
+import numpy as np
+
+from . import hierarchy, spec
+
+
+def export_params(net):
+    """torch NKSRNetwork -> {name: float32 ndarray}."""
+    return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in net.state_dict().items()}
+
+
+def conv3(x, nbr, W, b, relu=True):
+    out = np.tile(b.astype(np.float32), (x.shape[0], 1))
+    xp = np.concatenate([x, np.zeros((1, x.shape[1]), np.float32)])   # index -1 -> zero row
+    for s in range(27):
+        out += xp[nbr[:, s]] @ W[s]
+    return np.maximum(out, 0) if relu else out
+
+
+def splat(level, xyz, feat, voxel_size_d, mean):
+    inv_w = np.float32(spec.inv_w0_f32(voxel_size_d))
+    p = xyz.astype(np.float32) * inv_w
+    base = np.floor(p - np.float32(0.5)).astype(np.int32)
+    acc = np.zeros((level.n, feat.shape[1]), np.float64)
+    ws = np.zeros(level.n, np.float64)
+    for co in spec.CORNER_OFFSETS:
+        ijk = base + co[None]
+        w = np.prod(np.float32(1.0) - np.abs(p - (ijk.astype(np.float32) + np.float32(0.5))), axis=1)
+        j = level.lookup(ijk)
+        ok = (j >= 0) & (w > 0)
+        np.add.at(acc, j[ok], feat[ok].astype(np.float64) * w[ok, None])
+        np.add.at(ws, j[ok], w[ok])
+    if mean:
+        acc = acc / np.where(ws > 0, ws, 1.0)[:, None] * (ws > 0)[:, None]
+    return acc.astype(np.float32)
+
+
+def forward(P, xyz, normal, voxel_size, depth, kernel_dim, adaptive_depth):
+    """Returns (dec hierarchy, basis_features, normal_features, structure logits, trunk features)."""
+    enc = hierarchy.Hierarchy(voxel_size, depth).build_point_splatting(xyz)
+    cand = hierarchy.Hierarchy(voxel_size, depth).build_point_neighborhood(xyz)
+    # encoder
+    H0, p = spec.half_index(xyz, voxel_size)
+    u = (p - (H0 >> 1).astype(np.float32)).astype(np.float32)
+    inp = np.concatenate([u - np.float32(0.5), normal.astype(np.float32)], 1)
+    h = np.maximum(inp @ P['encoder.W1'].T + P['encoder.b1'], 0)
+    g = (h @ P['encoder.W2'].T + P['encoder.b2']).astype(np.float32)
+    e0 = splat(enc.levels[0], xyz, g, voxel_size, mean=True)
+    # down path
+    x = [conv3(e0, enc.levels[0].nbr, P['unet.down.0.weight'], P['unet.down.0.bias'])]
+    for d in range(1, depth):
+        Lc, Lp = enc.levels[d - 1], enc.levels[d]
+        par = Lp.lookup(Lc.ijk >> 1)
+        acc = np.zeros((Lp.n, e0.shape[1]), np.float64)
+        cnt = np.zeros(Lp.n)
+        ok = par >= 0
+        np.add.at(acc, par[ok], x[d - 1][ok].astype(np.float64))
+        np.add.at(cnt, par[ok], 1)
+        pool = (acc / np.maximum(cnt, 1)[:, None]).astype(np.float32)
+        x.append(conv3(pool, Lp.nbr, P['unet.down.%d.weight' % d], P['unet.down.%d.bias' % d]))
+    # top-down decoder
+    levels, trunk, logits = [None] * depth, [None] * depth, [None] * depth
+    y_up = keep_up = None
+    for d in range(depth - 1, -1, -1):
+        keys = cand.levels[d].keys
+        L = hierarchy.Level(keys, d, voxel_size)
+        if d < depth - 1:
+            par = levels[d + 1].lookup(L.ijk >> 1)
+            ok = (par >= 0) & keep_up[np.maximum(par, 0)]
+            L = hierarchy.Level(keys[ok], d, voxel_size)
+            par = levels[d + 1].lookup(L.ijk >> 1)
+        L.build_nbr()
+        je = enc.levels[d].lookup(L.ijk)
+        t = np.where((je >= 0)[:, None], x[d][np.maximum(je, 0)], np.float32(0)).astype(np.float32)
+        if d < depth - 1:
+            t = t + y_up[par]
+        y = conv3(t, L.nbr, P['unet.up.%d.weight' % d], P['unet.up.%d.bias' % d])
+        s = (y @ P['unet.structure_heads.%d.weight' % d].T + P['unet.structure_heads.%d.bias' % d]).astype(np.float32)
+        status = s.argmax(1)
+        exist = status != 0
+        if not exist.all():
+            y, s, status = y[exist], s[exist], status[exist]
+            L = hierarchy.Level(L.keys[exist], d, voxel_size)
+            L.build_nbr()
+        levels[d], trunk[d], logits[d] = L, y, s
+        y_up, keep_up = y, status == 2
+    dec = hierarchy.Hierarchy(voxel_size, depth)
+    dec.levels = levels
+    dec.finalize()
+    basis, normals, normal_norm = [], [None] * depth, [None] * depth
+    e0v = np.zeros(kernel_dim, np.float32)
+    e0v[0] = 1
+    for d in range(depth):
+        y = trunk[d]
+        basis.append((y @ P['unet.basis_heads.%d.weight' % d].T + P['unet.basis_heads.%d.bias' % d] + e0v).astype(np.float32))
+        if d < adaptive_depth:
+            sN = splat(levels[d], xyz, normal, voxel_size * (1 << d), mean=False)
+            nv = sN + (y @ P['unet.normal_heads.%d.weight' % d].T + P['unet.normal_heads.%d.bias' % d]).astype(np.float32)
+            normal_norm[d] = np.linalg.norm(nv, axis=1)
+            normals[d] = (nv / np.maximum(normal_norm[d][:, None], np.float32(1e-8))).astype(np.float32)
+    forward.last_normal_norm = normal_norm   # conditioning of the normalisation (used by the parity test)
+    return dec, basis, normals, logits, trunk

@@ -43,10 +43,21 @@ def splat_trilinear(level, xyz, feat, voxel_size_d):
 
 def reconstruct(xyz, normal, voxel_size=0.1, depth=4, adaptive_depth=1, kernel_dim=4, hidden=16, pos_weight=1e4,
                 normal_weight=1e4, reg_weight=1.0, tol=1e-5, max_iter=2000, approx_kernel_grad=False, interps=None,
-                feats=None, timing=None):
-    """xyz already in model units (finest voxel = voxel_size).  Returns a dict field."""
+                feats=None, timing=None, net_params=None):
+    """xyz already in model units (finest voxel = voxel_size).  Returns a dict field.
+    ``net_params`` (oracle.network.export_params): run the full encoder / U-Net restatement; without
+    it the analytic branch is used (identical results while the residual heads are zero)."""
     t0 = time.perf_counter()
-    hier = hierarchy.Hierarchy(voxel_size, depth).build_point_neighborhood(xyz)
+    net_normals = None
+    if net_params is not None:
+        from . import network as onet
+        hier, feats, net_normals, _, _ = onet.forward(net_params, xyz, normal, voxel_size, depth, kernel_dim, adaptive_depth)
+        if interps is None:
+            P = net_params
+            interps = [kernel.Interpolator(*[P['interpolators.%d.%s' % (d, k)] for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')])
+                       for d in range(depth)]
+    else:
+        hier = hierarchy.Hierarchy(voxel_size, depth).build_point_neighborhood(xyz)
     if feats is None:
         feats = []
         for L in hier.levels:
@@ -58,8 +69,11 @@ def reconstruct(xyz, normal, voxel_size=0.1, depth=4, adaptive_depth=1, kernel_d
     nxyz, nval = [], []
     for d in range(adaptive_depth):
         L = hier.levels[d]
-        s = splat_trilinear(L, xyz, normal, voxel_size * (1 << d))
-        nf = s / np.maximum(np.linalg.norm(s, axis=1, keepdims=True), np.float32(1e-8))
+        if net_normals is not None:
+            nf = net_normals[d]
+        else:
+            s = splat_trilinear(L, xyz, normal, voxel_size * (1 << d))
+            nf = s / np.maximum(np.linalg.norm(s, axis=1, keepdims=True), np.float32(1e-8))
         nxyz.append(L.centers())
         nval.append(nf.astype(np.float32))
     nxyz, nval = np.concatenate(nxyz), np.concatenate(nval)

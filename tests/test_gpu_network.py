@@ -1,0 +1,76 @@
+"""GPU parity of the sparse feature-hierarchy network (csrc/nn.hip: point MLP, splat-mean, fp32-MFMA
+sparse convolution, child pooling, transfer/up-sampling, heads, top-down structure pruning) against
+oracle/network.py with the same exported parameters."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(prune):
+    import nksr_amd
+    from nksr_amd import configs
+    from nksr_amd.nn.network import NKSRNetwork
+    from oracle import network as onet
+    dev = torch.device('cuda:0')
+    xyz, nrm = make_cloud('torus', 3000, 0.005, 2)
+    xyz = (xyz * np.float32(2.0)).astype(np.float32)
+    hp = configs.get_hparams('ks', head_init_scale=0.7, seed=3)
+    net = NKSRNetwork(hp)
+    rs = np.random.RandomState(0)
+    for m in list(net.unet.down) + list(net.unet.up):
+        m.bias.data = torch.from_numpy(rs.randn(32).astype(np.float32) * 0.1)
+    if prune:   # let the (random) structure head actually decide
+        for h in net.unet.structure_heads:
+            h.bias.data.zero_()
+            h.weight.data *= 4.0
+    P = onet.export_params(net)
+    net = net.to(dev)
+    dec_o, basis_o, normals_o, logits_o, trunk_o = onet.forward(P, xyz, nrm, 0.1, 4, 4, 1)
+    enc_svh = nksr_amd.SparseFeatureHierarchy(0.1, 4, dev).build_point_splatting(torch.from_numpy(xyz).to(dev))
+    enc = net.encoder(torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev), enc_svh, 0)
+    feat, dec, _ = net.unet(enc, enc_svh, adaptive_depth=1)
+    return dec_o, basis_o, normals_o, logits_o, trunk_o, feat, dec
+
+
+@pytest.mark.parametrize('prune', [False, True])
+def test_network_matches_oracle(prune):
+    dec_o, basis_o, normals_o, logits_o, trunk_o, feat, dec = _run(prune)
+    if prune:
+        assert any(dec_o.levels[d].n < n for d, n in enumerate([10 ** 9] * 4)) and dec_o.levels[0].n > 0
+    for d in range(4):
+        assert np.array_equal(dec.level(d).keys.cpu().numpy(), dec_o.levels[d].keys), 'decoder structure differs at level %d' % d
+        assert np.array_equal(dec.level(d).nbr.cpu().numpy(), dec_o.levels[d].nbr)
+        tg = feat.trunk_features[d].cpu().numpy()
+        scale = np.abs(trunk_o[d]).max()
+        np.testing.assert_allclose(tg, trunk_o[d], rtol=0, atol=2e-5 * scale)
+        np.testing.assert_allclose(feat.structure_features[d].cpu().numpy(), logits_o[d], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(feat.basis_features[d].cpu().numpy(), basis_o[d], rtol=0, atol=1e-4)
+    # unit normals: the normalisation amplifies fp32 noise by 1/|n_raw|
+    from oracle import network as onet
+    nn0 = onet.forward.last_normal_norm[0]
+    err = np.abs(feat.normal_features[0].cpu().numpy() - normals_o[0]).max(1)
+    assert (err <= 2e-5 / np.maximum(nn0, 1e-8) + 1e-5).all()
+
+
+def test_conv_is_not_transposed():
+    """A = I style check with an asymmetric weight: catches row/col swaps of the MFMA fragments."""
+    from nksr_amd.nn.network import SparseConv3
+    dev = torch.device('cuda:0')
+    n = 70
+    x = torch.randn(n, 32, device=dev)
+    nbr = torch.full((n, 27), -1, dtype=torch.int32, device=dev)
+    nbr[:, 13] = torch.arange(n, dtype=torch.int32, device=dev)        # centre tap only
+    nbr[:-1, 14] = torch.arange(1, n, dtype=torch.int32, device=dev)   # +z neighbour = next row
+    conv = SparseConv3(32).to(dev)
+    conv.weight.data.zero_()
+    W13 = torch.arange(32 * 32, dtype=torch.float32, device=dev).view(32, 32) / 1000.0   # asymmetric
+    conv.weight.data[13] = W13
+    conv.weight.data[14] = W13.T * 0.5
+    out = conv(x, nbr, relu=False)
+    ref = x @ W13
+    ref[:-1] += x[1:] @ (W13.T * 0.5)
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
