@@ -126,16 +126,6 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ 
     __shared__ double sm[PCG_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double dot = 0.0;
-    int4 c[SPMV_QUADS];
-    float4 v[SPMV_QUADS];
-    if (VARIANT == 2 && (int)blockIdx.x < nchunks) {
-#pragma unroll
-        for (int q = 0; q < SPMV_QUADS; ++q) {
-            const int k = blockIdx.x * SPMV_CHUNK + q * (PCG_BLOCK * 4) + tid * 4;
-            c[q] = *reinterpret_cast<const int4*>(cols + k);
-            v[q] = *reinterpret_cast<const float4*>(vals + k);
-        }
-    }
     for (int b = blockIdx.x; b < nchunks; b += gridDim.x) {
         const int base = b * SPMV_CHUNK;
         const int end = (base + SPMV_CHUNK < nnz) ? base + SPMV_CHUNK : nnz;
@@ -143,32 +133,9 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ 
         // 16-byte load of lane l is logical entry 64 j + l of the tile -> every gather instruction
         // below covers 64 consecutive entries of the stream.  Storage is zero-padded to a multiple
         // of SPMV_CHUNK, so no bounds checks are needed.
-        if (VARIANT == 2) {
-            // software pipeline: gathers of this chunk first, then the next chunk's stream loads
-            // (memory returns in order per wave: the wait for the gathers must not cover them)
-            float4 xg[SPMV_QUADS];
-#pragma unroll
-            for (int q = 0; q < SPMV_QUADS; ++q) {
-                xg[q].x = x[c[q].x]; xg[q].y = x[c[q].y]; xg[q].z = x[c[q].z]; xg[q].w = x[c[q].w];
-            }
-            float4 vc[SPMV_QUADS];
-#pragma unroll
-            for (int q = 0; q < SPMV_QUADS; ++q) vc[q] = v[q];
-            const int bn = b + gridDim.x;
-            if (bn < nchunks) {
-#pragma unroll
-                for (int q = 0; q < SPMV_QUADS; ++q) {
-                    const int k = bn * SPMV_CHUNK + q * (PCG_BLOCK * 4) + tid * 4;
-                    c[q] = *reinterpret_cast<const int4*>(cols + k);
-                    v[q] = *reinterpret_cast<const float4*>(vals + k);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < SPMV_QUADS; ++q) {
-                float* pt = prod + q * (PCG_BLOCK * 4) + wave * 256 + lane;
-                pt[0] = vc[q].x * xg[q].x; pt[64] = vc[q].y * xg[q].y; pt[128] = vc[q].z * xg[q].z; pt[192] = vc[q].w * xg[q].w;
-            }
-        } else {
+        int4 c[SPMV_QUADS];
+        float4 v[SPMV_QUADS];
+        {
 #pragma unroll
         for (int q = 0; q < SPMV_QUADS; ++q) {
             const int k = base + q * (PCG_BLOCK * 4) + tid * 4;
@@ -358,7 +325,7 @@ static int launch_spmv(const int32_t* rowptr, const int32_t* cols, const float* 
                        const float* x, float* y, double* part, const int* done, hipStream_t st) {
 #define SPMV_LAUNCH(V) hipLaunchKernelGGL((k_spmv<DOT, V>), dim3(spmv_grid(p.nchunks)), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, (int)nnz, \
                        p.nchunks, p.chunk_row, x, y, p.carry, p.carry_row, part, done)
-    if (g_spmv_variant == 1) SPMV_LAUNCH(1); else if (g_spmv_variant == 2) SPMV_LAUNCH(2); else SPMV_LAUNCH(0);
+    if (g_spmv_variant == 1) SPMV_LAUNCH(1); else SPMV_LAUNCH(0);
     hipLaunchKernelGGL(k_spmv_fixup, dim3(nksr_blocks(p.nchunks, 256)), dim3(256), 0, st, p.nchunks, p.carry, p.carry_row, y, done);
     return 0;
 }

@@ -12,7 +12,7 @@ from nksr_amd._lib import call, lib, ptr, stream
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-    variants = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 1, 2]
+    variants = [int(v) for v in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 1]
     dev = torch.device('cuda:0')
     xyz, nrm = utils.synth_scene(n, seed=0)
     rec = nksr_amd.Reconstructor(dev)
