@@ -165,6 +165,21 @@ int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const float* vals
  * Returns and resets the accumulated milliseconds / launch count, then sets the enable flag. */
 int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out);
 
+/* ---- grid-hash nearest neighbours (csrc/knn.hip) ----------------------------------------------------
+ * Points Morton-sorted by a uniform grid of size `cell` (keys from nksr_point_keys with inv_w0 =
+ * inv_cell); start/end = nksr_site_ranges of the occupied cells; hkeys/hvals = their hash. */
+/* kNN-PCA normals (unoriented): nksr.get_estimate_normal_preprocess_fn, examples/recons_waymo.py:36,
+ * recipe examples/recons_waymo_cpu.py:21-41.  valid_out[i]=0 where fewer than k points lie within
+ * max_ring cells. */
+int nksr_knn_pca_normals(const float* xyz_sorted, int64_t n, const int32_t* start, const int32_t* end,
+                         const int64_t* hkeys, const int32_t* hvals, int32_t hcap, float cell, float inv_cell, int k,
+                         int max_ring, float* normal_out, float* radius2_out, int32_t* valid_out, void* stream);
+/* index (into the sorted cloud) of the nearest point of every query: fields.PCNNField,
+ * examples/recons_colored_mesh.py:28 */
+int nksr_nearest_index(const float* xyz_sorted, const int32_t* start, const int32_t* end, const int64_t* hkeys,
+                       const int32_t* hvals, int32_t hcap, float cell, float inv_cell, const float* query, int64_t nq,
+                       int max_ring, int32_t* index_out, void* stream);
+
 /* ---- dual marching cubes (field.extract_dual_mesh, examples/recons_simple.py:27) ------- */
 /* flags[i]=1 where voxel i and its +x,+y,+z,... 7 partners are all active */
 int nksr_base_cell_flags(const int32_t* nbr, int32_t n, int32_t* flags, void* stream);

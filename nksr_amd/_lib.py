@@ -82,6 +82,8 @@ _PROTOS = {
     'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
     'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
+    'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
+    'nksr_nearest_index': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, _vp, _vp],
     'nksr_base_cell_flags': [_vp, _i32, _vp, _vp],
     'nksr_base_cell_keys': [_vp, _vp, _i64, C.c_int, _vp, _vp],
     'nksr_cell_corner_keys': [_vp, _i64, _vp, _vp],

@@ -71,16 +71,16 @@ class PCNNField(BaseField):
     def device(self):
         return self.xyz.device
 
-    def evaluate_color(self, xyz_world, block=4096):
-        """Brute-force blocked nearest neighbour (a grid-hash kNN is the 'next' row 8f-1/2)."""
-        out = torch.empty((xyz_world.shape[0], self.color.shape[1]), dtype=torch.float32, device=xyz_world.device)
-        ref = self.xyz.to(xyz_world.device)
+    def evaluate_color(self, xyz_world):
+        """Colour of the nearest input point (grid-hash nearest neighbour, csrc/knn.hip)."""
+        from ..normals import PointGrid, choose_cell_size
+        if getattr(self, '_grid', None) is None or self._grid.xyz.device != xyz_world.device:
+            ref = self.xyz.to(xyz_world.device)
+            self._grid = PointGrid(ref, choose_cell_size(ref, 8))
+        idx = self._grid.nearest(xyz_world, max_ring=64)
         col = self.color.to(xyz_world.device)
-        r2 = (ref * ref).sum(1)
-        for s in range(0, xyz_world.shape[0], block):
-            q = xyz_world[s:s + block]
-            d = r2[None, :] - 2.0 * (q @ ref.T)
-            out[s:s + block] = col[d.argmin(1)]
+        out = col[idx.clamp_min(0)]
+        out[idx < 0] = 0.0
         return out
 
     def to_(self, device):

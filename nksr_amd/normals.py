@@ -1,0 +1,90 @@
+"""kNN-PCA normal estimation + sensor orientation on the GPU (csrc/knn.hip).
+
+Mirrors the recipe the reference ships in source form (examples/recons_waymo_cpu.py:21-41, the
+stand-in for ``nksr.get_estimate_normal_preprocess_fn(64, 85.0)``, examples/recons_waymo.py:36):
+  1. unoriented normals = smallest PCA eigenvector of the k nearest neighbours (k includes the
+     point itself)
+  2. flip so that the normal faces the sensor:  (sensor - xyz) . n >= 0
+  3. drop grazing points: keep |cos| > cos(deg)
+"""
+import math
+
+import torch
+
+from . import ops
+from ._lib import call, ptr, stream
+from .svh import SparseGrid, inv_w0_f32
+
+
+class PointGrid:
+    """Uniform grid over a cloud: Morton-sorted points + per-cell ranges + cell hash."""
+
+    def __init__(self, xyz, cell):
+        xyz = xyz.to(torch.float32).contiguous()
+        n = xyz.shape[0]
+        dev = xyz.device
+        self.cell = float(cell)
+        self.inv_cell = inv_w0_f32(cell)
+        keys = torch.empty(n, dtype=torch.int64, device=dev)
+        call('nksr_point_keys', ptr(xyz), n, self.inv_cell, ptr(keys), stream())
+        ks, perm = ops.sort_pairs(keys, torch.arange(n, dtype=torch.int32, device=dev))
+        self.perm = perm.long()
+        self.xyz = xyz[self.perm].contiguous()
+        self.grid = SparseGrid(ops.unique_sorted(ks), 0, cell)
+        self.start = torch.empty(self.grid.num_voxels, dtype=torch.int32, device=dev)
+        self.end = torch.empty(self.grid.num_voxels, dtype=torch.int32, device=dev)
+        call('nksr_site_ranges', ptr(ks), n, ptr(self.grid.keys), self.grid.num_voxels, 0, ptr(self.start), ptr(self.end), stream())
+
+    def nearest(self, query, max_ring=8):
+        """Index (into the ORIGINAL cloud order) of the nearest point of every query."""
+        q = query.to(torch.float32).contiguous()
+        idx = torch.empty(q.shape[0], dtype=torch.int32, device=q.device)
+        h = self.grid.hash
+        call('nksr_nearest_index', ptr(self.xyz), ptr(self.start), ptr(self.end), ptr(h.hkeys), ptr(h.hvals), h.cap, self.cell,
+             self.inv_cell, ptr(q), q.shape[0], int(max_ring), ptr(idx), stream())
+        ok = idx >= 0
+        out = torch.full_like(idx, -1, dtype=torch.int64)
+        out[ok] = self.perm[idx[ok].long()]
+        return out
+
+
+def choose_cell_size(xyz, k):
+    """Cell size such that a ball of one cell radius holds ~2k surface samples: density from the
+    occupied-voxel count at one probe resolution (points on a surface: count ~ area / cell^2)."""
+    from .density import occupied_voxels
+    n = xyz.shape[0]
+    ext = float((xyz.max(0).values - xyz.min(0).values).max())
+    probe = max(ext / 256.0, 1e-6)
+    occ = max(occupied_voxels((xyz - xyz.mean(0, keepdim=True)).contiguous(), probe), 1)
+    area = occ * probe * probe                      # ~ surface area
+    rho = n / max(area, 1e-20)
+    return max(math.sqrt(2.0 * k / (math.pi * rho)), probe / 8)
+
+
+def estimate_normals_knn(xyz, normal, sensor, knn=64, deg=85.0):
+    """(xyz, normal=None, sensor) -> (xyz', normal', None), the preprocess_fn contract of
+    examples/recons_waymo_cpu.py:21-41."""
+    if normal is not None:
+        raise RuntimeError('normal already exists')
+    if sensor is None:
+        raise RuntimeError('please provide sensor positions for consistent orientations')
+    n = xyz.shape[0]
+    if n < knn:
+        raise RuntimeError('need at least knn=%d points' % knn)
+    pg = PointGrid(xyz, choose_cell_size(xyz, knn))
+    nrm = torch.empty((n, 3), dtype=torch.float32, device=xyz.device)
+    r2 = torch.empty(n, dtype=torch.float32, device=xyz.device)
+    valid = torch.empty(n, dtype=torch.int32, device=xyz.device)
+    h = pg.grid.hash
+    call('nksr_knn_pca_normals', ptr(pg.xyz), n, ptr(pg.start), ptr(pg.end), ptr(h.hkeys), ptr(h.hvals), h.cap, pg.cell,
+         pg.inv_cell, int(knn), 6, ptr(nrm), ptr(r2), ptr(valid), stream())
+    xs = pg.xyz
+    ss = sensor.to(torch.float32)[pg.perm]
+    view = ss - xs
+    view = view / (torch.linalg.norm(view, dim=-1, keepdim=True) + 1e-6)
+    cos = (view * nrm).sum(1)
+    nrm = torch.where((cos < 0)[:, None], -nrm, nrm)
+    keep = (cos.abs() > math.cos(math.radians(deg))) & (valid > 0)
+    # return in the original point order (stable w.r.t. the input, like the CPU recipe)
+    order = torch.argsort(pg.perm[keep])
+    return xs[keep][order].contiguous(), nrm[keep][order].contiguous(), None
