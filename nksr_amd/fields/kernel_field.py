@@ -129,10 +129,11 @@ class KernelField(BaseField):
         rowcount = torch.zeros(M + 1, dtype=torch.int32, device=dev)
         ws = torch.empty(int(_lib.lib.nksr_assemble_workspace_bytes(C.byref(self._hier))), dtype=torch.uint8, device=dev)
         call('nksr_assemble_count', C.byref(self._hier), ptr(ws), ptr(rowcount), stream())
+        nnz = int(rowcount.sum(dtype=torch.int64).item())
+        if nnz <= 0 or nnz >= 2 ** 31 - 4096:
+            raise RuntimeError('system too large for one chunk (M=%d, nnz=%d >= 2^31): pass chunk_size= to '
+                               'reconstruct() (examples/recons_by_chunk.py)' % (M, nnz))
         rowoff = ops.exclusive_sum_i32(rowcount)
-        nnz = int(rowoff[M].item())
-        if nnz <= 0 or nnz >= 2 ** 31 - 8:
-            raise RuntimeError('matrix too large for int32 indexing (nnz=%d): use chunk_size' % nnz)
         col_bits = ops._bits(M)
         coo_k = torch.empty(nnz, dtype=torch.int64, device=dev)
         coo_v = torch.empty(nnz, dtype=torch.float32, device=dev)
