@@ -65,6 +65,10 @@ int nksr_exclusive_sum_i64(void* tmp, size_t* tmp_bytes, const int64_t* in, int6
 /* mode 0: 8 nearest voxel centres per point (encoder hierarchy); mode 1: containing
  * cell + 26 neighbours (decoder structure rule).  keys_out has n*8 / n*27 entries. */
 int nksr_splat_keys(const float* xyz, int64_t n, float inv_w0, int level, int mode, int64_t* keys_out, void* stream);
+/* Same footprints generated from the unique level-`level` CELLS that hold points instead of from every
+ * point: mode 0 -> 8 keys per cell at level+1 (the level-(l+1) half index of a point is its level-l cell
+ * index), mode 1 -> 27 keys per cell at the same level. */
+int nksr_cell_footprint_keys(const int64_t* cell_keys, int64_t nc, int level, int mode, int64_t* keys_out, void* stream);
 /* Morton key of the level-0 cell containing each point. */
 int nksr_point_keys(const float* xyz, int64_t n, float inv_w0, int64_t* keys_out, void* stream);
 int nksr_decode_keys(const int64_t* keys, int64_t n, int level, int32_t* ijk_out, void* stream);

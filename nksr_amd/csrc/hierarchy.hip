@@ -203,3 +203,31 @@ extern "C" int nksr_splat_trilinear(const float* xyz_sorted, const float* feat_s
     LAUNCH1D(k_splat_trilinear, (int64_t)n, stream, xyz_sorted, feat_sorted, C, start, end, nbr, ijk, n, inv_w, out, wsum_out);
     return NKSR_OK;
 }
+
+// ---- footprints generated from the unique CELLS that contain points (not from every point) ----------
+// mode 0: the 8 voxel centres at level+1 nearest to any point inside a level-`level` cell: the level
+//         (l+1) half index of a point IS its level-l cell index, so base = (I - 1) >> 1  (8 keys/cell)
+// mode 1: the cell itself and its 26 neighbours at the same level                        (27 keys/cell)
+__global__ void k_cell_footprint_keys(const int64_t* __restrict__ cell_keys, int64_t nc, int level, int mode,
+                                      int64_t* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    int x, y, z;
+    morton_decode_biased(cell_keys[i], NKSR_BIAS0 >> level, x, y, z);
+    if (mode == 0) {
+        const int bias = NKSR_BIAS0 >> (level + 1);
+        const int bx = (x - 1) >> 1, by = (y - 1) >> 1, bz = (z - 1) >> 1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) out[i * 8 + c] = morton_biased(bx + (c >> 2), by + ((c >> 1) & 1), bz + (c & 1), bias);
+    } else {
+        const int bias = NKSR_BIAS0 >> level;
+        for (int s = 0; s < 27; ++s) out[i * 27 + s] = morton_biased(x + s / 9 - 1, y + (s / 3) % 3 - 1, z + s % 3 - 1, bias);
+    }
+}
+
+extern "C" int nksr_cell_footprint_keys(const int64_t* cell_keys, int64_t nc, int level, int mode, int64_t* keys_out,
+                                        void* stream) {
+    if (level < 0 || level + (mode == 0) >= NKSR_MAX_DEPTH || (mode != 0 && mode != 1)) return nksr_set_error(NKSR_ERR_ARG, "bad level/mode");
+    LAUNCH1D(k_cell_footprint_keys, nc, stream, cell_keys, nc, level, mode, keys_out);
+    return NKSR_OK;
+}

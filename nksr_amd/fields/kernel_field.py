@@ -96,8 +96,10 @@ class KernelField(BaseField):
         return starts, ends
 
     # ---- assembly -----------------------------------------------------------------------------------
-    def assemble(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0):
-        """Materialise the CSR normal equations.  Returns (rowptr, cols, vals, diag, b)."""
+    def assemble(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0,
+                 pos_sorted_keys=None, normal_sorted_keys=None):
+        """Materialise the CSR normal equations.  Returns (rowptr, cols, vals, diag, b).
+        ``*_sorted_keys``: level-0 Morton keys of site sets that are ALREADY Morton-sorted."""
         dev = self.device
         M = self.svh.num_unknowns
         if M == 0:
@@ -105,12 +107,16 @@ class KernelField(BaseField):
         keep = []  # keep every buffer alive until the launches are enqueued
         sets = (SiteSetT * 2)()
         nsets = 0
-        for xyz, target, weight, ncomp in ((pos_xyz, None, pos_weight, 1), (normal_xyz, normal_value, normal_weight, 3)):
+        for xyz, target, weight, ncomp, pre in ((pos_xyz, None, pos_weight, 1, pos_sorted_keys),
+                                                 (normal_xyz, normal_value, normal_weight, 3, normal_sorted_keys)):
             if xyz is None or xyz.shape[0] == 0:
                 continue
             xyz = xyz.to(dev, torch.float32).contiguous()
-            ks, perm = self._sorted_sites(xyz)
-            xs = xyz[perm].contiguous()
+            if pre is not None:
+                ks, perm, xs = pre, None, xyz
+            else:
+                ks, perm = self._sorted_sites(xyz)
+                xs = xyz[perm].contiguous()
             val, dval = self.kernel_rows(xs, grad=(ncomp == 3))
             rows = val if ncomp == 1 else dval
             st, en = self._site_ranges(ks)
@@ -119,7 +125,8 @@ class KernelField(BaseField):
             S.val = ptr(rows)
             tgt = None
             if target is not None:
-                tgt = target.to(dev, torch.float32)[perm].contiguous()
+                tgt = target.to(dev, torch.float32)
+                tgt = (tgt[perm] if perm is not None else tgt).contiguous()
                 S.target = ptr(tgt)
             for d in range(self.svh.depth):
                 S.start[d], S.end[d] = ptr(st[d]), ptr(en[d])
@@ -155,11 +162,13 @@ class KernelField(BaseField):
         return rowptr, cols, vals, diag, b
 
     # ---- solve ------------------------------------------------------------------------------------------
-    def solve_non_fused(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0):
+    def solve_non_fused(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0,
+                        pos_sorted_keys=None, normal_sorted_keys=None):
         """Assemble the sparse system explicitly and solve it with Jacobi-PCG."""
         from .. import solver
         t0 = time.perf_counter()
-        rowptr, cols, vals, diag, b = self.assemble(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight)
+        rowptr, cols, vals, diag, b = self.assemble(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight,
+                                                    pos_sorted_keys, normal_sorted_keys)
         if self.solver_config.get('verbose') or self.solver_config.get('sync_timing'):
             torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -176,11 +185,13 @@ class KernelField(BaseField):
                 b.numel(), self.nnz, iters, rel, t1 - t0, t2 - t1))
         return self
 
-    def solve(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0, fused_mode=True):
+    def solve(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0, fused_mode=True,
+              pos_sorted_keys=None, normal_sorted_keys=None):
         """``fused_mode`` selects the reference's memory-lean operator; on a 288 GB MI355X the
         materialised CSR is both smaller than G (nnz(A) < nnz(G) at >= 2 points/voxel) and the
         faster SpMV, so both modes run the CSR path."""
-        return self.solve_non_fused(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight)
+        return self.solve_non_fused(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight,
+                                    pos_sorted_keys, normal_sorted_keys)
 
     # ---- evaluation -------------------------------------------------------------------------------------
     def _evaluate_f_model(self, xyz, grad, max_points=1 << 22):

@@ -162,11 +162,15 @@ class PointEncoder(nn.Module):
         self.W2 = nn.Parameter(torch.randn(C_, C_, generator=generator) / C_ ** 0.5)
         self.b2 = nn.Parameter(torch.zeros(C_))
 
-    def forward(self, xyz, feat, svh, depth=0):
+    def forward(self, xyz, feat, svh, depth=0, sorted_keys=None):
+        """``sorted_keys``: level-0 Morton keys of an ALREADY Morton-sorted cloud (skips the sort)."""
         if feat is None:
             raise RuntimeError("this network needs an orientation feature (hparams.feature='normal')")
         enc = EncodedCloud()
-        enc.keys, enc.xyz, enc.feat = sort_cloud(xyz.contiguous(), feat.to(torch.float32).contiguous(), svh.inv_w0)
+        if sorted_keys is not None:
+            enc.keys, enc.xyz, enc.feat = sorted_keys, xyz.contiguous(), feat.to(torch.float32).contiguous()
+        else:
+            enc.keys, enc.xyz, enc.feat = sort_cloud(xyz.contiguous(), feat.to(torch.float32).contiguous(), svh.inv_w0)
         n = enc.xyz.shape[0]
         g = torch.empty((n, self.channels), dtype=torch.float32, device=xyz.device)
         call('nksr_point_mlp', ptr(enc.xyz), ptr(enc.feat), n, svh.inv_w0, self.channels, ptr(self.W1.detach().contiguous()),
@@ -205,7 +209,7 @@ class StructureUNet(nn.Module):
             x[d] = self.down[d](p, g.nbr)
         # ---- candidate decoder structure ------------------------------------------------------------
         cand = gt_decoder_svh if gt_decoder_svh is not None else \
-            SparseFeatureHierarchy(enc_svh.voxel_size, D, dev).build_point_neighborhood(enc.xyz)
+            SparseFeatureHierarchy(enc_svh.voxel_size, D, dev).build_point_neighborhood_sorted(enc.keys)
         feat = FeatureSet(D)
         dec_levels = [None] * D
         y_up, keep_up = None, None           # trunk features / "continue" flags of the level above

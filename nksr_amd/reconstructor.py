@@ -42,8 +42,12 @@ class Reconstructor:
         hp = self.hparams
         t = {}
         tic = time.perf_counter()
-        enc_svh = SparseFeatureHierarchy(hp.voxel_size, hp.tree_depth, self.device).build_point_splatting(xyz)
-        enc = self.network.encoder(xyz, normal, enc_svh, 0)
+        # one Morton sort of the cloud serves the hierarchy builds, the encoder and the assembly
+        from .nn.network import sort_cloud
+        from .svh import inv_w0_f32
+        ks, xyz, normal = sort_cloud(xyz, normal, inv_w0_f32(hp.voxel_size))
+        enc_svh = SparseFeatureHierarchy(hp.voxel_size, hp.tree_depth, self.device).build_point_splatting_sorted(xyz, ks)
+        enc = self.network.encoder(xyz, normal, enc_svh, 0, sorted_keys=ks)
         feat, dec_svh, udf_svh = self.network.unet(enc, enc_svh, adaptive_depth=hp.adaptive_depth)
         if all(dec_svh.grids[d] is None for d in range(hp.adaptive_depth)):
             raise RuntimeError('empty decoder hierarchy')
@@ -58,7 +62,8 @@ class Reconstructor:
         field.solve(pos_xyz=enc.xyz, normal_xyz=normal_xyz, normal_value=-normal_value,
                     pos_weight=hp.solver.pos_weight / xyz.shape[0],
                     normal_weight=hp.solver.normal_weight / normal_xyz.shape[0] * hp.voxel_size ** 2,
-                    reg_weight=1.0, fused_mode=fused_mode)
+                    reg_weight=1.0, fused_mode=fused_mode, pos_sorted_keys=enc.keys,
+                    normal_sorted_keys=dec_svh.level(0).keys if hp.adaptive_depth == 1 else None)
         field.set_mask_field(LayerField(dec_svh, hp.adaptive_depth))
         t.update({k: v for k, v in field.solve_info.items() if k.startswith('t_')})
         self.timing = t

@@ -113,6 +113,36 @@ class SparseFeatureHierarchy:
         structure rule of the decoder hierarchy."""
         return self._build_from_points(xyz, 1)
 
+    def _cells_with_points(self, point_keys_sorted, d):
+        """Unique level-d cells that contain a point, from the SORTED level-0 point keys."""
+        return ops.unique_sorted((point_keys_sorted >> (3 * d)).contiguous() if d else point_keys_sorted)
+
+    def _footprint(self, cells, level, mode):
+        per = 8 if mode == 0 else 27
+        raw = torch.empty(cells.numel() * per, dtype=torch.int64, device=self.device)
+        call('nksr_cell_footprint_keys', ptr(cells), cells.numel(), level, mode, ptr(raw), stream())
+        return ops.sort_unique(raw)
+
+    def build_point_splatting_sorted(self, xyz_sorted, point_keys_sorted):
+        """Same result as build_point_splatting, 3-8x fewer keys to sort: level 0 from the points,
+        level d >= 1 from the unique level-(d-1) cells (their index is the level-d half index)."""
+        xyz_sorted = self._check_xyz(xyz_sorted)
+        n = xyz_sorted.shape[0]
+        raw = torch.empty(n * 8, dtype=torch.int64, device=self.device)
+        call('nksr_splat_keys', ptr(xyz_sorted), n, self.inv_w0, 0, 0, ptr(raw), stream())
+        self._levels[0] = SparseGrid(ops.sort_unique(raw), 0, self.voxel_size)
+        for d in range(1, self.depth):
+            cells = self._cells_with_points(point_keys_sorted, d - 1)
+            self._levels[d] = SparseGrid(self._footprint(cells, d - 1, 0), d, self.voxel_size)
+        return self
+
+    def build_point_neighborhood_sorted(self, point_keys_sorted):
+        """Same result as build_point_neighborhood from the unique cells that hold points."""
+        for d in range(self.depth):
+            cells = self._cells_with_points(point_keys_sorted, d)
+            self._levels[d] = SparseGrid(self._footprint(cells, d, 1), d, self.voxel_size)
+        return self
+
     def build_from_keys(self, keys_per_level):
         for d in range(self.depth):
             k = keys_per_level[d]

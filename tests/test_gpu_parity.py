@@ -246,3 +246,20 @@ def test_against_committed_golden(name):
         np.testing.assert_allclose(gv, g['mesh_v_0'], rtol=0, atol=1e-3 * 0.1)
     else:
         assert abs(len(gf) - len(g['mesh_f_0'])) <= 0.01 * len(g['mesh_f_0'])
+
+
+def test_sorted_builders_equal_point_builders():
+    """The cell-based hierarchy builders give exactly the voxel sets of the per-point builders."""
+    import nksr_amd
+    from nksr_amd.nn.network import sort_cloud
+    xyz, nrm = make_cloud('torus', 20000, 0.005, 7)
+    x = torch.from_numpy((xyz * np.float32(3.0)).astype(np.float32)).to(_dev())
+    ks, xs, _ = sort_cloud(x, None, nksr_amd.svh.inv_w0_f32(0.1))
+    for depth in (4, 5):
+        a = nksr_amd.SparseFeatureHierarchy(0.1, depth, _dev()).build_point_splatting(x)
+        b = nksr_amd.SparseFeatureHierarchy(0.1, depth, _dev()).build_point_splatting_sorted(xs, ks)
+        c = nksr_amd.SparseFeatureHierarchy(0.1, depth, _dev()).build_point_neighborhood(x)
+        d = nksr_amd.SparseFeatureHierarchy(0.1, depth, _dev()).build_point_neighborhood_sorted(ks)
+        for lv in range(depth):
+            assert torch.equal(a.level(lv).keys, b.level(lv).keys)
+            assert torch.equal(c.level(lv).keys, d.level(lv).keys)
