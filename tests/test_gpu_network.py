@@ -74,3 +74,51 @@ def test_conv_is_not_transposed():
     ref = x @ W13
     ref[:-1] += x[1:] @ (W13.T * 0.5)
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_reconstruct_with_active_heads_matches_oracle_pipeline():
+    """Non-zero residual heads: the network output really feeds the kernel solve on both sides."""
+    import nksr_amd
+    from nksr_amd import configs
+    from oracle import network as onet, pipeline
+    dev = torch.device('cuda:0')
+    xyz, nrm = make_cloud('sphere', 3000, 0.005, 0)
+    hp = configs.get_hparams('ks', head_init_scale=0.15, interpolator_init_scale=0.4, seed=11)
+    rec = nksr_amd.Reconstructor(dev, hparams=hp)
+    P = onet.export_params(rec.network)
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev), voxel_size=0.05, solver_tol=1e-6)
+    xs = (xyz * np.float32(2.0)).astype(np.float32)
+    ofl = pipeline.reconstruct(xs, nrm, tol=1e-6, net_params=P)
+    assert fld.solve_info['M'] == ofl['A'].shape[0]
+    for d in range(4):
+        np.testing.assert_allclose(fld._feat[d].cpu().numpy(), ofl['feats'][d], rtol=0, atol=2e-4)
+    fo, go = pipeline.evaluate(ofl, xs, grad=True)
+    res = fld.evaluate_f(torch.from_numpy(xyz).to(dev), grad=True)
+    ref = np.abs(ofl['alpha']).max()
+    assert np.abs(res.value.cpu().numpy() - fo).max() <= 3e-3 * ref
+    assert np.abs(res.gradient.cpu().numpy() / 2.0 - go).max() <= 3e-3 * np.abs(go).max()
+
+
+def test_shapenet_3k_noise_config():
+    """BASELINE.json configs[1] stand-in: ShapeNet 3K-noise recipe (sigma=0.005, N=3000,
+    configs/shapenet/train_3k_noise.yaml:4-18: voxel_size 0.02, kernel_dim 16, interpolator 2x32) on an
+    analytic shape; HIP vs oracle: voxel sets exact, alpha / f within fp32 tolerance."""
+    import nksr_amd
+    from oracle import network as onet, pipeline
+    dev = torch.device('cuda:0')
+    xyz, nrm = make_cloud('sphere', 3000, 0.005, 0)
+    rec = nksr_amd.Reconstructor(dev, config='snet-n3k-wnormal')
+    assert rec.hparams.kernel_dim == 16 and rec.hparams.interpolator.hidden_dim == 32 and rec.hparams.voxel_size == 0.02
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev), detail_level=None, solver_tol=1e-6)
+    ofl = pipeline.reconstruct(xyz, nrm, voxel_size=0.02, kernel_dim=16, hidden=32, tol=1e-6,
+                               net_params=onet.export_params(rec.network))
+    for d in range(4):
+        assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
+    ref = np.abs(ofl['alpha']).max()
+    assert np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() <= 3e-3 * ref
+    fo, _ = pipeline.evaluate(ofl, xyz)
+    fg = fld.evaluate_f(torch.from_numpy(xyz).to(dev)).value.cpu().numpy()
+    assert np.abs(fg - fo).max() <= 3e-3 * ref
+    mesh = fld.extract_dual_mesh(mise_iter=0)
+    ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=0)
+    assert abs(mesh.f.shape[0] - len(of)) <= max(4, 0.01 * len(of))
