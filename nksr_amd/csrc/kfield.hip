@@ -68,41 +68,51 @@ __device__ __forceinline__ float sel3(const float w[3], int i) { return i == 0 ?
 
 struct SiteCell {
     int cell;      // voxel index of the containing cell or -1
+    int I[3];      // integer coordinates of the containing cell
     int hb[3];     // half bits
     float u[3];    // local coordinate in [0,1)
 };
 
+// neighbour slot s of the site's cell: through the 27-neighbour table when the cell is active,
+// through the hash otherwise (FALLBACK: query points in inactive cells still see every existing
+// voxel whose support covers them -- field.evaluate_f on arbitrary positions, models/loss.py:99)
+template <bool FALLBACK>
+__device__ __forceinline__ int nbr_of(const nksr_level_t& lv, int level, const SiteCell& sc, int s) {
+    if (sc.cell >= 0) return lv.nbr[(int64_t)sc.cell * 27 + s];
+    if (!FALLBACK) return -1;
+    return hash_find(lv.hkeys, lv.hvals, lv.hcap,
+                     morton_biased(sc.I[0] + s / 9 - 1, sc.I[1] + (s / 3) % 3 - 1, sc.I[2] + s % 3 - 1, NKSR_BIAS0 >> level));
+}
+
 __device__ __forceinline__ SiteCell locate_site(const nksr_level_t& lv, int level, float inv_w0, const float x[3]) {
     SiteCell sc;
-    int I[3];
     float scale = __int_as_float((127 - level) << 23);  // 2^-level
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float p;
         int Hd = half_index(x[a], inv_w0, p) >> level;
-        I[a] = Hd >> 1;
+        sc.I[a] = Hd >> 1;
         sc.hb[a] = Hd & 1;
-        sc.u[a] = p * scale - (float)I[a];
+        sc.u[a] = p * scale - (float)sc.I[a];
     }
-    sc.cell = hash_find(lv.hkeys, lv.hvals, lv.hcap, morton_biased(I[0], I[1], I[2], NKSR_BIAS0 >> level));
+    sc.cell = hash_find(lv.hkeys, lv.hvals, lv.hcap, morton_biased(sc.I[0], sc.I[1], sc.I[2], NKSR_BIAS0 >> level));
     return sc;
 }
 
 // trilinear interpolation of the level's basis features (+ spatial tangents in world units)
-template <int K, bool JAC>
-__device__ __forceinline__ void trilerp_feat(const nksr_level_t& lv, const SiteCell& sc, float inv_w, float t[K],
+template <int K, bool JAC, bool FALLBACK = false>
+__device__ __forceinline__ void trilerp_feat(const nksr_level_t& lv, int level, const SiteCell& sc, float inv_w, float t[K],
                                              float Jt[K][3]) {
 #pragma unroll
     for (int k = 0; k < K; ++k) { t[k] = 0.f; if (JAC) { Jt[k][0] = Jt[k][1] = Jt[k][2] = 0.f; } }
     float v[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) v[a] = sc.u[a] + 0.5f - (float)sc.hb[a];
-    const int32_t* nb = lv.nbr + (int64_t)sc.cell * 27;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         int cx = c >> 2, cy = (c >> 1) & 1, cz = c & 1;
         int s = (sc.hb[0] + cx) * 9 + (sc.hb[1] + cy) * 3 + (sc.hb[2] + cz);  // (hb-1+c)+1
-        int j = nb[s];
+        int j = nbr_of<FALLBACK>(lv, level, sc, s);
         if (j < 0) continue;
         float wx = cx ? v[0] : 1.f - v[0], wy = cy ? v[1] : 1.f - v[1], wz = cz ? v[2] : 1.f - v[2];
         float w = wx * wy * wz;
@@ -159,7 +169,7 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
     }
     float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
     float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
-    trilerp_feat<K, JAC>(lv, sc, inv_w, t, Jt);
+    trilerp_feat<K, JAC>(lv, d, sc, inv_w, t, Jt);
     MlpView<K, H> m(w);
     mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
     float bw[3][3], bd[3][3];
@@ -213,20 +223,19 @@ __global__ void __launch_bounds__(128) k_evaluate_f(nksr_hier_t hier, const floa
     float f = 0.f, gr[3] = {0.f, 0.f, 0.f};
     for (int d = 0; d < L; ++d) {
         const nksr_level_t& lv = hier.lv[d];
+        if (lv.n == 0) continue;
         SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
-        if (sc.cell < 0) continue;
         float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
         float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
-        trilerp_feat<K, JAC>(lv, sc, inv_w, t, Jt);
+        trilerp_feat<K, JAC, true>(lv, d, sc, inv_w, t, Jt);
         MlpView<K, H> m(wall + d * MlpView<K, H>::SIZE);
         mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
         float bw[3][3], bd[3][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
-        const int32_t* nb = lv.nbr + (int64_t)sc.cell * 27;
         float fl = 0.f, gl[3] = {0.f, 0.f, 0.f};
         for (int s = 0; s < 27; ++s) {
-            int j = nb[s];
+            int j = nbr_of<true>(lv, d, sc, s);
             if (j < 0) continue;
             const int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
             const float* ps = lv.psi + (int64_t)j * K;

@@ -221,3 +221,39 @@ class KernelField(BaseField):
         if self.mask_field is not None:
             self.mask_field.to_(device)
         return self
+
+
+class _PackedInterpolator:
+    """Interpolator stand-in carrying only the packed weights (used when a field is re-created from
+    a payload: serialisation, chunk exchange)."""
+
+    def __init__(self, kernel_dim, hidden_dim, packed):
+        self.kernel_dim, self.hidden_dim, self._packed = int(kernel_dim), int(hidden_dim), packed
+
+    def packed(self):
+        return self._packed
+
+
+def save_field(field, path):
+    """Serialise a solved KernelField (hierarchy keys, basis features, alpha, interpolator weights,
+    global scale).  SURVEY.md section 8(f)-3: the reference has no on-disk format for solved fields;
+    this enables spill-to-disk of chunks and checkpointing."""
+    from ..chunking import pack_field
+    ints, flts = pack_field(field)
+    torch.save({'format': 'nksr_amd.KernelField.v1', 'ints': ints.cpu(), 'flts': flts.cpu(), 'voxel_size': field.svh.voxel_size,
+                'hidden': field.hidden, 'kdim': field.kdim, 'scale': field.scale, 'mlp': [m.cpu() for m in field._mlp],
+                'solve_info': field.solve_info}, path)
+
+
+def load_field(path, device):
+    from ..chunking import unpack_field
+    from .mask_fields import LayerField
+    st = torch.load(path, map_location='cpu')
+    if st.get('format') != 'nksr_amd.KernelField.v1':
+        raise RuntimeError('%s is not a serialised KernelField' % path)
+    interps = [_PackedInterpolator(st['kdim'], st['hidden'], m) for m in st['mlp']]
+    fld = unpack_field(st['ints'], st['flts'], st['voxel_size'], interps, torch.device(device))
+    fld.set_scale(st['scale'])
+    fld.solve_info = st.get('solve_info', {})
+    fld.set_mask_field(LayerField(fld.svh, 1))
+    return fld

@@ -12,7 +12,7 @@ def evaluate_f(hier, feats, interps, psis, alpha, xyz, grad=False, approx_kernel
     vals, grads = [], []
     for s in range(0, xyz.shape[0], batch):
         x = xyz[s:s + batch]
-        cols, val, dval = kernel.kernel_rows(hier, feats, interps, psis, x, grad, approx_kernel_grad)
+        cols, val, dval = kernel.kernel_rows(hier, feats, interps, psis, x, grad, approx_kernel_grad, fallback=True)
         a = np.where(cols >= 0, alpha[np.maximum(cols, 0)], np.float32(0)).astype(np.float32)
         vals.append((a * val).reshape(x.shape[0], -1).sum(1, dtype=np.float64).astype(np.float32))
         if grad:

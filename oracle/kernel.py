@@ -39,11 +39,22 @@ def voxel_psi(feat_d, interp_d):
     return interp_d.forward(np.asarray(feat_d, np.float32))[0]
 
 
-def site_features(hier, feats, interps, xyz, need_jac):
+def _nbr(L, ijk_cell, cell, s, o, fallback):
+    """Neighbour slot s of every site's cell: table for active cells, coordinate lookup otherwise."""
+    ok = cell >= 0
+    j = np.where(ok, L.nbr[np.where(ok, cell, 0), s], -1)
+    if fallback and (~ok).any():
+        j = np.where(ok, j, L.lookup(ijk_cell + o[None]))
+    return j
+
+
+def site_features(hier, feats, interps, xyz, need_jac, fallback=False):
     """Per level: (cell, u, phi [n,K], Jphi [n,K,3] in world units or None)."""
     out = []
+    H0, _ = spec.half_index(xyz, hier.voxel_size)
     for d, (cell, u, hb) in enumerate(hier.site_cells(xyz)):
         L = hier.levels[d]
+        Icell = ((H0 >> d) >> 1).astype(np.int32)
         n = xyz.shape[0]
         K = feats[d].shape[1]
         inv_w = np.float32(spec.inv_w0_f32(hier.voxel_size) * np.float32(2.0 ** (-d)))
@@ -57,6 +68,8 @@ def site_features(hier, feats, interps, xyz, need_jac):
             s = (o[:, 0] + 1) * 9 + (o[:, 1] + 1) * 3 + (o[:, 2] + 1)
             j = L.nbr[cs, s]
             j = np.where(ok, j, -1)
+            if fallback and (~ok).any():
+                j = np.where(ok, j, L.lookup(Icell + o))
             f = np.where((j >= 0)[:, None], feats[d][np.maximum(j, 0)], np.float32(0)).astype(np.float32)
             wa = np.where(co[None, :] == 1, v, np.float32(1.0) - v).astype(np.float32)
             w = wa[:, 0] * wa[:, 1] * wa[:, 2]
@@ -67,11 +80,11 @@ def site_features(hier, feats, interps, xyz, need_jac):
                 Jt[:, :, 1] += f * (wa[:, 0] * sg[1] * wa[:, 2] * inv_w)[:, None]
                 Jt[:, :, 2] += f * (wa[:, 0] * wa[:, 1] * sg[2] * inv_w)[:, None]
         phi, J = interps[d].forward(t, Jt)
-        out.append((cell, u, phi, J, inv_w))
+        out.append((cell, u, phi, J, inv_w, Icell))
     return out
 
 
-def kernel_rows(hier, feats, interps, psis, xyz, grad, approx_kernel_grad):
+def kernel_rows(hier, feats, interps, psis, xyz, grad, approx_kernel_grad, fallback=False):
     """Dense-slot rows of the kernel matrix at the sites ``xyz``.
 
     Returns cols [n, L, 27] (global unknown index or -1), val [n, L, 27] and, when
@@ -82,14 +95,14 @@ def kernel_rows(hier, feats, interps, psis, xyz, grad, approx_kernel_grad):
     cols = np.full((n, Lv, 27), -1, np.int64)
     val = np.zeros((n, Lv, 27), np.float32)
     dval = np.zeros((n, 3, Lv, 27), np.float32) if grad else None
-    sf = site_features(hier, feats, interps, xyz, need_jac=grad and not approx_kernel_grad)
-    for d, (cell, u, phi, J, inv_w) in enumerate(sf):
+    sf = site_features(hier, feats, interps, xyz, need_jac=grad and not approx_kernel_grad, fallback=fallback)
+    for d, (cell, u, phi, J, inv_w, Icell) in enumerate(sf):
         L = hier.levels[d]
         ok = cell >= 0
         cs = np.where(ok, cell, 0)
         bw = [spec.bspline3(u[:, a]) for a in range(3)]
         for s, o in enumerate(spec.NBR_OFFSETS):
-            j = np.where(ok, L.nbr[cs, s], -1)
+            j = _nbr(L, Icell, cell, s, o, fallback)
             present = j >= 0
             psi = psis[d][np.maximum(j, 0)]
             dot = np.einsum('nk,nk->n', phi, psi).astype(np.float32)

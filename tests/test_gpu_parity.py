@@ -263,3 +263,20 @@ def test_sorted_builders_equal_point_builders():
         for lv in range(depth):
             assert torch.equal(a.level(lv).keys, b.level(lv).keys)
             assert torch.equal(c.level(lv).keys, d.level(lv).keys)
+
+
+def test_field_save_load_roundtrip(tmp_path):
+    """Serialised field evaluates and meshes bit-identically after a reload."""
+    import nksr_amd
+    from nksr_amd import fields
+    xyz, nrm = make_cloud('sphere', 3000, 0.005, 0)
+    rec = nksr_amd.Reconstructor(_dev())
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(_dev()), torch.from_numpy(nrm).to(_dev()), voxel_size=0.05)
+    p = str(tmp_path / 'field.pt')
+    fields.save_field(fld, p)
+    g = fields.load_field(p, _dev())
+    q = torch.from_numpy(xyz).to(_dev())
+    a, b = fld.evaluate_f(q, grad=True), g.evaluate_f(q, grad=True)
+    assert torch.equal(a.value, b.value) and torch.equal(a.gradient, b.gradient)
+    m0, m1 = fld.extract_dual_mesh(mise_iter=1), g.extract_dual_mesh(mise_iter=1)
+    assert torch.equal(m0.f, m1.f) and torch.equal(m0.v, m1.v)
