@@ -187,11 +187,29 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     nonempty = [c for c in range(nchunk) if counts[c] > 0]
     if ws > 1 and sim is None:
         payload = D.exchange_payloads({c: pack_field(f) for c, f in local.items()}, nonempty)
+        # a rank only evaluates the blend inside its own cores (+ one voxel): it needs exactly the
+        # chunks whose weight support (core +- ov) reaches there -- its spatial neighbours, not all N
+        need = needed_chunks(cores, ov + hp.voxel_size, grid, [c for c in nonempty if owner[c] == rank], nonempty)
         fields = {c: (local[c] if c in local else unpack_field(payload[c][0], payload[c][1], hp.voxel_size,
-                                                              rec.network.interpolators, dev)) for c in nonempty}
+                                                              rec.network.interpolators, dev)) for c in need}
     else:
         fields = local
         if rec.chunk_tmp_device != dev and sim is None:
             for f in fields.values():
                 f.to_(dev)                # meshing runs on the GPU: bring the parked chunks back
     return MultiChunkField(fields, cores, ov, lo, chunk_size, grid, owner, rank, ws, hp.voxel_size, dev)
+
+
+def needed_chunks(cores, margin, grid, owned, candidates):
+    """Chunks whose core grown by ``margin`` touches the core of an owned chunk (owned included)."""
+    out = set(owned)
+    for c in candidates:
+        if c in out:
+            continue
+        clo, chi = cores[c]
+        for o in owned:
+            olo, ohi = cores[o]
+            if all(grid[a] == 1 or (clo[a] - margin < ohi[a] and chi[a] + margin > olo[a]) for a in range(3)):
+                out.add(c)
+                break
+    return sorted(out)

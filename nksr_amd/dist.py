@@ -118,7 +118,9 @@ def merge_meshes(pieces):
 
 
 def gather_meshes(v, f, vkey, axis, dst=0):
-    """Gathers the per-rank mesh pieces and merges them on every rank (small data)."""
+    """Gathers the per-rank mesh pieces; rank ``dst`` merges the seams and returns the full mesh,
+    the other ranks keep their own piece (the merge is O(total mesh): doing it N times would cost
+    weak-scaling efficiency for nothing)."""
     rank, ws = world()
     if ws == 1:
         return v, f
@@ -126,5 +128,7 @@ def gather_meshes(v, f, vkey, axis, dst=0):
     fs = all_gather_variable(f.reshape(-1).contiguous())
     ks = all_gather_variable(vkey.contiguous())
     as_ = all_gather_variable(axis.to(torch.int64).contiguous())
+    if rank != dst:
+        return v, f
     pieces = [(a.view(-1, 3), b.view(-1, 3), c, d.to(torch.int8)) for a, b, c, d in zip(vs, fs, ks, as_)]
     return merge_meshes(pieces)

@@ -48,11 +48,14 @@ def _worker(rank, world, port, q):
         f = torch.tensor([[0, 1, 2], [0, 2, 3]])
         ax = torch.zeros(4, dtype=torch.int8)
         mv, mf = D.gather_meshes(v, f, key, ax)
-        assert mv.shape[0] == 6 and mf.shape[0] == 4
-        mfn = mf.numpy()
-        e = np.sort(np.concatenate([mfn[:, [0, 1]], mfn[:, [1, 2]], mfn[:, [2, 0]]]), 1)
-        _, cnt = np.unique(e, axis=0, return_counts=True)
-        assert (cnt == 2).sum() == 3          # two diagonals + the stitched seam edge
+        if rank == 0:
+            assert mv.shape[0] == 6 and mf.shape[0] == 4
+            mfn = mf.numpy()
+            e = np.sort(np.concatenate([mfn[:, [0, 1]], mfn[:, [1, 2]], mfn[:, [2, 0]]]), 1)
+            _, cnt = np.unique(e, axis=0, return_counts=True)
+            assert (cnt == 2).sum() == 3          # two diagonals + the stitched seam edge
+        else:
+            assert mv.shape[0] == 4 and mf.shape[0] == 2   # non-destination ranks keep their piece
         # --- empty contribution from a rank still completes the collective
         z = D.all_gather_variable(torch.arange(3 * rank, dtype=torch.int64))
         assert [t.numel() for t in z] == [0, 3]
@@ -84,5 +87,9 @@ def test_partition_is_balanced_and_deterministic():
     load = [sum(w[c] for c in range(len(w)) if o[c] == r) for r in range(4)]
     assert max(load) <= 100 and min(load) >= 30
     assert D.partition_chunks(3, 8) == [0, 1, 2]          # more ranks than chunks: idle ranks
+    from nksr_amd.chunking import needed_chunks
+    cores = {c: ([10.0 * c, 0, 0], [10.0 * c + 10, 10, 10]) for c in range(6)}
+    assert needed_chunks(cores, 0.9, [6, 1, 1], [2], list(range(6))) == [1, 2, 3]
+    assert needed_chunks(cores, 0.9, [6, 1, 1], [0, 5], list(range(6))) == [0, 1, 4, 5]
     assert D.merge_meshes([(torch.zeros((0, 3)), torch.zeros((0, 3), dtype=torch.int64), torch.zeros(0, dtype=torch.int64),
                             torch.zeros(0, dtype=torch.int8))])[0].shape[0] == 0
