@@ -152,8 +152,10 @@ class KernelField(BaseField):
         # physical (tile-interleaved, zero-padded) CSR arrays for the streaming SpMV
         npad = (nnz + 4095) // 4096 * 4096
         rowptr = torch.empty(M + 1, dtype=torch.int32, device=dev)
-        cols = torch.zeros(npad, dtype=torch.int32, device=dev)
-        vals = torch.zeros(npad, dtype=torch.float32, device=dev)
+        cols = torch.empty(npad, dtype=torch.int32, device=dev)
+        vals = torch.empty(npad, dtype=torch.float32, device=dev)
+        cols[nnz:].zero_()          # only the pad must be zero (valid column 0, value 0)
+        vals[nnz:].zero_()
         diag = torch.empty(M, dtype=torch.float32, device=dev)
         call('nksr_coo_to_csr', ptr(ks), ptr(vs.view(torch.float32)), nnz, M, col_bits, ptr(rowptr), ptr(cols), ptr(vals),
              ptr(diag), stream())

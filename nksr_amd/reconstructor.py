@@ -90,6 +90,10 @@ class Reconstructor:
         if normal is None:
             raise RuntimeError('oriented input required: pass normal=, or sensor= together with '
                                'preprocess_fn=nksr.get_estimate_normal_preprocess_fn(...)')
+        if xyz.shape[0] < 8:
+            raise RuntimeError('need at least 8 points to reconstruct (got %d)' % xyz.shape[0])
+        if not bool(torch.isfinite(xyz).all()) or not bool(torch.isfinite(normal).all()):
+            raise RuntimeError('non-finite coordinates / normals in the input')
         scale = self._global_scale(xyz, detail_level, voxel_size)
         xs = (xyz * scale).contiguous() if scale != 1.0 else xyz.contiguous()
         field = self._reconstruct_single(xs, normal.to(torch.float32).contiguous(), approx_kernel_grad, solver_max_iter,

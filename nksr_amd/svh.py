@@ -90,6 +90,11 @@ class SparseFeatureHierarchy:
         if xyz.dtype != torch.float32 or xyz.dim() != 2 or xyz.shape[1] != 3:
             raise RuntimeError('xyz must be a float32 [N,3] tensor')
         _lib.require_gpu(xyz.device)
+        if xyz.shape[0]:
+            amax = float(xyz.abs().max())
+            if not (amax * self.inv_w0 < (1 << 20) - 8):     # also catches NaN / inf
+                raise RuntimeError('coordinates out of range: |x| / voxel_size must stay below 2^20 (got %g); '
+                                   'recentre the cloud or use a larger voxel_size' % (amax * self.inv_w0))
         return xyz.contiguous()
 
     def _build_from_points(self, xyz, mode):

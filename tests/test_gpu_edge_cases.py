@@ -1,0 +1,116 @@
+"""Edge cases of the hot path on the GPU: empty / tiny / ragged / degenerate / out-of-range inputs,
+hash collisions, error behaviour (RuntimeError, never abort -- SURVEY.md section 5)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_cloud
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+
+
+def test_input_validation_raises_runtime_error():
+    import nksr
+    rec = nksr.Reconstructor(DEV)
+    xyz, nrm = make_cloud('sphere', 500, 0.0, 0)
+    x, n = torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV)
+    with pytest.raises(RuntimeError):
+        rec.reconstruct(x.double(), n)                         # non-float32 input must error
+    with pytest.raises(RuntimeError):
+        rec.reconstruct(x[:, :2].contiguous(), n)              # wrong shape
+    with pytest.raises(RuntimeError):
+        rec.reconstruct(x)                                     # no orientation information at all
+    with pytest.raises(RuntimeError):
+        rec.reconstruct(x[:5], n[:5], detail_level=None)       # fewer than 8 points
+    bad = x.clone()
+    bad[3, 1] = float('nan')
+    with pytest.raises(RuntimeError):
+        rec.reconstruct(bad, n, detail_level=None)
+    with pytest.raises(RuntimeError):
+        rec.reconstruct(x * 1e7, n, detail_level=None)         # beyond the 2^20-voxel key range
+    with pytest.raises(RuntimeError):
+        rec.reconstruct(x, n, chunk_size=1.0, voxel_size=0.05)  # NKSR-USAGE.md:137
+    # the session is still usable afterwards
+    f = rec.reconstruct(x, n, voxel_size=0.08)
+    assert f.extract_dual_mesh().f.shape[0] > 0
+
+
+def test_duplicates_boundaries_and_negative_coordinates():
+    """Many coincident points, points exactly on voxel faces / corners, negative coordinates:
+    integer decisions still agree with the oracle bit for bit."""
+    import nksr_amd
+    from oracle import hierarchy
+    rs = np.random.RandomState(0)
+    lattice = (rs.randint(-40, 40, size=(3000, 3)).astype(np.float32)) * np.float32(0.05)   # on faces / corners
+    dup = np.repeat(lattice[:50], 20, 0)
+    xyz = np.concatenate([lattice, dup, -np.abs(rs.randn(500, 3).astype(np.float32))])
+    oh = hierarchy.Hierarchy(0.1, 4).build_point_neighborhood(xyz)
+    oe = hierarchy.Hierarchy(0.1, 4).build_point_splatting(xyz)
+    x = torch.from_numpy(xyz).to(DEV)
+    gh = nksr_amd.SparseFeatureHierarchy(0.1, 4, DEV).build_point_neighborhood(x)
+    ge = nksr_amd.SparseFeatureHierarchy(0.1, 4, DEV).build_point_splatting(x)
+    for d in range(4):
+        assert np.array_equal(gh.level(d).keys.cpu().numpy(), oh.levels[d].keys)
+        assert np.array_equal(ge.level(d).keys.cpu().numpy(), oe.levels[d].keys)
+        assert np.array_equal(gh.level(d).nbr.cpu().numpy(), oh.levels[d].nbr)
+
+
+def test_hash_table_under_collisions_and_misses():
+    from nksr_amd import ops
+    # keys that agree in their low bits (stress linear probing) + a dense run
+    base = torch.arange(0, 20000, dtype=torch.int64, device=DEV)
+    keys = torch.cat([base * (1 << 20), base + 7]).unique()
+    keys = ops.sort_keys(keys.contiguous())
+    h = ops.HashTable(keys)
+    got = h.query(keys)
+    assert torch.equal(got.long(), torch.arange(keys.numel(), device=DEV))
+    miss = h.query((keys + (1 << 40)).contiguous())
+    assert bool((miss == -1).all())
+    assert h.query(torch.empty(0, dtype=torch.int64, device=DEV)).numel() == 0
+
+
+def test_tiny_clouds_and_single_voxel_systems():
+    import nksr
+    rec = nksr.Reconstructor(DEV)
+    # 8 points in one voxel: smallest legal input; must solve and evaluate without NaN
+    p = (torch.rand(8, 3, device=DEV) * 0.05)
+    n = torch.nn.functional.normalize(torch.randn(8, 3, device=DEV), dim=1)
+    f = rec.reconstruct(p, n, detail_level=None)
+    v = f.evaluate_f(p, grad=True)
+    assert torch.isfinite(v.value).all() and torch.isfinite(v.gradient).all()
+    assert f.solve_info['rel_residual'] <= 1e-5
+    m = f.extract_dual_mesh(mise_iter=2)
+    assert m.v.shape[1] == 3 and m.f.dtype == torch.int64
+    # evaluation far away from everything: exactly zero, no fault
+    far = torch.full((4, 3), 500.0, device=DEV)
+    assert float(f.evaluate_f(far).value.abs().max()) == 0.0
+    assert f.evaluate_f(torch.zeros((0, 3), device=DEV)).value.numel() == 0
+
+
+def test_compaction_and_scan_primitives():
+    from nksr_amd import ops
+    for n in (0, 1, 255, 256, 257, 100003):
+        fl = (torch.rand(n, device=DEV) < 0.37).to(torch.int32)
+        sel = ops.compact(fl)
+        assert torch.equal(sel.long(), torch.nonzero(fl).reshape(-1))
+        ex = ops.exclusive_sum_i32(fl)
+        ref = torch.cumsum(fl, 0) - fl
+        assert torch.equal(ex, ref.to(torch.int32))
+    k = torch.randint(0, 1 << 50, (200001,), dtype=torch.int64, device=DEV)
+    assert torch.equal(ops.sort_unique(k), torch.unique(k))
+
+
+def test_grid_upsample_and_max_points_batches():
+    import nksr
+    rec = nksr.Reconstructor(DEV)
+    xyz, nrm = make_cloud('sphere', 3000, 0.002, 0)
+    f = rec.reconstruct(torch.from_numpy(xyz).to(DEV), torch.from_numpy(nrm).to(DEV), voxel_size=0.06)
+    a = f.extract_dual_mesh(grid_upsample=2)
+    b = f.extract_dual_mesh(mise_iter=1)
+    # upsampling the base grid by 2 visits a superset of the MISE(1) cells: same lattice, >= triangles
+    assert a.f.shape[0] >= b.f.shape[0] > 0
+    c = f.extract_dual_mesh(mise_iter=1, max_points=1000)      # tiny evaluation batches
+    assert torch.equal(b.f, c.f) and torch.equal(b.v, c.v)
+    r = np.linalg.norm(a.v.cpu().numpy(), axis=1)
+    assert abs(np.median(r) - 0.45) < 0.01
