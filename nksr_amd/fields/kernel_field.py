@@ -154,8 +154,11 @@ class KernelField(BaseField):
         rowptr = torch.empty(M + 1, dtype=torch.int32, device=dev)
         cols = torch.empty(npad, dtype=torch.int32, device=dev)
         vals = torch.empty(npad, dtype=torch.float32, device=dev)
-        cols[nnz:].zero_()          # only the pad must be zero (valid column 0, value 0)
-        vals[nnz:].zero_()
+        # only the pad must be zero (valid column 0, value 0); the last 256-entry tile is interleaved,
+        # so its unwritten slots are scattered through the whole tile: clear it from its start
+        tail = nnz & ~255
+        cols[tail:].zero_()
+        vals[tail:].zero_()
         diag = torch.empty(M, dtype=torch.float32, device=dev)
         call('nksr_coo_to_csr', ptr(ks), ptr(vs.view(torch.float32)), nnz, M, col_bits, ptr(rowptr), ptr(cols), ptr(vals),
              ptr(diag), stream())
