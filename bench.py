@@ -28,15 +28,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
 
 
-def load_traffic():
-    """HBM bytes per SpMV launch from the committed rocprofv3 --pmc pass (or None)."""
+def load_traffic(bytes_per_launch=None):
+    """HBM bytes per SpMV launch from the committed rocprofv3 --pmc pass; None when the committed
+    pass was taken on a different matrix than this run's."""
     best = None
     pdir = os.path.join(ROOT, 'profiles')
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
             if f.endswith('_spmv_pmc.json'):
                 try:
-                    best = json.load(open(os.path.join(pdir, f))).get('hbm_bytes_per_launch')
+                    rec = json.load(open(os.path.join(pdir, f)))
+                    if bytes_per_launch is None or abs(rec.get('algorithmic_bytes_per_launch', 0) - bytes_per_launch) < 0.02 * bytes_per_launch:
+                        best = rec.get('hbm_bytes_per_launch')
                 except Exception:
                     pass
     return best
@@ -169,7 +172,7 @@ def main():
                    'parallelism': 'none' if world == 1 else 'chunks sharded 1/rank, all_gather of solved fields before meshing, mesh gather'},
         'roofline': {'bound': 'hbm', 'kernel': 'k_spmv<true> (CSR SpMV + fused p.Ap partial dot)',
                      'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
-                     'traffic': load_traffic(), 'bytes_per_launch': b_spmv, 'avg_launch_us': avg_s * 1e6,
+                     'traffic': load_traffic(b_spmv), 'bytes_per_launch': b_spmv, 'avg_launch_us': avg_s * 1e6,
                      'launches_timed': spmv_launches},
         'stages_s_per_step': {k: v / args.steps for k, v in sorted(stage_acc.items())},
     }

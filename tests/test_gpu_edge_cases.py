@@ -114,3 +114,27 @@ def test_grid_upsample_and_max_points_batches():
     assert torch.equal(b.f, c.f) and torch.equal(b.v, c.v)
     r = np.linalg.norm(a.v.cpu().numpy(), axis=1)
     assert abs(np.median(r) - 0.45) < 0.01
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the driver's keys + roofline + cpu_baseline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '1',
+                          '--points', '60000', '--cpu-sample', '1500'], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 1 and d['higher_is_better'] is True and d['vs_baseline'] is None
+    assert 'workload' in d['config'] and d['value'] > 0
+    r = d['roofline']
+    assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and 'sample' in c
