@@ -131,25 +131,30 @@ typedef struct {
     const int32_t* end[NKSR_MAX_DEPTH];
 } nksr_siteset_t;
 
-/* rowcount[row] = number of COO entries row `row` emits (2 per structural upper entry + the
- * diagonal).  A slot is structural iff the column voxel exists and the B-spline supports overlap. */
-int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, void* stream);
+/* Structure pass: rowcount[row] = number of structural upper entries of the row (column voxel exists,
+ * B-spline supports overlap, col > row); indeg[col] += 1 for each of them (integer atomics; indeg must
+ * be zeroed).  Final CSR row = [indeg mirrors][rowcount own upper][diagonal]. */
+int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, int32_t* indeg, void* stream);
 /* Bytes of scratch (per-cell blocks + per-row column map) shared by nksr_assemble_count / nksr_assemble. */
 size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h);
-/* Two-phase assembly (per-cell dense blocks, then per-row gather; csrc/assemble.hip).  Writes the
- * symmetric COO of  sum_s w_s R_s^T R_s + reg I  (keys = row<<col_bits | col, 2^col_bits >= M) at
- * rowoff = exclusive scan of rowcount, and b = sum_s w_s R_s^T t_s. */
+/* Two-phase assembly of  sum_s w_s R_s^T R_s + reg I  (csrc/assemble.hip): per-cell dense blocks, then
+ * one wavefront per row.  rowptr = exclusive scan of (indeg + rowcount + 1), mir_off = exclusive scan of
+ * rowcount.  Own upper entries + diagonal are written straight into cols_out / vals_out (tile-interleaved
+ * physical layout, see nksr_spmv_csr); the mirrored copies go to mir_keys (src_row << col_bits | dst_row)
+ * / mir_vals.  Also writes diag_out and b = sum_s w_s R_s^T t_s. */
 int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, int nsets, float reg, int col_bits,
-                  void* workspace, const int32_t* rowoff, uint64_t* coo_keys, float* coo_vals, float* b_out, void* stream);
-/* Sorted COO -> CSR (rowptr int32 [M+1]) + diagonal.  cols / vals_out are written in the SpMV's
- * physical layout: 256-entry tiles, logical entry m of a tile at 4*(m%64) + m/64; both arrays must
- * be zero-initialised and sized to nnz rounded up to a multiple of 4096. */
-int nksr_coo_to_csr(const uint64_t* keys_sorted, const float* vals, int64_t nnz, int32_t M, int col_bits,
-                    int32_t* rowptr, int32_t* cols, float* vals_out, float* diag, void* stream);
+                  void* workspace, const int32_t* rowptr, const int32_t* indeg, const int32_t* mir_off,
+                  int32_t* cols_out, float* vals_out, float* diag_out, uint64_t* mir_keys, float* mir_vals,
+                  float* b_out, void* stream);
+/* Mirrors stably sorted by destination row (low col_bits of the key) -> their CSR slots;
+ * mirptr = exclusive scan of indeg. */
+int nksr_place_mirrors(const uint64_t* keys_sorted, const float* vals_sorted, int64_t n, int col_bits,
+                       const int32_t* rowptr, const int32_t* mirptr, int32_t* cols_out, float* vals_out, void* stream);
 
 /* ---- PCG (the CG SpMV is the roofline kernel) -------------------- */
 /* nnz-chunked streaming CSR SpMV (csrc/pcg.hip).  cols/vals in the tile-interleaved physical layout
- * produced by nksr_coo_to_csr (zero-padded to a multiple of 4096 entries).  The plan (row
+ * produced by nksr_assemble / nksr_place_mirrors: 256-entry tiles, logical entry m of a tile at
+ * 4*(m%64) + m/64, zero-padded (valid column 0, value 0) to a multiple of 4096 entries.  The plan (row
  * of every 4096-entry chunk) lives in `workspace` (nksr_spmv_workspace_bytes) and must be built
  * once per matrix with nksr_spmv_plan. */
 size_t nksr_spmv_workspace_bytes(int64_t nnz);

@@ -9,14 +9,17 @@
 //     columns l and l+64, the 27 row factors are broadcast with readlane, the site row is one
 //     coalesced read.  Every site row is read once per level (instead of once per touching
 //     matrix row: 27x less traffic than a direct gather).
-//  2. row gather.  Row i (voxel at level d) adds, for each of its 27 neighbour cells c, the
-//     block row B[d][c][slot of i in c's stencil] into a structured (L-d) x 5^3 slot frame in
-//     LDS, then emits the upper triangle (coarser level, or same level and col > row) mirrored
-//     into a COO list at offsets obtained from an exclusive scan of per-row counts.  The
-//     Keys are (col << col_bits | row); a STABLE radix sort on the row bits only (3 passes instead
-//     of 6) then yields CSR rows = [mirrored entries, ascending source row = ascending column]
-//     [own upper entries in slot order][diagonal]: deterministic and exactly symmetric.  A slot is structural iff the column voxel exists and the two B-spline
-//     supports overlap (integer test), so count and fill agree without looking at values.
+//  2. structure.  k_row_count maps every structural upper slot of a row (column voxel exists and
+//     the two B-spline supports overlap: integer test) to its column (colmap), counts them and
+//     accumulates the in-degree of every destination row with INTEGER atomics (order-independent).
+//     Exclusive scans then give the final row pointers: row = [mirrors][own upper][diagonal].
+//  3. row gather.  Row i (voxel at level d) adds, for each of its 27 neighbour cells c, the block
+//     row B[d][c][slot of i in c's stencil] into a structured (L-d) x 5^3 slot frame in LDS and
+//     writes its own upper entries + diagonal straight into their final CSR slots; the mirrored
+//     copies go to a list keyed by destination row.
+//  4. a STABLE radix sort of that list on the destination-row bits (3 passes over HALF of the
+//     entries) orders every row's mirrors by ascending source row; k_place_mirrors drops them into
+//     the CSR.  Deterministic and exactly symmetric, no float atomics, no full COO.
 #include "common.h"
 
 #define ASM_WAVES 4
@@ -45,6 +48,12 @@ __device__ __forceinline__ int rel_slot(int cx, int cy, int cz, int ix, int iy, 
     int ry = ((cy >> dd) + (s / 3) % 3 - 1) - (iy >> dd) + 2;
     int rz = ((cz >> dd) + s % 3 - 1) - (iz >> dd) + 2;
     return dd * 125 + (rx * 5 + ry) * 5 + rz;
+}
+
+// physical CSR layout (see csrc/pcg.hip): 256-entry tiles, logical entry m of a tile at 4*(m%64) + m/64
+__device__ __forceinline__ int64_t csr_phys(int64_t k) {
+    const int64_t m = k & 255;
+    return (k & ~(int64_t)255) + 4 * (m & 63) + (m >> 6);
 }
 
 // ---- phase 1: one wavefront per (level, cell) -------------------------------------------------------
@@ -126,7 +135,8 @@ __device__ __forceinline__ int slot_column(const nksr_hier_t& h, int d, int ix, 
 }
 
 // ---- phase 2a: structure.  colmap[row slot] = column (> row) of every structural upper slot ------
-__global__ void __launch_bounds__(ASM_WAVES * 64) k_row_count(AsmArgs A, int32_t* __restrict__ rowcount) {
+__global__ void __launch_bounds__(ASM_WAVES * 64) k_row_count(AsmArgs A, int32_t* __restrict__ rowcount,
+                                                              int32_t* __restrict__ indeg) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * ASM_WAVES + wave;
     if (row >= A.M) return;
@@ -143,15 +153,19 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_count(AsmArgs A, int32_t
         int col = (t < nslots) ? slot_column(h, d, ix, iy, iz, t) : -1;
         if (col <= row) col = -1;
         if (t < nslots) cm[t] = col;
+        if (col >= 0) atomicAdd(&indeg[col], 1);     // integer: order-independent, deterministic
         cnt += __popcll(__ballot(col >= 0));
     }
-    if (lane == 0) rowcount[row] = 2 * cnt + 1;
+    if (lane == 0) rowcount[row] = cnt;
 }
 
 // ---- phase 2b: one wavefront per row: gather block rows into the slot frame, emit COO ----------------
 template <int NQ>
-__global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const int32_t* __restrict__ rowoff,
-                                                             uint64_t* __restrict__ coo_keys, float* __restrict__ coo_vals,
+__global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ indeg, const int32_t* __restrict__ mir_off,
+                                                             int32_t* __restrict__ cols_out, float* __restrict__ vals_out,
+                                                             float* __restrict__ diag_out, uint64_t* __restrict__ mir_keys,
+                                                             float* __restrict__ mir_vals,
                                                              float* __restrict__ b_out, int row_begin, int row_end) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -225,26 +239,50 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const in
 
     // emission: structure comes from the count pass (no hashing here)
     const int32_t* cm = A.colmap[d] + (int64_t)i * nslots;
-    int64_t wpos = (int64_t)rowoff[row];
+    // own upper entries go straight to their final CSR slot (row = [mirrors][own upper][diagonal]);
+    // the mirrored copies go to a list keyed by destination row, sorted afterwards
+    int64_t opos = (int64_t)rowptr[row] + indeg[row];
+    int64_t mpos = (int64_t)mir_off[row];
     for (int t0 = 0; t0 < nslots; t0 += 64) {
         const int t = t0 + lane;
         const int col = (t < nslots) ? cm[t] : -1;
         const bool keep = col >= 0;
         const unsigned long long mask = __ballot(keep);
         if (keep) {
-            const int64_t pos = wpos + 2 * __popcll(mask & ((1ull << lane) - 1ull));
+            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
             const float v = acc[t];
-            coo_keys[pos] = ((uint64_t)col << A.col_bits) | (uint64_t)row;
-            coo_vals[pos] = v;
-            coo_keys[pos + 1] = ((uint64_t)row << A.col_bits) | (uint64_t)col;
-            coo_vals[pos + 1] = v;
+            const int64_t k = opos + rank;
+            const int64_t ph = csr_phys(k);
+            cols_out[ph] = col;
+            vals_out[ph] = v;
+            mir_keys[mpos + rank] = ((uint64_t)row << A.col_bits) | (uint64_t)col;   // low bits = destination row
+            mir_vals[mpos + rank] = v;
         }
-        wpos += 2 * __popcll(mask);
+        const int n = __popcll(mask);
+        opos += n;
+        mpos += n;
     }
     if (lane == 0) {
-        coo_keys[wpos] = ((uint64_t)row << A.col_bits) | (uint64_t)row;
-        coo_vals[wpos] = acc[62] + A.reg;  // slot (dd=0, rel=(2,2,2))
+        const float dv = acc[62] + A.reg;  // slot (dd=0, rel=(2,2,2))
+        const int64_t ph = csr_phys(opos);
+        cols_out[ph] = row;
+        vals_out[ph] = dv;
+        diag_out[row] = dv;
     }
+}
+
+// mirrored entries, stably sorted by destination row (sources ascending): final CSR slot
+__global__ void k_place_mirrors(const uint64_t* __restrict__ keys, const float* __restrict__ vals, int64_t n, int col_bits,
+                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ mirptr,
+                                int32_t* __restrict__ cols_out, float* __restrict__ vals_out) {
+    int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n) return;
+    const uint64_t key = keys[m];
+    const int r = (int)(key & (((uint64_t)1 << col_bits) - 1));
+    const int src = (int)(key >> col_bits);
+    const int64_t ph = csr_phys((int64_t)rowptr[r] + (m - (int64_t)mirptr[r]));
+    cols_out[ph] = src;
+    vals_out[ph] = vals[m];
 }
 
 static int fill_args(AsmArgs& A, const nksr_hier_t* h, const nksr_siteset_t* sets, int nsets, float reg, int col_bits,
@@ -280,7 +318,7 @@ extern "C" size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h) {
     return tot;
 }
 
-extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, void* stream) {
+extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, int32_t* indeg, void* stream) {
     AsmArgs A;
     int M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
     int cb = 1;
@@ -288,14 +326,15 @@ extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_
     int rc = fill_args(A, h, nullptr, 0, 0.f, cb, workspace);
     if (rc) return rc;
     if (A.M <= 0) return NKSR_OK;
-    hipLaunchKernelGGL(k_row_count, dim3(nksr_blocks(A.M, ASM_WAVES)), dim3(ASM_WAVES * 64), 0, (hipStream_t)stream, A, rowcount);
+    hipLaunchKernelGGL(k_row_count, dim3(nksr_blocks(A.M, ASM_WAVES)), dim3(ASM_WAVES * 64), 0, (hipStream_t)stream, A, rowcount, indeg);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
 
 extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, int nsets, float reg, int col_bits,
-                             void* workspace, const int32_t* rowoff, uint64_t* coo_keys, float* coo_vals, float* b_out,
-                             void* stream) {
+                             void* workspace, const int32_t* rowptr, const int32_t* indeg, const int32_t* mir_off,
+                             int32_t* cols_out, float* vals_out, float* diag_out, uint64_t* mir_keys, float* mir_vals,
+                             float* b_out, void* stream) {
     AsmArgs A;
     int rc = fill_args(A, h, sets, nsets, reg, col_bits, workspace);
     if (rc) return rc;
@@ -319,52 +358,19 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
         const int T = (h->depth - d) * 27;
         const int r0 = h->lv[d].offset, r1 = r0 + n;
         const dim3 grid(nksr_blocks(n, ASM_WAVES));
-        if (T > 128) hipLaunchKernelGGL((k_row_fill<3>), grid, blk, lds, st, A, rowoff, coo_keys, coo_vals, b_out, r0, r1);
-        else if (T > 64) hipLaunchKernelGGL((k_row_fill<2>), grid, blk, lds, st, A, rowoff, coo_keys, coo_vals, b_out, r0, r1);
-        else hipLaunchKernelGGL((k_row_fill<1>), grid, blk, lds, st, A, rowoff, coo_keys, coo_vals, b_out, r0, r1);
+#define ROWFILL(NQ) hipLaunchKernelGGL((k_row_fill<NQ>), grid, blk, lds, st, A, rowptr, indeg, mir_off, cols_out, vals_out, diag_out, \
+                                       mir_keys, mir_vals, b_out, r0, r1)
+        if (T > 128) ROWFILL(3); else if (T > 64) ROWFILL(2); else ROWFILL(1);
         NKSR_CHECK_LAUNCH();
     }
     return NKSR_OK;
 }
 
-// ---- sorted COO -> CSR ------------------------------------------------------------------------
-__global__ void k_coo_rowptr(const uint64_t* __restrict__ keys, int64_t nnz, int M, int col_bits, int32_t* __restrict__ rowptr) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > M) return;
-    const uint64_t target = (uint64_t)r, rmask = ((uint64_t)1 << col_bits) - 1;
-    int64_t lo = 0, hi = nnz;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if ((keys[mid] & rmask) < target) lo = mid + 1; else hi = mid;
-    }
-    rowptr[r] = (int32_t)lo;
-}
-
-__global__ void k_coo_cols(const uint64_t* __restrict__ keys, const float* __restrict__ vals, int64_t nnz, int col_bits,
-                           int32_t* __restrict__ cols, float* __restrict__ vals_out, float* __restrict__ diag) {
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= nnz) return;
-    uint64_t key = keys[k];
-    int row = (int)(key & (((uint64_t)1 << col_bits) - 1));
-    int col = (int)(key >> col_bits);
-    // physical layout: 256-entry tiles, logical entry m of a tile is stored at 4*(m%64) + m/64, so a
-    // wavefront's 16-byte loads deliver 64 CONSECUTIVE logical entries per vector component
-    // (csrc/pcg.hip: x-gather instructions then touch few cache lines)
-    const int64_t m = k & 255;
-    const int64_t phys = (k & ~(int64_t)255) + 4 * (m & 63) + (m >> 6);
-    cols[phys] = col;
-    vals_out[phys] = vals[k];
-    if (row == col) diag[row] = vals[k];
-}
-
-extern "C" int nksr_coo_to_csr(const uint64_t* keys_sorted, const float* vals, int64_t nnz, int32_t M, int col_bits,
-                               int32_t* rowptr, int32_t* cols, float* vals_out, float* diag, void* stream) {
-    if (nnz >= ((int64_t)1 << 31)) return nksr_set_error(NKSR_ERR_CAPACITY, "nnz %lld exceeds int32 row pointers; use chunking", (long long)nnz);
-    hipLaunchKernelGGL(k_coo_rowptr, dim3(nksr_blocks((int64_t)M + 1, 256)), dim3(256), 0, (hipStream_t)stream, keys_sorted, nnz, M, col_bits, rowptr);
+extern "C" int nksr_place_mirrors(const uint64_t* keys_sorted, const float* vals_sorted, int64_t n, int col_bits,
+                                  const int32_t* rowptr, const int32_t* mirptr, int32_t* cols_out, float* vals_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    hipLaunchKernelGGL(k_place_mirrors, dim3(nksr_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, keys_sorted, vals_sorted, n,
+                       col_bits, rowptr, mirptr, cols_out, vals_out);
     NKSR_CHECK_LAUNCH();
-    if (nnz > 0) {
-        hipLaunchKernelGGL(k_coo_cols, dim3(nksr_blocks(nnz, 256)), dim3(256), 0, (hipStream_t)stream, keys_sorted, vals, nnz, col_bits, cols, vals_out, diag);
-        NKSR_CHECK_LAUNCH();
-    }
     return NKSR_OK;
 }

@@ -132,26 +132,24 @@ class KernelField(BaseField):
                 S.start[d], S.end[d] = ptr(st[d]), ptr(en[d])
             keep += [xs, rows, st, en, tgt, ks]
             nsets += 1
-        # per-row structural counts -> exclusive scan -> COO offsets (no atomics, deterministic)
+        # structure pass: own-upper counts + in-degrees -> exclusive scans -> final CSR row pointers
         rowcount = torch.zeros(M + 1, dtype=torch.int32, device=dev)
+        indeg = torch.zeros(M + 1, dtype=torch.int32, device=dev)
         ws = torch.empty(int(_lib.lib.nksr_assemble_workspace_bytes(C.byref(self._hier))), dtype=torch.uint8, device=dev)
-        call('nksr_assemble_count', C.byref(self._hier), ptr(ws), ptr(rowcount), stream())
-        nnz = int(rowcount.sum(dtype=torch.int64).item())
-        if nnz <= 0 or nnz >= 2 ** 31 - 4096:
+        call('nksr_assemble_count', C.byref(self._hier), ptr(ws), ptr(rowcount), ptr(indeg), stream())
+        n_mir = int(rowcount.sum(dtype=torch.int64).item())
+        nnz = 2 * n_mir + M
+        if nnz >= 2 ** 31 - 4096:
             raise RuntimeError('system too large for one chunk (M=%d, nnz=%d >= 2^31): pass chunk_size= to '
                                'reconstruct() (examples/recons_by_chunk.py)' % (M, nnz))
-        rowoff = ops.exclusive_sum_i32(rowcount)
+        rowlen = indeg + rowcount + 1
+        rowlen[M] = 0
+        rowptr = ops.exclusive_sum_i32(rowlen)
+        mir_off = ops.exclusive_sum_i32(rowcount)
+        mirptr = ops.exclusive_sum_i32(indeg)
         col_bits = ops._bits(M)
-        coo_k = torch.empty(nnz, dtype=torch.int64, device=dev)
-        coo_v = torch.empty(nnz, dtype=torch.float32, device=dev)
-        b = torch.empty(M, dtype=torch.float32, device=dev)
-        call('nksr_assemble', C.byref(self._hier), sets, nsets, float(reg_weight), col_bits, ptr(ws), ptr(rowoff), ptr(coo_k),
-             ptr(coo_v), ptr(b), stream())
-        ks, vs = ops.sort_pairs(coo_k, coo_v.view(torch.int32), end_bit=col_bits)   # stable, row bits only
-        del coo_k, coo_v, ws
         # physical (tile-interleaved, zero-padded) CSR arrays for the streaming SpMV
         npad = (nnz + 4095) // 4096 * 4096
-        rowptr = torch.empty(M + 1, dtype=torch.int32, device=dev)
         cols = torch.empty(npad, dtype=torch.int32, device=dev)
         vals = torch.empty(npad, dtype=torch.float32, device=dev)
         # only the pad must be zero (valid column 0, value 0); the last 256-entry tile is interleaved,
@@ -160,8 +158,17 @@ class KernelField(BaseField):
         cols[tail:].zero_()
         vals[tail:].zero_()
         diag = torch.empty(M, dtype=torch.float32, device=dev)
-        call('nksr_coo_to_csr', ptr(ks), ptr(vs.view(torch.float32)), nnz, M, col_bits, ptr(rowptr), ptr(cols), ptr(vals),
-             ptr(diag), stream())
+        b = torch.empty(M, dtype=torch.float32, device=dev)
+        mir_k = torch.empty(n_mir, dtype=torch.int64, device=dev)
+        mir_v = torch.empty(n_mir, dtype=torch.float32, device=dev)
+        call('nksr_assemble', C.byref(self._hier), sets, nsets, float(reg_weight), col_bits, ptr(ws), ptr(rowptr), ptr(indeg),
+             ptr(mir_off), ptr(cols), ptr(vals), ptr(diag), ptr(mir_k), ptr(mir_v), ptr(b), stream())
+        del ws
+        ks, vs = ops.sort_pairs(mir_k, mir_v.view(torch.int32), end_bit=col_bits)   # stable, destination-row bits only
+        del mir_k, mir_v
+        call('nksr_place_mirrors', ptr(ks), ptr(vs.view(torch.float32)), n_mir, col_bits, ptr(rowptr), ptr(mirptr), ptr(cols),
+             ptr(vals), stream())
+        del ks, vs
         self.nnz = nnz
         del keep
         return rowptr, cols, vals, diag, b
