@@ -208,6 +208,11 @@ int nksr_cell_active_flags(const int32_t* config, int64_t ncell, int32_t* flags,
  * counts) ordered scatter of the flagged indices -- wave ballot + popcount prefix */
 int nksr_compact_block_counts(const int32_t* flags, int64_t n, int32_t* block_counts, void* stream);
 int nksr_compact_scatter(const int32_t* flags, int64_t n, const int32_t* block_offsets, int32_t* sel, void* stream);
+/* MISE hanging-vertex constraint: a refined vertex on a coarse edge / face gets the mean of the coarse
+ * end points / face corners unless every coarse cell sharing that edge / face was refined (sorted key
+ * lists; f_fine is updated in place) -- closes T-junction cracks between refined and unrefined cells */
+int nksr_mise_constrain(const int64_t* vkeys_fine, int64_t nv, float* f_fine, const int64_t* vkeys_coarse, int64_t nvc,
+                        const float* f_coarse, const int64_t* active_cells, int64_t na, void* stream);
 /* children of the flagged cells: out has 8 keys per selected cell */
 int nksr_cell_children(const int64_t* cell_keys, const int32_t* sel, int64_t nsel, int64_t* child_keys, void* stream);
 /* triangle emission: edge keys (lower vertex index*3+axis) [ntri_total,3] */

@@ -119,6 +119,21 @@ class MultiChunkField(BaseField):
         own = torch.tensor(self.owner, dtype=torch.long, device=ijk.device)
         return own[self.chunk_of(centers)] == self.rank
 
+    def base_cell_halo_mask(self, ijk):
+        """Owned cells plus one ring of neighbours: the MISE hanging-vertex rule needs to know whether
+        the cells across a rank seam were refined, so they are evaluated (but not meshed) here too."""
+        if self.world_size == 1:
+            return torch.ones(ijk.shape[0], dtype=torch.bool, device=ijk.device)
+        own = torch.tensor(self.owner, dtype=torch.long, device=ijk.device)
+        centers = (ijk.to(torch.float32) + 0.5) * self.svh.voxel_size
+        m = torch.zeros(ijk.shape[0], dtype=torch.bool, device=ijk.device)
+        w = self.svh.voxel_size
+        for dx in (-w, 0.0, w):
+            for dy in (-w, 0.0, w):
+                for dz in (-w, 0.0, w):
+                    m |= own[self.chunk_of(centers + torch.tensor([dx, dy, dz], device=ijk.device))] == self.rank
+        return m
+
     def finalize_mesh(self, res):
         if self.world_size == 1:
             return res

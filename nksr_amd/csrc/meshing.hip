@@ -211,3 +211,67 @@ extern "C" int nksr_mc_vertices(const int64_t* edge_keys, int64_t nedge, const i
     LAUNCH1D(k_mc_vertices, nedge, stream, edge_keys, nedge, vkeys, nv, vpos, f, h, verts_out);
     return NKSR_OK;
 }
+
+// ---- MISE hanging-vertex constraint ------------------------------------------------------------------
+// A refined lattice vertex that sits on a coarse edge (one odd coordinate) or coarse face (two odd
+// coordinates) is "hanging" unless EVERY coarse cell sharing that edge / face was refined too.  Its
+// value is then replaced by the mean of the coarse end points / face corners: an unrefined neighbour
+// has equal-sign corners, so no sign change can appear on the shared face and the refined mesh closes
+// against it (no T-junction cracks).
+__device__ __forceinline__ int64_t find_key(const int64_t* __restrict__ a, int64_t n, int64_t v) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return (lo < n && a[lo] == v) ? lo : -1;
+}
+
+__global__ void k_mise_constrain(const int64_t* __restrict__ vkeys_fine, int64_t nv, float* __restrict__ f_fine,
+                                 const int64_t* __restrict__ vkeys_coarse, int64_t nvc, const float* __restrict__ f_coarse,
+                                 const int64_t* __restrict__ active_cells, int64_t na) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv) return;
+    int g[3];
+    morton_decode_biased(vkeys_fine[i], NKSR_BIAS0, g[0], g[1], g[2]);
+    const int odd[3] = {g[0] & 1, g[1] & 1, g[2] & 1};
+    const int k = odd[0] + odd[1] + odd[2];
+    if (k == 3) return;
+    if (k == 0) {   // coincides with a coarse vertex: inherit its (possibly constrained) value
+        const int64_t j = find_key(vkeys_coarse, nvc, morton_biased(g[0] >> 1, g[1] >> 1, g[2] >> 1, NKSR_BIAS0));
+        if (j >= 0) f_fine[i] = f_coarse[j];
+        return;
+    }
+    // coarse cells sharing the edge / face: along an ODD axis the cell is fixed ((g-1)/2), along an EVEN
+    // axis both cells g/2 - 1 and g/2 touch it
+    int lo[3], cnt[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = odd[a] ? (g[a] - 1) >> 1 : (g[a] >> 1) - 1;
+        cnt[a] = odd[a] ? 1 : 2;
+    }
+    bool all_active = true;
+    for (int x = 0; x < cnt[0]; ++x)
+        for (int y = 0; y < cnt[1]; ++y)
+            for (int z = 0; z < cnt[2]; ++z)
+                all_active = all_active && find_key(active_cells, na, morton_biased(lo[0] + x, lo[1] + y, lo[2] + z, NKSR_BIAS0)) >= 0;
+    if (all_active) return;
+    // mean over the coarse vertices spanning the edge / face: odd axes take both (g-1)/2 and (g+1)/2
+    float s = 0.f;
+    int n = 0;
+    for (int x = 0; x <= odd[0]; ++x)
+        for (int y = 0; y <= odd[1]; ++y)
+            for (int z = 0; z <= odd[2]; ++z) {
+                const int cx = odd[0] ? ((g[0] - 1) >> 1) + x : g[0] >> 1, cy = odd[1] ? ((g[1] - 1) >> 1) + y : g[1] >> 1,
+                          cz = odd[2] ? ((g[2] - 1) >> 1) + z : g[2] >> 1;
+                const int64_t j = find_key(vkeys_coarse, nvc, morton_biased(cx, cy, cz, NKSR_BIAS0));
+                if (j >= 0) { s += f_coarse[j]; ++n; }
+            }
+    if (n == (1 << k)) f_fine[i] = s * (k == 1 ? 0.5f : 0.25f);
+}
+
+extern "C" int nksr_mise_constrain(const int64_t* vkeys_fine, int64_t nv, float* f_fine, const int64_t* vkeys_coarse, int64_t nvc,
+                                   const float* f_coarse, const int64_t* active_cells, int64_t na, void* stream) {
+    LAUNCH1D(k_mise_constrain, nv, stream, vkeys_fine, nv, f_fine, vkeys_coarse, nvc, f_coarse, active_cells, na);
+    return NKSR_OK;
+}

@@ -49,8 +49,9 @@ def _extract(field, mise_iter, grid_upsample, max_points):
 
     flags = torch.empty(g0.num_voxels, dtype=torch.int32, device=dev)
     call('nksr_base_cell_flags', ptr(g0.nbr), g0.num_voxels, ptr(flags), stream())
-    if hasattr(field, 'base_cell_mask'):      # chunked / distributed fields: only cells this rank owns
-        flags = (flags * field.base_cell_mask(g0.ijk).to(torch.int32)).contiguous()
+    owned_only = hasattr(field, 'base_cell_mask') and getattr(field, 'world_size', 1) > 1
+    if owned_only:      # distributed fields: cells this rank owns + a one-cell halo (evaluated, not meshed)
+        flags = (flags * field.base_cell_halo_mask(g0.ijk).to(torch.int32)).contiguous()
     sel = ops.compact(flags)
     if sel.numel() == 0:
         return empty
@@ -58,12 +59,16 @@ def _extract(field, mise_iter, grid_upsample, max_points):
     call('nksr_base_cell_keys', ptr(g0.ijk), ptr(sel), sel.numel(), U, ptr(raw), stream())
 
     h = w0 / U
+    prev = None          # (vertex keys, values, active cell keys) of the coarser MISE level
     for m in range(mise_iter + 1):
         cells, vkeys, cidx = _cell_vertices(raw)
         nv, nc = vkeys.numel(), cells.numel()
         pos = torch.empty((nv, 3), dtype=torch.float32, device=dev)
         call('nksr_lattice_positions', ptr(vkeys), nv, float(h), float(0.5 * w0), ptr(pos), stream())
         f = field._evaluate_f_model(pos, False, max_points=batch).value
+        if prev is not None:   # hanging vertices take the coarse interpolant: no T-junction cracks
+            call('nksr_mise_constrain', ptr(vkeys), nv, ptr(f), ptr(prev[0]), prev[0].numel(), ptr(prev[1]), ptr(prev[2]),
+                 prev[2].numel(), stream())
         config = torch.empty(nc, dtype=torch.int32, device=dev)
         ntri = torch.empty(nc + 1, dtype=torch.int32, device=dev)
         ntri[nc] = 0
@@ -76,8 +81,16 @@ def _extract(field, mise_iter, grid_upsample, max_points):
                 return empty
             raw = torch.empty(asel.numel() * 8, dtype=torch.int64, device=dev)
             call('nksr_cell_children', ptr(cells), ptr(asel), asel.numel(), ptr(raw), stream())
+            prev = (vkeys, f, cells[asel.long()].contiguous())      # cells is sorted => so is the subset
             h = h / 2
 
+    if owned_only:      # halo cells emit nothing: ownership follows the base voxel that contains the cell
+        gc = torch.empty((nc, 3), dtype=torch.int32, device=dev)
+        call('nksr_decode_keys', ptr(cells), nc, -1, ptr(gc), stream())
+        base_ijk = torch.div(gc, U * (1 << mise_iter), rounding_mode='floor').to(torch.int32)
+        keep_c = field.base_cell_mask(base_ijk).to(torch.int32)
+        ntri[:nc] *= keep_c
+        config = (config * keep_c).contiguous()     # configuration 0 emits nothing in nksr_mc_emit
     tri_off = ops.exclusive_sum_i32(ntri)
     T = int(tri_off[nc].item())
     if T == 0:

@@ -58,22 +58,63 @@ def cell_vertices(cells):
     return cells, vk, idx.astype(np.int32)
 
 
+def _find(sorted_keys, q):
+    pos = np.searchsorted(sorted_keys, q)
+    pos_c = np.minimum(pos, max(len(sorted_keys) - 1, 0))
+    hit = (pos < len(sorted_keys)) & (sorted_keys[pos_c] == q) if len(sorted_keys) else np.zeros(q.shape, bool)
+    return np.where(hit, pos_c, -1)
+
+
+def constrain_hanging(g, f, vk_coarse, f_coarse, active_keys):
+    """MISE hanging-vertex rule: a refined vertex on a coarse edge / face takes
+    the mean of the coarse end points / face corners unless every coarse cell sharing it was refined."""
+    f = f.copy()
+    g = g.astype(np.int64)
+    odd = g & 1
+    k = odd.sum(1)
+    even = np.nonzero(k == 0)[0]          # coincide with coarse vertices: inherit their (constrained) value
+    j = _find(vk_coarse, lattice_key(g[even] >> 1))
+    f[even[j >= 0]] = f_coarse[j[j >= 0]]
+    for idx in np.nonzero((k == 1) | (k == 2))[0]:
+        gi, oi = g[idx], odd[idx]
+        lo = [((gi[a] - 1) >> 1) if oi[a] else (gi[a] >> 1) - 1 for a in range(3)]
+        cnt = [1 if oi[a] else 2 for a in range(3)]
+        cells = np.array([[lo[0] + x, lo[1] + y, lo[2] + z] for x in range(cnt[0]) for y in range(cnt[1]) for z in range(cnt[2])])
+        if (_find(active_keys, lattice_key(cells)) >= 0).all():
+            continue
+        vs = np.array([[(((gi[0] - 1) >> 1) + x) if oi[0] else gi[0] >> 1,
+                        (((gi[1] - 1) >> 1) + y) if oi[1] else gi[1] >> 1,
+                        (((gi[2] - 1) >> 1) + z) if oi[2] else gi[2] >> 1]
+                       for x in range(oi[0] + 1) for y in range(oi[1] + 1) for z in range(oi[2] + 1)])
+        j = _find(vk_coarse, lattice_key(vs))
+        if (j >= 0).all():
+            s = np.float32(0)
+            for v in f_coarse[j]:
+                s = np.float32(s + v)
+            f[idx] = s * np.float32(0.5 if k[idx] == 1 else 0.25)
+    return f
+
+
 def extract(level0_voxel_size, level0, eval_fn, mise_iter=0, grid_upsample=1, mask_fn=None):
     """eval_fn(xyz[n,3] f32) -> f[n] f32;  mask_fn(xyz) -> bool[n] (True = keep)."""
     w0 = float(level0_voxel_size)
     U = int(grid_upsample)
     cells = base_cells(level0, U)
     h = w0 / U
+    prev = None
     for m in range(mise_iter + 1):
         cells, vk, cidx = cell_vertices(cells)
         g = lattice_decode(vk)
         pos = lattice_positions(g, h, 0.5 * w0)
         f = eval_fn(pos) if len(pos) else np.zeros(0, np.float32)
+        if prev is not None and len(f):
+            f = constrain_hanging(g, f, *prev)
         inside = f > 0
         ci = inside[cidx] if len(cidx) else np.zeros((0, 8), bool)
         config = (ci * (1 << np.arange(8))[None]).sum(1).astype(np.int32) if len(cidx) else np.zeros(0, np.int32)
         if m < mise_iter:
             act = (config != 0) & (config != 255)
+            prev = (vk, f, np.sort(lattice_key(cells[act])))
             cells = (cells[act][:, None, :] * 2 + spec.CORNER_OFFSETS[None].astype(np.int64)).reshape(-1, 3)
             h = h / 2
     # marching cubes on the final cell set

@@ -138,8 +138,13 @@ def test_mesh_is_closed_genus0_and_accurate(sphere_field):
     # outward orientation: triangle normals point away from the centre
     n = np.cross(v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]])
     assert ((n * v[t].mean(1)).sum(1) > 0).mean() > 0.999
-    v1, t1 = pipeline.extract_dual_mesh(fld, mise_iter=1)
-    assert len(t1) > 3 * len(t)
+    # MISE keeps the mesh closed: hanging vertices take the coarse interpolant (no T-junction cracks)
+    for mi, grow in ((1, 3), (2, 12)):
+        v1, t1 = pipeline.extract_dual_mesh(fld, mise_iter=mi)
+        assert len(t1) > grow * len(t)
+        e1 = np.sort(np.concatenate([t1[:, [0, 1]], t1[:, [1, 2]], t1[:, [2, 0]]]), 1)
+        ue1, cnt1 = np.unique(e1, axis=0, return_counts=True)
+        assert (cnt1 == 2).all() and len(v1) - len(ue1) + len(t1) == 2
 
 
 @pytest.mark.parametrize('name', ['bunny_2k', 'sphere_3k'])
