@@ -280,3 +280,26 @@ def test_field_save_load_roundtrip(tmp_path):
     assert torch.equal(a.value, b.value) and torch.equal(a.gradient, b.gradient)
     m0, m1 = fld.extract_dual_mesh(mise_iter=1), g.extract_dual_mesh(mise_iter=1)
     assert torch.equal(m0.f, m1.f) and torch.equal(m0.v, m1.v)
+
+
+def test_tree_depth_5_matches_oracle():
+    """BASELINE.json configs[4] uses tree_depth=5 (non-default): 135 entries per site row exercise the
+    3-column block kernel and the 3-pass row fill."""
+    import nksr_amd
+    from nksr_amd import configs
+    from oracle import network as onet, pipeline
+    xyz, nrm = make_cloud('sphere', 4000, 0.003, 0)
+    hp = configs.get_hparams('ks', tree_depth=5)
+    rec = nksr_amd.Reconstructor(_dev(), hparams=hp)
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(_dev()), torch.from_numpy(nrm).to(_dev()), voxel_size=0.03, solver_tol=1e-6)
+    xs = (xyz * np.float32(0.1 / 0.03)).astype(np.float32)
+    ofl = pipeline.reconstruct(xs, nrm, depth=5, tol=1e-6, net_params=onet.export_params(rec.network))
+    assert fld.svh.depth == 5 and fld.solve_info['M'] == ofl['A'].shape[0]
+    for d in range(5):
+        assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
+    ref = np.abs(ofl['alpha']).max()
+    assert np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() <= 3e-3 * ref
+    np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), ofl['A'].diagonal(), rtol=1e-4)
+    mesh = fld.extract_dual_mesh(mise_iter=1)
+    ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=1)
+    assert abs(mesh.f.shape[0] - len(of)) <= max(4, 0.01 * len(of))
