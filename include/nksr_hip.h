@@ -111,6 +111,17 @@ int nksr_gather_rows(const float* src, const int32_t* idx, int64_t n, int C, con
 /* per-voxel linear head: out [n, Cout] = in [n, 32] W^T + b */
 int nksr_linear(const float* in, int64_t n, int Cin, const float* W, const float* b, int Cout, float* out, void* stream);
 
+/* ---- UDF mask branch: NeuralField(svh=udf_svh, decoder=network.udf_decoder, features=feat.udf_features)
+ *      .set_level_set(2 * voxel_size)  (models/nksr_net.py:124-130; configs/carla/train.yaml:8-9) ---------- */
+/* plane features of one level, out [n, 8] = (occupied, centroid offset xyz in voxel units, unit mean normal
+ * xyz, 0): trilinear-weighted over the Morton-sorted points around every voxel */
+int nksr_splat_plane(const float* xyz_sorted, const float* normal_sorted, const int32_t* start, const int32_t* end,
+                     const int32_t* nbr, const int32_t* ijk, int32_t n, float inv_w, float* out, void* stream);
+/* unsigned plane distance decoded from the 8 voxel centres around every query (1e30 where none is
+ * occupied); only_unset != 0 keeps entries already decoded at a finer level */
+int nksr_udf_decode(const nksr_level_t* level, int level_index, const float* feat, const float* xyz, int64_t n,
+                    float inv_w, float voxel_size, int only_unset, float* out, void* stream);
+
 /* ---- neural kernel (KernelField, models/nksr_net.py:91-96) --------------------------- */
 int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden, const float* mlp, float* psi_out, void* stream);
 /* Dense-slot kernel rows at arbitrary sites.  val [n, L, 27]; dval [n, 3, L, 27] (may be

@@ -25,7 +25,7 @@ from . import dist as D
 from . import ops
 from .fields.base_field import BaseField, EvaluationResult
 from .fields.kernel_field import KernelField
-from .fields.mask_fields import LayerField
+from .fields.mask_fields import LayerField, NeuralField
 from .svh import SparseFeatureHierarchy
 
 
@@ -34,20 +34,34 @@ def chunk_grid(lo, hi, chunk_size):
     return n
 
 
+def _udf_levels(f):
+    m = f.mask_field
+    if not isinstance(m, NeuralField):
+        return 0
+    n = 0
+    while n < f.svh.depth and n < len(m.features) and m.features[n] is not None:
+        n += 1
+    return n
+
+
 def pack_field(f):
-    """KernelField -> (int64 tensor, float32 tensor)."""
+    """KernelField (+ its UDF mask features, when the mask is a NeuralField) -> (int64 tensor, float32 tensor)."""
     svh = f.svh
-    head = [svh.depth, f.kdim, int(f.approx_kernel_grad)] + [svh.num_voxels(d) for d in range(svh.depth)]
+    nu = _udf_levels(f)
+    head = [svh.depth, f.kdim, int(f.approx_kernel_grad), nu] + [svh.num_voxels(d) for d in range(svh.depth)]
     ints = torch.cat([torch.tensor(head, dtype=torch.int64, device=svh.device)] + [svh.level(d).keys for d in range(svh.depth)])
-    flts = torch.cat([f._feat[d].reshape(-1) for d in range(svh.depth)] + [f.alpha])
-    return ints, flts
+    parts = [f._feat[d].reshape(-1) for d in range(svh.depth)] + [f.alpha]
+    if nu:
+        parts += [f.mask_field.features[d].reshape(-1) for d in range(nu)]
+        parts.append(torch.tensor([f.mask_field.level_set], dtype=torch.float32, device=svh.device))
+    return ints, torch.cat(parts)
 
 
 def unpack_field(ints, flts, voxel_size, interpolators, device):
     ints, flts = ints.to(device), flts.to(device)
-    depth, kdim, approx = int(ints[0]), int(ints[1]), bool(int(ints[2]))
-    ns = [int(v) for v in ints[3:3 + depth]]
-    off = 3 + depth
+    depth, kdim, approx, nu = int(ints[0]), int(ints[1]), bool(int(ints[2])), int(ints[3])
+    ns = [int(v) for v in ints[4:4 + depth]]
+    off = 4 + depth
     keys = []
     for n in ns:
         keys.append(ints[off:off + n].contiguous())
@@ -59,7 +73,40 @@ def unpack_field(ints, flts, voxel_size, interpolators, device):
         fo += n * kdim
     fld = KernelField(svh, interpolators, feats, approx_kernel_grad=approx)
     fld.alpha = flts[fo:fo + sum(ns)].contiguous()
+    fo += sum(ns)
+    if nu:
+        from .nn.network import UDFDecoder
+        uf = [None] * depth
+        for d in range(nu):
+            uf[d] = flts[fo:fo + ns[d] * 8].view(ns[d], 8).contiguous()
+            fo += ns[d] * 8
+        mask = NeuralField(svh, UDFDecoder(), uf)
+        mask.set_level_set(float(flts[fo]))
+        fld.set_mask_field(mask)
     return fld
+
+
+class ChunkUnionMask(BaseField):
+    """Mask of a chunked field whose chunks carry NeuralField (UDF) masks: a vertex survives when any
+    chunk that contributes to the blend there keeps it."""
+
+    def __init__(self, multi):
+        super().__init__(multi.svh)
+        self.multi = multi
+
+    def evaluate_mask(self, xyz_model):
+        keep = torch.zeros(xyz_model.shape[0], dtype=torch.bool, device=xyz_model.device)
+        for c in sorted(self.multi.fields):
+            f = self.multi.fields[c]
+            if f.mask_field is None:
+                continue
+            sel = torch.nonzero(self.multi._weight(c, xyz_model) > 0).reshape(-1)
+            if sel.numel():
+                keep[sel] |= f.mask_field.evaluate_mask(xyz_model[sel].contiguous())
+        return keep
+
+    def to_(self, device):
+        return self
 
 
 class MultiChunkField(BaseField):
@@ -74,6 +121,8 @@ class MultiChunkField(BaseField):
         union.build_from_keys([torch.cat(keys) if keys else None])
         super().__init__(union)
         self.mask_field = LayerField(union, 1)
+        if any(isinstance(f.mask_field, NeuralField) for f in fields.values()):
+            self.mask_field = ChunkUnionMask(self)
         self.solve_info = {}
 
     # ---- blend weights ------------------------------------------------------------------------

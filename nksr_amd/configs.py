@@ -44,7 +44,7 @@ _PRESETS = {
     'default': {},
     'ks': {},                                           # kitchen-sink: default architecture
     'snet-n3k-wnormal': {'voxel_size': 0.02, 'kernel_dim': 16, 'interpolator': {'n_hidden': 2, 'hidden_dim': 32}},
-    'carla': {'adaptive_depth': 2},
+    'carla': {'adaptive_depth': 2, 'udf': {'enabled': True}},      # configs/carla/train.yaml:6-9
 }
 
 

@@ -88,6 +88,77 @@ __global__ void k_splat_mean_c(const float* __restrict__ xyz, const float* __res
     for (int c2 = 0; c2 < nc; ++c2) out[(int64_t)j * C + c0 + c2] = acc[c2] * inv;
 }
 
+// ---- UDF mask branch (NeuralField, models/nksr_net.py:124-130) -------------------------------------------------
+// Plane features of one level: per voxel j the trilinear-weighted centroid offset (voxel units, relative
+// to the voxel centre) and mean normal of the surrounding points.  out [n, 8] = (occupied, off xyz,
+// unit normal xyz, 0).  One thread per voxel, same gather form (and point order) as k_splat_mean_c.
+__global__ void k_splat_plane(const float* __restrict__ xyz, const float* __restrict__ nrm, const int32_t* __restrict__ start,
+                              const int32_t* __restrict__ end, const int32_t* __restrict__ nbr,
+                              const int32_t* __restrict__ ijk, int n, float inv_w, float* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float cx = (float)ijk[j * 3] + 0.5f, cy = (float)ijk[j * 3 + 1] + 0.5f, cz = (float)ijk[j * 3 + 2] + 0.5f;
+    float wsum = 0.f, ox = 0.f, oy = 0.f, oz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    for (int s = 0; s < 27; ++s) {
+        const int c = nbr[(int64_t)j * 27 + s];
+        if (c < 0) continue;
+        for (int k = start[c]; k < end[c]; ++k) {
+            const float rx = __fmul_rn(xyz[(int64_t)k * 3], inv_w) - cx, ry = __fmul_rn(xyz[(int64_t)k * 3 + 1], inv_w) - cy,
+                        rz = __fmul_rn(xyz[(int64_t)k * 3 + 2], inv_w) - cz;
+            const float wx = 1.f - fabsf(rx), wy = 1.f - fabsf(ry), wz = 1.f - fabsf(rz);
+            if (wx <= 0.f || wy <= 0.f || wz <= 0.f) continue;
+            const float w = wx * wy * wz;
+            wsum += w;
+            ox = fmaf(w, rx, ox); oy = fmaf(w, ry, oy); oz = fmaf(w, rz, oz);
+            nx = fmaf(w, nrm[(int64_t)k * 3], nx); ny = fmaf(w, nrm[(int64_t)k * 3 + 1], ny); nz = fmaf(w, nrm[(int64_t)k * 3 + 2], nz);
+        }
+    }
+    float* o = out + (int64_t)j * 8;
+    const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+    const float nn = sqrtf(nx * nx + ny * ny + nz * nz);
+    const float invn = nn > 1e-8f ? 1.f / nn : 0.f;
+    o[0] = wsum > 0.f ? 1.f : 0.f;
+    o[1] = ox * inv; o[2] = oy * inv; o[3] = oz * inv;
+    o[4] = nx * invn; o[5] = ny * invn; o[6] = nz * invn;
+    o[7] = 0.f;
+}
+
+// udf(x) = w_d | sum_c t_c(x) <x/w_d - centre_c - off_c, n_c> | / sum_c t_c(x) over the occupied voxels among
+// the 8 centres surrounding x (t = trilinear weight); NKSR_UDF_FAR where none is occupied.  With
+// only_unset, queries that already hold a value from a finer level are left alone.
+#define NKSR_UDF_FAR 1e30f
+__global__ void k_udf_decode(nksr_level_t lv, const float* __restrict__ feat, const float* __restrict__ xyz, int64_t nq,
+                             float inv_w, float w, int level, int only_unset, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    if (only_unset && out[i] < 0.5f * NKSR_UDF_FAR) return;
+    const float px = __fmul_rn(xyz[i * 3], inv_w), py = __fmul_rn(xyz[i * 3 + 1], inv_w), pz = __fmul_rn(xyz[i * 3 + 2], inv_w);
+    const float fx = floorf(px - 0.5f), fy = floorf(py - 0.5f), fz = floorf(pz - 0.5f);
+    const int bx = (int)fx, by = (int)fy, bz = (int)fz;
+    const float vx = px - 0.5f - fx, vy = py - 0.5f - fy, vz = pz - 0.5f - fz;
+    float sw = 0.f, sd = 0.f;
+    for (int c = 0; c < 8; ++c) {
+        const int cx = c >> 2, cy = (c >> 1) & 1, cz = c & 1;
+        const int j = hash_find(lv.hkeys, lv.hvals, lv.hcap, morton_biased(bx + cx, by + cy, bz + cz, NKSR_BIAS0 >> level));
+        if (j < 0) continue;
+        const float* f = feat + (int64_t)j * 8;
+        if (!(f[0] > 0.5f)) continue;
+        const float t = (cx ? vx : 1.f - vx) * (cy ? vy : 1.f - vy) * (cz ? vz : 1.f - vz);
+        const float rx = px - ((float)(bx + cx) + 0.5f) - f[1], ry = py - ((float)(by + cy) + 0.5f) - f[2],
+                    rz = pz - ((float)(bz + cz) + 0.5f) - f[3];
+        const float d = fmaf(rx, f[4], fmaf(ry, f[5], rz * f[6]));
+        sw += t;
+        sd = fmaf(t, d, sd);
+    }
+    if (sw > 0.f) out[i] = fabsf(sd / sw) * w;
+    else if (!only_unset) out[i] = NKSR_UDF_FAR;
+}
+
+__global__ void k_fill_f32(float* __restrict__ p, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 // ---- 3x3x3 submanifold sparse convolution, C_in = C_out = 32, fp32 MFMA ---------------------------------------
 // out[i] = act( b + sum_s W[s]^T in[nbr[i][s]] ),  W [27, Cin, Cout] row-major, optional residual add.
 // mfma_f32_32x32x2f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
@@ -226,5 +297,21 @@ extern "C" int nksr_linear(const float* in, int64_t n, int Cin, const float* W, 
                            void* stream) {
     if (Cin != NN_C || Cout < 1 || Cout > NN_C) return nksr_set_error(NKSR_ERR_ARG, "linear head expects Cin=%d, Cout<=%d", NN_C, NN_C);
     LAUNCH1D(k_linear, n * Cout, stream, in, n, W, b, Cout, out);
+    return NKSR_OK;
+}
+
+extern "C" int nksr_splat_plane(const float* xyz_sorted, const float* normal_sorted, const int32_t* start, const int32_t* end,
+                                const int32_t* nbr, const int32_t* ijk, int32_t n, float inv_w, float* out, void* stream) {
+    LAUNCH1D(k_splat_plane, n, stream, xyz_sorted, normal_sorted, start, end, nbr, ijk, n, inv_w, out);
+    return NKSR_OK;
+}
+extern "C" int nksr_udf_decode(const nksr_level_t* level, int level_index, const float* feat, const float* xyz, int64_t n,
+                               float inv_w, float voxel_size, int only_unset, float* out, void* stream) {
+    if (!level) return nksr_set_error(NKSR_ERR_ARG, "null level");
+    if (level->n <= 0) {
+        if (!only_unset && n > 0) { LAUNCH1D(k_fill_f32, n, stream, out, n, NKSR_UDF_FAR); }
+        return NKSR_OK;
+    }
+    LAUNCH1D(k_udf_decode, n, stream, *level, feat, xyz, n, inv_w, voxel_size, level_index, only_unset, out);
     return NKSR_OK;
 }

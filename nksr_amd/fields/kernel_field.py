@@ -252,7 +252,7 @@ def save_field(field, path):
     this enables spill-to-disk of chunks and checkpointing."""
     from ..chunking import pack_field
     ints, flts = pack_field(field)
-    torch.save({'format': 'nksr_amd.KernelField.v1', 'ints': ints.cpu(), 'flts': flts.cpu(), 'voxel_size': field.svh.voxel_size,
+    torch.save({'format': 'nksr_amd.KernelField.v2', 'adaptive_depth': int(getattr(field.mask_field, 'adaptive_depth', 1)), 'ints': ints.cpu(), 'flts': flts.cpu(), 'voxel_size': field.svh.voxel_size,
                 'hidden': field.hidden, 'kdim': field.kdim, 'scale': field.scale, 'mlp': [m.cpu() for m in field._mlp],
                 'solve_info': field.solve_info}, path)
 
@@ -261,11 +261,12 @@ def load_field(path, device):
     from ..chunking import unpack_field
     from .mask_fields import LayerField
     st = torch.load(path, map_location='cpu')
-    if st.get('format') != 'nksr_amd.KernelField.v1':
+    if st.get('format') != 'nksr_amd.KernelField.v2':
         raise RuntimeError('%s is not a serialised KernelField' % path)
     interps = [_PackedInterpolator(st['kdim'], st['hidden'], m) for m in st['mlp']]
     fld = unpack_field(st['ints'], st['flts'], st['voxel_size'], interps, torch.device(device))
     fld.set_scale(st['scale'])
     fld.solve_info = st.get('solve_info', {})
-    fld.set_mask_field(LayerField(fld.svh, 1))
+    if fld.mask_field is None:          # a UDF (NeuralField) mask travels inside the payload
+        fld.set_mask_field(LayerField(fld.svh, st.get('adaptive_depth', 1)))
     return fld

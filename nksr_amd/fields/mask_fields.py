@@ -53,6 +53,13 @@ class NeuralField(BaseField):
         return self._evaluate_f_model(xyz_model, False).value < self.level_set
 
     def to_(self, device):
+        device = torch.device(device)
+        if isinstance(self.features, (list, tuple)):
+            self.features = [None if f is None else f.to(device) for f in self.features]
+        elif torch.is_tensor(self.features):
+            self.features = self.features.to(device)
+        if self.svh.device != device:     # usually shared with (and already moved by) the output field
+            self.svh.to_(device)
         return self
 
 

@@ -23,10 +23,12 @@ seeded -- trunk weights are He-random (seeded), the residual heads are zero and 
 is biased to "exist-continue", which makes an untrained network a sound non-learned kernel solver.
 A user-supplied ``state_dict`` replaces all of it.
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _lib, ops
 from .._lib import call, ptr, stream
 from ..svh import SparseFeatureHierarchy, SparseGrid
 
@@ -109,6 +111,16 @@ def splat_mean(grid, d, inv_w0, site_keys, xyz_sorted, feat_sorted):
     st, en = site_ranges(site_keys, grid, d)
     out = torch.empty((n, C_), dtype=torch.float32, device=grid.device)
     call('nksr_splat_mean', ptr(xyz_sorted), ptr(feat_sorted), C_, ptr(st), ptr(en), ptr(grid.nbr), ptr(grid.ijk), n,
+         float(inv_w0 * 2.0 ** (-d)), ptr(out), stream())
+    return out
+
+
+def splat_plane(grid, d, inv_w0, site_keys, xyz_sorted, normal_sorted):
+    """Plane features [n, 8] = (occupied, centroid offset, unit mean normal, 0) of level-d ``grid``."""
+    n = grid.num_voxels
+    st, en = site_ranges(site_keys, grid, d)
+    out = torch.empty((n, 8), dtype=torch.float32, device=grid.device)
+    call('nksr_splat_plane', ptr(xyz_sorted), ptr(normal_sorted), ptr(st), ptr(en), ptr(grid.nbr), ptr(grid.ijk), n,
          float(inv_w0 * 2.0 ** (-d)), ptr(out), stream())
     return out
 
@@ -245,8 +257,13 @@ class StructureUNet(nn.Module):
         for d in range(D):
             y = feat.trunk_features[d]
             feat.basis_features[d] = self.basis_heads[d](y) + e0
-            feat.udf_features[d] = self.udf_heads[d](y)
             if d < adaptive_depth:
+                if bool(hp.udf.enabled):
+                    # UDF branch: analytic plane features (+ the learned head, zero at init)
+                    pl = splat_plane(cand.level(d), d, enc_svh.inv_w0, enc.keys, enc.xyz, enc.feat)
+                    if dec_levels[d] is not cand.level(d):
+                        pl = gather_rows(pl, cand.level(d).hash.query(dec_levels[d].keys))
+                    feat.udf_features[d] = pl + self.udf_heads[d](y)
                 # splat on the CANDIDATE grid (it holds every cell that contains a point; the gather
                 # form of the splat walks neighbour voxels), then keep the rows of surviving voxels
                 s, _ = splat_trilinear(cand.level(d), d, enc_svh.inv_w0, enc.keys, enc.xyz, enc.feat)
@@ -255,6 +272,32 @@ class StructureUNet(nn.Module):
                 nv = s + self.normal_heads[d](y)
                 feat.normal_features[d] = nv / nv.norm(dim=1, keepdim=True).clamp_min(1e-8)
         return feat, dec_svh, dec_svh
+
+
+class UDFDecoder(nn.Module):
+    """``network.udf_decoder`` (models/nksr_net.py:127): decodes the unsigned distance to the input
+    surface from per-voxel plane features, finest level first (csrc/nn.hip: k_udf_decode).  The
+    decoder is fixed-function; what is learned lives in the U-Net's udf head."""
+    FAR = 1e30
+
+    def forward(self, xyz, svh, features):
+        xyz = xyz.contiguous()
+        n = xyz.shape[0]
+        out = torch.full((n,), self.FAR, dtype=torch.float32, device=xyz.device)
+        first = True
+        for d in range(svh.depth):
+            if d >= len(features) or features[d] is None:
+                continue
+            g = svh.level(d)
+            lv = _lib.LevelT()
+            lv.n, lv.offset = g.num_voxels, 0
+            lv.keys, lv.ijk, lv.nbr = ptr(g.keys), ptr(g.ijk), ptr(g.nbr)
+            lv.hkeys, lv.hvals, lv.hcap = ptr(g.hash.hkeys), ptr(g.hash.hvals), g.hash.cap
+            f = features[d].contiguous()
+            call('nksr_udf_decode', C.byref(lv), d, ptr(f), ptr(xyz), n, float(svh.inv_w0 * 2.0 ** (-d)),
+                 float(svh.voxel_size * (1 << d)), 0 if first else 1, ptr(out), stream())
+            first = False
+        return out
 
 
 class NKSRNetwork(nn.Module):
@@ -269,4 +312,4 @@ class NKSRNetwork(nn.Module):
         self.encoder = PointEncoder(hparams, gen)
         self.unet = StructureUNet(hparams, gen)
         self.sdf_decoder = None
-        self.udf_decoder = None
+        self.udf_decoder = UDFDecoder() if bool(hparams.udf.enabled) else None

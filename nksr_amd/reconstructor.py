@@ -13,7 +13,7 @@ import time
 import torch
 
 from . import _lib, configs
-from .fields import KernelField, LayerField
+from .fields import KernelField, LayerField, NeuralField
 from .nn.network import NKSRNetwork
 from .svh import SparseFeatureHierarchy
 
@@ -64,7 +64,12 @@ class Reconstructor:
                     normal_weight=hp.solver.normal_weight / normal_xyz.shape[0] * hp.voxel_size ** 2,
                     reg_weight=1.0, fused_mode=fused_mode, pos_sorted_keys=enc.keys,
                     normal_sorted_keys=dec_svh.level(0).keys if hp.adaptive_depth == 1 else None)
-        field.set_mask_field(LayerField(dec_svh, hp.adaptive_depth))
+        if bool(hp.udf.enabled):          # models/nksr_net.py:124-130
+            mask = NeuralField(svh=udf_svh, decoder=self.network.udf_decoder, features=feat.udf_features)
+            mask.set_level_set(2 * hp.voxel_size)
+        else:
+            mask = LayerField(dec_svh, hp.adaptive_depth)
+        field.set_mask_field(mask)
         t.update({k: v for k, v in field.solve_info.items() if k.startswith('t_')})
         self.timing = t
         return field

@@ -38,7 +38,7 @@ def splat(level, xyz, feat, voxel_size_d, mean):
     return acc.astype(np.float32)
 
 
-def forward(P, xyz, normal, voxel_size, depth, kernel_dim, adaptive_depth):
+def forward(P, xyz, normal, voxel_size, depth, kernel_dim, adaptive_depth, udf=False):
     """Returns (dec hierarchy, basis_features, normal_features, structure logits, trunk features)."""
     enc = hierarchy.Hierarchy(voxel_size, depth).build_point_splatting(xyz)
     cand = hierarchy.Hierarchy(voxel_size, depth).build_point_neighborhood(xyz)
@@ -101,5 +101,69 @@ def forward(P, xyz, normal, voxel_size, depth, kernel_dim, adaptive_depth):
             nv = sN + (y @ P['unet.normal_heads.%d.weight' % d].T + P['unet.normal_heads.%d.bias' % d]).astype(np.float32)
             normal_norm[d] = np.linalg.norm(nv, axis=1)
             normals[d] = (nv / np.maximum(normal_norm[d][:, None], np.float32(1e-8))).astype(np.float32)
+    forward.last_udf = None
+    if udf:     # UDF branch: plane features + the (zero-initialised) learned head
+        forward.last_udf = [None] * depth
+        for d in range(min(adaptive_depth, depth)):
+            head = (trunk[d] @ P['unet.udf_heads.%d.weight' % d].T + P['unet.udf_heads.%d.bias' % d]).astype(np.float32)
+            forward.last_udf[d] = (plane_features(levels[d], xyz, normal, voxel_size * (1 << d)) + head).astype(np.float32)
     forward.last_normal_norm = normal_norm   # conditioning of the normalisation (used by the parity test)
     return dec, basis, normals, logits, trunk
+
+
+# ---- UDF mask branch (NeuralField + network.udf_decoder, models/nksr_net.py:124-130) -------------------
+UDF_FAR = np.float32(1e30)
+
+
+def plane_features(level, xyz, normal, voxel_size_d):
+    """[n, 8] = (occupied, trilinear-weighted centroid offset in voxel units, unit mean normal, 0)."""
+    inv_w = np.float32(spec.inv_w0_f32(voxel_size_d))
+    p = xyz.astype(np.float32) * inv_w
+    base = np.floor(p - np.float32(0.5)).astype(np.int32)
+    acc = np.zeros((level.n, 6), np.float64)
+    ws = np.zeros(level.n, np.float64)
+    for co in spec.CORNER_OFFSETS:
+        ijk = base + co[None]
+        r = (p - (ijk.astype(np.float32) + np.float32(0.5))).astype(np.float32)
+        w = np.prod(np.float32(1.0) - np.abs(r), axis=1)
+        j = level.lookup(ijk)
+        ok = (j >= 0) & (w > 0)
+        np.add.at(acc, j[ok], np.concatenate([r[ok], normal[ok].astype(np.float32)], 1).astype(np.float64) * w[ok, None])
+        np.add.at(ws, j[ok], w[ok])
+    out = np.zeros((level.n, 8), np.float32)
+    occ = ws > 0
+    out[:, 0] = occ
+    out[:, 1:4] = (acc[:, :3] / np.where(occ, ws, 1.0)[:, None]) * occ[:, None]
+    nn_ = np.linalg.norm(acc[:, 3:], axis=1)
+    out[:, 4:7] = acc[:, 3:] / np.where(nn_ > 1e-8, nn_, 1.0)[:, None] * (nn_ > 1e-8)[:, None]
+    return out
+
+
+def udf_decode(hier, feats, xyz):
+    """Unsigned plane distance, finest level with an occupied surrounding voxel first."""
+    out = np.full(xyz.shape[0], UDF_FAR, np.float32)
+    for d, L in enumerate(hier.levels):
+        if d >= len(feats) or feats[d] is None:
+            continue
+        w_d = hier.voxel_size * (1 << d)
+        inv_w = np.float32(spec.inv_w0_f32(hier.voxel_size) * np.float32(2.0 ** (-d)))
+        p = xyz.astype(np.float32) * inv_w
+        fl = np.floor(p - np.float32(0.5))
+        base = fl.astype(np.int32)
+        v = (p - np.float32(0.5) - fl).astype(np.float32)
+        sw = np.zeros(xyz.shape[0], np.float32)
+        sd = np.zeros(xyz.shape[0], np.float32)
+        for co in spec.CORNER_OFFSETS:
+            ijk = base + co[None]
+            j = L.lookup(ijk)
+            f = feats[d][np.maximum(j, 0)]
+            ok = (j >= 0) & (f[:, 0] > 0.5)
+            t = np.prod(np.where(co[None] == 1, v, np.float32(1.0) - v), axis=1).astype(np.float32)
+            r = (p - (ijk.astype(np.float32) + np.float32(0.5)) - f[:, 1:4]).astype(np.float32)
+            dist = (r * f[:, 4:7]).sum(1).astype(np.float32)
+            sw += np.where(ok, t, np.float32(0))
+            sd += np.where(ok, t * dist, np.float32(0))
+        val = (np.abs(sd / np.where(sw > 0, sw, np.float32(1))) * np.float32(w_d)).astype(np.float32)
+        take = (out >= np.float32(0.5) * UDF_FAR) & (sw > 0)
+        out[take] = val[take]
+    return out

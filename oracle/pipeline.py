@@ -43,15 +43,16 @@ def splat_trilinear(level, xyz, feat, voxel_size_d):
 
 def reconstruct(xyz, normal, voxel_size=0.1, depth=4, adaptive_depth=1, kernel_dim=4, hidden=16, pos_weight=1e4,
                 normal_weight=1e4, reg_weight=1.0, tol=1e-5, max_iter=2000, approx_kernel_grad=False, interps=None,
-                feats=None, timing=None, net_params=None):
+                feats=None, timing=None, net_params=None, udf=False):
     """xyz already in model units (finest voxel = voxel_size).  Returns a dict field.
     ``net_params`` (oracle.network.export_params): run the full encoder / U-Net restatement; without
     it the analytic branch is used (identical results while the residual heads are zero)."""
     t0 = time.perf_counter()
-    net_normals = None
+    net_normals = udf_feats = None
     if net_params is not None:
         from . import network as onet
-        hier, feats, net_normals, _, _ = onet.forward(net_params, xyz, normal, voxel_size, depth, kernel_dim, adaptive_depth)
+        hier, feats, net_normals, _, _ = onet.forward(net_params, xyz, normal, voxel_size, depth, kernel_dim, adaptive_depth, udf=udf)
+        udf_feats = onet.forward.last_udf
         if interps is None:
             P = net_params
             interps = [kernel.Interpolator(*[P['interpolators.%d.%s' % (d, k)] for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')])
@@ -88,7 +89,7 @@ def reconstruct(xyz, normal, voxel_size=0.1, depth=4, adaptive_depth=1, kernel_d
                        'M': A.shape[0], 'nnz': A.nnz})
     return {'hier': hier, 'feats': feats, 'interps': interps, 'psis': psis, 'alpha': alpha, 'A': A, 'b': b,
             'iters': iters, 'rel': rel, 'normal_xyz': nxyz, 'normal_value': nval,
-            'approx_kernel_grad': approx_kernel_grad, 'voxel_size': voxel_size}
+            'approx_kernel_grad': approx_kernel_grad, 'voxel_size': voxel_size, 'udf_feats': udf_feats}
 
 
 def evaluate(fld, xyz, grad=False):
@@ -97,4 +98,9 @@ def evaluate(fld, xyz, grad=False):
 
 
 def extract_dual_mesh(fld, mise_iter=0, grid_upsample=1):
-    return meshing.extract(fld['voxel_size'], fld['hier'].levels[0], lambda p: evaluate(fld, p)[0], mise_iter, grid_upsample)
+    mask_fn = None
+    if fld.get('udf_feats') is not None:      # NeuralField mask, level set 2 * voxel_size (models/nksr_net.py:130)
+        from . import network as onet
+        mask_fn = lambda p: onet.udf_decode(fld['hier'], fld['udf_feats'], p) < np.float32(fld.get('udf_level_set', 2 * fld['voxel_size']))
+    return meshing.extract(fld['voxel_size'], fld['hier'].levels[0], lambda p: evaluate(fld, p)[0], mise_iter, grid_upsample,
+                           mask_fn=mask_fn)

@@ -108,3 +108,28 @@ def test_simulated_two_ranks_equal_one_rank():
     fm = f.cpu().numpy()
     fm = fm[np.lexsort((fm[:, 2], fm[:, 1], fm[:, 0]))]
     assert np.array_equal(fm, f1)                                                  # index-exact topology
+
+
+def test_chunked_udf_mask_travels_with_the_chunks():
+    """udf.enabled in chunk mode: per-chunk NeuralField masks are OR-ed over the blend support, and the
+    packed payload (rank exchange / save_field) carries the mask features."""
+    import nksr_amd
+    from nksr_amd import chunking, configs, fields
+    dev = torch.device('cuda:0')
+    xyz, nrm = _scene()
+    rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('carla'))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ext = float(xyz[:, 0].max() - xyz[:, 0].min())
+    full = rec.reconstruct(t(xyz), t(nrm), detail_level=None)
+    chunked = rec.reconstruct(t(xyz), t(nrm), detail_level=None, chunk_size=ext / 2 + 1e-3)
+    assert isinstance(chunked.mask_field, chunking.ChunkUnionMask)
+    mfull, mch = full.extract_dual_mesh(mise_iter=0), chunked.extract_dual_mesh(mise_iter=0)
+    assert abs(mch.f.shape[0] - mfull.f.shape[0]) < 0.03 * mfull.f.shape[0]
+    q = t(xyz[::7].copy())
+    for f in chunked.fields.values():
+        ints, flts = chunking.pack_field(f)
+        g = chunking.unpack_field(ints.clone(), flts.clone(), rec.hparams.voxel_size, rec.network.interpolators, dev)
+        assert isinstance(g.mask_field, fields.NeuralField) and g.mask_field.level_set == pytest.approx(f.mask_field.level_set)
+        a = f.mask_field._evaluate_f_model(q, False).value
+        b = g.mask_field._evaluate_f_model(q, False).value
+        assert torch.equal(a, b)

@@ -122,3 +122,66 @@ def test_shapenet_3k_noise_config():
     mesh = fld.extract_dual_mesh(mise_iter=0)
     ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=0)
     assert abs(mesh.f.shape[0] - len(of)) <= max(4, 0.01 * len(of))
+
+
+def _open_sheet(n, seed):
+    """Open surface (a wavy sheet): the kernel field closes it far from the data; the UDF mask trims that."""
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(-1.0, 1.0, (n, 2)).astype(np.float32)
+    z = (0.15 * np.sin(2.5 * u[:, 0]) * np.cos(2.0 * u[:, 1])).astype(np.float32)
+    xyz = np.stack([u[:, 0], u[:, 1], z], 1).astype(np.float32)
+    gx = 0.15 * 2.5 * np.cos(2.5 * u[:, 0]) * np.cos(2.0 * u[:, 1])
+    gy = -0.15 * 2.0 * np.sin(2.5 * u[:, 0]) * np.sin(2.0 * u[:, 1])
+    nrm = np.stack([-gx, -gy, np.ones(n)], 1)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    return xyz, nrm
+
+
+def test_udf_mask_branch_matches_oracle():
+    """udf.enabled (configs/carla/train.yaml:8-9): NeuralField(udf_svh, udf_decoder, udf_features) with
+    level set 2*voxel_size (models/nksr_net.py:124-130) against the oracle restatement."""
+    import nksr_amd
+    from nksr_amd import configs
+    from oracle import network as onet, pipeline
+    dev = torch.device('cuda:0')
+    xyz, nrm = _open_sheet(6000, 0)
+    hp = configs.get_hparams('carla')
+    assert hp.udf.enabled and hp.adaptive_depth == 2
+    rec = nksr_amd.Reconstructor(dev, hparams=hp)
+    vs = 0.05
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev), voxel_size=vs, solver_tol=1e-6)
+    assert isinstance(fld.mask_field, nksr_amd.fields.NeuralField) and fld.mask_field.level_set == pytest.approx(0.2)
+    xs = (xyz * np.float32(0.1 / vs)).astype(np.float32)
+    ofl = pipeline.reconstruct(xs, nrm, adaptive_depth=2, tol=1e-6, net_params=onet.export_params(rec.network), udf=True)
+    for d in range(2):
+        got = fld.mask_field.features[d].cpu().numpy()
+        np.testing.assert_allclose(got, ofl['udf_feats'][d], atol=2e-4)   # fp32 vs fp64 accumulation of a ratio
+    # decoded distances: on the data, off the data, far away
+    rng = np.random.default_rng(1)
+    q = np.concatenate([xs[:2000], xs[:2000] + rng.normal(0, 0.08, (2000, 3)).astype(np.float32),
+                        rng.uniform(-3, 3, (2000, 3)).astype(np.float32)]).astype(np.float32)
+    got = fld.mask_field._evaluate_f_model(torch.from_numpy(q).to(dev), False).value.cpu().numpy()
+    ref = onet.udf_decode(ofl['hier'], ofl['udf_feats'], q)
+    far = ref > 1e29
+    assert np.array_equal(far, got > 1e29)
+    np.testing.assert_allclose(got[~far], ref[~far], atol=2e-5)
+    assert np.median(got[:2000]) < 0.02            # on the sheet: distance ~ 0 (model units, voxel = 0.1)
+    # meshes: same trimming; the trimmed mesh stays within 2 voxels of the data plane estimate
+    mesh = fld.extract_dual_mesh(mise_iter=0)
+    ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=0)
+    assert abs(mesh.f.shape[0] - len(of)) <= max(4, 0.01 * len(of))
+    d_v = rec.network.udf_decoder(mesh.v.to(dev) * fld.scale, fld.svh, ofl_feats_to_torch(ofl, dev))
+    assert float(d_v.max()) < 0.2 + 1e-6
+    # a tight level set actually trims (noise-free sheet: vertices farther than 0.004 from the plane estimate)
+    fld.mask_field.set_level_set(0.004)
+    ofl['udf_level_set'] = 0.004
+    tight = fld.extract_dual_mesh(mise_iter=0)
+    tv, tf = pipeline.extract_dual_mesh(ofl, mise_iter=0)
+    assert 0 < tight.f.shape[0] < mesh.f.shape[0]
+    assert abs(tight.f.shape[0] - len(tf)) <= max(8, 0.03 * len(tf))
+    fld.to_('cpu')                                  # the mask's features travel with the field
+    assert fld.mask_field.features[0].device.type == 'cpu'
+
+
+def ofl_feats_to_torch(ofl, dev):
+    return [None if f is None else torch.from_numpy(f).to(dev) for f in ofl['udf_feats']]
