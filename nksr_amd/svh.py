@@ -148,6 +148,33 @@ class SparseFeatureHierarchy:
             self._levels[d] = SparseGrid(self._footprint(cells, d, 1), d, self.voxel_size)
         return self
 
+    def build_adaptive_normal_variation(self, xyz, normal, tau=0.1, adaptive_depth=1):
+        """Ground-truth structure for the structure loss (models/nksr_net.py:175-179,
+        configs/default/train.yaml:45-47).  Levels d >= adaptive_depth: plain point splatting.  A finer
+        level d < adaptive_depth is splatted only from the points whose level-(d+1) cell is *varied*:
+        1 - |mean unit normal of the cell's points| > tau (and whose coarser cells were varied too),
+        so flat regions stop at a coarse level.  (Spec: DESIGN.md section 2.2; implementation absent
+        from the reference tree.)"""
+        from .nn.network import sort_cloud
+        xyz = self._check_xyz(xyz)
+        normal = normal.to(torch.float32).contiguous()
+        ks, xs, ns = sort_cloud(xyz, normal, self.inv_w0)
+        n = xs.shape[0]
+        alive = torch.ones(n, dtype=torch.bool, device=self.device)
+        for d in range(self.depth - 1, -1, -1):
+            if d < adaptive_depth and d + 1 < self.depth:
+                cell = ks >> (3 * (d + 1))
+                _, inv, cnt = torch.unique_consecutive(cell, return_inverse=True, return_counts=True)
+                acc = torch.zeros((cnt.numel(), 3), dtype=torch.float64, device=self.device)
+                acc.index_add_(0, inv, ns.double())
+                variation = 1.0 - acc.norm(dim=1) / cnt.double()
+                alive = alive & (variation > float(tau))[inv]
+            pts = xs if bool(alive.all()) else xs[alive].contiguous()
+            raw = torch.empty(pts.shape[0] * 8, dtype=torch.int64, device=self.device)
+            call('nksr_splat_keys', ptr(pts), pts.shape[0], self.inv_w0, d, 0, ptr(raw), stream())
+            self._levels[d] = SparseGrid(ops.sort_unique(raw), d, self.voxel_size)
+        return self
+
     def build_from_keys(self, keys_per_level):
         for d in range(self.depth):
             k = keys_per_level[d]

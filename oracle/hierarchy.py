@@ -56,6 +56,25 @@ class Hierarchy:
         self.finalize()
         return self
 
+    def build_adaptive_normal_variation(self, xyz, normal, tau=0.1, adaptive_depth=1):
+        """Training-GT structure (models/nksr_net.py:175-179): levels below adaptive_depth are splatted
+        only from points whose next-coarser cell has normal variation 1 - |mean normal| > tau."""
+        H0, _ = spec.half_index(xyz, self.voxel_size)
+        alive = np.ones(xyz.shape[0], bool)
+        for d in range(self.depth - 1, -1, -1):
+            if d < adaptive_depth and d + 1 < self.depth:
+                cell = spec.morton_key((H0 >> (d + 1)) >> 1, d + 1)
+                _, inv, cnt = np.unique(cell, return_inverse=True, return_counts=True)
+                acc = np.zeros((len(cnt), 3), np.float64)
+                np.add.at(acc, inv, normal.astype(np.float64))
+                variation = 1.0 - np.linalg.norm(acc, axis=1) / cnt
+                alive = alive & (variation > tau)[inv]
+            base = ((H0[alive] >> d) - 1) >> 1
+            ijk = (base[:, None, :] + spec.CORNER_OFFSETS[None]).reshape(-1, 3)
+            self.levels[d] = Level(np.unique(spec.morton_key(ijk, d)), d, self.voxel_size)
+        self.finalize()
+        return self
+
     def build_point_neighborhood(self, xyz):
         """Activate, at every level, the cell containing each point and its 26
         neighbours (the analytic structure rule of the decoder hierarchy,

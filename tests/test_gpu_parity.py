@@ -303,3 +303,26 @@ def test_tree_depth_5_matches_oracle():
     mesh = fld.extract_dual_mesh(mise_iter=1)
     ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=1)
     assert abs(mesh.f.shape[0] - len(of)) <= max(4, 0.01 * len(of))
+
+
+def test_build_adaptive_normal_variation_matches_oracle():
+    """Training-GT hierarchy (models/nksr_net.py:175-179): flat regions stop at a coarse level."""
+    from nksr_amd import SparseFeatureHierarchy
+    from oracle import hierarchy as oh
+    rng = np.random.default_rng(0)
+    # a flat plate (no normal variation) next to a small sphere (high variation)
+    u = rng.uniform(-1, 1, (6000, 2)).astype(np.float32)
+    plate = np.stack([u[:, 0] * 2 + 4, u[:, 1] * 2, np.zeros(6000, np.float32)], 1)
+    pn = np.tile(np.array([[0, 0, 1]], np.float32), (6000, 1))
+    sph, sn = make_cloud('sphere', 6000, 0.0, 1)
+    xyz = np.concatenate([plate, sph * 2]).astype(np.float32)
+    nrm = np.concatenate([pn, sn]).astype(np.float32)
+    for ad in (1, 2):
+        svh = SparseFeatureHierarchy(0.1, 4, _dev())
+        svh.build_adaptive_normal_variation(torch.from_numpy(xyz).to(_dev()), torch.from_numpy(nrm).to(_dev()), tau=0.001, adaptive_depth=ad)
+        oh_ = oh.Hierarchy(0.1, 4).build_adaptive_normal_variation(xyz, nrm, tau=0.001, adaptive_depth=ad)
+        for d in range(4):
+            assert np.array_equal(svh.level(d).keys.cpu().numpy(), oh_.levels[d].keys), (ad, d)
+        c0 = svh.get_voxel_centers(0).cpu().numpy()
+        assert len(c0) > 0 and (c0[:, 0] < 2.5).all()      # nothing fine on the plate
+        assert (svh.get_voxel_centers(3).cpu().numpy()[:, 0] > 3).any()
