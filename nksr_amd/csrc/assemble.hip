@@ -56,10 +56,16 @@ __device__ __forceinline__ int64_t csr_phys(int64_t k) {
     return (k & ~(int64_t)255) + 4 * (m & 63) + (m >> 6);
 }
 
-// ---- phase 1: one wavefront per (level, cell) -------------------------------------------------------
-// NC = columns per lane (T <= 64 NC).  Products are accumulated unweighted and symmetric
-// (fmaf(r_s, r_t, acc)); the set weight is applied once per set at the end.
-template <int NC>
+// ---- phase 1: one wavefront per (level, cell) on the fp32 matrix cores ------------------------------
+// B[d][c] = sum_sets w (R_d)^T [R_d .. R_{L-1} | t]  is a (27 x K)(K x (T+1)) product, K = site rows of
+// the cell: v_mfma_f32_32x32x2_f32 with M = 27 (of 32) block rows, NT = ceil((T+1)/32) column tiles and
+// two site rows per instruction (lanes 0-31 feed row 2m, lanes 32-63 row 2m+1; lane l supplies
+// A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]).  Column T carries the right-hand side
+// (27 m is never a multiple of 32, so a spare column always exists).  The set weight scales the A
+// operand.  Accumulator register r of lane l is D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31].
+typedef float asm_f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NT>
 __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const nksr_level_t& lv = A.hier.lv[d];
@@ -67,56 +73,56 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
     if (c >= lv.n) return;
     const int L = A.hier.depth;
     const int T = (L - d) * 27;
-    float tot[NC][27];
+    const int j = lane & 31, half = lane >> 5;
+    asm_f32x16 acc[NT];
 #pragma unroll
-    for (int q = 0; q < NC; ++q)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int s = 0; s < 27; ++s) tot[q][s] = 0.f;
-    float btot = 0.f;
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     int total = 0;
     for (int si = 0; si < A.nsets; ++si) {
         const nksr_siteset_t& S = A.sets[si];
         const int k0 = S.start[d][c], k1 = S.end[d][c];
         if (k0 >= k1) continue;
-        const int ncomp = S.ncomp;
         total += k1 - k0;
-        float acc[NC][27];
+        const int64_t q0 = (int64_t)k0 * S.ncomp;
+        const int nrows = (k1 - k0) * S.ncomp;
+        const float w = S.weight;
+        for (int m0 = 0; m0 < nrows; m0 += 2) {
+            const bool valid = m0 + half < nrows;
+            const int64_t q = q0 + m0 + half;
+            const float* ra = S.val + (q * L + d) * 27;
+            float b[NT];
 #pragma unroll
-        for (int q = 0; q < NC; ++q)
-#pragma unroll
-            for (int s = 0; s < 27; ++s) acc[q][s] = 0.f;
-        float bacc = 0.f;
-        for (int k = k0; k < k1; ++k) {
-            for (int a = 0; a < ncomp; ++a) {
-                const float* ra = S.val + (((int64_t)k * ncomp + a) * L + d) * 27;
-                float v[NC];
-#pragma unroll
-                for (int q = 0; q < NC; ++q) v[q] = (lane + 64 * q < T) ? ra[lane + 64 * q] : 0.f;
-                if (S.target && lane < 27) bacc = fmaf(v[0], S.target[(int64_t)k * ncomp + a], bacc);
-#pragma unroll
-                for (int s = 0; s < 27; ++s) {
-                    const float gs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[0]), s));
-#pragma unroll
-                    for (int q = 0; q < NC; ++q) acc[q][s] = fmaf(gs, v[q], acc[q][s]);
+            for (int n = 0; n < NT; ++n) {
+                const int col = 32 * n + j;
+                b[n] = 0.f;
+                if (valid) {
+                    if (col < T) b[n] = ra[col];
+                    else if (col == T && S.target) b[n] = S.target[q];
                 }
             }
+            const float a = (j < 27) ? w * b[0] : 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
         }
-        const float w = S.weight;
-#pragma unroll
-        for (int q = 0; q < NC; ++q)
-#pragma unroll
-            for (int s = 0; s < 27; ++s) tot[q][s] = fmaf(w, acc[q][s], tot[q][s]);
-        btot = fmaf(w, bacc, btot);
     }
     if (lane == 0) A.nsites[d][c] = total;
     if (total == 0) return;
     float* out = A.blocks[d] + (int64_t)c * 27 * T;
+    float* bv = A.bvec[d] + (int64_t)c * 27;
 #pragma unroll
-    for (int s = 0; s < 27; ++s)
+    for (int n = 0; n < NT; ++n) {
+        const int col = 32 * n + j;
 #pragma unroll
-        for (int q = 0; q < NC; ++q)
-            if (lane + 64 * q < T) out[s * T + lane + 64 * q] = tot[q][s];
-    if (lane < 27) A.bvec[d][(int64_t)c * 27 + lane] = btot;
+        for (int r = 0; r < 16; ++r) {
+            const int s = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (s < 27) {
+                if (col < T) out[s * T + col] = acc[n][r];
+                else if (col == T) bv[s] = acc[n][r];
+            }
+        }
+    }
 }
 
 // ---- structural test shared by count and fill -----------------------------------------------------
@@ -135,28 +141,93 @@ __device__ __forceinline__ int slot_column(const nksr_hier_t& h, int d, int ix, 
 }
 
 // ---- phase 2a: structure.  colmap[row slot] = column (> row) of every structural upper slot ------
-__global__ void __launch_bounds__(ASM_WAVES * 64) k_row_count(AsmArgs A, int32_t* __restrict__ rowcount,
-                                                              int32_t* __restrict__ indeg) {
+// One wavefront per row, RC_ROWS consecutive rows per workgroup.  Morton-consecutive rows share their
+// coarse ancestors, hence the 5^3 column frames of the coarser levels: the first row of every run of
+// equal ancestors (the run leader) does the hash lookups of a frame once, the others read them from
+// LDS; the cross-level in-degree is counted per frame in LDS and flushed with one global integer atomic
+// per touched column (instead of one per structural entry).  Same-level lower neighbours are
+// counted from the row's own frame.  Integer atomics only: order-independent, deterministic.
+#define RC_ROWS 16
+__global__ void __launch_bounds__(RC_ROWS * 64) k_row_count(AsmArgs A, int32_t* __restrict__ rowcount,
+                                                            int32_t* __restrict__ indeg) {
+    extern __shared__ int32_t rc_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * ASM_WAVES + wave;
-    if (row >= A.M) return;
     const nksr_hier_t& h = A.hier;
-    const int d = row_level(h, row);
-    const nksr_level_t& lv = h.lv[d];
-    const int i = row - lv.offset;
-    const int ix = lv.ijk[i * 3], iy = lv.ijk[i * 3 + 1], iz = lv.ijk[i * 3 + 2];
-    const int nslots = (h.depth - d) * 125;
-    int32_t* cm = A.colmap[d] + (int64_t)i * nslots;
-    int cnt = 0;
-    for (int t0 = 0; t0 < nslots; t0 += 64) {
-        const int t = t0 + lane;
-        int col = (t < nslots) ? slot_column(h, d, ix, iy, iz, t) : -1;
-        if (col <= row) col = -1;
-        if (t < nslots) cm[t] = col;
-        if (col >= 0) atomicAdd(&indeg[col], 1);     // integer: order-independent, deterministic
-        cnt += __popcll(__ballot(col >= 0));
+    const int L = h.depth, F = L - 1;
+    int32_t* anc = rc_lds;                                  // [RC_ROWS][4]  level, ix, iy, iz
+    int32_t* colf = rc_lds + RC_ROWS * 4;                   // [RC_ROWS][F][125]
+    int32_t* cntf = colf + RC_ROWS * F * 125;               // [RC_ROWS][F][125]
+    const int row = blockIdx.x * RC_ROWS + wave;
+    const bool live = row < A.M;
+    int d = -1, i = 0, ix = 0, iy = 0, iz = 0;
+    if (live) {
+        d = row_level(h, row);
+        i = row - h.lv[d].offset;
+        ix = h.lv[d].ijk[i * 3]; iy = h.lv[d].ijk[i * 3 + 1]; iz = h.lv[d].ijk[i * 3 + 2];
     }
-    if (lane == 0) rowcount[row] = cnt;
+    if (lane == 0) { anc[wave * 4] = d; anc[wave * 4 + 1] = ix; anc[wave * 4 + 2] = iy; anc[wave * 4 + 3] = iz; }
+    __syncthreads();
+    // run leaders and their frame lookups
+    int lead[NKSR_MAX_DEPTH];
+    for (int dd = 1; live && d + dd < L; ++dd) {
+        int w = wave;
+        while (w > 0 && anc[(w - 1) * 4] == d && (anc[(w - 1) * 4 + 1] >> dd) == (ix >> dd) &&
+               (anc[(w - 1) * 4 + 2] >> dd) == (iy >> dd) && (anc[(w - 1) * 4 + 3] >> dd) == (iz >> dd)) --w;
+        lead[dd] = w;
+        if (w != wave) continue;
+        const nksr_level_t& lc = h.lv[d + dd];
+        int32_t* cf = colf + (wave * F + dd - 1) * 125;
+        int32_t* nf = cntf + (wave * F + dd - 1) * 125;
+        for (int r = lane; r < 125; r += 64) {
+            const int x = (ix >> dd) + r / 25 - 2, y = (iy >> dd) + (r / 5) % 5 - 2, z = (iz >> dd) + r % 5 - 2;
+            const int j = hash_find(lc.hkeys, lc.hvals, lc.hcap, morton_biased(x, y, z, NKSR_BIAS0 >> (d + dd)));
+            cf[r] = j < 0 ? -1 : lc.offset + j;
+            nf[r] = 0;
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const int nslots = (L - d) * 125;
+        int32_t* cm = A.colmap[d] + (int64_t)i * nslots;
+        int cnt = 0, lower = 0;
+        // same level: every slot of the 5^3 frame overlaps (|dI| <= 2)
+        for (int r = lane; r < 128; r += 64) {
+            int col = (r < 125) ? slot_column(h, d, ix, iy, iz, r) : -1;
+            lower += __popcll(__ballot(col >= 0 && col < row));
+            if (col <= row) col = -1;
+            if (r < 125) cm[r] = col;
+            cnt += __popcll(__ballot(col >= 0));
+        }
+        for (int dd = 1; d + dd < L; ++dd) {
+            const int32_t* cf = colf + (lead[dd] * F + dd - 1) * 125;
+            int32_t* nf = cntf + (lead[dd] * F + dd - 1) * 125;
+            const int lim = 3 * (1 + (1 << dd));
+            for (int r = lane; r < 128; r += 64) {
+                int col = -1;
+                if (r < 125) {
+                    const int x = (ix >> dd) + r / 25 - 2, y = (iy >> dd) + (r / 5) % 5 - 2, z = (iz >> dd) + r % 5 - 2;
+                    const int ax = (2 * ix + 1) - ((2 * x + 1) << dd), ay = (2 * iy + 1) - ((2 * y + 1) << dd),
+                              az = (2 * iz + 1) - ((2 * z + 1) << dd);
+                    if (abs(ax) < lim && abs(ay) < lim && abs(az) < lim) col = cf[r];
+                    cm[dd * 125 + r] = col;
+                    if (col >= 0) atomicAdd(&nf[r], 1);
+                }
+                cnt += __popcll(__ballot(col >= 0));
+            }
+        }
+        if (lane == 0) {
+            rowcount[row] = cnt;
+            if (lower) atomicAdd(&indeg[row], lower);
+        }
+    }
+    __syncthreads();
+    for (int dd = 1; live && d + dd < L; ++dd) {
+        if (lead[dd] != wave) continue;
+        const int32_t* cf = colf + (wave * F + dd - 1) * 125;
+        const int32_t* nf = cntf + (wave * F + dd - 1) * 125;
+        for (int r = lane; r < 125; r += 64)
+            if (nf[r] > 0) atomicAdd(&indeg[cf[r]], nf[r]);
+    }
 }
 
 // ---- phase 2b: one wavefront per row: gather block rows into the slot frame, emit COO ----------------
@@ -326,7 +397,10 @@ extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_
     int rc = fill_args(A, h, nullptr, 0, 0.f, cb, workspace);
     if (rc) return rc;
     if (A.M <= 0) return NKSR_OK;
-    hipLaunchKernelGGL(k_row_count, dim3(nksr_blocks(A.M, ASM_WAVES)), dim3(ASM_WAVES * 64), 0, (hipStream_t)stream, A, rowcount, indeg);
+    const size_t lds = (size_t)(RC_ROWS * 4 + 2 * RC_ROWS * (h->depth - 1) * 125) * sizeof(int32_t);
+    if (lds > 48 * 1024)
+        NKSR_CHECK_HIP(hipFuncSetAttribute((const void*)k_row_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_row_count, dim3(nksr_blocks(A.M, RC_ROWS)), dim3(RC_ROWS * 64), lds, (hipStream_t)stream, A, rowcount, indeg);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -347,9 +421,14 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
         if (n <= 0) continue;
         const int T = (h->depth - d) * 27;
         const dim3 grid(nksr_blocks(n, ASM_WAVES));
-        if (T > 128) hipLaunchKernelGGL((k_cell_blocks<3>), grid, blk, 0, st, A, d);
-        else if (T > 64) hipLaunchKernelGGL((k_cell_blocks<2>), grid, blk, 0, st, A, d);
-        else hipLaunchKernelGGL((k_cell_blocks<1>), grid, blk, 0, st, A, d);
+        switch ((T + 32) / 32) {      // column tiles incl. the right-hand-side column
+            case 1: hipLaunchKernelGGL((k_cell_blocks<1>), grid, blk, 0, st, A, d); break;
+            case 2: hipLaunchKernelGGL((k_cell_blocks<2>), grid, blk, 0, st, A, d); break;
+            case 3: hipLaunchKernelGGL((k_cell_blocks<3>), grid, blk, 0, st, A, d); break;
+            case 4: hipLaunchKernelGGL((k_cell_blocks<4>), grid, blk, 0, st, A, d); break;
+            case 5: hipLaunchKernelGGL((k_cell_blocks<5>), grid, blk, 0, st, A, d); break;
+            default: hipLaunchKernelGGL((k_cell_blocks<6>), grid, blk, 0, st, A, d); break;
+        }
         NKSR_CHECK_LAUNCH();
     }
     for (int d = 0; d < h->depth; ++d) {
