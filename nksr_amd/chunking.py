@@ -209,8 +209,9 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     hp = rec.hparams
     dev = rec.device
     rank, ws = sim if sim is not None else D.world()
-    lo = [float(v) for v in xyz.min(0).values.tolist()]
-    hi = [float(v) for v in xyz.max(0).values.tolist()]
+    from .density import bbox_center
+    lo_t, hi_t, _ = bbox_center(xyz)
+    lo, hi = [float(v) for v in lo_t.tolist()], [float(v) for v in hi_t.tolist()]
     grid = chunk_grid(lo, hi, chunk_size)
     ov = max(overlap_ratio * chunk_size, 1.6 * hp.voxel_size * 2 ** (hp.tree_depth - 1))
     nchunk = grid[0] * grid[1] * grid[2]

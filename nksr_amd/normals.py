@@ -51,11 +51,12 @@ class PointGrid:
 def choose_cell_size(xyz, k):
     """Cell size such that a ball of one cell radius holds ~2k surface samples: density from the
     occupied-voxel count at one probe resolution (points on a surface: count ~ area / cell^2)."""
-    from .density import occupied_voxels
+    from .density import bbox_center, occupied_voxels
     n = xyz.shape[0]
-    ext = float((xyz.max(0).values - xyz.min(0).values).max())
+    lo, hi, center = bbox_center(xyz)
+    ext = float((hi - lo).max())
     probe = max(ext / 256.0, 1e-6)
-    occ = max(occupied_voxels((xyz - xyz.mean(0, keepdim=True)).contiguous(), probe), 1)
+    occ = max(occupied_voxels((xyz - center[None]).contiguous(), probe), 1)
     area = occ * probe * probe                      # ~ surface area
     rho = n / max(area, 1e-20)
     return max(math.sqrt(2.0 * k / (math.pi * rho)), probe / 8)

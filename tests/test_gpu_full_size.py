@@ -1,0 +1,114 @@
+"""Size-independent properties at BASELINE.json's full single-GPU size (configs[2]: 1 000 000 points,
+detail_level=1.0): the oracle cannot run at this size, the invariants of SURVEY.md section 8c(3) can."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def big():
+    import nksr_amd
+    from nksr_amd import utils
+    dev = torch.device('cuda:0')
+    xyz, nrm = utils.synth_scene(1_000_000, seed=0)
+    xyz, nrm = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
+    rec = nksr_amd.Reconstructor(dev)
+    fld = rec.reconstruct(xyz, nrm, detail_level=1.0)
+    return rec, fld, xyz, nrm
+
+
+def test_hierarchy_is_sorted_and_nested(big):
+    _, fld, _, _ = big
+    svh = fld.svh
+    for d in range(svh.depth):
+        k = svh.level(d).keys
+        assert bool((k[1:] > k[:-1]).all())                       # strictly ascending Morton order, no duplicates
+        if d + 1 < svh.depth:                                     # every voxel has its parent one level up
+            assert bool((svh.level(d + 1).hash.query((k >> 3).contiguous()) >= 0).all())
+        nb = svh.level(d).nbr
+        assert bool((nb[:, 13] == torch.arange(nb.shape[0], device=nb.device, dtype=nb.dtype)).all())   # self slot
+        # neighbour symmetry on a sample: nbr[nbr[i][s]][26 - s] == i
+        idx = torch.randint(0, nb.shape[0], (20000,), device=nb.device)
+        for s in (0, 4, 12, 22, 26):
+            j = nb[idx, s].long()
+            ok = j >= 0
+            assert bool((nb[j[ok], 26 - s].long() == idx[ok]).all())
+
+
+def test_matrix_is_exactly_symmetric_and_positive(big):
+    from nksr_amd import solver
+    _, fld, _, _ = big
+    rowptr, cols_p, vals_p, diag = fld.matrix
+    M = rowptr.numel() - 1
+    nnz = int(rowptr[-1])
+    assert nnz > 3e8 and M > 1e6
+    cols, vals = solver.csr_logical(rowptr, cols_p, vals_p)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    rp = rowptr.long()
+    rows = torch.repeat_interleave(torch.arange(M, device=rowptr.device), rp[1:] - rp[:-1])
+    assert bool((cols[rp[1:] - 1].long() == torch.arange(M, device=rowptr.device)).all())      # diagonal closes every row
+    assert bool((vals[rp[1:] - 1] == diag).all())
+    # all 3.8e8 entries: the multiset {(i, j, a_ij)} equals {(j, i, a_ij)} bit for bit
+    a, ia = torch.sort(rows * M + cols.long())
+    assert bool((a[1:] != a[:-1]).all()), 'duplicate (row, col) entries'
+    b, ib = torch.sort(cols.long() * M + rows)
+    assert bool((a == b).all()), 'structural asymmetry'
+    assert bool((vals[ia] == vals[ib]).all()), 'mirrored value differs'
+    del a, b, ia, ib, rows
+    # bilinear-form symmetry and positivity through the product SpMV (fp64 accumulation of the dots)
+    x = torch.randn(M, generator=g).to(rowptr.device)
+    y = torch.randn(M, generator=g).to(rowptr.device)
+    Ax, Ay = solver.spmv(rowptr, cols_p, vals_p, x), solver.spmv(rowptr, cols_p, vals_p, y)
+    a, b = float((y.double() * Ax.double()).sum()), float((x.double() * Ay.double()).sum())
+    assert abs(a - b) <= 1e-5 * max(abs(a), abs(b), float(Ax.double().norm() * y.double().norm()) * 1e-2)
+    assert float((x.double() * Ax.double()).sum()) > 0
+    assert bool((diag > 0).all())
+
+
+def test_solution_satisfies_the_system(big):
+    from nksr_amd import solver
+    _, fld, _, _ = big
+    rowptr, cols_p, vals_p, _ = fld.matrix
+    res = fld.rhs.double() - solver.spmv(rowptr, cols_p, vals_p, fld.alpha).double()
+    rel = float(res.norm() / fld.rhs.double().norm())
+    assert rel <= 2e-5, rel                                       # solver_tol 1e-5, independent residual
+    assert fld.solve_info['rel_residual'] <= 1e-5 and fld.solve_info['iters'] < 200
+
+
+def test_field_fits_the_input(big):
+    _, fld, xyz, nrm = big
+    sel = torch.randperm(xyz.shape[0], device=xyz.device)[:200000]
+    res = fld.evaluate_f(xyz[sel].contiguous(), grad=True)
+    f, g = res.value, res.gradient
+    w = 0.1 / fld.scale                                           # finest voxel in world units
+    assert float(f.abs().median()) < 0.15                         # noise sigma = 0.01 ~ 0.1 voxel
+    cosang = -(g * nrm[sel]).sum(1) / g.norm(dim=1).clamp_min(1e-12)
+    assert float(cosang.mean()) > 0.95 and float((cosang > 0).float().mean()) > 0.995
+    # f changes sign across the surface (f > 0 inside, models/loss.py:192-196): step one voxel along the normal
+    fin = fld.evaluate_f((xyz[sel] - w * nrm[sel]).contiguous()).value
+    fout = fld.evaluate_f((xyz[sel] + w * nrm[sel]).contiguous()).value
+    assert float((fin > 0).float().mean()) > 0.97 and float((fout < 0).float().mean()) > 0.97
+
+
+@pytest.mark.parametrize('mise_iter', [0, 1])
+def test_mesh_is_watertight_and_on_the_data(big, mise_iter):
+    _, fld, xyz, _ = big
+    mesh = fld.extract_dual_mesh(mise_iter=mise_iter)
+    f = mesh.f.long()
+    V = mesh.v.shape[0]
+    assert f.shape[0] > 5e5 and int(f.min()) == 0 and int(f.max()) == V - 1
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    key = torch.minimum(e[:, 0], e[:, 1]) * V + torch.maximum(e[:, 0], e[:, 1])
+    _, cnt = torch.unique(key, return_counts=True)
+    # manifold everywhere; open edges only where the noisy level set leaves the band of active voxels
+    assert int(cnt.max()) == 2, 'non-manifold edges: %s' % torch.bincount(cnt)[:6].tolist()
+    assert int((cnt == 1).sum()) <= 2e-4 * cnt.numel(), 'open edges: %s' % torch.bincount(cnt)[:6].tolist()
+    # orientation consistency: every directed edge appears exactly once
+    dkey = e[:, 0] * V + e[:, 1]
+    assert torch.unique(dkey).numel() == dkey.numel()
+    # vertices sit on the zero level set and next to the data
+    fv = fld.evaluate_f(mesh.v).value
+    assert float(fv.abs().max()) < 0.5
+    assert bool(torch.isfinite(mesh.v).all())
