@@ -170,7 +170,7 @@ def main():
                    'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]),
                    'global_scale': field.scale if world == 1 else scale,
                    'parallelism': 'none' if world == 1 else 'chunks sharded 1/rank, all_gather of solved fields before meshing, mesh gather'},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_spmv<true> (CSR SpMV + fused p.Ap partial dot)',
+        'roofline': {'bound': 'hbm', 'kernel': 'k_spmv<0> + k_spmv_fixup (CSR SpMV inside the PCG loop)',
                      'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
                      'traffic': load_traffic(b_spmv), 'bytes_per_launch': b_spmv, 'avg_launch_us': avg_s * 1e6,
                      'launches_timed': spmv_launches},

@@ -1,8 +1,8 @@
 // Jacobi-preconditioned conjugate gradients on the CSR normal equations.
 // The CSR SpMV is the roofline kernel of this project:
 //   algorithmic bytes per launch  B_spmv = 8*nnz + 12*M + 4   (fp32 vals, int32 cols/rowptr)
-// Per iteration: (1) y = A p fused with the partial dot p.y, (2) x,r,z update fused with the
-// partial dots r.r and r.z, (3) p update.  alpha/beta never leave the device; dot products are
+// Per iteration: (1) y = A p, (2) partial dot p.y (own small kernel, see k_pcg_dot), (3) x,r,z update
+// fused with the partial dots r.r and r.z, (4) p update.  alpha/beta never leave the device; dot products are
 // accumulated in fp64 with a fixed reduction order (deterministic).  A device-side `done` flag
 // turns the remaining launches of a chunk into no-ops, so the host only syncs every
 // `check_every` iterations.
@@ -114,18 +114,15 @@ __global__ void k_spmv_plan(const int32_t* __restrict__ rowptr, int M, int64_t n
     chunk_row[b] = lo;
 }
 
-template <bool DOT, int VARIANT>
+template <int VARIANT>
 __global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                     const float* __restrict__ vals, int M, int nnz, int nchunks,
                                                     const int32_t* __restrict__ chunk_row, const float* __restrict__ x,
                                                     float* __restrict__ y, float* __restrict__ carry,
-                                                    int32_t* __restrict__ carry_row, double* __restrict__ part,
-                                                    const int* __restrict__ done) {
-    if (DOT && *done) return;
+                                                    int32_t* __restrict__ carry_row, const int* __restrict__ done) {
+    if (done && *done) return;
     __shared__ __attribute__((aligned(16))) float prod[SPMV_CHUNK];
-    __shared__ double sm[PCG_BLOCK / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double dot = 0.0;
     // chunks are dealt round-robin to the workgroups (a contiguous range per workgroup measured 8 %
     // slower: the concurrently active chunks then crowd the same HBM channels)
     for (int b = blockIdx.x; b < nchunks; b += gridDim.x) {
@@ -172,14 +169,9 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ 
             if (lane == 0) {
                 if (p0 >= base) y[r] = s;
                 else { carry[b] = s; carry_row[b] = r; }
-                if (DOT) dot += (double)s * (double)x[r];
             }
         }
         __syncthreads();
-    }
-    if (DOT) {
-        double t = block_sum(dot, sm);
-        if (tid == 0) part[blockIdx.x] = t;
     }
 }
 
@@ -231,6 +223,18 @@ __global__ void k_pcg_init_finish(PcgWork w, int nb) {
         w.sc->iter = 0;
         w.sc->done = (bb == 0.0) ? 1 : 0;
     }
+}
+
+// partial sums of p.Ap (fp64, fixed order).  Kept out of the SpMV on purpose: fused there, lane 0 of every
+// wavefront waited for a dependent x[r] load once per row, which cost the SpMV ~10 % (761 vs 680 us).
+__global__ void __launch_bounds__(PCG_BLOCK) k_pcg_dot(int M, PcgWork w) {
+    if (w.sc->done) return;
+    __shared__ double sm[PCG_BLOCK / 64];
+    double acc = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
+        acc += (double)w.p[i] * (double)w.y[i];
+    const double t = block_sum(acc, sm);
+    if (threadIdx.x == 0) w.part1[blockIdx.x] = t;
 }
 
 // x += alpha p ; r -= alpha y ; z = r / diag ; partial r.r and r.z
@@ -322,11 +326,10 @@ extern "C" int nksr_spmv_plan(const int32_t* rowptr, int32_t M, int64_t nnz, voi
 static int g_spmv_variant = 0;
 extern "C" int nksr_spmv_set_variant(int v) { g_spmv_variant = v; return NKSR_OK; }
 
-template <bool DOT>
 static int launch_spmv(const int32_t* rowptr, const int32_t* cols, const float* vals, int M, int64_t nnz, const SpmvPlan& p,
-                       const float* x, float* y, double* part, const int* done, hipStream_t st) {
-#define SPMV_LAUNCH(V) hipLaunchKernelGGL((k_spmv<DOT, V>), dim3(spmv_grid(p.nchunks)), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, (int)nnz, \
-                       p.nchunks, p.chunk_row, x, y, p.carry, p.carry_row, part, done)
+                       const float* x, float* y, const int* done, hipStream_t st) {
+#define SPMV_LAUNCH(V) hipLaunchKernelGGL((k_spmv<V>), dim3(spmv_grid(p.nchunks)), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, (int)nnz, \
+                       p.nchunks, p.chunk_row, x, y, p.carry, p.carry_row, done)
     if (g_spmv_variant == 1) SPMV_LAUNCH(1); else SPMV_LAUNCH(0);
     hipLaunchKernelGGL(k_spmv_fixup, dim3(nksr_blocks(p.nchunks, 256)), dim3(256), 0, st, p.nchunks, p.carry, p.carry_row, y, done);
     return 0;
@@ -337,7 +340,7 @@ extern "C" int nksr_spmv_csr(const int32_t* rowptr, const int32_t* cols, const f
     if (M <= 0) return NKSR_OK;
     if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL (run nksr_spmv_plan first)");
     SpmvPlan p = carve_spmv(workspace, nnz);
-    launch_spmv<false>(rowptr, cols, vals, M, nnz, p, x, y, nullptr, nullptr, (hipStream_t)stream);
+    launch_spmv(rowptr, cols, vals, M, nnz, p, x, y, nullptr, (hipStream_t)stream);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -371,7 +374,6 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const 
     if (rc) return rc;
     SpmvPlan plan = carve_spmv(spmv_ws, nnz);
     const int nbv = nksr_blocks(M, PCG_BLOCK) > PCG_MAX_BLOCKS ? PCG_MAX_BLOCKS : nksr_blocks(M, PCG_BLOCK);
-    const int nbs = spmv_grid(plan.nchunks);
     hipLaunchKernelGGL(k_pcg_init, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, b, diag, w, x);
     hipLaunchKernelGGL(k_pcg_init_finish, dim3(1), dim3(PCG_BLOCK), 0, st, w, nbv);
     NKSR_CHECK_LAUNCH();
@@ -390,9 +392,10 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const 
         for (int c = 0; c < chunk; ++c) {
             const int parity = (launched + c) & 1;
             if (prof) hipEventRecord(g_prof_events[2 * c], st);
-            launch_spmv<true>(rowptr, cols, vals, M, nnz, plan, w.p, w.y, w.part1, &w.sc->done, st);
+            launch_spmv(rowptr, cols, vals, M, nnz, plan, w.p, w.y, &w.sc->done, st);
             if (prof) hipEventRecord(g_prof_events[2 * c + 1], st);
-            hipLaunchKernelGGL(k_pcg_update, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, diag, w, x, nbs, parity);
+            hipLaunchKernelGGL(k_pcg_dot, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w);
+            hipLaunchKernelGGL(k_pcg_update, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, diag, w, x, nbv, parity);
             hipLaunchKernelGGL(k_pcg_pupdate, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w, nbv, parity, tol);
         }
         NKSR_CHECK_LAUNCH();
