@@ -132,6 +132,14 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ 
         // 16-byte load of lane l is logical entry 64 j + l of the tile -> every gather instruction
         // below covers 64 consecutive entries of the stream.  Storage is zero-padded to a multiple
         // of SPMV_CHUNK, so no bounds checks are needed.
+        // row pointers of the rows this wavefront will reduce (lane j: row r_first + wave + 4 j), fetched
+        // now so that their latency hides behind the stream loads instead of stalling the row loop
+        const int r_first = chunk_row[b], r_lim = chunk_row[b + 1];      // r_lim: row holding entry `end` (or M)
+        int pre0 = 0x7fffffff, pre1 = 0x7fffffff;
+        {
+            const int r = r_first + wave + (PCG_BLOCK / 64) * lane;
+            if (r <= r_lim && r < M) { pre0 = rowptr[r]; pre1 = rowptr[r + 1]; }
+        }
         int4 c[SPMV_QUADS];
         float4 v[SPMV_QUADS];
         {
@@ -155,12 +163,13 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ 
         }
         }
         __syncthreads();
-        const int r_first = chunk_row[b];
-        int r_last = chunk_row[b + 1];                    // row holding entry `end` (or M)
-        if (r_last >= M || rowptr[r_last] >= end) r_last -= 1;
-        if (tid == 0 && rowptr[r_first] >= base) carry_row[b] = -1;   // no row continues into this chunk
-        for (int r = r_first + wave; r <= r_last; r += PCG_BLOCK / 64) {
-            const int p0 = rowptr[r], p1 = rowptr[r + 1];
+        if (tid == 0 && pre0 >= base) carry_row[b] = -1;   // no row continues into this chunk
+        int j = 0;
+        for (int r = r_first + wave; r <= r_lim && r < M; r += PCG_BLOCK / 64, ++j) {
+            int p0, p1;
+            if (j < 64) { p0 = __builtin_amdgcn_readlane(pre0, j); p1 = __builtin_amdgcn_readlane(pre1, j); }
+            else { p0 = rowptr[r]; p1 = rowptr[r + 1]; }
+            if (p0 >= end) break;                          // row r_lim starts exactly at `end`: next chunk's
             const int k0 = p0 > base ? p0 : base, k1 = p1 < end ? p1 : end;
             float s = 0.f;
             for (int k = k0 + lane; k < k1; k += 64) s += prod[k - base];
