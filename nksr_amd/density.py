@@ -42,7 +42,7 @@ def scale_for_detail_level(xyz, detail_level, model_voxel_size, refine_iters=2):
     ext = float((hi3 - lo3).max())
     if ext <= 0:
         return 1.0
-    xc = (xyz - center[None]).contiguous()     # keep |x / vs| small while probing tiny voxels
+    xc = (xyz - lo3[None]).contiguous()        # small non-negative coordinates: short Morton keys, fewer radix passes
     vs0 = ext / 4096.0
     keys = torch.empty(n, dtype=torch.int64, device=xyz.device)
     call('nksr_point_keys', ptr(xc), n, inv_w0_f32(vs0), ptr(keys), stream())

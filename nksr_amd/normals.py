@@ -56,7 +56,7 @@ def choose_cell_size(xyz, k):
     lo, hi, center = bbox_center(xyz)
     ext = float((hi - lo).max())
     probe = max(ext / 256.0, 1e-6)
-    occ = max(occupied_voxels((xyz - center[None]).contiguous(), probe), 1)
+    occ = max(occupied_voxels((xyz - lo[None]).contiguous(), probe), 1)
     area = occ * probe * probe                      # ~ surface area
     rho = n / max(area, 1e-20)
     return max(math.sqrt(2.0 * k / (math.pi * rho)), probe / 8)

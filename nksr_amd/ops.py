@@ -13,22 +13,35 @@ def _bits(n):
     return b
 
 
-def sort_keys(keys, end_bit=63):
+def varying_bits(keys):
+    """Number of low bits that differ anywhere in ``keys``: Morton keys of one cloud share their high bits
+    (always when the cloud lies in one octant of the biased lattice), and every 8 constant bits save one
+    radix pass.  Small inputs are not worth the host round trip."""
+    if keys.numel() < (1 << 17):
+        return 63
+    return max(1, int((keys ^ keys[:1]).max()).bit_length())
+
+
+def sort_keys(keys, end_bit=None):
     """Ascending radix sort of non-negative int64 keys."""
     n = keys.numel()
     out = torch.empty_like(keys)
     if n:
+        if end_bit is None:
+            end_bit = varying_bits(keys)
         with_tmp('nksr_sort_keys_u64', keys.device, ptr(keys), ptr(out), n, 0, int(end_bit), stream())
     return out
 
 
-def sort_pairs(keys, vals32, end_bit=63, pad=0):
+def sort_pairs(keys, vals32, end_bit=None, pad=0):
     """Sort (int64 key, 32-bit payload) pairs by key.  ``pad`` extra (zeroed) elements are kept
     behind the returned views so that 16-byte loads may run past the end."""
     n = keys.numel()
     ko = torch.empty_like(keys)
     vo = torch.zeros(n + pad, dtype=vals32.dtype, device=vals32.device)[:n] if pad else torch.empty_like(vals32)
     if n:
+        if end_bit is None:
+            end_bit = varying_bits(keys)
         with_tmp('nksr_sort_pairs_u64_u32', keys.device, ptr(keys), ptr(ko), ptr(vals32), ptr(vo), n, 0, int(end_bit), stream())
     return ko, vo
 
