@@ -230,6 +230,22 @@ __global__ void __launch_bounds__(RC_ROWS * 64) k_row_count(AsmArgs A, int32_t* 
     }
 }
 
+// NQ consecutive floats per lane from a 4-byte aligned block row: ONE vector-memory instruction per row
+// (a row fill issues ~100 of them per matrix row and each costs ~16 clocks in the CU's address unit)
+template <int NQ> struct cols_u { float v[NQ]; } __attribute__((packed, aligned(4)));
+template <int NQ>
+__device__ __forceinline__ void load_cols(const float* __restrict__ row, int lane, int T, float out[NQ]) {
+    const int t0 = NQ * lane;
+    if (t0 + NQ <= T) {
+        const cols_u<NQ> c = *reinterpret_cast<const cols_u<NQ>*>(row + t0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) out[q] = c.v[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) out[q] = (t0 + q < T) ? row[t0 + q] : 0.f;
+    }
+}
+
 // ---- phase 2b: one wavefront per row: gather block rows into the slot frame, emit COO ----------------
 template <int NQ>
 __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const int32_t* __restrict__ rowptr,
@@ -265,8 +281,8 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const in
     // per-lane entry decomposition (independent of the neighbour cell)
     int edd[NQ], esx[NQ], esy[NQ], esz[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int t = lane + 64 * q, s = t % 27;
+    for (int q = 0; q < NQ; ++q) {      // lane l holds the NQ consecutive block columns NQ l .. NQ l + NQ - 1 (one vector load)
+        const int t = NQ * lane + q, s = t % 27;
         edd[q] = t / 27;
         esx[q] = s / 9 - 1; esy[q] = (s / 3) % 3 - 1; esz[q] = s % 3 - 1;
     }
@@ -278,9 +294,7 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const in
         spc = __ffsll((long long)act) - 1;
         act &= act - 1;
         const int c = __builtin_amdgcn_readlane(cme, spc);
-        const float* brow = A.blocks[d] + ((int64_t)c * 27 + (26 - spc)) * T;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) vcur[q] = (lane + 64 * q < T) ? brow[lane + 64 * q] : 0.f;
+        load_cols<NQ>(A.blocks[d] + ((int64_t)c * 27 + (26 - spc)) * T, lane, T, vcur);
     }
     while (spc >= 0) {
         int spn = -1;
@@ -288,14 +302,12 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const in
             spn = __ffsll((long long)act) - 1;
             act &= act - 1;
             const int c = __builtin_amdgcn_readlane(cme, spn);
-            const float* brow = A.blocks[d] + ((int64_t)c * 27 + (26 - spn)) * T;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) vnext[q] = (lane + 64 * q < T) ? brow[lane + 64 * q] : 0.f;
+            load_cols<NQ>(A.blocks[d] + ((int64_t)c * 27 + (26 - spn)) * T, lane, T, vnext);
         }
         const int cx = ix + spc / 9 - 1, cy = iy + (spc / 3) % 3 - 1, cz = iz + spc % 3 - 1;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            if (lane + 64 * q < T) {
+            if (NQ * lane + q < T) {
                 const int dd = edd[q];
                 const int rx = ((cx >> dd) + esx[q]) - (ix >> dd) + 2, ry = ((cy >> dd) + esy[q]) - (iy >> dd) + 2,
                           rz = ((cz >> dd) + esz[q]) - (iz >> dd) + 2;
