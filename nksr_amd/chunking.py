@@ -66,7 +66,7 @@ def unpack_field(ints, flts, voxel_size, interpolators, device):
     for n in ns:
         keys.append(ints[off:off + n].contiguous())
         off += n
-    svh = SparseFeatureHierarchy(voxel_size, depth, device).build_from_keys(keys)
+    svh = SparseFeatureHierarchy(voxel_size, depth, device).build_from_keys(keys, sorted_unique=True)
     feats, fo = [], 0
     for n in ns:
         feats.append(flts[fo:fo + n * kdim].view(n, kdim).contiguous())
@@ -174,13 +174,37 @@ class MultiChunkField(BaseField):
         if self.world_size == 1:
             return torch.ones(ijk.shape[0], dtype=torch.bool, device=ijk.device)
         own = torch.tensor(self.owner, dtype=torch.long, device=ijk.device)
-        centers = (ijk.to(torch.float32) + 0.5) * self.svh.voxel_size
-        m = torch.zeros(ijk.shape[0], dtype=torch.bool, device=ijk.device)
         w = self.svh.voxel_size
-        for dx in (-w, 0.0, w):
-            for dy in (-w, 0.0, w):
-                for dz in (-w, 0.0, w):
-                    m |= own[self.chunk_of(centers + torch.tensor([dx, dy, dz], device=ijk.device))] == self.rank
+        centers = (ijk.to(torch.float32) + 0.5) * w
+        # chunk index of centre - w / centre / centre + w along every split axis; only voxels next to a chunk
+        # boundary (lo != hi on some axis) can see a different owner than their own chunk's
+        split = [a for a in range(3) if self.grid[a] > 1]
+        idx = {}
+        for a in split:
+            for k, off in ((0, -w), (1, 0.0), (2, w)):
+                idx[(a, k)] = torch.floor((centers[:, a] + off - self.origin[a]) / self.chunk_size).long().clamp_(0, self.grid[a] - 1)
+
+        def lin(sel, ks):
+            out = torch.zeros(1, dtype=torch.long, device=ijk.device)
+            for a in range(3):
+                ia = idx[(a, ks[a])][sel] if a in split else 0
+                out = out * self.grid[a] + ia
+            return out
+
+        every = slice(None)
+        m = own[lin(every, (1, 1, 1))] == self.rank
+        near = torch.zeros(ijk.shape[0], dtype=torch.bool, device=ijk.device)
+        for a in split:
+            near |= idx[(a, 0)] != idx[(a, 2)]
+        sel = torch.nonzero(near).reshape(-1)
+        if sel.numel():
+            ms = m[sel]
+            combos = [()]
+            for a in range(3):
+                combos = [c + (k,) for c in combos for k in ((0, 1, 2) if a in split else (1,))]
+            for ks in combos:
+                ms = ms | (own[lin(sel, ks)] == self.rank)
+            m[sel] = ms
         return m
 
     def finalize_mesh(self, res):
@@ -215,25 +239,34 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     grid = chunk_grid(lo, hi, chunk_size)
     ov = max(overlap_ratio * chunk_size, 1.6 * hp.voxel_size * 2 ** (hp.tree_depth - 1))
     nchunk = grid[0] * grid[1] * grid[2]
-    cores, sel_idx, counts = {}, {}, []
+    cores = {}
     for c in range(nchunk):
         cz, cy, cx = c % grid[2], (c // grid[2]) % grid[1], c // (grid[1] * grid[2])
         clo = [lo[0] + cx * chunk_size, lo[1] + cy * chunk_size, lo[2] + cz * chunk_size]
-        chi = [clo[a] + chunk_size for a in range(3)]
-        cores[c] = (clo, chi)
-        m = torch.ones(xyz.shape[0], dtype=torch.bool, device=dev)
-        for a in range(3):
-            if grid[a] > 1:
-                m &= (xyz[:, a] >= clo[a] - 2 * ov) & (xyz[:, a] < chi[a] + 2 * ov)
-        sel_idx[c] = torch.nonzero(m).reshape(-1)
-        counts.append(int(sel_idx[c].numel()))
+        cores[c] = (clo, [clo[a] + chunk_size for a in range(3)])
+    # points per core in one pass (the load-balance weights; a chunk whose core is empty is skipped: the
+    # bands around it are covered by its neighbours' weights)
+    cid = torch.zeros(xyz.shape[0], dtype=torch.long, device=dev)
+    for a in range(3):
+        if grid[a] > 1:
+            ia = torch.floor((xyz[:, a] - lo[a]) / chunk_size).long().clamp_(0, grid[a] - 1)
+        else:
+            ia = 0
+        cid = cid * grid[a] + ia
+    counts = torch.bincount(cid, minlength=nchunk).tolist()
     owner = D.partition_chunks(nchunk, ws, counts)
     local = {}
     timing = {}
     for c in range(nchunk):
         if owner[c] != rank or counts[c] == 0:
             continue
-        idx = sel_idx[c]
+        clo, chi = cores[c]
+        m = None                                  # points inside core +- 2 ov (only along the split axes)
+        for a in range(3):
+            if grid[a] > 1:
+                ma = (xyz[:, a] >= clo[a] - 2 * ov) & (xyz[:, a] < chi[a] + 2 * ov)
+                m = ma if m is None else (m & ma)
+        idx = torch.nonzero(m).reshape(-1) if m is not None else torch.arange(xyz.shape[0], device=dev)
         cx_, cn_, cs_ = xyz[idx].contiguous(), (normal[idx].contiguous() if normal is not None else None), \
             (sensor[idx].contiguous() if sensor is not None else None)
         if preprocess_fn is not None:

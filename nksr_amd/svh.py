@@ -175,12 +175,14 @@ class SparseFeatureHierarchy:
             self._levels[d] = SparseGrid(ops.sort_unique(raw), d, self.voxel_size)
         return self
 
-    def build_from_keys(self, keys_per_level):
+    def build_from_keys(self, keys_per_level, sorted_unique=False):
+        """``sorted_unique``: the keys are already in canonical order (a packed field's payload)."""
         for d in range(self.depth):
             k = keys_per_level[d]
             if k is None:
                 k = torch.empty(0, dtype=torch.int64, device=self.device)
-            self._levels[d] = SparseGrid(ops.sort_unique(k.to(self.device).contiguous()), d, self.voxel_size)
+            k = k.to(self.device).contiguous()
+            self._levels[d] = SparseGrid(k if sorted_unique else ops.sort_unique(k), d, self.voxel_size)
         return self
 
     def build_from_grid_coords(self, depth, ijk):
