@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this driver (RCCL peer mappings)
+
 import numpy as np
 import torch
 
@@ -80,14 +82,14 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     dist = None
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local_rank)            # before the process group: RCCL binds to the current device
+    dev = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # backend "nccl" is RCCL on ROCm; NKSR_DIST_BACKEND=gloo lets two ranks share one GPU in tests
         dist.init_process_group(os.environ.get('NKSR_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
 
     import nksr_amd
     from nksr_amd import solver, utils
