@@ -72,7 +72,11 @@ def exchange_payloads(local, expected_ids):
     if ws == 1:
         return dict(local)
     ids = sorted(local)
-    dev = local[ids[0]][0].device if ids else torch.device('cpu')
+    if ids:
+        dev = local[ids[0]][0].device
+    else:                                  # idle rank (more ranks than chunks): still takes part in the collectives
+        import torch.distributed as dist
+        dev = torch.device('cpu') if dist.get_backend() == 'gloo' else torch.device('cuda', torch.cuda.current_device())
     head = torch.tensor([v for c in ids for v in (c, local[c][0].numel(), local[c][1].numel())], dtype=torch.int64, device=dev)
     ibuf = torch.cat([local[c][0].reshape(-1) for c in ids]) if ids else torch.zeros(0, dtype=torch.int64, device=dev)
     fbuf = torch.cat([local[c][1].reshape(-1) for c in ids]) if ids else torch.zeros(0, dtype=torch.float32, device=dev)
