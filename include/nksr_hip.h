@@ -142,21 +142,25 @@ typedef struct {
     const int32_t* end[NKSR_MAX_DEPTH];
 } nksr_siteset_t;
 
-/* Structure pass: rowcount[row] = number of structural upper entries of the row (column voxel exists,
- * B-spline supports overlap, col > row); indeg[col] += 1 for each of them (integer atomics; indeg must
- * be zeroed).  Final CSR row = [indeg mirrors][rowcount own upper][diagonal]. */
-int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, int32_t* indeg, void* stream);
+/* Structure pass.  Per row: rowcount = structural upper entries (column voxel exists, B-spline supports
+ * overlap, col > row), crosscount = those of them whose column lies on a coarser level (only these are
+ * mirrored), samelow = same-level neighbours with col < row (emitted by the row itself: bitwise equal to the
+ * transposed entry); indeg[col] += 1 for every cross-level upper entry (integer atomics; indeg must be
+ * zeroed).  Final CSR row = [indeg cross-level mirrors][samelow][rowcount own upper][diagonal]. */
+int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, int32_t* crosscount, int32_t* samelow,
+                        int32_t* indeg, void* stream);
 /* Bytes of scratch (per-cell blocks + per-row column map) shared by nksr_assemble_count / nksr_assemble. */
 size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h);
-/* Two-phase assembly of  sum_s w_s R_s^T R_s + reg I  (csrc/assemble.hip): per-cell dense blocks, then
- * one wavefront per row.  rowptr = exclusive scan of (indeg + rowcount + 1), mir_off = exclusive scan of
- * rowcount.  Own upper entries + diagonal are written straight into cols_out / vals_out (tile-interleaved
- * physical layout, see nksr_spmv_csr); the mirrored copies go to mir_keys (src_row << col_bits | dst_row)
- * / mir_vals.  Also writes diag_out and b = sum_s w_s R_s^T t_s. */
+/* Two-phase assembly of  sum_s w_s R_s^T R_s + reg I  (csrc/assemble.hip): per-cell dense blocks (fp32 MFMA),
+ * then one wavefront per row.  rowptr = exclusive scan of (indeg + samelow + rowcount + 1), mir_off =
+ * exclusive scan of crosscount.  Same-level lower, own upper entries and the diagonal are written straight
+ * into cols_out / vals_out (tile-interleaved physical layout, see nksr_spmv_csr); the mirrored copies of the
+ * cross-level entries go to mir_keys (src_row << col_bits | dst_row) / mir_vals.  Also writes diag_out and
+ * b = sum_s w_s R_s^T t_s. */
 int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, int nsets, float reg, int col_bits,
-                  void* workspace, const int32_t* rowptr, const int32_t* indeg, const int32_t* mir_off,
-                  int32_t* cols_out, float* vals_out, float* diag_out, uint64_t* mir_keys, float* mir_vals,
-                  float* b_out, void* stream);
+                  void* workspace, const int32_t* rowptr, const int32_t* indeg, const int32_t* samelow,
+                  const int32_t* mir_off, int32_t* cols_out, float* vals_out, float* diag_out, uint64_t* mir_keys,
+                  float* mir_vals, float* b_out, void* stream);
 /* Mirrors stably sorted by destination row (low col_bits of the key) -> their CSR slots;
  * mirptr = exclusive scan of indeg. */
 int nksr_place_mirrors(const uint64_t* keys_sorted, const float* vals_sorted, int64_t n, int col_bits,

@@ -87,7 +87,9 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
         total += k1 - k0;
         const int64_t q0 = (int64_t)k0 * S.ncomp;
         const int nrows = (k1 - k0) * S.ncomp;
-        const float w = S.weight;
+        // sqrt(w) on BOTH operands: the products (sw r_s)(sw r_t) are then bitwise symmetric in (s, t), so a row
+        // can emit its same-level LOWER entries from its own frame (no mirror needed for them)
+        const float sw = sqrtf(S.weight);
         for (int m0 = 0; m0 < nrows; m0 += 2) {
             const bool valid = m0 + half < nrows;
             const int64_t q = q0 + m0 + half;
@@ -98,11 +100,11 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
                 const int col = 32 * n + j;
                 b[n] = 0.f;
                 if (valid) {
-                    if (col < T) b[n] = ra[col];
-                    else if (col == T && S.target) b[n] = S.target[q];
+                    if (col < T) b[n] = sw * ra[col];
+                    else if (col == T && S.target) b[n] = sw * S.target[q];
                 }
             }
-            const float a = (j < 27) ? w * b[0] : 0.f;
+            const float a = (j < 27) ? b[0] : 0.f;
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
         }
@@ -149,6 +151,7 @@ __device__ __forceinline__ int slot_column(const nksr_hier_t& h, int d, int ix, 
 // counted from the row's own frame.  Integer atomics only: order-independent, deterministic.
 #define RC_ROWS 16
 __global__ void __launch_bounds__(RC_ROWS * 64) k_row_count(AsmArgs A, int32_t* __restrict__ rowcount,
+                                                            int32_t* __restrict__ crosscount, int32_t* __restrict__ samelow,
                                                             int32_t* __restrict__ indeg) {
     extern __shared__ int32_t rc_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -189,14 +192,17 @@ __global__ void __launch_bounds__(RC_ROWS * 64) k_row_count(AsmArgs A, int32_t* 
     if (live) {
         const int nslots = (L - d) * 125;
         int32_t* cm = A.colmap[d] + (int64_t)i * nslots;
-        int cnt = 0, lower = 0;
-        // same level: every slot of the 5^3 frame overlaps (|dI| <= 2)
+        int cnt = 0, lower = 0, cross = 0;
+        // same level: every slot of the 5^3 frame overlaps (|dI| <= 2).  Upper neighbours are stored as
+        // their column, lower ones as -2 - column (emitted by the row itself, bitwise equal to the
+        // transposed entry), the diagonal / absent slots as -1.
         for (int r = lane; r < 128; r += 64) {
             int col = (r < 125) ? slot_column(h, d, ix, iy, iz, r) : -1;
-            lower += __popcll(__ballot(col >= 0 && col < row));
-            if (col <= row) col = -1;
-            if (r < 125) cm[r] = col;
-            cnt += __popcll(__ballot(col >= 0));
+            const bool lo = col >= 0 && col < row;
+            lower += __popcll(__ballot(lo));
+            if (col == row) col = -1;
+            cnt += __popcll(__ballot(col > row));
+            if (r < 125) cm[r] = lo ? -2 - col : col;
         }
         for (int dd = 1; d + dd < L; ++dd) {
             const int32_t* cf = colf + (lead[dd] * F + dd - 1) * 125;
@@ -212,12 +218,13 @@ __global__ void __launch_bounds__(RC_ROWS * 64) k_row_count(AsmArgs A, int32_t* 
                     cm[dd * 125 + r] = col;
                     if (col >= 0) atomicAdd(&nf[r], 1);
                 }
-                cnt += __popcll(__ballot(col >= 0));
+                cross += __popcll(__ballot(col >= 0));
             }
         }
         if (lane == 0) {
-            rowcount[row] = cnt;
-            if (lower) atomicAdd(&indeg[row], lower);
+            rowcount[row] = cnt + cross;
+            crosscount[row] = cross;
+            samelow[row] = lower;
         }
     }
     __syncthreads();
@@ -249,7 +256,8 @@ __device__ __forceinline__ void load_cols(const float* __restrict__ row, int lan
 // ---- phase 2b: one wavefront per row: gather block rows into the slot frame, emit COO ----------------
 template <int NQ>
 __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const int32_t* __restrict__ rowptr,
-                                                             const int32_t* __restrict__ indeg, const int32_t* __restrict__ mir_off,
+                                                             const int32_t* __restrict__ indeg, const int32_t* __restrict__ samelow,
+                                                             const int32_t* __restrict__ mir_off,
                                                              int32_t* __restrict__ cols_out, float* __restrict__ vals_out,
                                                              float* __restrict__ diag_out, uint64_t* __restrict__ mir_keys,
                                                              float* __restrict__ mir_vals,
@@ -322,28 +330,33 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const in
 
     // emission: structure comes from the count pass (no hashing here)
     const int32_t* cm = A.colmap[d] + (int64_t)i * nslots;
-    // own upper entries go straight to their final CSR slot (row = [mirrors][own upper][diagonal]);
-    // the mirrored copies go to a list keyed by destination row, sorted afterwards
-    int64_t opos = (int64_t)rowptr[row] + indeg[row];
+    // row = [cross-level mirrors (from finer rows)][same-level lower][own upper][diagonal].  Same-level lower and
+    // own upper entries go straight to their final CSR slot; only the cross-level upper entries have a
+    // mirrored copy, which goes to a list keyed by destination row, sorted afterwards
+    int64_t lpos = (int64_t)rowptr[row] + indeg[row];
+    int64_t opos = lpos + samelow[row];
     int64_t mpos = (int64_t)mir_off[row];
     for (int t0 = 0; t0 < nslots; t0 += 64) {
         const int t = t0 + lane;
-        const int col = (t < nslots) ? cm[t] : -1;
-        const bool keep = col >= 0;
-        const unsigned long long mask = __ballot(keep);
-        if (keep) {
-            const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        const int cv = (t < nslots) ? cm[t] : -1;
+        const bool up = cv >= 0, low = cv <= -2, mir = up && t >= 125;
+        const unsigned long long mu = __ballot(up), ml = __ballot(low), mm = __ballot(mir);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (up | low) {
             const float v = acc[t];
-            const int64_t k = opos + rank;
+            const int64_t k = up ? opos + __popcll(mu & below) : lpos + __popcll(ml & below);
             const int64_t ph = csr_phys(k);
-            cols_out[ph] = col;
+            cols_out[ph] = up ? cv : -2 - cv;
             vals_out[ph] = v;
-            mir_keys[mpos + rank] = ((uint64_t)row << A.col_bits) | (uint64_t)col;   // low bits = destination row
-            mir_vals[mpos + rank] = v;
+            if (mir) {
+                const int64_t m = mpos + __popcll(mm & below);
+                mir_keys[m] = ((uint64_t)row << A.col_bits) | (uint64_t)cv;   // low bits = destination row
+                mir_vals[m] = v;
+            }
         }
-        const int n = __popcll(mask);
-        opos += n;
-        mpos += n;
+        opos += __popcll(mu);
+        lpos += __popcll(ml);
+        mpos += __popcll(mm);
     }
     if (lane == 0) {
         const float dv = acc[62] + A.reg;  // slot (dd=0, rel=(2,2,2))
@@ -401,7 +414,8 @@ extern "C" size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h) {
     return tot;
 }
 
-extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, int32_t* indeg, void* stream) {
+extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, int32_t* crosscount, int32_t* samelow,
+                                   int32_t* indeg, void* stream) {
     AsmArgs A;
     int M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
     int cb = 1;
@@ -412,13 +426,14 @@ extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_
     const size_t lds = (size_t)(RC_ROWS * 4 + 2 * RC_ROWS * (h->depth - 1) * 125) * sizeof(int32_t);
     if (lds > 48 * 1024)
         NKSR_CHECK_HIP(hipFuncSetAttribute((const void*)k_row_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_row_count, dim3(nksr_blocks(A.M, RC_ROWS)), dim3(RC_ROWS * 64), lds, (hipStream_t)stream, A, rowcount, indeg);
+    hipLaunchKernelGGL(k_row_count, dim3(nksr_blocks(A.M, RC_ROWS)), dim3(RC_ROWS * 64), lds, (hipStream_t)stream, A, rowcount, crosscount, samelow, indeg);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
 
 extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, int nsets, float reg, int col_bits,
-                             void* workspace, const int32_t* rowptr, const int32_t* indeg, const int32_t* mir_off,
+                             void* workspace, const int32_t* rowptr, const int32_t* indeg, const int32_t* samelow,
+                             const int32_t* mir_off,
                              int32_t* cols_out, float* vals_out, float* diag_out, uint64_t* mir_keys, float* mir_vals,
                              float* b_out, void* stream) {
     AsmArgs A;
@@ -449,7 +464,7 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
         const int T = (h->depth - d) * 27;
         const int r0 = h->lv[d].offset, r1 = r0 + n;
         const dim3 grid(nksr_blocks(n, ASM_WAVES));
-#define ROWFILL(NQ) hipLaunchKernelGGL((k_row_fill<NQ>), grid, blk, lds, st, A, rowptr, indeg, mir_off, cols_out, vals_out, diag_out, \
+#define ROWFILL(NQ) hipLaunchKernelGGL((k_row_fill<NQ>), grid, blk, lds, st, A, rowptr, indeg, samelow, mir_off, cols_out, vals_out, diag_out, \
                                        mir_keys, mir_vals, b_out, r0, r1)
         if (T > 128) ROWFILL(3); else if (T > 64) ROWFILL(2); else ROWFILL(1);
         NKSR_CHECK_LAUNCH();

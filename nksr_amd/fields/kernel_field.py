@@ -133,19 +133,19 @@ class KernelField(BaseField):
             keep += [xs, rows, st, en, tgt, ks]
             nsets += 1
         # structure pass: own-upper counts + in-degrees -> exclusive scans -> final CSR row pointers
-        rowcount = torch.zeros(M + 1, dtype=torch.int32, device=dev)
-        indeg = torch.zeros(M + 1, dtype=torch.int32, device=dev)
+        counts = torch.zeros((4, M + 1), dtype=torch.int32, device=dev)
+        rowcount, crosscount, samelow, indeg = counts[0], counts[1], counts[2], counts[3]
         ws = torch.empty(int(_lib.lib.nksr_assemble_workspace_bytes(C.byref(self._hier))), dtype=torch.uint8, device=dev)
-        call('nksr_assemble_count', C.byref(self._hier), ptr(ws), ptr(rowcount), ptr(indeg), stream())
-        n_mir = int(rowcount.sum(dtype=torch.int64).item())
-        nnz = 2 * n_mir + M
+        call('nksr_assemble_count', C.byref(self._hier), ptr(ws), ptr(rowcount), ptr(crosscount), ptr(samelow), ptr(indeg), stream())
+        n_up, n_mir = [int(v) for v in counts[:2].sum(dim=1, dtype=torch.int64).tolist()]
+        nnz = 2 * n_up + M
         if nnz >= 2 ** 31 - 4096:
             raise RuntimeError('system too large for one chunk (M=%d, nnz=%d >= 2^31): pass chunk_size= to '
                                'reconstruct() (examples/recons_by_chunk.py)' % (M, nnz))
-        rowlen = indeg + rowcount + 1
+        rowlen = indeg + samelow + rowcount + 1     # [cross-level mirrors][same-level lower][own upper][diagonal]
         rowlen[M] = 0
         rowptr = ops.exclusive_sum_i32(rowlen)
-        mir_off = ops.exclusive_sum_i32(rowcount)
+        mir_off = ops.exclusive_sum_i32(crosscount)
         mirptr = ops.exclusive_sum_i32(indeg)
         col_bits = ops._bits(M)
         # physical (tile-interleaved, zero-padded) CSR arrays for the streaming SpMV
@@ -162,7 +162,7 @@ class KernelField(BaseField):
         mir_k = torch.empty(n_mir, dtype=torch.int64, device=dev)
         mir_v = torch.empty(n_mir, dtype=torch.float32, device=dev)
         call('nksr_assemble', C.byref(self._hier), sets, nsets, float(reg_weight), col_bits, ptr(ws), ptr(rowptr), ptr(indeg),
-             ptr(mir_off), ptr(cols), ptr(vals), ptr(diag), ptr(mir_k), ptr(mir_v), ptr(b), stream())
+             ptr(samelow), ptr(mir_off), ptr(cols), ptr(vals), ptr(diag), ptr(mir_k), ptr(mir_v), ptr(b), stream())
         del ws
         ks, vs = ops.sort_pairs(mir_k, mir_v.view(torch.int32), end_bit=col_bits)   # stable, destination-row bits only
         del mir_k, mir_v
