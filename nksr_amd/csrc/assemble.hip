@@ -188,22 +188,41 @@ __global__ void __launch_bounds__(RC_ROWS * 64) k_row_count(AsmArgs A, int32_t* 
             nf[r] = 0;
         }
     }
-    __syncthreads();
+    // same level (independent of the leaders: runs while they wait for their frame lookups): every slot of
+    // the 5^3 frame overlaps (|dI| <= 2).  Upper neighbours are stored as their column, lower ones as
+    // -2 - column (emitted by the row itself, bitwise equal to the transposed entry), the diagonal /
+    // absent slots as -1.
+    int cnt = 0, lower = 0, cross = 0;
+    const int nslots = live ? (L - d) * 125 : 0;
+    int32_t* cm = live ? A.colmap[d] + (int64_t)i * nslots : nullptr;
     if (live) {
-        const int nslots = (L - d) * 125;
-        int32_t* cm = A.colmap[d] + (int64_t)i * nslots;
-        int cnt = 0, lower = 0, cross = 0;
-        // same level: every slot of the 5^3 frame overlaps (|dI| <= 2).  Upper neighbours are stored as
-        // their column, lower ones as -2 - column (emitted by the row itself, bitwise equal to the
-        // transposed entry), the diagonal / absent slots as -1.
+        // the 5^3 frame through the 27-neighbour table: slot (dx,dy,dz), |d| <= 2, is neighbour (d - e) of
+        // neighbour e = clamp(d, -1, 1).  Two reads inside 108-byte table rows that Morton-adjacent matrix
+        // rows share, instead of a random hash probe per slot (141 M probes ~ 18 GB of sector traffic at
+        // 1M points); the hash is only consulted when the intermediate voxel does not exist.
+        const nksr_level_t& lv0 = h.lv[d];
+        const int nb_lane = (lane < 27) ? lv0.nbr[(int64_t)i * 27 + lane] : -1;
         for (int r = lane; r < 128; r += 64) {
-            int col = (r < 125) ? slot_column(h, d, ix, iy, iz, r) : -1;
+            int col = -1;
+            const int rr = r < 125 ? r : 124;
+            const int dx = rr / 25 - 2, dy = (rr / 5) % 5 - 2, dz = rr % 5 - 2;
+            const int ex = dx < -1 ? -1 : (dx > 1 ? 1 : dx), ey = dy < -1 ? -1 : (dy > 1 ? 1 : dy), ez = dz < -1 ? -1 : (dz > 1 ? 1 : dz);
+            const int n1 = __shfl(nb_lane, (ex + 1) * 9 + (ey + 1) * 3 + (ez + 1));
+            if (r < 125) {
+                int j;
+                if (n1 >= 0) j = lv0.nbr[(int64_t)n1 * 27 + (dx - ex + 1) * 9 + (dy - ey + 1) * 3 + (dz - ez + 1)];
+                else j = hash_find(lv0.hkeys, lv0.hvals, lv0.hcap, morton_biased(ix + dx, iy + dy, iz + dz, NKSR_BIAS0 >> d));
+                col = j < 0 ? -1 : lv0.offset + j;
+            }
             const bool lo = col >= 0 && col < row;
             lower += __popcll(__ballot(lo));
             if (col == row) col = -1;
             cnt += __popcll(__ballot(col > row));
             if (r < 125) cm[r] = lo ? -2 - col : col;
         }
+    }
+    __syncthreads();
+    if (live) {
         for (int dd = 1; d + dd < L; ++dd) {
             const int32_t* cf = colf + (lead[dd] * F + dd - 1) * 125;
             int32_t* nf = cntf + (lead[dd] * F + dd - 1) * 125;
