@@ -90,6 +90,10 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # backend "nccl" is RCCL on ROCm; NKSR_DIST_BACKEND=gloo lets two ranks share one GPU in tests
         dist.init_process_group(os.environ.get('NKSR_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
+        # create the communicator (RCCL ring / peer mappings) now, outside every timed region
+        warm = torch.zeros(1, device=dev if dist.get_backend() != 'gloo' else 'cpu')
+        dist.all_reduce(warm)
+        dist.all_gather([torch.zeros_like(warm) for _ in range(world)], warm)
 
     import nksr_amd
     from nksr_amd import solver, utils
