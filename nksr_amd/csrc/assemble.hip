@@ -406,7 +406,10 @@ static int fill_args(AsmArgs& A, const nksr_hier_t* h, const nksr_siteset_t* set
     if (nsets < 0 || nsets > 3) return nksr_set_error(NKSR_ERR_ARG, "at most 3 site sets");
     memset(&A, 0, sizeof(A));
     A.hier = *h;
-    for (int s = 0; s < nsets; ++s) A.sets[s] = sets[s];
+    for (int s = 0; s < nsets; ++s) {
+        if (!(sets[s].weight >= 0.f)) return nksr_set_error(NKSR_ERR_ARG, "site-set weights must be >= 0 (set %d: %g)", s, (double)sets[s].weight);
+        A.sets[s] = sets[s];
+    }
     A.nsets = nsets;
     A.M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
     A.col_bits = col_bits;
