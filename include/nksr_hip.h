@@ -159,32 +159,41 @@ size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h);
  * b = sum_s w_s R_s^T t_s. */
 int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, int nsets, float reg, int col_bits,
                   void* workspace, const int32_t* rowptr, const int32_t* indeg, const int32_t* samelow,
-                  const int32_t* mir_off, int32_t* cols_out, float* vals_out, float* diag_out, uint64_t* mir_keys,
-                  float* mir_vals, float* b_out, void* stream);
+                  const int32_t* mir_off, int col_format, int32_t* cols_out, float* vals_out, float* diag_out,
+                  uint64_t* mir_keys, float* mir_vals, float* b_out, void* stream);
 /* Mirrors stably sorted by destination row (low col_bits of the key) -> their CSR slots;
  * mirptr = exclusive scan of indeg. */
 int nksr_place_mirrors(const uint64_t* keys_sorted, const float* vals_sorted, int64_t n, int col_bits,
-                       const int32_t* rowptr, const int32_t* mirptr, int32_t* cols_out, float* vals_out, void* stream);
+                       const int32_t* rowptr, const int32_t* mirptr, int col_format, int32_t* cols_out, float* vals_out,
+                       void* stream);
 
 /* ---- PCG (the CG SpMV is the roofline kernel) -------------------- */
-/* nnz-chunked streaming CSR SpMV (csrc/pcg.hip).  cols/vals in the tile-interleaved physical layout
- * produced by nksr_assemble / nksr_place_mirrors: 256-entry tiles, logical entry m of a tile at
- * 4*(m%64) + m/64, zero-padded (valid column 0, value 0) to a multiple of 4096 entries.  The plan (row
- * of every 4096-entry chunk) lives in `workspace` (nksr_spmv_workspace_bytes) and must be built
+/* nnz-chunked streaming CSR SpMV (csrc/pcg.hip).  cols/vals live in a tile-interleaved physical layout
+ * chosen by col_format (the same value must be given to nksr_assemble / nksr_place_mirrors, which
+ * write it):
+ *   0: 256-entry tiles, logical entry m of a tile at 4*(m%64) + m/64, int32 columns, zero-padded (valid
+ *      column 0, value 0) to a multiple of 4096 entries;
+ *   1: 192-entry tiles, entry m at 3*(m%64) + m/64, padded to a multiple of 4608 entries; the SpMV reads
+ *      the columns as one 64-bit word per three entries (21 bits each, nksr_pack_cols21 converts the
+ *      int32 array written by the assembly): 6.67 instead of 8 bytes per entry, requires M <= 2^21.
+ * The plan (first row of every chunk) lives in `workspace` (nksr_spmv_workspace_bytes) and must be built
  * once per matrix with nksr_spmv_plan. */
 size_t nksr_spmv_workspace_bytes(int64_t nnz);
-int nksr_spmv_plan(const int32_t* rowptr, int32_t M, int64_t nnz, void* workspace, void* stream);
-int nksr_spmv_csr(const int32_t* rowptr, const int32_t* cols, const float* vals, int32_t M, int64_t nnz,
+int nksr_spmv_plan(const int32_t* rowptr, int32_t M, int64_t nnz, int col_format, void* workspace, void* stream);
+int nksr_spmv_csr(const int32_t* rowptr, const void* cols, const float* vals, int32_t M, int64_t nnz, int col_format,
                   const float* x, float* y, void* workspace, void* stream);
+/* int32 columns in the col_format-1 layout (n_padded entries, a multiple of 192) -> packed 64-bit words
+ * (n_padded / 3 of them) */
+int nksr_pack_cols21(const int32_t* cols32, int64_t n_padded, uint64_t* packed_out, void* stream);
 /* Experimental kernel variants for tools/spmv_probe.py (0 = default). */
 int nksr_spmv_set_variant(int v);
 /* Scratch bytes required by nksr_pcg_solve. */
 size_t nksr_pcg_workspace_bytes(int32_t M, int64_t nnz);
 /* Jacobi-PCG, x0 = 0.  info_out (host, may be NULL): [0]=iterations [1]=relative residual.
  * Checks convergence every `check_every` iterations (one stream sync each) -- syncs. */
-int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t M,
-                   int64_t nnz, const float* b, float* x, float tol, int max_iter, int check_every, void* workspace,
-                   double* info_out, void* stream);
+int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, const float* diag, int32_t M,
+                   int64_t nnz, int col_format, const float* b, float* x, float tol, int max_iter, int check_every,
+                   void* workspace, double* info_out, void* stream);
 /* Live profiling of the SpMV launches inside nksr_pcg_solve (HIP events on the solve's stream).
  * Returns and resets the accumulated milliseconds / launch count, then sets the enable flag. */
 int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out);

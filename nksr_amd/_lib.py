@@ -78,12 +78,13 @@ _PROTOS = {
     'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _vp, _vp, _vp],
     'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, _vp, _vp, _vp],
     'nksr_assemble_count': [_P(HierT), _vp, _vp, _vp, _vp, _vp, _vp],
-    'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    'nksr_place_mirrors': [_vp, _vp, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp],
+    'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'nksr_place_mirrors': [_vp, _vp, _i64, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp],
     'nksr_spmv_set_variant': [C.c_int],
-    'nksr_spmv_plan': [_vp, _i32, _i64, _vp, _vp],
-    'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp],
-    'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
+    'nksr_spmv_plan': [_vp, _i32, _i64, C.c_int, _vp, _vp],
+    'nksr_pack_cols21': [_vp, _i64, _vp, _vp],
+    'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _vp, _vp],
+    'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
     'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
     'nksr_nearest_index': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, _vp, _vp],

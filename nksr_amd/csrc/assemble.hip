@@ -35,6 +35,7 @@ struct AsmArgs {
     float* bvec[NKSR_MAX_DEPTH];     // [n_d, 27]
     int32_t* nsites[NKSR_MAX_DEPTH]; // [n_d]
     int32_t* colmap[NKSR_MAX_DEPTH]; // [n_d, (L-d) 125] column of every structural upper slot or -1
+    int col_format;                  // physical layout of cols_out / vals_out (csr_phys)
 };
 
 __device__ __forceinline__ int row_level(const nksr_hier_t& h, int row) {
@@ -50,10 +51,15 @@ __device__ __forceinline__ int rel_slot(int cx, int cy, int cz, int ix, int iy, 
     return dd * 125 + (rx * 5 + ry) * 5 + rz;
 }
 
-// physical CSR layout (see csrc/pcg.hip): 256-entry tiles, logical entry m of a tile at 4*(m%64) + m/64
-__device__ __forceinline__ int64_t csr_phys(int64_t k) {
-    const int64_t m = k & 255;
-    return (k & ~(int64_t)255) + 4 * (m & 63) + (m >> 6);
+// physical CSR layout (see csrc/pcg.hip): tiles of 64 EPL entries, logical entry m of a tile at
+// EPL (m % 64) + m / 64;  EPL = 4 (col_format 0, 256-entry tiles) or 3 (col_format 1, 192-entry tiles)
+__device__ __forceinline__ int64_t csr_phys(int64_t k, int fmt) {
+    if (fmt == 0) {
+        const int64_t m = k & 255;
+        return (k & ~(int64_t)255) + 4 * (m & 63) + (m >> 6);
+    }
+    const int64_t t = k / 192, m = k - t * 192;
+    return t * 192 + 3 * (m & 63) + (m >> 6);
 }
 
 // ---- phase 1: one wavefront per (level, cell) on the fp32 matrix cores ------------------------------
@@ -364,7 +370,7 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const in
         if (up | low) {
             const float v = acc[t];
             const int64_t k = up ? opos + __popcll(mu & below) : lpos + __popcll(ml & below);
-            const int64_t ph = csr_phys(k);
+            const int64_t ph = csr_phys(k, A.col_format);
             cols_out[ph] = up ? cv : -2 - cv;
             vals_out[ph] = v;
             if (mir) {
@@ -379,7 +385,7 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const in
     }
     if (lane == 0) {
         const float dv = acc[62] + A.reg;  // slot (dd=0, rel=(2,2,2))
-        const int64_t ph = csr_phys(opos);
+        const int64_t ph = csr_phys(opos, A.col_format);
         cols_out[ph] = row;
         vals_out[ph] = dv;
         diag_out[row] = dv;
@@ -389,13 +395,13 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const in
 // mirrored entries, stably sorted by destination row (sources ascending): final CSR slot
 __global__ void k_place_mirrors(const uint64_t* __restrict__ keys, const float* __restrict__ vals, int64_t n, int col_bits,
                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ mirptr,
-                                int32_t* __restrict__ cols_out, float* __restrict__ vals_out) {
+                                int32_t* __restrict__ cols_out, float* __restrict__ vals_out, int fmt) {
     int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n) return;
     const uint64_t key = keys[m];
     const int r = (int)(key & (((uint64_t)1 << col_bits) - 1));
     const int src = (int)(key >> col_bits);
-    const int64_t ph = csr_phys((int64_t)rowptr[r] + (m - (int64_t)mirptr[r]));
+    const int64_t ph = csr_phys((int64_t)rowptr[r] + (m - (int64_t)mirptr[r]), fmt);
     cols_out[ph] = src;
     vals_out[ph] = vals[m];
 }
@@ -455,12 +461,14 @@ extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_
 
 extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, int nsets, float reg, int col_bits,
                              void* workspace, const int32_t* rowptr, const int32_t* indeg, const int32_t* samelow,
-                             const int32_t* mir_off,
+                             const int32_t* mir_off, int col_format,
                              int32_t* cols_out, float* vals_out, float* diag_out, uint64_t* mir_keys, float* mir_vals,
                              float* b_out, void* stream) {
     AsmArgs A;
     int rc = fill_args(A, h, sets, nsets, reg, col_bits, workspace);
     if (rc) return rc;
+    if (col_format != 0 && col_format != 1) return nksr_set_error(NKSR_ERR_ARG, "col_format must be 0 or 1");
+    A.col_format = col_format;
     if (A.M <= 0) return NKSR_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 blk(ASM_WAVES * 64);
@@ -495,10 +503,12 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
 }
 
 extern "C" int nksr_place_mirrors(const uint64_t* keys_sorted, const float* vals_sorted, int64_t n, int col_bits,
-                                  const int32_t* rowptr, const int32_t* mirptr, int32_t* cols_out, float* vals_out, void* stream) {
+                                  const int32_t* rowptr, const int32_t* mirptr, int col_format, int32_t* cols_out, float* vals_out,
+                                  void* stream) {
     if (n <= 0) return NKSR_OK;
+    if (col_format != 0 && col_format != 1) return nksr_set_error(NKSR_ERR_ARG, "col_format must be 0 or 1");
     hipLaunchKernelGGL(k_place_mirrors, dim3(nksr_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, keys_sorted, vals_sorted, n,
-                       col_bits, rowptr, mirptr, cols_out, vals_out);
+                       col_bits, rowptr, mirptr, cols_out, vals_out, col_format);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }

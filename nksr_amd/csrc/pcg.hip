@@ -87,25 +87,38 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
 }
 
 // ---- SpMV ---------------------------------------------------------------------------------------
-// nnz-balanced streaming CSR SpMV.  The (col,val) stream is cut into chunks of SPMV_CHUNK
-// entries regardless of row boundaries (rows range from ~30 to several thousand entries: a
-// coarse voxel couples to every fine voxel under its support), so every workgroup moves the same
-// number of bytes with perfectly coalesced 16-byte loads: 16 entries = 128 B in flight per lane,
-// 32 KiB per workgroup, ~8 workgroups per CU.  Products go to LDS; each wavefront then reduces
-// whole row segments from LDS (butterfly), writing y for rows that START in the chunk and one
-// carry per chunk for the row that started earlier.  A tiny fix-up kernel adds the carries in
-// chunk order, so the result is deterministic.  x gathers hit L2 (Morton-ordered unknowns).
-// cols/vals must be readable (cols valid, vals zero) up to the next multiple of 4 past nnz.
-#define SPMV_CHUNK 4096
-#define SPMV_QUADS (SPMV_CHUNK / (PCG_BLOCK * 4))
+// nnz-balanced streaming CSR SpMV.  The (col,val) stream is cut into chunks of CHUNK entries
+// regardless of row boundaries (rows range from ~30 to several thousand entries: a coarse voxel
+// couples to every fine voxel under its support), so every workgroup moves the same number of
+// bytes with perfectly coalesced wide loads, ~32 KiB in flight per workgroup, ~8 workgroups per CU.
+// Products go to LDS; each wavefront then reduces whole row segments from LDS (butterfly), writing y
+// for rows that START in the chunk and one carry per chunk for the row that started earlier.  A tiny
+// fix-up kernel adds the carries in chunk order, so the result is deterministic.  x gathers hit L2
+// (Morton-ordered unknowns).
+//
+// Two physical layouts (nksr_hip.h, col_format), both interleaved so that component j of the load of
+// lane l is logical entry 64 j + l of its tile -- every gather instruction covers 64 CONSECUTIVE
+// entries of the stream:
+//   format 0: EPL = 4 entries per lane, 256-entry tiles, int32 columns (16 + 16 bytes per lane)
+//   format 1: EPL = 3 entries per lane, 192-entry tiles, three 21-bit columns packed in one 64-bit
+//             word (8 + 12 bytes per lane): 6.67 instead of 8 bytes per entry, M <= 2^21.
+// Storage is zero-padded (column 0, value 0) to a multiple of the chunk size: no bounds checks.
+template <int EPL> struct SpmvFmt {
+    static constexpr int TILE = 64 * EPL;
+    static constexpr int QUAD = PCG_BLOCK * EPL;          // entries per workgroup-wide load
+    static constexpr int QUADS = EPL == 4 ? 4 : 6;
+    static constexpr int CHUNK = QUADS * QUAD;            // 4096 / 4608
+};
+#define SPMV_CHUNK_MIN 4096
+static int spmv_chunk(int fmt) { return fmt == 1 ? SpmvFmt<3>::CHUNK : SpmvFmt<4>::CHUNK; }
 
-__global__ void k_spmv_plan(const int32_t* __restrict__ rowptr, int M, int64_t nnz, int nchunks,
+__global__ void k_spmv_plan(const int32_t* __restrict__ rowptr, int M, int64_t nnz, int nchunks, int chunk,
                             int32_t* __restrict__ chunk_row) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nchunks) return;
     if (b == nchunks) { chunk_row[b] = M; return; }
     // row containing entry b*CHUNK: last r with rowptr[r] <= k
-    const int64_t k = (int64_t)b * SPMV_CHUNK;
+    const int64_t k = (int64_t)b * chunk;
     int lo = 0, hi = M;  // invariant: rowptr[lo] <= k < rowptr[hi]
     while (hi - lo > 1) {
         int mid = (lo + hi) >> 1;
@@ -114,24 +127,23 @@ __global__ void k_spmv_plan(const int32_t* __restrict__ rowptr, int M, int64_t n
     chunk_row[b] = lo;
 }
 
-template <int VARIANT>
-__global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+struct f32x3_u { float x, y, z; } __attribute__((packed, aligned(4)));
+
+template <int EPL, int VARIANT>
+__global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ rowptr, const void* __restrict__ cols_,
                                                     const float* __restrict__ vals, int M, int nnz, int nchunks,
                                                     const int32_t* __restrict__ chunk_row, const float* __restrict__ x,
                                                     float* __restrict__ y, float* __restrict__ carry,
                                                     int32_t* __restrict__ carry_row, const int* __restrict__ done) {
     if (done && *done) return;
-    __shared__ __attribute__((aligned(16))) float prod[SPMV_CHUNK];
+    typedef SpmvFmt<EPL> F;
+    __shared__ __attribute__((aligned(16))) float prod[F::CHUNK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // chunks are dealt round-robin to the workgroups (a contiguous range per workgroup measured 8 %
     // slower: the concurrently active chunks then crowd the same HBM channels)
     for (int b = blockIdx.x; b < nchunks; b += gridDim.x) {
-        const int base = b * SPMV_CHUNK;
-        const int end = (base + SPMV_CHUNK < nnz) ? base + SPMV_CHUNK : nnz;
-        // cols/vals are stored in 256-entry interleaved tiles (see k_coo_cols): component j of the
-        // 16-byte load of lane l is logical entry 64 j + l of the tile -> every gather instruction
-        // below covers 64 consecutive entries of the stream.  Storage is zero-padded to a multiple
-        // of SPMV_CHUNK, so no bounds checks are needed.
+        const int base = b * F::CHUNK;
+        const int end = (base + F::CHUNK < nnz) ? base + F::CHUNK : nnz;
         // row pointers of the rows this wavefront will reduce (lane j: row r_first + wave + 4 j), fetched
         // now so that their latency hides behind the stream loads instead of stalling the row loop
         const int r_first = chunk_row[b], r_lim = chunk_row[b + 1];      // r_lim: row holding entry `end` (or M)
@@ -140,27 +152,29 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ 
             const int r = r_first + wave + (PCG_BLOCK / 64) * lane;
             if (r <= r_lim && r < M) { pre0 = rowptr[r]; pre1 = rowptr[r + 1]; }
         }
-        int4 c[SPMV_QUADS];
-        float4 v[SPMV_QUADS];
-        {
+        int c[F::QUADS][EPL];
+        float v[F::QUADS][EPL];
 #pragma unroll
-        for (int q = 0; q < SPMV_QUADS; ++q) {
-            const int k = base + q * (PCG_BLOCK * 4) + tid * 4;
-            c[q] = *reinterpret_cast<const int4*>(cols + k);
-            v[q] = *reinterpret_cast<const float4*>(vals + k);
-        }
-#pragma unroll
-        for (int q = 0; q < SPMV_QUADS; ++q) {
-            float* pt = prod + q * (PCG_BLOCK * 4) + wave * 256 + lane;
-            if (VARIANT == 1) {   // probe only: no gather (streaming ceiling)
-                pt[0] = v[q].x * (float)c[q].x; pt[64] = v[q].y * (float)c[q].y; pt[128] = v[q].z * (float)c[q].z; pt[192] = v[q].w * (float)c[q].w;
+        for (int q = 0; q < F::QUADS; ++q) {
+            const int64_t g = (int64_t)(base + q * F::QUAD) / EPL + tid;       // lane slot (EPL entries)
+            if (EPL == 4) {
+                const int4 ci = reinterpret_cast<const int4*>(cols_)[g];
+                const float4 vi = reinterpret_cast<const float4*>(vals)[g];
+                c[q][0] = ci.x; c[q][1] = ci.y; c[q][2] = ci.z; c[q][EPL - 1] = ci.w;
+                v[q][0] = vi.x; v[q][1] = vi.y; v[q][2] = vi.z; v[q][EPL - 1] = vi.w;
             } else {
-                pt[0] = v[q].x * x[c[q].x];
-                pt[64] = v[q].y * x[c[q].y];
-                pt[128] = v[q].z * x[c[q].z];
-                pt[192] = v[q].w * x[c[q].w];
+                const unsigned long long pk = reinterpret_cast<const unsigned long long*>(cols_)[g];
+                const f32x3_u vi = reinterpret_cast<const f32x3_u*>(vals)[g];
+                c[q][0] = (int)(pk & 0x1FFFFFull); c[q][1] = (int)((pk >> 21) & 0x1FFFFFull); c[q][2] = (int)((pk >> 42) & 0x1FFFFFull);
+                v[q][0] = vi.x; v[q][1] = vi.y; v[q][2] = vi.z;
             }
         }
+#pragma unroll
+        for (int q = 0; q < F::QUADS; ++q) {
+            float* pt = prod + q * F::QUAD + wave * F::TILE + lane;
+#pragma unroll
+            for (int j = 0; j < EPL; ++j)
+                pt[64 * j] = v[q][j] * (VARIANT == 1 ? (float)c[q][j] : x[c[q][j]]);   // VARIANT 1: probe without the gather
         }
         __syncthreads();
         if (tid == 0 && pre0 >= base) carry_row[b] = -1;   // no row continues into this chunk
@@ -182,6 +196,14 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ 
         }
         __syncthreads();
     }
+}
+
+// three int32 columns (< 2^21) of one lane slot -> one 64-bit word (format 1)
+__global__ void k_pack_cols21(const int32_t* __restrict__ cols32, int64_t nslots, unsigned long long* __restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nslots) return;
+    const unsigned long long a = (unsigned)cols32[3 * g], b = (unsigned)cols32[3 * g + 1], c = (unsigned)cols32[3 * g + 2];
+    out[g] = a | (b << 21) | (c << 42);
 }
 
 // adds the per-chunk carries to y in chunk order (one thread per run of equal rows)
@@ -301,16 +323,16 @@ struct SpmvPlan {
     int32_t* carry_row;   // [nchunks]
 };
 
-static int spmv_nchunks(int64_t nnz) { return (int)((nnz + SPMV_CHUNK - 1) / SPMV_CHUNK); }
+static int spmv_nchunks(int64_t nnz, int fmt) { return (int)((nnz + spmv_chunk(fmt) - 1) / spmv_chunk(fmt)); }
 
 extern "C" size_t nksr_spmv_workspace_bytes(int64_t nnz) {
-    size_t nc = (size_t)spmv_nchunks(nnz);
+    size_t nc = (size_t)((nnz + SPMV_CHUNK_MIN - 1) / SPMV_CHUNK_MIN);   // enough for either format
     return align_up((nc + 1) * sizeof(int32_t), 256) + 2 * align_up(nc * sizeof(float), 256) + 256;
 }
 
-static SpmvPlan carve_spmv(void* ws, int64_t nnz) {
+static SpmvPlan carve_spmv(void* ws, int64_t nnz, int fmt) {
     SpmvPlan p;
-    p.nchunks = spmv_nchunks(nnz);
+    p.nchunks = spmv_nchunks(nnz, fmt);
     char* c = (char*)ws;
     p.chunk_row = (int32_t*)c; c += align_up(((size_t)p.nchunks + 1) * sizeof(int32_t), 256);
     p.carry = (float*)c; c += align_up((size_t)p.nchunks * sizeof(float), 256);
@@ -322,34 +344,54 @@ static int spmv_grid(int nchunks) {
     return nchunks < 1 ? 1 : (nchunks > PCG_MAX_BLOCKS ? PCG_MAX_BLOCKS : nchunks);
 }
 
-extern "C" int nksr_spmv_plan(const int32_t* rowptr, int32_t M, int64_t nnz, void* workspace, void* stream) {
+static int check_format(int col_format, int M) {
+    if (col_format != 0 && col_format != 1) return nksr_set_error(NKSR_ERR_ARG, "col_format must be 0 or 1");
+    if (col_format == 1 && M > (1 << 21)) return nksr_set_error(NKSR_ERR_CAPACITY, "col_format 1 packs 21-bit columns: M = %d > 2^21", M);
+    return NKSR_OK;
+}
+
+extern "C" int nksr_spmv_plan(const int32_t* rowptr, int32_t M, int64_t nnz, int col_format, void* workspace, void* stream) {
     if (M <= 0 || nnz <= 0) return NKSR_OK;
-    if (nnz >= ((int64_t)1 << 31)) return nksr_set_error(NKSR_ERR_CAPACITY, "nnz exceeds int32");
-    SpmvPlan p = carve_spmv(workspace, nnz);
+    if (nnz >= ((int64_t)1 << 31) - SpmvFmt<3>::CHUNK) return nksr_set_error(NKSR_ERR_CAPACITY, "nnz exceeds int32");
+    if (int rc = check_format(col_format, M)) return rc;
+    SpmvPlan p = carve_spmv(workspace, nnz, col_format);
     hipLaunchKernelGGL(k_spmv_plan, dim3(nksr_blocks(p.nchunks + 1, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, M, nnz,
-                       p.nchunks, p.chunk_row);
+                       p.nchunks, spmv_chunk(col_format), p.chunk_row);
     NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+extern "C" int nksr_pack_cols21(const int32_t* cols32, int64_t n_padded, uint64_t* packed_out, void* stream) {
+    if (n_padded % SpmvFmt<3>::TILE) return nksr_set_error(NKSR_ERR_ARG, "n_padded must be a multiple of %d", SpmvFmt<3>::TILE);
+    const int64_t nslots = n_padded / 3;
+    if (nslots > 0) {
+        hipLaunchKernelGGL(k_pack_cols21, dim3(nksr_blocks(nslots, 256)), dim3(256), 0, (hipStream_t)stream, cols32, nslots,
+                           (unsigned long long*)packed_out);
+        NKSR_CHECK_LAUNCH();
+    }
     return NKSR_OK;
 }
 
 static int g_spmv_variant = 0;
 extern "C" int nksr_spmv_set_variant(int v) { g_spmv_variant = v; return NKSR_OK; }
 
-static int launch_spmv(const int32_t* rowptr, const int32_t* cols, const float* vals, int M, int64_t nnz, const SpmvPlan& p,
+static int launch_spmv(const int32_t* rowptr, const void* cols, const float* vals, int M, int64_t nnz, int fmt, const SpmvPlan& p,
                        const float* x, float* y, const int* done, hipStream_t st) {
-#define SPMV_LAUNCH(V) hipLaunchKernelGGL((k_spmv<V>), dim3(spmv_grid(p.nchunks)), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, (int)nnz, \
+#define SPMV_LAUNCH(E, V) hipLaunchKernelGGL((k_spmv<E, V>), dim3(spmv_grid(p.nchunks)), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, (int)nnz, \
                        p.nchunks, p.chunk_row, x, y, p.carry, p.carry_row, done)
-    if (g_spmv_variant == 1) SPMV_LAUNCH(1); else SPMV_LAUNCH(0);
+    if (fmt == 1) { if (g_spmv_variant == 1) SPMV_LAUNCH(3, 1); else SPMV_LAUNCH(3, 0); }
+    else { if (g_spmv_variant == 1) SPMV_LAUNCH(4, 1); else SPMV_LAUNCH(4, 0); }
     hipLaunchKernelGGL(k_spmv_fixup, dim3(nksr_blocks(p.nchunks, 256)), dim3(256), 0, st, p.nchunks, p.carry, p.carry_row, y, done);
     return 0;
 }
 
-extern "C" int nksr_spmv_csr(const int32_t* rowptr, const int32_t* cols, const float* vals, int32_t M, int64_t nnz,
+extern "C" int nksr_spmv_csr(const int32_t* rowptr, const void* cols, const float* vals, int32_t M, int64_t nnz, int col_format,
                              const float* x, float* y, void* workspace, void* stream) {
     if (M <= 0) return NKSR_OK;
     if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL (run nksr_spmv_plan first)");
-    SpmvPlan p = carve_spmv(workspace, nnz);
-    launch_spmv(rowptr, cols, vals, M, nnz, p, x, y, nullptr, (hipStream_t)stream);
+    if (int rc = check_format(col_format, M)) return rc;
+    SpmvPlan p = carve_spmv(workspace, nnz, col_format);
+    launch_spmv(rowptr, cols, vals, M, nnz, col_format, p, x, y, nullptr, (hipStream_t)stream);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -370,8 +412,8 @@ extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_ou
     return NKSR_OK;
 }
 
-extern "C" int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t M,
-                              int64_t nnz, const float* b, float* x, float tol, int max_iter, int check_every,
+extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, const float* diag, int32_t M,
+                              int64_t nnz, int col_format, const float* b, float* x, float tol, int max_iter, int check_every,
                               void* workspace, double* info_out, void* stream) {
     if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
     if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
@@ -379,9 +421,9 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const 
     hipStream_t st = (hipStream_t)stream;
     PcgWork w = carve(workspace, M);
     void* spmv_ws = (char*)workspace + pcg_vector_bytes(M);
-    int rc = nksr_spmv_plan(rowptr, M, nnz, spmv_ws, stream);
+    int rc = nksr_spmv_plan(rowptr, M, nnz, col_format, spmv_ws, stream);
     if (rc) return rc;
-    SpmvPlan plan = carve_spmv(spmv_ws, nnz);
+    SpmvPlan plan = carve_spmv(spmv_ws, nnz, col_format);
     const int nbv = nksr_blocks(M, PCG_BLOCK) > PCG_MAX_BLOCKS ? PCG_MAX_BLOCKS : nksr_blocks(M, PCG_BLOCK);
     hipLaunchKernelGGL(k_pcg_init, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, b, diag, w, x);
     hipLaunchKernelGGL(k_pcg_init_finish, dim3(1), dim3(PCG_BLOCK), 0, st, w, nbv);
@@ -401,7 +443,7 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const int32_t* cols, const 
         for (int c = 0; c < chunk; ++c) {
             const int parity = (launched + c) & 1;
             if (prof) hipEventRecord(g_prof_events[2 * c], st);
-            launch_spmv(rowptr, cols, vals, M, nnz, plan, w.p, w.y, &w.sc->done, st);
+            launch_spmv(rowptr, cols, vals, M, nnz, col_format, plan, w.p, w.y, &w.sc->done, st);
             if (prof) hipEventRecord(g_prof_events[2 * c + 1], st);
             hipLaunchKernelGGL(k_pcg_dot, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w);
             hipLaunchKernelGGL(k_pcg_update, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, diag, w, x, nbv, parity);

@@ -148,13 +148,16 @@ class KernelField(BaseField):
         mir_off = ops.exclusive_sum_i32(crosscount)
         mirptr = ops.exclusive_sum_i32(indeg)
         col_bits = ops._bits(M)
-        # physical (tile-interleaved, zero-padded) CSR arrays for the streaming SpMV
-        npad = (nnz + 4095) // 4096 * 4096
+        # physical (tile-interleaved, zero-padded) CSR arrays for the streaming SpMV: packed 21-bit columns
+        # (6.67 bytes per entry) whenever the unknowns fit, int32 columns otherwise (include/nksr_hip.h)
+        fmt = 1 if M <= (1 << 21) and int(self.solver_config.get('col_format', 1)) == 1 else 0
+        chunk, tile = (4608, 192) if fmt else (4096, 256)
+        npad = (nnz + chunk - 1) // chunk * chunk
         cols = torch.empty(npad, dtype=torch.int32, device=dev)
         vals = torch.empty(npad, dtype=torch.float32, device=dev)
-        # only the pad must be zero (valid column 0, value 0); the last 256-entry tile is interleaved,
-        # so its unwritten slots are scattered through the whole tile: clear it from its start
-        tail = nnz & ~255
+        # only the pad must be zero (valid column 0, value 0); the last tile is interleaved, so its
+        # unwritten slots are scattered through the whole tile: clear it from its start
+        tail = nnz // tile * tile
         cols[tail:].zero_()
         vals[tail:].zero_()
         diag = torch.empty(M, dtype=torch.float32, device=dev)
@@ -162,13 +165,17 @@ class KernelField(BaseField):
         mir_k = torch.empty(n_mir, dtype=torch.int64, device=dev)
         mir_v = torch.empty(n_mir, dtype=torch.float32, device=dev)
         call('nksr_assemble', C.byref(self._hier), sets, nsets, float(reg_weight), col_bits, ptr(ws), ptr(rowptr), ptr(indeg),
-             ptr(samelow), ptr(mir_off), ptr(cols), ptr(vals), ptr(diag), ptr(mir_k), ptr(mir_v), ptr(b), stream())
+             ptr(samelow), ptr(mir_off), fmt, ptr(cols), ptr(vals), ptr(diag), ptr(mir_k), ptr(mir_v), ptr(b), stream())
         del ws
         ks, vs = ops.sort_pairs(mir_k, mir_v.view(torch.int32), end_bit=col_bits)   # stable, destination-row bits only
         del mir_k, mir_v
-        call('nksr_place_mirrors', ptr(ks), ptr(vs.view(torch.float32)), n_mir, col_bits, ptr(rowptr), ptr(mirptr), ptr(cols),
+        call('nksr_place_mirrors', ptr(ks), ptr(vs.view(torch.float32)), n_mir, col_bits, ptr(rowptr), ptr(mirptr), fmt, ptr(cols),
              ptr(vals), stream())
         del ks, vs
+        if fmt:
+            packed = torch.empty(npad // 3, dtype=torch.int64, device=dev)
+            call('nksr_pack_cols21', ptr(cols), npad, ptr(packed), stream())
+            cols = packed
         self.nnz = nnz
         del keep
         return rowptr, cols, vals, diag, b

@@ -8,14 +8,21 @@ import torch
 from ._lib import call, lib, ptr, stream
 
 
+def col_format(cols):
+    """Physical layout of a matrix from KernelField.assemble (include/nksr_hip.h, col_format): int32 columns in
+    256-entry tiles (0) or three 21-bit columns per int64 word in 192-entry tiles (1)."""
+    return 1 if cols.dtype == torch.int64 else 0
+
+
 def spmv(rowptr, cols, vals, x):
     """y = A x.  ``cols`` / ``vals`` must come from KernelField.assemble (padded storage)."""
     M = rowptr.numel() - 1
     nnz = int(rowptr[M].item())
+    fmt = col_format(cols)
     y = torch.empty(M, dtype=torch.float32, device=x.device)
     ws = torch.empty(int(lib.nksr_spmv_workspace_bytes(nnz)), dtype=torch.uint8, device=x.device)
-    call('nksr_spmv_plan', ptr(rowptr), M, nnz, ptr(ws), stream())
-    call('nksr_spmv_csr', ptr(rowptr), ptr(cols), ptr(vals), M, nnz, ptr(x), ptr(y), ptr(ws), stream())
+    call('nksr_spmv_plan', ptr(rowptr), M, nnz, fmt, ptr(ws), stream())
+    call('nksr_spmv_csr', ptr(rowptr), ptr(cols), ptr(vals), M, nnz, fmt, ptr(x), ptr(y), ptr(ws), stream())
     return y
 
 
@@ -28,7 +35,7 @@ def pcg_solve(rowptr, cols, vals, diag, b, tol=1e-5, max_iter=2000, check_every=
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
     info = (C.c_double * 2)()
-    call('nksr_pcg_solve', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), M, nnz, ptr(b), ptr(x), float(tol), int(max_iter),
+    call('nksr_pcg_solve', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), M, nnz, col_format(cols), ptr(b), ptr(x), float(tol), int(max_iter),
          int(check_every), ptr(workspace), info, stream())
     return x, int(info[0]), float(info[1])
 
@@ -46,6 +53,12 @@ def csr_logical(rowptr, cols, vals):
     Test / export helper -- not on the hot path."""
     nnz = int(rowptr[-1].item())
     k = torch.arange(nnz, device=cols.device)
-    m = k & 255
-    phys = (k & ~255) + 4 * (m & 63) + (m >> 6)
-    return cols[phys], vals[phys]
+    if col_format(cols) == 0:
+        m = k & 255
+        phys = (k & ~255) + 4 * (m & 63) + (m >> 6)
+        return cols[phys], vals[phys]
+    t, m = k // 192, k % 192
+    phys = t * 192 + 3 * (m & 63) + (m >> 6)
+    word = cols[phys // 3]
+    c = (word >> (21 * (phys % 3))) & 0x1FFFFF
+    return c.to(torch.int32), vals[phys]

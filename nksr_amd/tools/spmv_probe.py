@@ -23,18 +23,19 @@ def main():
     x = torch.randn(M, device=dev)
     y = torch.empty(M, device=dev)
     ws = torch.empty(int(lib.nksr_spmv_workspace_bytes(nnz)), dtype=torch.uint8, device=dev)
-    call('nksr_spmv_plan', ptr(rowptr), M, nnz, ptr(ws), stream())
-    print('M=%d nnz=%d nnz/row=%.1f bytes=%.3f GB' % (M, nnz, nnz / M, B / 1e9))
+    fmt = solver.col_format(cols)
+    call('nksr_spmv_plan', ptr(rowptr), M, nnz, fmt, ptr(ws), stream())
+    print('M=%d nnz=%d nnz/row=%.1f bytes=%.3f GB col_format=%d' % (M, nnz, nnz / M, B / 1e9, fmt))
     for v in variants:
         call('nksr_spmv_set_variant', v)
         for _ in range(3):
-            call('nksr_spmv_csr', ptr(rowptr), ptr(cols), ptr(vals), M, nnz, ptr(x), ptr(y), ptr(ws), stream())
+            call('nksr_spmv_csr', ptr(rowptr), ptr(cols), ptr(vals), M, nnz, fmt, ptr(x), ptr(y), ptr(ws), stream())
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20
         e0.record()
         for _ in range(reps):
-            call('nksr_spmv_csr', ptr(rowptr), ptr(cols), ptr(vals), M, nnz, ptr(x), ptr(y), ptr(ws), stream())
+            call('nksr_spmv_csr', ptr(rowptr), ptr(cols), ptr(vals), M, nnz, fmt, ptr(x), ptr(y), ptr(ws), stream())
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
