@@ -6,9 +6,8 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
-from common import warning_on_low_memory
+import common  # noqa: F401  (puts the repository on sys.path)
 import nksr
 from nksr_amd import configs, utils
 from nksr_amd.density import scale_for_detail_level

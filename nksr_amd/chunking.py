@@ -22,7 +22,6 @@ import math
 import torch
 
 from . import dist as D
-from . import ops
 from .fields.base_field import BaseField, EvaluationResult
 from .fields.kernel_field import KernelField
 from .fields.mask_fields import LayerField, NeuralField

@@ -7,7 +7,6 @@ Reference interface (call sites): ``LayerField(dec_svh, adaptive_depth)`` models
 """
 import torch
 
-from .. import _lib
 from .base_field import BaseField
 
 

@@ -2,7 +2,6 @@
 hash).  PyTorch supplies device memory and the stream only."""
 import torch
 
-from . import _lib
 from ._lib import call, ptr, stream, with_tmp
 
 

@@ -1,4 +1,8 @@
-import time, cProfile, pstats, torch, numpy as np, sys
+import cProfile
+import pstats
+import time
+
+import torch
 
 import nksr_amd
 from nksr_amd import utils

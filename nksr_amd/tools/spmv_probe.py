@@ -1,7 +1,6 @@
 """SpMV micro-benchmark on the matrix of the bench workload: times kernel variants with HIP
 events (torch events on the launch stream).  python -m nksr_amd.tools.spmv_probe [points]"""
 import sys
-import time
 
 import torch
 

@@ -1,6 +1,5 @@
 """Size-independent properties at BASELINE.json's full single-GPU size (configs[2]: 1 000 000 points,
 detail_level=1.0): the oracle cannot run at this size, the invariants of SURVEY.md section 8c(3) can."""
-import numpy as np
 import pytest
 import torch
 
