@@ -63,3 +63,35 @@ def test_api_surface():
     sig = inspect.signature(fields.BaseField.extract_dual_mesh)
     for kw in ('mise_iter', 'grid_upsample', 'max_points'):
         assert kw in sig.parameters
+
+
+def test_csr_physical_layouts_roundtrip_on_cpu():
+    """include/nksr_hip.h col_format 0 / 1: the host-side decoder (solver.csr_logical) inverts the documented
+    tile interleave and the 21-bit column packing."""
+    import numpy as np
+    import torch
+    from nksr_amd import solver
+    rng = np.random.default_rng(0)
+    nnz = 5000
+    cols = rng.integers(0, 1 << 21, nnz).astype(np.int64)
+    vals = rng.standard_normal(nnz).astype(np.float32)
+    rowptr = torch.tensor([0, nnz], dtype=torch.int32)
+    k = np.arange(nnz)
+    # format 0: 256-entry tiles, entry m of a tile at 4 (m % 64) + m / 64, int32 columns
+    m = k & 255
+    phys = (k & ~255) + 4 * (m & 63) + (m >> 6)
+    npad = (nnz + 4095) // 4096 * 4096
+    c0, v0 = np.zeros(npad, np.int32), np.zeros(npad, np.float32)
+    c0[phys], v0[phys] = cols, vals
+    lc, lv = solver.csr_logical(rowptr, torch.from_numpy(c0), torch.from_numpy(v0))
+    assert np.array_equal(lc.numpy(), cols) and np.array_equal(lv.numpy(), vals)
+    # format 1: 192-entry tiles, entry m at 3 (m % 64) + m / 64, three 21-bit columns per 64-bit word
+    t, m = k // 192, k % 192
+    phys = t * 192 + 3 * (m & 63) + (m >> 6)
+    npad = (nnz + 4607) // 4608 * 4608
+    c32, v1 = np.zeros(npad, np.int64), np.zeros(npad, np.float32)
+    c32[phys], v1[phys] = cols, vals
+    packed = c32[0::3] | (c32[1::3] << 21) | (c32[2::3] << 42)
+    lc, lv = solver.csr_logical(rowptr, torch.from_numpy(packed), torch.from_numpy(v1))
+    assert lc.dtype == torch.int32 and np.array_equal(lc.numpy(), cols) and np.array_equal(lv.numpy(), vals)
+    assert solver.col_format(torch.from_numpy(packed)) == 1 and solver.col_format(torch.from_numpy(c0)) == 0
