@@ -121,6 +121,20 @@ def test_assembly_and_spmv():
     # same matrix, fp32: |dy| <= 1e-5 * |A||x|  (rel-tol 1e-5 on SpMV)
     bound = 1e-5 * (abs(Ag) @ abs(x))
     assert (abs(y - yo) <= bound + 1e-30).all()
+    # both physical layouts (include/nksr_hip.h col_format): packed 21-bit columns is the default here, the
+    # int32 layout (used when M > 2^21) must hold the same matrix and give the same product and solve
+    assert solver.col_format(cols) == 1
+    fld.solver_config['col_format'] = 0
+    rowptr0, cols0, vals0, diag0, gb0 = fld.assemble(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
+    assert solver.col_format(cols0) == 0 and torch.equal(rowptr0, rowptr) and torch.equal(diag0, diag) and torch.equal(gb0, gb)
+    lc0, lv0 = solver.csr_logical(rowptr0, cols0, vals0)
+    assert torch.equal(lc0, lc) and torch.equal(lv0, lv)
+    y0 = solver.spmv(rowptr0, cols0, vals0, t(x)).cpu().numpy()
+    assert (abs(y0 - yo) <= bound + 1e-30).all()
+    s1 = solver.pcg_solve(rowptr, cols, vals, diag, gb, tol=1e-6)
+    s0 = solver.pcg_solve(rowptr0, cols0, vals0, diag0, gb0, tol=1e-6)
+    assert s1[2] <= 1e-6 and s0[2] <= 1e-6
+    assert float((s1[0] - s0[0]).abs().max()) <= 1e-4 * float(s1[0].abs().max())
 
 
 def test_pcg_matches_oracle_and_scipy():
