@@ -340,3 +340,28 @@ def test_build_adaptive_normal_variation_matches_oracle():
         c0 = svh.get_voxel_centers(0).cpu().numpy()
         assert len(c0) > 0 and (c0[:, 0] < 2.5).all()      # nothing fine on the plate
         assert (svh.get_voxel_centers(3).cpu().numpy()[:, 0] > 3).any()
+
+
+@pytest.mark.parametrize('depth', [1, 2, 3, 6])
+def test_other_tree_depths_match_oracle(depth):
+    """tree_depth from 1 to NKSR_MAX_DEPTH = 6: exercises every block-tile / row-frame instantiation of the
+    assembly (T = 27 .. 162) and the > 64 KB dynamic-LDS path of the structure pass (depth 6)."""
+    import nksr_amd
+    from nksr_amd import configs
+    from oracle import network as onet, pipeline
+    xyz, nrm = make_cloud('sphere', 2500, 0.003, depth)
+    hp = configs.get_hparams('ks', tree_depth=depth)
+    rec = nksr_amd.Reconstructor(_dev(), hparams=hp)
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(_dev()), torch.from_numpy(nrm).to(_dev()), voxel_size=0.04, solver_tol=1e-6)
+    xs = (xyz * np.float32(0.1 / 0.04)).astype(np.float32)
+    ofl = pipeline.reconstruct(xs, nrm, depth=depth, tol=1e-6, net_params=onet.export_params(rec.network))
+    assert fld.svh.depth == depth and fld.solve_info['M'] == ofl['A'].shape[0]
+    for d in range(depth):
+        assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
+    np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), ofl['A'].diagonal(), rtol=1e-4)
+    ref = np.abs(ofl['alpha']).max()
+    assert np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() <= 3e-3 * ref
+    q = (xs[:500] + np.float32(0.03)).astype(np.float32)
+    f_gpu = fld.evaluate_f(torch.from_numpy(q / np.float32(fld.scale)).to(_dev())).value.cpu().numpy()
+    f_ref = pipeline.evaluate(ofl, q)[0]
+    assert np.abs(f_gpu - f_ref).max() <= 3e-3 * max(np.abs(f_ref).max(), 1e-6)
