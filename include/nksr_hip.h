@@ -125,8 +125,10 @@ int nksr_udf_decode(const nksr_level_t* level, int level_index, const float* fea
 /* ---- neural kernel (KernelField, models/nksr_net.py:91-96) --------------------------- */
 int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden, const float* mlp, float* psi_out, void* stream);
 /* Dense-slot kernel rows at arbitrary sites.  val [n, L, 27]; dval [n, 3, L, 27] (may be
- * NULL).  approx!=0 drops the d(phi)/dx term (approx_kernel_grad, recons_waymo.py:33). */
-int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float* val, float* dval, void* stream);
+ * NULL).  approx!=0 drops the d(phi)/dx term (approx_kernel_grad, recons_waymo.py:33).  Every output is
+ * multiplied by row_scale (the assembly takes rows pre-multiplied by sqrt(set weight), see nksr_assemble). */
+int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, float* val, float* dval,
+                     void* stream);
 /* f(x) (and gradient if grad_out != NULL): field.evaluate_f, models/loss.py:189-198. */
 int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx,
                     float* f_out, float* grad_out, void* stream);
@@ -135,7 +137,7 @@ int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, 
 typedef struct {
     int64_t n;                 /* sites                                                */
     int32_t ncomp;             /* 1 (position rows, G) or 3 (gradient rows, Q)         */
-    float weight;              /* pos_weight or normal_weight                          */
+    float weight;              /* weight of the set (>= 0); rows pre-multiplied by sqrt(w) are passed with weight 1 */
     const float* val;          /* [n, ncomp, L, 27] dense-slot rows                    */
     const float* target;       /* [n, ncomp] right-hand side values or NULL (zero)     */
     const int32_t* start[NKSR_MAX_DEPTH]; /* per level: [n_d] site range per voxel     */

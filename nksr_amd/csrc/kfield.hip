@@ -159,8 +159,8 @@ __device__ __forceinline__ void store_row27(float* __restrict__ p, const float v
 // ---- dense-slot kernel rows -------------------------------------------------------------------
 // grid.y = level; one thread per site.
 template <int K, int H, bool GRAD, bool JAC>
-__global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float* __restrict__ val,
-                              float* __restrict__ dval) {
+__global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float row_scale,
+                              float* __restrict__ val, float* __restrict__ dval) {
     const int d = blockIdx.y, L = hier.depth;
     const nksr_level_t& lv = hier.lv[d];
     __shared__ float w[MlpView<K, H>::SIZE];
@@ -215,8 +215,8 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
                 if (JAC) { g[0] = fmaf(jd[0], B, g[0]); g[1] = fmaf(jd[1], B, g[1]); g[2] = fmaf(jd[2], B, g[2]); }
             }
         }
-        ov[s] = v;
-        if (GRAD) { og[0][s] = g[0]; og[1][s] = g[1]; og[2][s] = g[2]; }
+        ov[s] = v * row_scale;
+        if (GRAD) { og[0][s] = g[0] * row_scale; og[1][s] = g[1] * row_scale; og[2][s] = g[2] * row_scale; }
     }
     store_row27(vrow, ov);
     if (GRAD) {
@@ -300,15 +300,15 @@ extern "C" int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden
     return NKSR_OK;
 }
 
-extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float* val, float* dval,
+extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, float* val, float* dval,
                                 void* stream) {
     if (n <= 0) return NKSR_OK;
     if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
     dim3 grid(nksr_blocks(n, 128), h->depth), block(128);
     DISPATCH_KH(h->kdim, h->hidden, {
-        if (!dval) hipLaunchKernelGGL((k_kernel_rows<K, H, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, val, dval);
-        else if (approx) hipLaunchKernelGGL((k_kernel_rows<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, val, dval);
-        else hipLaunchKernelGGL((k_kernel_rows<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, val, dval);
+        if (!dval) hipLaunchKernelGGL((k_kernel_rows<K, H, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, val, dval);
+        else if (approx) hipLaunchKernelGGL((k_kernel_rows<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, val, dval);
+        else hipLaunchKernelGGL((k_kernel_rows<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, val, dval);
     })
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;

@@ -67,12 +67,12 @@ class KernelField(BaseField):
         return h
 
     # ---- kernel rows ---------------------------------------------------------------------------------
-    def kernel_rows(self, xyz, grad):
-        """Dense-slot rows: val [n, L, 27] and (grad) dval [n, 3, L, 27] (model units)."""
+    def kernel_rows(self, xyz, grad, scale=1.0):
+        """Dense-slot rows: val [n, L, 27] and (grad) dval [n, 3, L, 27] (model units), times ``scale``."""
         n, L = xyz.shape[0], self.svh.depth
         val = torch.empty((n, L, 27), dtype=torch.float32, device=self.device)
         dval = torch.empty((n, 3, L, 27), dtype=torch.float32, device=self.device) if grad else None
-        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), n, int(self.approx_kernel_grad), ptr(val), ptr(dval), stream())
+        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), ptr(val), ptr(dval), stream())
         return val, dval
 
     def _sorted_sites(self, xyz):
@@ -117,16 +117,21 @@ class KernelField(BaseField):
             else:
                 ks, perm = self._sorted_sites(xyz)
                 xs = xyz[perm].contiguous()
-            val, dval = self.kernel_rows(xs, grad=(ncomp == 3))
+            if not float(weight) >= 0.0:
+                raise RuntimeError('solver weights must be >= 0')
+            # rows (and targets) are produced pre-multiplied by sqrt(weight): the Gram products of the
+            # assembly are then bitwise symmetric and its matrix-core operands need no scaling
+            sw = float(weight) ** 0.5
+            val, dval = self.kernel_rows(xs, grad=(ncomp == 3), scale=sw)
             rows = val if ncomp == 1 else dval
             st, en = self._site_ranges(ks)
             S = sets[nsets]
-            S.n, S.ncomp, S.weight = xs.shape[0], ncomp, float(weight)
+            S.n, S.ncomp, S.weight = xs.shape[0], ncomp, 1.0
             S.val = ptr(rows)
             tgt = None
             if target is not None:
                 tgt = target.to(dev, torch.float32)
-                tgt = (tgt[perm] if perm is not None else tgt).contiguous()
+                tgt = ((tgt[perm] if perm is not None else tgt) * sw).contiguous()
                 S.target = ptr(tgt)
             for d in range(self.svh.depth):
                 S.start[d], S.end[d] = ptr(st[d]), ptr(en[d])
