@@ -137,7 +137,8 @@ int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, 
 typedef struct {
     int64_t n;                 /* sites                                                */
     int32_t ncomp;             /* 1 (position rows, G) or 3 (gradient rows, Q)         */
-    float weight;              /* weight of the set (>= 0); rows pre-multiplied by sqrt(w) are passed with weight 1 */
+    float weight;              /* weight of the set (>= 0).  For a bitwise symmetric matrix pass val / target
+                                * pre-multiplied by sqrt(w) (nksr_kernel_rows row_scale) and weight = 1 */
     const float* val;          /* [n, ncomp, L, 27] dense-slot rows                    */
     const float* target;       /* [n, ncomp] right-hand side values or NULL (zero)     */
     const int32_t* start[NKSR_MAX_DEPTH]; /* per level: [n_d] site range per voxel     */

@@ -68,39 +68,8 @@ __device__ __forceinline__ int64_t csr_phys(int64_t k, int fmt) {
 // two site rows per instruction (lanes 0-31 feed row 2m, lanes 32-63 row 2m+1; lane l supplies
 // A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]).  Column T carries the right-hand side
 // (27 m is never a multiple of 32, so a spare column always exists).  The set weight scales the A
-// operand.  Accumulator register r of lane l is D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31].
+// operand (the host passes rows pre-multiplied by sqrt(w) and weight 1, see below).  Accumulator register r of lane l is D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31].
 typedef float asm_f32x16 __attribute__((ext_vector_type(16)));
-
-template <int NT, bool SCALED>
-__device__ __forceinline__ void cell_accumulate(const nksr_siteset_t& S, int64_t q0, int nrows, int L, int d, int T, int j, int half,
-                                                float sw, asm_f32x16 (&acc)[NT]) {
-    const float* __restrict__ val = S.val;
-    const float* __restrict__ tgt = S.target;
-    for (int m0 = 0; m0 < nrows; m0 += 2) {
-        // branch-free operand fetch: addresses are clamped into the row (and the odd tail to the last row),
-        // all NT + 1 loads are issued back to back, out-of-range lanes are zeroed with selects afterwards
-        const bool valid = m0 + half < nrows;
-        const int64_t q = valid ? q0 + m0 + half : q0 + nrows - 1;
-        const float* ra = val + (q * L + d) * 27;
-        float ld[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int col = 32 * n + j;
-            ld[n] = ra[col < T ? col : T - 1];
-        }
-        const float tg = tgt ? tgt[q] : 0.f;
-        float b[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int col = 32 * n + j;
-            b[n] = !valid ? 0.f : (col < T ? ld[n] : (col == T ? tg : 0.f));
-            if (SCALED) b[n] *= sw;
-        }
-        const float a = (j < 27) ? b[0] : 0.f;
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
-    }
-}
 
 template <int NT>
 __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d) {
@@ -124,11 +93,30 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
         total += k1 - k0;
         const int64_t q0 = (int64_t)k0 * S.ncomp;
         const int nrows = (k1 - k0) * S.ncomp;
-        // sqrt(w) on BOTH operands: the products (sw r_s)(sw r_t) are then bitwise symmetric in (s, t), so a row
-        // can emit its same-level LOWER entries from its own frame (no mirror needed for them).  The host passes
-        // rows pre-multiplied by sqrt(w) with weight 1: that path feeds the loads straight into the matrix cores.
-        if (S.weight == 1.f) cell_accumulate<NT, false>(S, q0, nrows, L, d, T, j, half, 1.f, acc);
-        else cell_accumulate<NT, true>(S, q0, nrows, L, d, T, j, half, sqrtf(S.weight), acc);
+        // The set weight multiplies the A operand.  Callers that need BITWISE symmetric same-level blocks (the
+        // row fill emits same-level lower entries from the row's own frame) pass rows and targets
+        // pre-multiplied by sqrt(w) and weight 1 (nksr_amd/fields/kernel_field.py does): the products
+        // (sw r_s)(sw r_t) then commute exactly.  Keep this loop as it is -- variants that dropped the multiply,
+        // added a second code path (88 VGPRs) or called sqrtf here all measured 20 % slower.
+        const float w = S.weight;
+        for (int m0 = 0; m0 < nrows; m0 += 2) {
+            const bool valid = m0 + half < nrows;
+            const int64_t q = q0 + m0 + half;
+            const float* ra = S.val + (q * L + d) * 27;
+            float b[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int col = 32 * n + j;
+                b[n] = 0.f;
+                if (valid) {
+                    if (col < T) b[n] = ra[col];
+                    else if (col == T && S.target) b[n] = S.target[q];
+                }
+            }
+            const float a = (j < 27) ? w * b[0] : 0.f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
+        }
     }
     if (lane == 0) A.nsites[d][c] = total;
     if (total == 0) return;
