@@ -58,8 +58,9 @@ __device__ __forceinline__ int64_t csr_phys(int64_t k, int fmt) {
         const int64_t m = k & 255;
         return (k & ~(int64_t)255) + 4 * (m & 63) + (m >> 6);
     }
-    const int64_t t = k / 192, m = k - t * 192;
-    return t * 192 + 3 * (m & 63) + (m >> 6);
+    const uint32_t kk = (uint32_t)k;               // nnz < 2^31: 32-bit magic-number division, not the 64-bit expansion
+    const uint32_t t = kk / 192u, m = kk - t * 192u;
+    return (int64_t)(t * 192u + 3u * (m & 63u) + (m >> 6));
 }
 
 // ---- phase 1: one wavefront per (level, cell) on the fp32 matrix cores ------------------------------
