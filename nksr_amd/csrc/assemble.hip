@@ -152,73 +152,76 @@ __device__ __forceinline__ int slot_column(const nksr_hier_t& h, int d, int ix, 
     return j < 0 ? -1 : lc.offset + j;
 }
 
-// ---- phase 2a: structure.  colmap[row slot] = column (> row) of every structural upper slot ------
-// One wavefront per row, RC_ROWS consecutive rows per workgroup.  Morton-consecutive rows share their
-// coarse ancestors, hence the 5^3 column frames of the coarser levels: the first row of every run of
-// equal ancestors (the run leader) does the hash lookups of a frame once, the others read them from
-// LDS; the cross-level in-degree is counted per frame in LDS and flushed with one global integer atomic
-// per touched column (instead of one per structural entry).  Same-level lower neighbours are
-// counted from the row's own frame.  Integer atomics only: order-independent, deterministic.
-#define RC_ROWS 16
-__global__ void __launch_bounds__(RC_ROWS * 64) k_row_count(AsmArgs A, int32_t* __restrict__ rowcount,
-                                                            int32_t* __restrict__ crosscount, int32_t* __restrict__ samelow,
-                                                            int32_t* __restrict__ indeg) {
-    extern __shared__ int32_t rc_lds[];
+// ---- phase 2a: structure.  colmap[row slot] = column of every structural slot ---------------------------
+// One wavefront walks RC_RUN Morton-consecutive rows.  Such rows share their coarse ancestors, hence the
+// 5^3 column frames of the coarser levels: a frame (125 hash lookups) is fetched when the ancestor changes
+// and stays in REGISTERS -- lane l owns frame slots l and l + 64, together with the number of rows of the
+// run that coupled to them, which becomes ONE global integer atomic per touched column when the frame is
+// retired (instead of one per structural entry).  No LDS, no barriers, no float atomics; integer
+// atomics are order-independent, so the result is deterministic.
+// colmap encoding: upper neighbour -> column, same-level lower neighbour -> -2 - column (emitted by the
+// row itself: bitwise equal to the transposed entry), diagonal / absent / non-overlapping -> -1.
+#define RC_RUN 32
+__global__ void __launch_bounds__(ASM_WAVES * 64) k_row_count(AsmArgs A, int32_t* __restrict__ rowcount,
+                                                              int32_t* __restrict__ crosscount, int32_t* __restrict__ samelow,
+                                                              int32_t* __restrict__ indeg) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const nksr_hier_t& h = A.hier;
-    const int L = h.depth, F = L - 1;
-    int32_t* anc = rc_lds;                                  // [RC_ROWS][4]  level, ix, iy, iz
-    int32_t* colf = rc_lds + RC_ROWS * 4;                   // [RC_ROWS][F][125]
-    int32_t* cntf = colf + RC_ROWS * F * 125;               // [RC_ROWS][F][125]
-    const int row = blockIdx.x * RC_ROWS + wave;
-    const bool live = row < A.M;
-    int d = -1, i = 0, ix = 0, iy = 0, iz = 0;
-    if (live) {
-        d = row_level(h, row);
-        i = row - h.lv[d].offset;
-        ix = h.lv[d].ijk[i * 3]; iy = h.lv[d].ijk[i * 3 + 1]; iz = h.lv[d].ijk[i * 3 + 2];
-    }
-    if (lane == 0) { anc[wave * 4] = d; anc[wave * 4 + 1] = ix; anc[wave * 4 + 2] = iy; anc[wave * 4 + 3] = iz; }
-    __syncthreads();
-    // run leaders and their frame lookups
-    int lead[NKSR_MAX_DEPTH];
-    for (int dd = 1; live && d + dd < L; ++dd) {
-        int w = wave;
-        while (w > 0 && anc[(w - 1) * 4] == d && (anc[(w - 1) * 4 + 1] >> dd) == (ix >> dd) &&
-               (anc[(w - 1) * 4 + 2] >> dd) == (iy >> dd) && (anc[(w - 1) * 4 + 3] >> dd) == (iz >> dd)) --w;
-        lead[dd] = w;
-        if (w != wave) continue;
-        const nksr_level_t& lc = h.lv[d + dd];
-        int32_t* cf = colf + (wave * F + dd - 1) * 125;
-        int32_t* nf = cntf + (wave * F + dd - 1) * 125;
-        for (int r = lane; r < 125; r += 64) {
-            const int x = (ix >> dd) + r / 25 - 2, y = (iy >> dd) + (r / 5) % 5 - 2, z = (iz >> dd) + r % 5 - 2;
-            const int j = hash_find(lc.hkeys, lc.hvals, lc.hcap, morton_biased(x, y, z, NKSR_BIAS0 >> (d + dd)));
-            cf[r] = j < 0 ? -1 : lc.offset + j;
-            nf[r] = 0;
-        }
-    }
-    // same level (independent of the leaders: runs while they wait for their frame lookups): every slot of
-    // the 5^3 frame overlaps (|dI| <= 2).  Upper neighbours are stored as their column, lower ones as
-    // -2 - column (emitted by the row itself, bitwise equal to the transposed entry), the diagonal /
-    // absent slots as -1.
-    int cnt = 0, lower = 0, cross = 0;
-    const int nslots = live ? (L - d) * 125 : 0;
-    int32_t* cm = live ? A.colmap[d] + (int64_t)i * nslots : nullptr;
-    if (live) {
-        // the 5^3 frame through the 27-neighbour table: slot (dx,dy,dz), |d| <= 2, is neighbour (d - e) of
-        // neighbour e = clamp(d, -1, 1).  Two reads inside 108-byte table rows that Morton-adjacent matrix
-        // rows share, instead of a random hash probe per slot (141 M probes ~ 18 GB of sector traffic at
-        // 1M points); the hash is only consulted when the intermediate voxel does not exist.
+    const int L = h.depth;
+    const int row0 = (blockIdx.x * ASM_WAVES + wave) * RC_RUN;
+    if (row0 >= A.M) return;
+    constexpr int F = NKSR_MAX_DEPTH - 1;
+    int cf[F][2], nf[F][2];                 // frame dd (index dd - 1): columns and coupling counts of slots lane, lane + 64
+    int kd[F], kx[F], ky[F], kz[F];         // ancestor the cached frame belongs to (kd < 0: none)
+#pragma unroll
+    for (int f = 0; f < F; ++f) { kd[f] = -1; kx[f] = ky[f] = kz[f] = 0; cf[f][0] = cf[f][1] = -1; nf[f][0] = nf[f][1] = 0; }
+    const int r1 = lane + 64 < 125 ? lane + 64 : 124;       // second slot of the lane (lanes 61..63 idle there)
+    const bool has1 = lane + 64 < 125;
+
+    for (int row = row0; row < row0 + RC_RUN && row < A.M; ++row) {
+        const int d = row_level(h, row);
         const nksr_level_t& lv0 = h.lv[d];
+        const int i = row - lv0.offset;
+        const int ix = lv0.ijk[i * 3], iy = lv0.ijk[i * 3 + 1], iz = lv0.ijk[i * 3 + 2];
+        const int nslots = (L - d) * 125;
+        int32_t* cm = A.colmap[d] + (int64_t)i * nslots;
+        int cnt = 0, lower = 0, cross = 0;
+
+        // coarser levels: (re)load the frames whose ancestor changed, retiring the old ones
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int dd = f + 1;
+            if (d + dd >= L) continue;
+            const int ax = ix >> dd, ay = iy >> dd, az = iz >> dd;
+            if (kd[f] == d && kx[f] == ax && ky[f] == ay && kz[f] == az) continue;
+            if (kd[f] >= 0) {
+                if (nf[f][0] > 0) atomicAdd(&indeg[cf[f][0]], nf[f][0]);
+                if (nf[f][1] > 0) atomicAdd(&indeg[cf[f][1]], nf[f][1]);
+            }
+            const nksr_level_t& lc = h.lv[d + dd];
+            const int bias = NKSR_BIAS0 >> (d + dd);
+            int j0 = hash_find(lc.hkeys, lc.hvals, lc.hcap, morton_biased(ax + lane / 25 - 2, ay + (lane / 5) % 5 - 2, az + lane % 5 - 2, bias));
+            int j1 = has1 ? hash_find(lc.hkeys, lc.hvals, lc.hcap, morton_biased(ax + r1 / 25 - 2, ay + (r1 / 5) % 5 - 2, az + r1 % 5 - 2, bias)) : -1;
+            cf[f][0] = j0 < 0 ? -1 : lc.offset + j0;
+            cf[f][1] = j1 < 0 ? -1 : lc.offset + j1;
+            nf[f][0] = nf[f][1] = 0;
+            kd[f] = d; kx[f] = ax; ky[f] = ay; kz[f] = az;
+        }
+
+        // same level: the 5^3 frame through the 27-neighbour table -- slot (dx,dy,dz), |d| <= 2, is neighbour
+        // (d - e) of neighbour e = clamp(d, -1, 1): two reads inside 108-byte table rows that Morton-adjacent
+        // matrix rows share, instead of a random hash probe per slot; the hash is only consulted when the
+        // intermediate voxel does not exist.  Every slot of this frame overlaps (|dI| <= 2).
         const int nb_lane = (lane < 27) ? lv0.nbr[(int64_t)i * 27 + lane] : -1;
-        for (int r = lane; r < 128; r += 64) {
-            int col = -1;
-            const int rr = r < 125 ? r : 124;
-            const int dx = rr / 25 - 2, dy = (rr / 5) % 5 - 2, dz = rr % 5 - 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = u == 0 ? lane : r1;
+            const bool on = u == 0 || has1;
+            const int dx = r / 25 - 2, dy = (r / 5) % 5 - 2, dz = r % 5 - 2;
             const int ex = dx < -1 ? -1 : (dx > 1 ? 1 : dx), ey = dy < -1 ? -1 : (dy > 1 ? 1 : dy), ez = dz < -1 ? -1 : (dz > 1 ? 1 : dz);
             const int n1 = __shfl(nb_lane, (ex + 1) * 9 + (ey + 1) * 3 + (ez + 1));
-            if (r < 125) {
+            int col = -1;
+            if (on) {
                 int j;
                 if (n1 >= 0) j = lv0.nbr[(int64_t)n1 * 27 + (dx - ex + 1) * 9 + (dy - ey + 1) * 3 + (dz - ez + 1)];
                 else j = hash_find(lv0.hkeys, lv0.hvals, lv0.hcap, morton_biased(ix + dx, iy + dy, iz + dz, NKSR_BIAS0 >> d));
@@ -228,25 +231,26 @@ __global__ void __launch_bounds__(RC_ROWS * 64) k_row_count(AsmArgs A, int32_t* 
             lower += __popcll(__ballot(lo));
             if (col == row) col = -1;
             cnt += __popcll(__ballot(col > row));
-            if (r < 125) cm[r] = lo ? -2 - col : col;
+            if (on) cm[r] = lo ? -2 - col : col;
         }
-    }
-    __syncthreads();
-    if (live) {
-        for (int dd = 1; d + dd < L; ++dd) {
-            const int32_t* cf = colf + (lead[dd] * F + dd - 1) * 125;
-            int32_t* nf = cntf + (lead[dd] * F + dd - 1) * 125;
+
+        // coarser levels: integer support-overlap test  |(2I+1) - (2J+1) 2^dd| < 3 (1 + 2^dd)  on every axis
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int dd = f + 1;
+            if (d + dd >= L) continue;
             const int lim = 3 * (1 + (1 << dd));
-            for (int r = lane; r < 128; r += 64) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = u == 0 ? lane : r1;
+                const bool on = u == 0 || has1;
+                const int x = (ix >> dd) + r / 25 - 2, y = (iy >> dd) + (r / 5) % 5 - 2, z = (iz >> dd) + r % 5 - 2;
+                const int ox = (2 * ix + 1) - ((2 * x + 1) << dd), oy = (2 * iy + 1) - ((2 * y + 1) << dd),
+                          oz = (2 * iz + 1) - ((2 * z + 1) << dd);
                 int col = -1;
-                if (r < 125) {
-                    const int x = (ix >> dd) + r / 25 - 2, y = (iy >> dd) + (r / 5) % 5 - 2, z = (iz >> dd) + r % 5 - 2;
-                    const int ax = (2 * ix + 1) - ((2 * x + 1) << dd), ay = (2 * iy + 1) - ((2 * y + 1) << dd),
-                              az = (2 * iz + 1) - ((2 * z + 1) << dd);
-                    if (abs(ax) < lim && abs(ay) < lim && abs(az) < lim) col = cf[r];
-                    cm[dd * 125 + r] = col;
-                    if (col >= 0) atomicAdd(&nf[r], 1);
-                }
+                if (on && abs(ox) < lim && abs(oy) < lim && abs(oz) < lim) col = cf[f][u];
+                if (on) cm[dd * 125 + r] = col;
+                if (col >= 0) nf[f][u] += 1;
                 cross += __popcll(__ballot(col >= 0));
             }
         }
@@ -256,13 +260,12 @@ __global__ void __launch_bounds__(RC_ROWS * 64) k_row_count(AsmArgs A, int32_t* 
             samelow[row] = lower;
         }
     }
-    __syncthreads();
-    for (int dd = 1; live && d + dd < L; ++dd) {
-        if (lead[dd] != wave) continue;
-        const int32_t* cf = colf + (wave * F + dd - 1) * 125;
-        const int32_t* nf = cntf + (wave * F + dd - 1) * 125;
-        for (int r = lane; r < 125; r += 64)
-            if (nf[r] > 0) atomicAdd(&indeg[cf[r]], nf[r]);
+    // retire the frames that are still cached
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        if (kd[f] < 0) continue;
+        if (nf[f][0] > 0) atomicAdd(&indeg[cf[f][0]], nf[f][0]);
+        if (nf[f][1] > 0) atomicAdd(&indeg[cf[f][1]], nf[f][1]);
     }
 }
 
@@ -455,10 +458,8 @@ extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_
     int rc = fill_args(A, h, nullptr, 0, 0.f, cb, workspace);
     if (rc) return rc;
     if (A.M <= 0) return NKSR_OK;
-    const size_t lds = (size_t)(RC_ROWS * 4 + 2 * RC_ROWS * (h->depth - 1) * 125) * sizeof(int32_t);
-    if (lds > 48 * 1024)
-        NKSR_CHECK_HIP(hipFuncSetAttribute((const void*)k_row_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_row_count, dim3(nksr_blocks(A.M, RC_ROWS)), dim3(RC_ROWS * 64), lds, (hipStream_t)stream, A, rowcount, crosscount, samelow, indeg);
+    hipLaunchKernelGGL(k_row_count, dim3(nksr_blocks(A.M, ASM_WAVES * RC_RUN)), dim3(ASM_WAVES * 64), 0, (hipStream_t)stream, A, rowcount,
+                       crosscount, samelow, indeg);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
