@@ -124,8 +124,8 @@ int nksr_udf_decode(const nksr_level_t* level, int level_index, const float* fea
 
 /* ---- neural kernel (KernelField, models/nksr_net.py:91-96) --------------------------- */
 int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden, const float* mlp, float* psi_out, void* stream);
-/* Dense-slot kernel rows at arbitrary sites.  val [n, L, 27]; dval [n, 3, L, 27] (may be
- * NULL).  approx!=0 drops the d(phi)/dx term (approx_kernel_grad, recons_waymo.py:33).  Every output is
+/* Dense-slot kernel rows at arbitrary sites.  val [n, L, 27] (may be NULL when only the gradient rows are
+ * wanted); dval [n, 3, L, 27] (may be NULL).  approx!=0 drops the d(phi)/dx term (approx_kernel_grad, recons_waymo.py:33).  Every output is
  * multiplied by row_scale (the assembly takes rows pre-multiplied by sqrt(set weight), see nksr_assemble). */
 int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, float* val, float* dval,
                      void* stream);

@@ -172,7 +172,8 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
     SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
     float* vrow = val + (i * L + d) * 27;
     if (sc.cell < 0) {
-        for (int s = 0; s < 27; ++s) vrow[s] = 0.f;
+        if (val)
+            for (int s = 0; s < 27; ++s) vrow[s] = 0.f;
         if (GRAD)
             for (int a = 0; a < 3; ++a)
                 for (int s = 0; s < 27; ++s) dval[((i * 3 + a) * L + d) * 27 + s] = 0.f;
@@ -218,7 +219,7 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
         ov[s] = v * row_scale;
         if (GRAD) { og[0][s] = g[0] * row_scale; og[1][s] = g[1] * row_scale; og[2][s] = g[2] * row_scale; }
     }
-    store_row27(vrow, ov);
+    if (val) store_row27(vrow, ov);
     if (GRAD) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) store_row27(dval + ((i * 3 + a) * L + d) * 27, og[a]);
@@ -303,6 +304,7 @@ extern "C" int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden
 extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, float* val, float* dval,
                                 void* stream) {
     if (n <= 0) return NKSR_OK;
+    if (!val && !dval) return nksr_set_error(NKSR_ERR_ARG, "val and dval are both NULL");
     if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
     dim3 grid(nksr_blocks(n, 128), h->depth), block(128);
     DISPATCH_KH(h->kdim, h->hidden, {

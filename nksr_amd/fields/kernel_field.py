@@ -67,10 +67,11 @@ class KernelField(BaseField):
         return h
 
     # ---- kernel rows ---------------------------------------------------------------------------------
-    def kernel_rows(self, xyz, grad, scale=1.0):
-        """Dense-slot rows: val [n, L, 27] and (grad) dval [n, 3, L, 27] (model units), times ``scale``."""
+    def kernel_rows(self, xyz, grad, scale=1.0, values=True):
+        """Dense-slot rows: val [n, L, 27] (``None`` with values=False) and (grad) dval [n, 3, L, 27]
+        (model units), times ``scale``."""
         n, L = xyz.shape[0], self.svh.depth
-        val = torch.empty((n, L, 27), dtype=torch.float32, device=self.device)
+        val = torch.empty((n, L, 27), dtype=torch.float32, device=self.device) if values else None
         dval = torch.empty((n, 3, L, 27), dtype=torch.float32, device=self.device) if grad else None
         call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), ptr(val), ptr(dval), stream())
         return val, dval
@@ -122,7 +123,7 @@ class KernelField(BaseField):
             # rows (and targets) are produced pre-multiplied by sqrt(weight): the Gram products of the
             # assembly are then bitwise symmetric and its matrix-core operands need no scaling
             sw = float(weight) ** 0.5
-            val, dval = self.kernel_rows(xs, grad=(ncomp == 3), scale=sw)
+            val, dval = self.kernel_rows(xs, grad=(ncomp == 3), scale=sw, values=(ncomp == 1))
             rows = val if ncomp == 1 else dval
             st, en = self._site_ranges(ks)
             S = sets[nsets]
