@@ -95,3 +95,29 @@ def test_csr_physical_layouts_roundtrip_on_cpu():
     lc, lv = solver.csr_logical(rowptr, torch.from_numpy(packed), torch.from_numpy(v1))
     assert lc.dtype == torch.int32 and np.array_equal(lc.numpy(), cols) and np.array_equal(lv.numpy(), vals)
     assert solver.col_format(torch.from_numpy(packed)) == 1 and solver.col_format(torch.from_numpy(c0)) == 0
+
+
+def test_c_abi_argument_errors_without_a_gpu():
+    """Argument validation happens before any launch: these calls fail cleanly (error code + message) on a
+    machine without a GPU, never abort."""
+    import ctypes as C
+    from nksr_amd import _lib
+    lib = _lib.lib
+    lib.nksr_last_error.restype = C.c_char_p
+    null = C.c_void_p(0)
+
+    def err():
+        return lib.nksr_last_error().decode()
+
+    assert lib.nksr_pack_cols21(null, C.c_int64(100), null, null) != 0 and '192' in err()
+    assert lib.nksr_spmv_csr(null, null, null, C.c_int32(10), C.c_int64(100), C.c_int(0), null, null, null, null) != 0
+    assert 'workspace' in err()
+    assert lib.nksr_spmv_plan(null, C.c_int32(10), C.c_int64(100), C.c_int(7), null, null) != 0 and 'col_format' in err()
+    assert lib.nksr_spmv_plan(null, C.c_int32(3 << 20), C.c_int64(100), C.c_int(1), null, null) != 0 and '2^21' in err()
+    assert lib.nksr_splat_trilinear(null, null, C.c_int(9), null, null, null, null, C.c_int32(1), C.c_float(1.0), null, null, null) != 0
+    assert 'channels' in err()
+    h = _lib.HierT()
+    h.depth = 4
+    assert lib.nksr_kernel_rows(C.byref(h), null, C.c_int64(5), C.c_int(0), C.c_float(1.0), null, null, null) != 0 and 'NULL' in err()
+    with __import__('pytest').raises(RuntimeError):
+        _lib.call('nksr_pack_cols21', null, 100, null, null)

@@ -56,6 +56,10 @@ def _worker(rank, world, port, q):
             assert (cnt == 2).sum() == 3          # two diagonals + the stitched seam edge
         else:
             assert mv.shape[0] == 4 and mf.shape[0] == 2   # non-destination ranks keep their piece
+        # --- an idle rank (more ranks than chunks) owns nothing but still receives everything
+        one = {0: (torch.arange(5, dtype=torch.int64), torch.ones(3))} if rank == 1 else {}
+        got1 = D.exchange_payloads(one, [0])
+        assert sorted(got1) == [0] and torch.equal(got1[0][0], torch.arange(5, dtype=torch.int64)) and got1[0][1].numel() == 3
         # --- empty contribution from a rank still completes the collective
         z = D.all_gather_variable(torch.arange(3 * rank, dtype=torch.int64))
         assert [t.numel() for t in z] == [0, 3]
