@@ -148,10 +148,19 @@ def main():
     solver.profile_spmv(True)
     fence()
     t0 = time.perf_counter()
+    step_ends = []
+    field = mesh = None
     for _ in range(args.steps):
+        # the previous result is released first: every step then has the memory footprint of the warmup step
+        # and the caching allocator serves it from its pool (holding the old field while building the new one
+        # made the second timed step pay ~40 ms of fresh hipMalloc)
+        field = mesh = None
         field, mesh = step()
+        step_ends.append(time.perf_counter())     # step() ends with a device sync
     fence()
     dt = time.perf_counter() - t0
+    if os.environ.get('NKSR_BENCH_VERBOSE'):
+        print('per-step ms:', [round((b - a) * 1e3, 1) for a, b in zip([t0] + step_ends[:-1], step_ends)], file=sys.stderr)
     spmv_ms, spmv_launches = solver.profile_spmv(False)
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
