@@ -221,7 +221,7 @@ class StructureUNet(nn.Module):
             x[d] = self.down[d](p, g.nbr)
         # ---- candidate decoder structure ------------------------------------------------------------
         cand = gt_decoder_svh if gt_decoder_svh is not None else \
-            SparseFeatureHierarchy(enc_svh.voxel_size, D, dev).build_point_neighborhood_sorted(enc.keys)
+            SparseFeatureHierarchy(enc_svh.voxel_size, D, dev).build_point_neighborhood_sorted(enc.keys, getattr(enc, 'cells', None))
         feat = FeatureSet(D)
         dec_levels = [None] * D
         y_up, keep_up = None, None           # trunk features / "continue" flags of the level above

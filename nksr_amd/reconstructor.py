@@ -46,8 +46,10 @@ class Reconstructor:
         from .nn.network import sort_cloud
         from .svh import inv_w0_f32
         ks, xyz, normal = sort_cloud(xyz, normal, inv_w0_f32(hp.voxel_size))
-        enc_svh = SparseFeatureHierarchy(hp.voxel_size, hp.tree_depth, self.device).build_point_splatting_sorted(xyz, ks)
+        cells = SparseFeatureHierarchy.cells_with_points(ks, hp.tree_depth)       # shared by both hierarchies
+        enc_svh = SparseFeatureHierarchy(hp.voxel_size, hp.tree_depth, self.device).build_point_splatting_sorted(xyz, ks, cells)
         enc = self.network.encoder(xyz, normal, enc_svh, 0, sorted_keys=ks)
+        enc.cells = cells
         feat, dec_svh, udf_svh = self.network.unet(enc, enc_svh, adaptive_depth=hp.adaptive_depth)
         if all(dec_svh.grids[d] is None for d in range(hp.adaptive_depth)):
             raise RuntimeError('empty decoder hierarchy')

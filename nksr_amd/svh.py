@@ -118,9 +118,14 @@ class SparseFeatureHierarchy:
         structure rule of the decoder hierarchy."""
         return self._build_from_points(xyz, 1)
 
-    def _cells_with_points(self, point_keys_sorted, d):
-        """Unique level-d cells that contain a point, from the SORTED level-0 point keys."""
-        return ops.unique_sorted((point_keys_sorted >> (3 * d)).contiguous() if d else point_keys_sorted)
+    @staticmethod
+    def cells_with_points(point_keys_sorted, depth):
+        """Per level: the unique cells that contain a point, from the SORTED level-0 point keys.  Level d + 1
+        is derived from the (much shorter) level-d list: the parent of a cell is ``key >> 3``."""
+        cells = [ops.unique_sorted(point_keys_sorted)]
+        for d in range(1, depth):
+            cells.append(ops.unique_sorted((cells[-1] >> 3).contiguous()))
+        return cells
 
     def _footprint(self, cells, level, mode):
         per = 8 if mode == 0 else 27
@@ -128,24 +133,27 @@ class SparseFeatureHierarchy:
         call('nksr_cell_footprint_keys', ptr(cells), cells.numel(), level, mode, ptr(raw), stream())
         return ops.sort_unique(raw)
 
-    def build_point_splatting_sorted(self, xyz_sorted, point_keys_sorted):
+    def build_point_splatting_sorted(self, xyz_sorted, point_keys_sorted, cells=None):
         """Same result as build_point_splatting, 3-8x fewer keys to sort: level 0 from the points,
-        level d >= 1 from the unique level-(d-1) cells (their index is the level-d half index)."""
+        level d >= 1 from the unique level-(d-1) cells (their index is the level-d half index).
+        ``cells``: result of cells_with_points (shared with build_point_neighborhood_sorted)."""
         xyz_sorted = self._check_xyz(xyz_sorted)
         n = xyz_sorted.shape[0]
         raw = torch.empty(n * 8, dtype=torch.int64, device=self.device)
         call('nksr_splat_keys', ptr(xyz_sorted), n, self.inv_w0, 0, 0, ptr(raw), stream())
         self._levels[0] = SparseGrid(ops.sort_unique(raw), 0, self.voxel_size)
+        if cells is None and self.depth > 1:
+            cells = self.cells_with_points(point_keys_sorted, self.depth - 1)
         for d in range(1, self.depth):
-            cells = self._cells_with_points(point_keys_sorted, d - 1)
-            self._levels[d] = SparseGrid(self._footprint(cells, d - 1, 0), d, self.voxel_size)
+            self._levels[d] = SparseGrid(self._footprint(cells[d - 1], d - 1, 0), d, self.voxel_size)
         return self
 
-    def build_point_neighborhood_sorted(self, point_keys_sorted):
+    def build_point_neighborhood_sorted(self, point_keys_sorted, cells=None):
         """Same result as build_point_neighborhood from the unique cells that hold points."""
+        if cells is None:
+            cells = self.cells_with_points(point_keys_sorted, self.depth)
         for d in range(self.depth):
-            cells = self._cells_with_points(point_keys_sorted, d)
-            self._levels[d] = SparseGrid(self._footprint(cells, d, 1), d, self.voxel_size)
+            self._levels[d] = SparseGrid(self._footprint(cells[d], d, 1), d, self.voxel_size)
         return self
 
     def build_adaptive_normal_variation(self, xyz, normal, tau=0.1, adaptive_depth=1):
