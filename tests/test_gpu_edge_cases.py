@@ -138,3 +138,24 @@ def test_bench_contract_line():
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and 'sample' in c
+
+
+def test_reconstruct_is_bitwise_deterministic():
+    """No float atomics anywhere on the path (integer atomics only, fixed reduction orders): two runs on the
+    same input give bit-identical coefficients, matrix and mesh."""
+    import nksr_amd
+    from nksr_amd import utils
+    dev = torch.device('cuda:0')
+    xyz, nrm = utils.synth_scene(120000, seed=3, extent=(12.0, 12.0, 6.0), n_objects=4)
+    xyz, nrm = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
+    rec = nksr_amd.Reconstructor(dev)
+    runs = []
+    for _ in range(2):
+        fld = rec.reconstruct(xyz, nrm, detail_level=1.0)
+        mesh = fld.extract_dual_mesh(mise_iter=1)
+        runs.append((fld.alpha.clone(), fld.matrix[1].clone(), fld.matrix[2].clone(), fld.rhs.clone(), mesh.v.clone(), mesh.f.clone(),
+                     fld.solve_info['iters']))
+    a, b = runs
+    assert a[6] == b[6]
+    for u, v in zip(a[:6], b[:6]):
+        assert torch.equal(u, v)
