@@ -330,38 +330,49 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const in
         edd[q] = t / 27;
         esx[q] = s / 9 - 1; esy[q] = (s / 3) % 3 - 1; esz[q] = s % 3 - 1;
     }
-    // software pipeline over the active neighbour cells: next block row is in flight while the
-    // current one is accumulated in LDS
-    float vcur[NQ], vnext[NQ];
-    int spc = -1;
-    if (act) {
-        spc = __ffsll((long long)act) - 1;
-        act &= act - 1;
-        const int c = __builtin_amdgcn_readlane(cme, spc);
-        load_cols<NQ>(A.blocks[d] + ((int64_t)c * 27 + (26 - spc)) * T, lane, T, vcur);
-    }
-    while (spc >= 0) {
-        int spn = -1;
-        if (act) {
-            spn = __ffsll((long long)act) - 1;
-            act &= act - 1;
-            const int c = __builtin_amdgcn_readlane(cme, spn);
-            load_cols<NQ>(A.blocks[d] + ((int64_t)c * 27 + (26 - spn)) * T, lane, T, vnext);
-        }
-        const int cx = ix + spc / 9 - 1, cy = iy + (spc / 3) % 3 - 1, cz = iz + spc % 3 - 1;
+    // neighbour cells in batches of RF_BATCH: the block rows of a batch are requested together, and the next
+    // batch is requested before the current one is accumulated in LDS (ablation: the block-row loads are
+    // 3.2 of this kernel's 5.7 ms and latency-, not pattern-bound; one row in flight was too few, all 27 too many)
+    constexpr int RF_BATCH = 4;
+    float vb[2][RF_BATCH][NQ];
+    int sp[2][RF_BATCH];
+    auto fetch = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            if (NQ * lane + q < T) {
-                const int dd = edd[q];
-                const int rx = ((cx >> dd) + esx[q]) - (ix >> dd) + 2, ry = ((cy >> dd) + esy[q]) - (iy >> dd) + 2,
-                          rz = ((cz >> dd) + esz[q]) - (iz >> dd) + 2;
-                const int sl = dd * 125 + (rx * 5 + ry) * 5 + rz;
-                acc[sl] += vcur[q];
+        for (int u = 0; u < RF_BATCH; ++u) {
+            sp[buf][u] = -1;
+            if (act) {
+                const int spc = __ffsll((long long)act) - 1;
+                act &= act - 1;
+                sp[buf][u] = spc;
+                const int c = __builtin_amdgcn_readlane(cme, spc);
+                load_cols<NQ>(A.blocks[d] + ((int64_t)c * 27 + (26 - spc)) * T, lane, T, vb[buf][u]);
             }
         }
+    };
+    auto accumulate = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) vcur[q] = vnext[q];
-        spc = spn;
+        for (int u = 0; u < RF_BATCH; ++u) {
+            const int spc = sp[buf][u];
+            if (spc < 0) continue;
+            const int cx = ix + spc / 9 - 1, cy = iy + (spc / 3) % 3 - 1, cz = iz + spc % 3 - 1;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (NQ * lane + q < T) {
+                    const int dd = edd[q];
+                    const int rx = ((cx >> dd) + esx[q]) - (ix >> dd) + 2, ry = ((cy >> dd) + esy[q]) - (iy >> dd) + 2,
+                              rz = ((cz >> dd) + esz[q]) - (iz >> dd) + 2;
+                    acc[dd * 125 + (rx * 5 + ry) * 5 + rz] += vb[buf][u][q];
+                }
+            }
+        }
+    };
+    fetch(0);
+    while (sp[0][0] >= 0) {
+        fetch(1);
+        accumulate(0);
+        if (sp[1][0] < 0) break;
+        fetch(0);
+        accumulate(1);
     }
 
     // emission: structure comes from the count pass (no hashing here)
