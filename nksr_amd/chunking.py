@@ -43,15 +43,49 @@ def _udf_levels(f):
     return n
 
 
-def pack_field(f):
-    """KernelField (+ its UDF mask features, when the mask is a NeuralField) -> (int64 tensor, float32 tensor)."""
+def exchange_band(core, cidx3, grid, ov, w0):
+    """Where OTHER ranks evaluate this chunk's field: along every split axis with a neighbouring chunk, from
+    2.5 finest voxels inside the shared face (their one-ring of halo cells and its refined lattice) to ``ov``
+    outside it (the end of the blend weight).  Returns [(axis, lo, hi), ...]; see pack_field(band=)."""
+    clo, chi = core
+    out = []
+    for a in range(3):
+        if grid[a] <= 1:
+            continue
+        if cidx3[a] > 0:
+            out.append((a, clo[a] - ov, clo[a] + 2.5 * w0))
+        if cidx3[a] < grid[a] - 1:
+            out.append((a, chi[a] - 2.5 * w0, chi[a] + ov))
+    return out
+
+
+def pack_field(f, band=None):
+    """KernelField (+ its UDF mask features, when the mask is a NeuralField) -> (int64 tensor, float32 tensor).
+    ``band`` (exchange_band): keep only the voxels that can contribute to an evaluation inside the band -- at
+    level d those whose centre lies within 2.5 w_d of it (B-spline support 1.5 w_d, trilinear feature
+    stencil 1 w_d).  This is the "halo" payload of the rank exchange: evaluations
+    inside the band are bit-identical to those of the full field."""
     svh = f.svh
     nu = _udf_levels(f)
-    head = [svh.depth, f.kdim, int(f.approx_kernel_grad), nu] + [svh.num_voxels(d) for d in range(svh.depth)]
-    ints = torch.cat([torch.tensor(head, dtype=torch.int64, device=svh.device)] + [svh.level(d).keys for d in range(svh.depth)])
-    parts = [f._feat[d].reshape(-1) for d in range(svh.depth)] + [f.alpha]
+    keep = [None] * svh.depth
+    if band is not None:
+        for d in range(svh.depth):
+            g = svh.level(d)
+            w = g.voxel_size
+            m = torch.zeros(g.num_voxels, dtype=torch.bool, device=svh.device)
+            for a, lo, hi in band:
+                ca = (g.ijk[:, a].to(torch.float32) + 0.5) * w
+                m |= (ca >= lo - 2.5 * w) & (ca <= hi + 2.5 * w)
+            keep[d] = m
+    sel = lambda t, d: t if keep[d] is None else t[keep[d]]
+    off = svh.offsets
+    ns = [int(svh.num_voxels(d) if keep[d] is None else keep[d].sum()) for d in range(svh.depth)]
+    head = [svh.depth, f.kdim, int(f.approx_kernel_grad), nu] + ns
+    ints = torch.cat([torch.tensor(head, dtype=torch.int64, device=svh.device)] + [sel(svh.level(d).keys, d) for d in range(svh.depth)])
+    parts = [sel(f._feat[d], d).reshape(-1) for d in range(svh.depth)]
+    parts += [sel(f.alpha[off[d]:off[d] + svh.num_voxels(d)], d) for d in range(svh.depth)]
     if nu:
-        parts += [f.mask_field.features[d].reshape(-1) for d in range(nu)]
+        parts += [sel(f.mask_field.features[d], d).reshape(-1) for d in range(nu)]
         parts.append(torch.tensor([f.mask_field.level_set], dtype=torch.float32, device=svh.device))
     return ints, torch.cat(parts)
 
@@ -309,7 +343,11 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     rec.timing = timing
     nonempty = [c for c in range(nchunk) if counts[c] > 0]
     if ws > 1 and sim is None:
-        payload = D.exchange_payloads({c: pack_field(f) for c, f in local.items()}, nonempty)
+        # the exchange carries the halo of every chunk (the voxels other ranks can touch), not the whole field
+        def band_of(c):
+            c3 = (c // (grid[1] * grid[2]), (c // grid[2]) % grid[1], c % grid[2])
+            return exchange_band(cores[c], c3, grid, ov, hp.voxel_size)
+        payload = D.exchange_payloads({c: pack_field(f, band_of(c)) for c, f in local.items()}, nonempty)
         # a rank only evaluates the blend inside its own cores (+ one voxel): it needs exactly the
         # chunks whose weight support (core +- ov) reaches there -- its spatial neighbours, not all N
         need = needed_chunks(cores, ov + hp.voxel_size, grid, [c for c in nonempty if owner[c] == rank], nonempty)

@@ -37,12 +37,17 @@ def main():
         t0 = sync()
         mine = chunking.reconstruct_by_chunk(*args, sim=(me, world))
         t1 = sync()
-        payload = {c: chunking.pack_field(f) for c, f in mine.fields.items()}
+        payload = {}
+        for c, f in mine.fields.items():
+            c3 = (c // (mine.grid[1] * mine.grid[2]), (c // mine.grid[2]) % mine.grid[1], c % mine.grid[2])
+            payload[c] = chunking.pack_field(f, chunking.exchange_band(mine.cores[c], c3, mine.grid, mine.ov, rec.hparams.voxel_size))
         t2 = sync()
     others = {}
     for r in range(world):
         if r != me:
-            others.update({c: chunking.pack_field(f) for c, f in chunking.reconstruct_by_chunk(*args, sim=(r, world)).fields.items()})
+            for c, f in chunking.reconstruct_by_chunk(*args, sim=(r, world)).fields.items():
+                c3 = (c // (mine.grid[1] * mine.grid[2]), (c // mine.grid[2]) % mine.grid[1], c % mine.grid[2])
+                others[c] = chunking.pack_field(f, chunking.exchange_band(mine.cores[c], c3, mine.grid, mine.ov, rec.hparams.voxel_size))
     nonempty = sorted(list(payload) + list(others))
     owned = list(payload)
     need = chunking.needed_chunks(mine.cores, mine.ov + rec.hparams.voxel_size, mine.grid, owned, nonempty)

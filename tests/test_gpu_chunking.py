@@ -62,11 +62,19 @@ def test_chunked_matches_unchunked_geometry():
     assert np.abs(fa - fb).mean() < 0.02 * np.abs(full.alpha.cpu().numpy()).max()
 
 
-def test_simulated_two_ranks_equal_one_rank():
+def _wide_scene():
+    from nksr_amd import utils
+    xyz, nrm = utils.synth_scene(160000, seed=5, extent=(24.0, 10.0, 6.0), noise=0.0, n_objects=6)
+    return (xyz - xyz.min(0)).astype(np.float32), nrm
+
+
+@pytest.mark.parametrize('scene', ['small', 'wide'])
+def test_simulated_two_ranks_equal_one_rank(scene):
+    """'wide': chunks much wider than the overlap, so the exchanged halo is a small part of each field."""
     import nksr_amd
     from nksr_amd import chunking, dist
     dev = torch.device('cuda:0')
-    xyz, nrm = _scene()
+    xyz, nrm = _scene() if scene == 'small' else _wide_scene()
     rec = nksr_amd.Reconstructor(dev)
     t = lambda a: torch.from_numpy(a).to(dev)
     ext = float(xyz[:, 0].max() - xyz[:, 0].min())
@@ -84,9 +92,20 @@ def test_simulated_two_ranks_equal_one_rank():
             g = chunking.unpack_field(ints.clone(), flts.clone(), rec.hparams.voxel_size, rec.network.interpolators, dev)
             assert torch.equal(g.alpha, f.alpha) and all(torch.equal(g.svh.level(d).keys, f.svh.level(d).keys) for d in range(4))
             allf[c] = g
+    # what actually travels between ranks is the halo of every chunk (chunking.exchange_band): a rank sees its
+    # own chunks in full and the others cropped -- the merged mesh must not change by a single bit
+    halo = {}
+    for src in (r0, r1):
+        for c, f in src.fields.items():
+            c3 = (c // (one.grid[1] * one.grid[2]), (c // one.grid[2]) % one.grid[1], c % one.grid[2])
+            band = chunking.exchange_band(one.cores[c], c3, one.grid, one.ov, rec.hparams.voxel_size)
+            ints, flts = chunking.pack_field(f, band)
+            assert ints.numel() <= chunking.pack_field(f)[0].numel() * (1.0 if scene == 'small' else 0.6)
+            halo[c] = chunking.unpack_field(ints, flts, rec.hparams.voxel_size, rec.network.interpolators, dev)
     pieces = []
-    for r in (0, 1):
-        mf = r0.for_rank(r, 2, allf)          # r0 carries the 2-rank ownership table
+    for r, mine in ((0, r0), (1, r1)):
+        seen = {c: (mine.fields[c] if c in mine.fields else halo[c]) for c in allf}
+        mf = r0.for_rank(r, 2, seen)          # r0 carries the 2-rank ownership table
         from nksr_amd import meshing
         p = meshing._extract(mf, 1, 1, -1)
         pieces.append((p.v, p.f, p.edge_vkey, p.edge_axis))
