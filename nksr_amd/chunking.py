@@ -143,6 +143,11 @@ class ChunkUnionMask(BaseField):
 
 
 class MultiChunkField(BaseField):
+    """Partition-of-unity blend of the chunk fields.  With one rank it holds every chunk and is valid everywhere.
+    With several ranks a rank holds its own chunks in full and only the HALO of its spatial neighbours
+    (chunking.exchange_band): ``evaluate_f`` is then exact inside the rank's own cores (+ the one-voxel ring it
+    meshes) and must not be used elsewhere -- ``extract_dual_mesh`` respects that and gathers the pieces."""
+
     def __init__(self, fields, cores, ov, origin, chunk_size, grid, owner, rank, world_size, voxel_size, device):
         self.fields = fields              # {chunk id: KernelField}
         self.cores = cores                # {chunk id: (lo[3], hi[3])} model units
