@@ -1,22 +1,28 @@
 #!/usr/bin/env python
 """Headline benchmark (driver contract):  python bench.py --gpus N --steps K --warmup W
 
-metric  : reconstructed points/sec (solve + mesh), BASELINE.json
-workload: BASELINE.json configs[2] -- synthetic 1M-point oriented cloud per GPU,
-          detail_level=1.0, reconstruct() + extract_dual_mesh(mise_iter=1).  One "step" = one
-          full pass of the hot path over the rank's resident cloud.  Weak scaling: every rank
-          owns one 40x40x10 tile of the scene (tiles adjacent along x).
-roofline: the CG SpMV (csrc/pcg.hip k_spmv), algorithmic bytes 8*nnz + 12*M + 4 per launch
-          divided by the average launch duration measured live with HIP events on the solve
-          stream inside the timed region (nksr_pcg_profile).
-cpu_baseline: the CPU oracle ("port" -- the reference's own CPU path is the absent wheel) on a
-          bounded spatial crop of the same workload, timed on rank 0 at N=1.
+metric  : reconstructed points/sec (solve + mesh); CG SpMV HBM GB/s        (BASELINE.json)
+N = 1   : BASELINE.json configs[2] -- synthetic 1M-point oriented cloud, detail_level=1.0, reconstruct() +
+          extract_dual_mesh(mise_iter=1): the configuration the SpMV roofline is quoted on.  One "step" = one full pass
+          of the hot path over the resident cloud.  The line also carries
+            scale_scene  : configs[4] (below) on this one GPU, warm -- the N=1 point of the scaling curve
+            cpu_baseline : the reference's examples/recons_waymo_cpu.py call sequence on assets/bunny.ply on the host
+                           cores (oracle port, oracle/waymo_cpu.py), the GPU on the same input beside it, and a bounded
+                           crop of the configs[2] cloud through the oracle
+N > 1   : BASELINE.json configs[4] -- the north_star scaling scene: synthetic 10M-point km-scale terrain (8 x 8 tiles of
+          125 m, tree_depth=5), recons_by_chunk over 64 chunks, STRONG scaling: the same scene on 1/2/4/8 ranks.  Every
+          rank generates only the tiles of its own chunks and their neighbours (sharded input), solves its chunks with no
+          collective, exchanges chunk halos once (RCCL), meshes its cells; rank 0 gathers + stitches the mesh.
+roofline: the CG SpMV (csrc/pcg.hip k_spmv).  achieved = ALGORITHMIC bytes (8 nnz + 12 M + 4 per launch, SURVEY.md
+          section 8d) / average launch duration, measured live with HIP events on the solve stream inside the timed
+          region; ``achieved_physical`` counts the bytes the packed layout really streams.
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
 import sys
+import tempfile
 import time
 
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC only on this driver (RCCL peer mappings)
@@ -28,42 +34,70 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
+TILE = 125.0       # metres, configs[4]: 8 x 8 chunks of 125 m
+TILES = 8
 
 
-def load_traffic(bytes_per_launch=None):
-    """HBM bytes per SpMV launch from the committed rocprofv3 --pmc pass; None when the committed
-    pass was taken on a different matrix than this run's."""
-    best = None
+def load_traffic(bytes_per_launch):
+    """HBM bytes per SpMV launch from the committed rocprofv3 --pmc pass (profiles/*_spmv_pmc.json), used only when
+    that pass was taken on the same matrix as this run (same algorithmic bytes).  Returns (bytes, source file)."""
+    best = (None, None)
     pdir = os.path.join(ROOT, 'profiles')
     if os.path.isdir(pdir):
         for f in sorted(os.listdir(pdir)):
             if f.endswith('_spmv_pmc.json'):
                 try:
                     rec = json.load(open(os.path.join(pdir, f)))
-                    if bytes_per_launch is None or abs(rec.get('algorithmic_bytes_per_launch', 0) - bytes_per_launch) < 0.02 * bytes_per_launch:
-                        best = rec.get('hbm_bytes_per_launch')
+                    if abs(rec.get('algorithmic_bytes_per_launch', 0) - bytes_per_launch) < 0.02 * bytes_per_launch:
+                        best = (rec.get('hbm_bytes_per_launch'), 'profiles/' + f)
                 except Exception:
                     pass
     return best
 
 
-def cpu_baseline(xyz, nrm, scale, n_sample, mise_iter, net_params=None):
-    """Oracle pipeline on a spatial crop holding ~n_sample points (same density as the GPU run)."""
-    from oracle import pipeline
-    c = xyz[0]
-    d = np.abs(xyz - c).max(1)
-    idx = np.argsort(d)[:n_sample]
-    xs = (xyz[idx] * np.float32(scale)).astype(np.float32)
-    ns = nrm[idx]
-    t0 = time.perf_counter()
-    timing = {}
-    fld = pipeline.reconstruct(xs, ns, tol=1e-5, timing=timing, net_params=net_params)
-    v, f = pipeline.extract_dual_mesh(fld, mise_iter=mise_iter)
-    dt = time.perf_counter() - t0
-    return {'value': len(idx) / dt, 'unit': 'points/s', 'cores': 1, 'kind': 'port',
-            'sample': 'oracle.pipeline reconstruct+extract_dual_mesh(mise_iter=%d) on a %d-point spatial crop of the '
-                      'same cloud at the same scale: %.1fs (M=%d nnz=%d iters=%d)' % (
-                          mise_iter, len(idx), dt, timing.get('M', 0), timing.get('nnz', 0), timing.get('iters', 0))}
+def roofline_record(ms, launches, alg, phys):
+    avg_s = (ms / max(launches, 1)) * 1e-3
+    a = alg / max(launches, 1)
+    p = phys / max(launches, 1)
+    ach = a / avg_s if avg_s > 0 else 0.0
+    traffic, src = load_traffic(a) if launches else (None, None)
+    return {'bound': 'hbm', 'kernel': 'k_spmv<3,0> + k_spmv_fixup (packed-column CSR SpMV inside the PCG loop)',
+            'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': ach / HBM_PEAK,
+            'achieved_physical': (p / avg_s if avg_s > 0 else 0.0) / 1e9, 'frac_physical': (p / avg_s if avg_s > 0 else 0.0) / HBM_PEAK,
+            'traffic': traffic, 'traffic_source': src if traffic is not None else None,
+            'bytes_per_launch': a, 'physical_bytes_per_launch': p, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
+
+
+# ---- configs[4]: the scaling scene ------------------------------------------------------------------------------------
+def terrain_setup(rec, dev, n_total, rank, world):
+    """Sharded input of the 10M-point scene: the tiles of this rank's chunks and of their neighbours.  The chunk ->
+    rank map is the Morton-contiguous partition of nksr_amd.dist on equal weights (every tile holds n_total / 64
+    points), passed explicitly to reconstruct() so loader and solver agree."""
+    from nksr_amd import dist as D, utils
+    from nksr_amd.density import scale_for_detail_level
+    per = n_total // (TILES * TILES)
+    nchunk = TILES * TILES
+    owner = D.partition_chunks(nchunk, world, [per] * nchunk, grid=(TILES, TILES, 1))
+    t00 = utils.terrain_tile((0, 0), per, TILE, seed=0)[0]
+    scale = scale_for_detail_level(torch.from_numpy(t00).to(dev), 1.0, rec.hparams.voxel_size)   # same tile on every rank
+    need = set()
+    for c in range(nchunk):
+        if owner[c] == rank:
+            cx, cy = c // TILES, c % TILES            # chunk id = (cx * grid_y + cy) * grid_z + cz
+            for dx in (-1, 0, 1):
+                for dy in (-1, 0, 1):
+                    if 0 <= cx + dx < TILES and 0 <= cy + dy < TILES:
+                        need.add((cx + dx, cy + dy))
+    xs, ns = [], []
+    for t in sorted(need):
+        p, q = utils.terrain_tile(t, per, TILE, seed=0)
+        xs.append(p)
+        ns.append(q)
+    xyz = torch.from_numpy(np.concatenate(xs) * np.float32(scale)).to(dev)
+    nrm = torch.from_numpy(np.concatenate(ns)).to(dev)
+    n_scene = per * nchunk
+    bounds = ([0.0, 0.0, -40.0 * scale], [TILES * TILE * scale, TILES * TILE * scale, 40.0 * scale])
+    return xyz, nrm, scale, owner, bounds, n_scene, len(need)
 
 
 def main():
@@ -71,11 +105,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--points', type=int, default=1_000_000, help='points per GPU')
+    ap.add_argument('--points', type=int, default=1_000_000, help='configs[2] cloud size (N=1 headline)')
+    ap.add_argument('--scene-points', type=int, default=10_000_000, help='configs[4] scene size')
     ap.add_argument('--mise-iter', type=int, default=1)
     ap.add_argument('--detail-level', type=float, default=1.0)
-    ap.add_argument('--cpu-sample', type=int, default=20000)
+    ap.add_argument('--cpu-sample', type=int, default=10000, help='points of the configs[2] crop every CPU worker solves')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-scale-scene', action='store_true')
+    ap.add_argument('--scene', choices=['auto', 'cloud', 'terrain'], default='auto',
+                    help="'terrain' runs configs[4] as the headline at N=1 too")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -96,45 +134,7 @@ def main():
         dist.all_gather([torch.zeros_like(warm) for _ in range(world)], warm)
 
     import nksr_amd
-    from nksr_amd import solver, utils
-
-    extent = (40.0, 40.0, 10.0)
-    rec = nksr_amd.Reconstructor(dev)
-    rec.sync_timing = True
-    stage_acc = {}
-    if world == 1:
-        xyz_np, nrm_np = utils.synth_scene(args.points, seed=0, extent=extent, noise=0.01)
-        xyz = torch.from_numpy(xyz_np).to(dev)
-        nrm = torch.from_numpy(nrm_np).to(dev)
-        chunk_size = None
-    else:
-        # N tiles side by side along x, every rank holds the full cloud (reference semantics: one
-        # reconstruct() call over the scene); chunk_size = tile width => one chunk per rank.  The
-        # detail_level scale of the N=1 run is applied up front because chunk mode takes a pre-scaled
-        # cloud (NKSR-USAGE.md:137).
-        tiles = [utils.synth_scene(args.points, seed=r, extent=extent, noise=0.01, origin=(r * extent[0], 0.0, 0.0))
-                 for r in range(world)]
-        from nksr_amd.density import scale_for_detail_level
-        scale = scale_for_detail_level(torch.from_numpy(tiles[0][0]).to(dev), args.detail_level, rec.hparams.voxel_size)
-        xyz_np = np.concatenate([t[0] for t in tiles]) * np.float32(scale)
-        xyz_np[:, 0] -= xyz_np[:, 0].min()
-        nrm_np = np.concatenate([t[1] for t in tiles])
-        xyz = torch.from_numpy(xyz_np.astype(np.float32)).to(dev)
-        nrm = torch.from_numpy(nrm_np).to(dev)
-        chunk_size = float(xyz_np[:, 0].max()) / world + 1e-3
-
-    def step():
-        if chunk_size is None:
-            field = rec.reconstruct(xyz, nrm, detail_level=args.detail_level)
-        else:
-            field = rec.reconstruct(xyz, nrm, detail_level=None, chunk_size=chunk_size)
-        t0 = time.perf_counter()
-        mesh = field.extract_dual_mesh(mise_iter=args.mise_iter)
-        torch.cuda.synchronize()
-        tm = time.perf_counter() - t0
-        for k, v in list(rec.timing.items()) + [('t_mesh', tm)]:
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
-        return field, mesh
+    from nksr_amd import configs, solver, utils
 
     def fence():
         torch.cuda.synchronize()
@@ -142,59 +142,143 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    stage_acc.clear()
-    solver.profile_spmv(True)
-    fence()
-    t0 = time.perf_counter()
-    step_ends = []
-    field = mesh = None
-    for _ in range(args.steps):
-        # the previous result is released first: every step then has the memory footprint of the warmup step
-        # and the caching allocator serves it from its pool (holding the old field while building the new one
-        # made the second timed step pay ~40 ms of fresh hipMalloc)
-        field = mesh = None
-        field, mesh = step()
-        step_ends.append(time.perf_counter())     # step() ends with a device sync
-    fence()
-    dt = time.perf_counter() - t0
-    if os.environ.get('NKSR_BENCH_VERBOSE'):
-        print('per-step ms:', [round((b - a) * 1e3, 1) for a, b in zip([t0] + step_ends[:-1], step_ends)], file=sys.stderr)
-    spmv_ms, spmv_launches = solver.profile_spmv(False)
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed_loop(step, steps, warmup, stage_acc):
+        """W untimed warm-up steps, then EXACTLY K timed steps between two barrier + device-sync fences; max over ranks."""
+        for _ in range(warmup):
+            step(None)
+        stage_acc.clear()
+        solver.profile_spmv(True)
+        solver.profile_spmv_bytes()
+        fence()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            # the previous result is released first: every step then has the memory footprint of the warm-up step and
+            # the caching allocator serves it from its pool
+            out = None
+            out = step(stage_acc)
+        fence()
+        dt = time.perf_counter() - t0
+        ms, launches = solver.profile_spmv(False)
+        alg, phys = solver.profile_spmv_bytes()
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, out, (ms, launches, alg, phys)
 
-    info = field.solve_info if world == 1 else [f for f in field.fields.values() if f.solve_info][0].solve_info
-    M, nnz = info['M'], info['nnz']
-    b_spmv = 8.0 * nnz + 12.0 * M + 4.0
-    avg_s = (spmv_ms / max(spmv_launches, 1)) * 1e-3
-    achieved = b_spmv / avg_s if avg_s > 0 else 0.0
-    total_points = args.points * world * args.steps
+    def acc_stages(acc, rec, tm):
+        if acc is not None:
+            for k, v in list(rec.timing.items()) + [('t_mesh', tm)]:
+                acc[k] = acc.get(k, 0.0) + v
+
+    # ---- configs[4]: strong-scaling scene ----------------------------------------------------------------------------
+    def run_terrain(steps, warmup):
+        rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', tree_depth=5))
+        rec.sync_timing = True
+        xyz, nrm, scale, owner, bounds, n_scene, ntiles = terrain_setup(rec, dev, args.scene_points, rank, world)
+        chunk_size = TILE * scale
+
+        def step(acc):
+            field = rec.reconstruct(xyz, nrm, detail_level=None, chunk_size=chunk_size, sharded_input=True, chunk_owner=owner,
+                                    chunk_bounds=bounds)
+            t0 = time.perf_counter()
+            mesh = field.extract_dual_mesh(mise_iter=args.mise_iter)
+            torch.cuda.synchronize()
+            acc_stages(acc, rec, time.perf_counter() - t0)
+            return field, mesh
+
+        acc = {}
+        dt, (field, mesh), prof = timed_loop(step, steps, warmup, acc)
+        infos = [f.solve_info for f in field.fields.values() if f.solve_info]
+        cfg = {'workload': 'configs[4]: synthetic %d-point km-scale terrain + boxes (8x8 tiles of 125 m), tree_depth=5, chunk_size=125 m '
+                           '(64 chunks), reconstruct(chunk_size=)+extract_dual_mesh(mise_iter=%d), STRONG scaling' % (n_scene, args.mise_iter),
+               'scene_points': n_scene, 'tree_depth': 5, 'kernel_dim': rec.hparams.kernel_dim, 'global_scale': scale,
+               'chunks': TILES * TILES, 'chunks_this_rank': sum(1 for c in owner if c == rank), 'tiles_loaded_this_rank': ntiles,
+               'points_resident_this_rank': int(xyz.shape[0]),
+               'unknowns_M_per_chunk': int(np.mean([i['M'] for i in infos])) if infos else 0,
+               'nnz_A_per_chunk': int(np.mean([i['nnz'] for i in infos])) if infos else 0,
+               'pcg_iters_per_chunk': float(np.mean([i['iters'] for i in infos])) if infos else 0,
+               'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]),
+               'parallelism': 'none' if world == 1 else 'chunks sharded over %d ranks (Morton-contiguous), sharded input, no collective in the solve, '
+                                                        'one halo exchange, mesh gather + stitch on rank 0' % world}
+        return dt, n_scene, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}
+
+    # ---- configs[2]: the roofline workload ---------------------------------------------------------------------------
+    def run_cloud(steps, warmup):
+        rec = nksr_amd.Reconstructor(dev)
+        rec.sync_timing = True
+        xyz_np, nrm_np = utils.synth_scene(args.points, seed=0, extent=(40.0, 40.0, 10.0), noise=0.01)
+        xyz, nrm = torch.from_numpy(xyz_np).to(dev), torch.from_numpy(nrm_np).to(dev)
+
+        def step(acc):
+            field = rec.reconstruct(xyz, nrm, detail_level=args.detail_level)
+            t0 = time.perf_counter()
+            mesh = field.extract_dual_mesh(mise_iter=args.mise_iter)
+            torch.cuda.synchronize()
+            acc_stages(acc, rec, time.perf_counter() - t0)
+            return field, mesh
+
+        acc = {}
+        dt, (field, mesh), prof = timed_loop(step, steps, warmup, acc)
+        info = field.solve_info
+        cfg = {'workload': 'configs[2]: synthetic %d-point oriented cloud (8 spheres/tori in a 40x40x10 box, sigma=0.01), '
+                           'detail_level=%.1f, reconstruct()+extract_dual_mesh(mise_iter=%d)' % (args.points, args.detail_level, args.mise_iter),
+               'points': args.points, 'tree_depth': rec.hparams.tree_depth, 'kernel_dim': rec.hparams.kernel_dim,
+               'unknowns_M': info['M'], 'nnz_A': info['nnz'], 'pcg_iters': info['iters'], 'pcg_rel_residual': info['rel_residual'],
+               'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]), 'global_scale': field.scale,
+               'parallelism': 'none'}
+        return dt, args.points, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}, (rec, xyz_np, nrm_np, field.scale)
+
+    terrain_headline = world > 1 or args.scene == 'terrain'
+    extra = None
+    if terrain_headline:
+        dt, npts, cfg, prof, stages = run_terrain(args.steps, args.warmup)
+    else:
+        dt, npts, cfg, prof, stages, extra = run_cloud(args.steps, args.warmup)
     out = {
-        'metric': 'reconstructed points/sec (solve+mesh)', 'value': total_points / dt, 'unit': 'points/s',
+        'metric': 'reconstructed points/sec (solve+mesh)', 'value': npts * args.steps / dt, 'unit': 'points/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'configs[2]: synthetic %d-point oriented cloud per GPU (8 spheres/tori in a 40x40x10 tile, '
-                               'sigma=0.01), detail_level=%.1f, reconstruct()+extract_dual_mesh(mise_iter=%d)' % (
-                                   args.points, args.detail_level, args.mise_iter),
-                   'points_per_gpu': args.points, 'tree_depth': rec.hparams.tree_depth, 'kernel_dim': rec.hparams.kernel_dim,
-                   'unknowns_M': M, 'nnz_A': nnz, 'pcg_iters': info['iters'], 'pcg_rel_residual': info['rel_residual'],
-                   'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]),
-                   'global_scale': field.scale if world == 1 else scale,
-                   'parallelism': 'none' if world == 1 else 'chunks sharded 1/rank, all_gather of solved fields before meshing, mesh gather'},
-        'roofline': {'bound': 'hbm', 'kernel': 'k_spmv<0> + k_spmv_fixup (CSR SpMV inside the PCG loop)',
-                     'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK,
-                     'traffic': load_traffic(b_spmv), 'bytes_per_launch': b_spmv, 'avg_launch_us': avg_s * 1e6,
-                     'launches_timed': spmv_launches},
-        'stages_s_per_step': {k: v / args.steps for k, v in sorted(stage_acc.items())},
+        'higher_is_better': True, 'scaling': 'strong' if terrain_headline else 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic', 'config': cfg, 'roofline': roofline_record(*prof), 'stages_s_per_step': stages,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import network as onet
-        out['cpu_baseline'] = cpu_baseline(xyz_np, nrm_np, field.scale, args.cpu_sample, args.mise_iter,
-                                           onet.export_params(rec.network))
+    if not terrain_headline and not args.no_scale_scene:
+        # the same scene the N > 1 runs solve, on this one GPU (1 warm-up + 2 timed steps): the N=1 point of the curve
+        torch.cuda.empty_cache()
+        sdt, sn, scfg, sprof, sstages = run_terrain(2, 1)
+        out['scale_scene'] = {'value': sn * 2 / sdt, 'unit': 'points/s', 'ms_per_step': sdt / 2 * 1e3, 'steps': 2, 'warmup': 1,
+                              'config': scfg, 'roofline': roofline_record(*sprof), 'stages_s_per_step': sstages}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and extra is not None:
+        from oracle import waymo_cpu
+        rec, xyz_np, nrm_np, scale = extra
+        # bounded crop of the configs[2] cloud (model units), one per CPU worker
+        c = xyz_np[0]
+        idx = np.argsort(np.abs(xyz_np - c).max(1))[:args.cpu_sample]
+        crop = os.path.join(tempfile.gettempdir(), 'nksr_bench_crop_%d.npz' % os.getpid())
+        np.savez(crop, xyz=(xyz_np[idx] * np.float32(scale)).astype(np.float32), normal=nrm_np[idx], mise_iter=args.mise_iter)
+        try:
+            cb = waymo_cpu.measure(cores=os.cpu_count(), repeats=4, crop=crop)
+        finally:
+            if os.path.exists(crop):
+                os.remove(crop)
+        # the GPU on the same input (same call sequence, sensor-only, through the product's preprocess_fn)
+        d = np.load(waymo_cpu.BUNNY)
+        bx = torch.from_numpy(d['xyz']).to(dev)
+        bs = torch.from_numpy(waymo_cpu.synth_sensors(d['xyz'], d['normal'])).to(dev)
+        fn = nksr_amd.get_estimate_normal_preprocess_fn(64, 85.0)
+
+        def gpu_seq():
+            f = rec.reconstruct(bx, sensor=bs, detail_level=None, approx_kernel_grad=True, solver_tol=1e-4, fused_mode=True, preprocess_fn=fn)
+            return f.extract_dual_mesh(mise_iter=1)
+        gpu_seq()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            m = gpu_seq()
+        torch.cuda.synchronize()
+        cb['gpu_same_input'] = {'value': 5 * bx.shape[0] / (time.perf_counter() - t0), 'unit': 'points/s', 'mesh_triangles': int(m.f.shape[0]),
+                                'note': 'one 10 000-point scan at a time on one MI355X: launch-latency bound, not a throughput figure'}
+        out['cpu_baseline'] = cb
     elif rank == 0:
         out['cpu_baseline'] = None
     if rank == 0:

@@ -200,6 +200,9 @@ int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, c
 /* Live profiling of the SpMV launches inside nksr_pcg_solve (HIP events on the solve's stream).
  * Returns and resets the accumulated milliseconds / launch count, then sets the enable flag. */
 int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out);
+/* Bytes of the launches timed since the last call (then reset): the algorithmic CSR figure 8 nnz + 12 M + 4 per
+ * launch and the bytes the physical layout streams (col_format, padding). */
+int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_out);
 
 /* ---- grid-hash nearest neighbours (csrc/knn.hip) ----------------------------------------------------
  * Points Morton-sorted by a uniform grid of size `cell` (keys from nksr_point_keys with inv_w0 =

@@ -33,9 +33,12 @@ def _load():
     if _build.needs_build():
         try:
             _build.build_library()
-        except Exception as e:  # stale/missing library and no compiler: fail loudly
+        except Exception as e:  # stale/missing library and no working compiler: fail loudly, never load a stale build silently
             if not os.path.exists(path):
                 raise RuntimeError('libnksr_hip.so is missing and could not be built: %s' % e)
+            if not os.environ.get('NKSR_ALLOW_STALE_LIB'):
+                raise RuntimeError('libnksr_hip.so is older than its sources and the rebuild failed (%s); set '
+                                   'NKSR_ALLOW_STALE_LIB=1 to load it anyway' % e)
     return C.CDLL(path)
 
 
@@ -86,6 +89,7 @@ _PROTOS = {
     'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _vp, _vp],
     'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
+    'nksr_pcg_profile_bytes': [_P(C.c_double), _P(C.c_double)],
     'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
     'nksr_nearest_index': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, _vp, _vp],
     'nksr_base_cell_flags': [_vp, _i32, _vp, _vp],

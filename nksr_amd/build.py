@@ -4,6 +4,8 @@ No torch types cross the boundary, so the library is built with plain hipcc and 
 through ctypes (nksr_amd/_lib.py).  The .so stays in-tree (git-ignored) so it travels to
 the GPU box with the snapshot.
 """
+import fcntl
+import hashlib
 import os
 import subprocess
 import sys
@@ -24,11 +26,25 @@ def _deps():
     return files
 
 
+STAMP = LIB + '.srchash'        # hash of the sources + flags the library was built from (travels with the .so)
+
+
+def source_hash():
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for f in sorted(_deps()):
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """Stale when the library is missing or was built from other sources / flags.  Content hash, not mtimes: a
+    snapshot copied to another box (gpurun) does not preserve them."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in _deps())
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def _compile(src):
@@ -44,17 +60,33 @@ def _compile(src):
 
 
 def build_library(force=False, verbose=False):
+    """Compile + link under an exclusive file lock (one process per GPU imports this package at the same time under
+    torchrun); the library is linked to a temporary name and renamed into place, so a concurrent loader never sees a
+    truncated file."""
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if not force and not needs_build():
         return LIB
-    if not os.path.exists(HIPCC):
-        raise RuntimeError('hipcc not found at %s and %s is missing/stale' % (HIPCC, LIB))
-    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        objs = list(ex.map(_compile, srcs))
-    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    with open(LIB + '.lock', 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():      # another process built it while we waited
+                return LIB
+            if not os.path.exists(HIPCC):
+                raise RuntimeError('hipcc not found at %s and %s is missing/stale' % (HIPCC, LIB))
+            stamp = source_hash()
+            with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+                objs = list(ex.map(_compile, srcs))
+            tmp = '%s.tmp.%d' % (LIB, os.getpid())
+            cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+            os.replace(tmp, LIB)
+            with open(STAMP + '.tmp', 'w') as fh:
+                fh.write(stamp + '\n')
+            os.replace(STAMP + '.tmp', STAMP)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     if verbose:
         print('built', LIB, file=sys.stderr)
     return LIB

@@ -5,7 +5,7 @@ normal, detail_level=None, chunk_size=50.0)`` examples/recons_by_chunk.py:29; so
 parked on ``chunk_tmp_device`` (:27); "Tuning detail_level / voxel_size is not supported if
 chunk_size is provided" NKSR-USAGE.md:137.  Spec:
   * the bounding box is cut into a grid of ``chunk_size`` cubes; chunk c solves the points inside
-    core_c +- 2*ov (ov = max(overlap_ratio*chunk_size, 1.6 * coarsest voxel size))
+    core_c +- band (ov = max(overlap_ratio*chunk_size, OV_FLOOR coarsest voxels), band = ov + BAND_EXTRA coarsest voxels)
   * the global field is the partition-of-unity blend  f = sum_c w_c f_c / sum_c w_c  with
     w_c(x) = prod_axis ramp((x - (lo-ov)) / 2ov) * ramp(((hi+ov) - x) / 2ov)  (linear ramps of
     neighbouring chunks add up to 1 inside the 2*ov band; a chunk's weight vanishes ov inside
@@ -13,9 +13,10 @@ chunk_size is provided" NKSR-USAGE.md:137.  Spec (DESIGN.md s
   * all chunks share ONE global voxel lattice (cells are floor(x / w) in global coordinates), so
     the union of the chunks' finest levels is a consistent dual grid; every dual cell is meshed by
     the rank that owns the chunk whose core contains the cell's base voxel centre.
-Multi-GPU (one process per GPU): chunks are sharded over ranks (nksr_amd.dist); each rank must be
-given the same full cloud.  No collective on the solve path, one all_gather of the packed chunk
-fields before meshing, one gather of the mesh pieces after it.
+Multi-GPU (one process per GPU): chunks are sharded over ranks (nksr_amd.dist) along a Morton curve; every rank is
+given either the same full cloud or -- ``sharded_input=True`` -- only the points of its own chunks (+ band).  No
+collective on the solve path, one all_gather of the chunk HALOS before meshing, one point-to-point gather of the
+mesh pieces to rank 0 after it.
 """
 import math
 
@@ -291,17 +292,50 @@ class MultiChunkField(BaseField):
         return self
 
 
+OV_FLOOR = 1.6        # blend half-width floor, in coarsest voxels
+BAND_EXTRA = None     # data margin beyond core +- ov, in coarsest voxels; None = ov (chunk solves core +- 2 ov)
+MIN_CHUNK_POINTS = 8
+
+
+def chunk_geometry(hp, chunk_size, overlap_ratio):
+    wc = hp.voxel_size * 2 ** (hp.tree_depth - 1)
+    ov = max(overlap_ratio * chunk_size, OV_FLOOR * wc)
+    band = 2 * ov if BAND_EXTRA is None else ov + BAND_EXTRA * wc
+    return ov, band
+
+
 def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, approx_kernel_grad, solver_max_iter,
-                         solver_tol, fused_mode, preprocess_fn, sim=None):
-    """``sim=(rank, world_size)`` runs one simulated rank without a process group (tests)."""
+                         solver_tol, fused_mode, preprocess_fn, sim=None, sharded_input=False, chunk_owner=None, chunk_bounds=None):
+    """``sim=(rank, world_size)`` runs one simulated rank without a process group (tests).
+    ``sharded_input``: every rank passes only ITS part of the cloud -- at least the points inside core +- band of the
+    chunks it owns ("each rank receives only its chunks' points (+overlap)").  The chunk grid then
+    comes from ``chunk_bounds`` = (lo[3], hi[3]) or from an all_reduce of the local bounding boxes, the per-core point
+    counts from an all_reduce(MAX) (some rank holds every core completely), and ``chunk_owner`` (list, one rank per
+    chunk) lets the caller that distributed the data dictate the ownership it assumed."""
     hp = rec.hparams
     dev = rec.device
     rank, ws = sim if sim is not None else D.world()
+    collective = sharded_input and ws > 1 and sim is None
     from .density import bbox_center
-    lo_t, hi_t, _ = bbox_center(xyz)
-    lo, hi = [float(v) for v in lo_t.tolist()], [float(v) for v in hi_t.tolist()]
+    if xyz.shape[0] and (not bool(torch.isfinite(xyz).all())):
+        raise RuntimeError('non-finite coordinates in the input')
+    if chunk_bounds is not None:
+        lo, hi = [float(v) for v in chunk_bounds[0]], [float(v) for v in chunk_bounds[1]]
+    else:
+        if xyz.shape[0]:
+            lo_t, hi_t, _ = bbox_center(xyz)
+        else:
+            lo_t = torch.full((3,), float('inf'), device=dev)
+            hi_t = -lo_t
+        if collective:
+            import torch.distributed as dist
+            cd = D._comm_device(lo_t)
+            lo_t, hi_t = lo_t.to(cd), hi_t.to(cd)
+            dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+        lo, hi = [float(v) for v in lo_t.tolist()], [float(v) for v in hi_t.tolist()]
     grid = chunk_grid(lo, hi, chunk_size)
-    ov = max(overlap_ratio * chunk_size, 1.6 * hp.voxel_size * 2 ** (hp.tree_depth - 1))
+    ov, band = chunk_geometry(hp, chunk_size, overlap_ratio)
     nchunk = grid[0] * grid[1] * grid[2]
     cores = {}
     for c in range(nchunk):
@@ -317,26 +351,50 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
         else:
             ia = 0
         cid = cid * grid[a] + ia
-    counts = torch.bincount(cid, minlength=nchunk).tolist()
-    owner = D.partition_chunks(nchunk, ws, counts)
+    counts_t = torch.bincount(cid, minlength=nchunk)
+    local_counts = counts_t.tolist()
+    if collective:
+        import torch.distributed as dist
+        ct = counts_t.to(D._comm_device(counts_t))
+        dist.all_reduce(ct, op=dist.ReduceOp.MAX)
+        counts = ct.tolist()
+    else:
+        counts = local_counts
+    if chunk_owner is not None:
+        if len(chunk_owner) != nchunk:
+            raise RuntimeError('chunk_owner has %d entries, the chunk grid %s has %d chunks' % (len(chunk_owner), grid, nchunk))
+        owner = [int(o) for o in chunk_owner]
+    else:
+        owner = D.partition_chunks(nchunk, ws, counts, grid)
     local = {}
     timing = {}
     for c in range(nchunk):
         if owner[c] != rank or counts[c] == 0:
             continue
+        if sharded_input and local_counts[c] != counts[c]:
+            raise RuntimeError('sharded input: rank %d owns chunk %d but holds %d of its %d core points' % (rank, c, local_counts[c], counts[c]))
         clo, chi = cores[c]
-        m = None                                  # points inside core +- 2 ov (only along the split axes)
+        m = None                                  # points inside core +- band (only along the split axes)
         for a in range(3):
             if grid[a] > 1:
-                ma = (xyz[:, a] >= clo[a] - 2 * ov) & (xyz[:, a] < chi[a] + 2 * ov)
+                ma = (xyz[:, a] >= clo[a] - band) & (xyz[:, a] < chi[a] + band)
                 m = ma if m is None else (m & ma)
         idx = torch.nonzero(m).reshape(-1) if m is not None else torch.arange(xyz.shape[0], device=dev)
         cx_, cn_, cs_ = xyz[idx].contiguous(), (normal[idx].contiguous() if normal is not None else None), \
             (sensor[idx].contiguous() if sensor is not None else None)
         if preprocess_fn is not None:
-            cx_, cn_, cs_ = preprocess_fn(cx_, cn_, cs_)
+            try:
+                cx_, cn_, cs_ = preprocess_fn(cx_, cn_, cs_)
+            except RuntimeError as e:
+                if 'need at least' in str(e):     # too few points for the normal estimator: treat the chunk as empty
+                    continue
+                raise
         if cn_ is None:
             raise RuntimeError('oriented input required (normal= or sensor= with a normal-estimating preprocess_fn)')
+        if cx_.shape[0] < MIN_CHUNK_POINTS:       # a handful of stray points: nothing to solve, neighbours cover the band
+            continue
+        if not bool(torch.isfinite(cn_).all()):
+            raise RuntimeError('non-finite normals in the input')
         fld = rec._reconstruct_single(cx_.contiguous(), cn_.to(torch.float32).contiguous(), approx_kernel_grad,
                                       solver_max_iter, solver_tol, fused_mode)
         for k, v in rec.timing.items():
@@ -346,16 +404,17 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
             fld.to_(rec.chunk_tmp_device)  # reference semantics: park solved chunks elsewhere
         local[c] = fld
     rec.timing = timing
-    nonempty = [c for c in range(nchunk) if counts[c] > 0]
     if ws > 1 and sim is None:
-        # the exchange carries the halo of every chunk (the voxels other ranks can touch), not the whole field
+        # the exchange carries the halo of every chunk (the voxels other ranks can touch), not the whole field; which
+        # chunks were actually solved travels with it (a sparse chunk may have been skipped by its owner)
         def band_of(c):
             c3 = (c // (grid[1] * grid[2]), (c // grid[2]) % grid[1], c % grid[2])
             return exchange_band(cores[c], c3, grid, ov, hp.voxel_size)
-        payload = D.exchange_payloads({c: pack_field(f, band_of(c)) for c, f in local.items()}, nonempty)
-        # a rank only evaluates the blend inside its own cores (+ one voxel): it needs exactly the
+        payload = D.exchange_payloads({c: pack_field(f, band_of(c)) for c, f in local.items()})
+        solved = sorted(payload)
+        # a rank only evaluates the blend inside its own cores (+ the halo ring it evaluates): it needs exactly the
         # chunks whose weight support (core +- ov) reaches there -- its spatial neighbours, not all N
-        need = needed_chunks(cores, ov + hp.voxel_size, grid, [c for c in nonempty if owner[c] == rank], nonempty)
+        need = needed_chunks(cores, ov + 2.5 * hp.voxel_size, grid, [c for c in solved if owner[c] == rank], solved)
         fields = {c: (local[c] if c in local else unpack_field(payload[c][0], payload[c][1], hp.voxel_size,
                                                               rec.network.interpolators, dev)) for c in need}
     else:

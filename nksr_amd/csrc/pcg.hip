@@ -401,7 +401,24 @@ extern "C" int nksr_spmv_csr(const int32_t* rowptr, const void* cols, const floa
 static int g_prof_enable = 0;
 static double g_prof_ms = 0.0;
 static long long g_prof_launches = 0;
+static double g_prof_alg_bytes = 0.0, g_prof_phys_bytes = 0.0;
 static std::vector<hipEvent_t> g_prof_events;
+
+// bytes one SpMV launch moves: algorithmic CSR figure of SURVEY.md section 8d (8 nnz + 12 M + 4) and what the physical
+// layout actually streams (values + packed / int32 columns over the padded storage + row pointers + x + y)
+static void spmv_bytes(int M, int64_t nnz, int fmt, double* alg, double* phys) {
+    *alg = 8.0 * (double)nnz + 12.0 * (double)M + 4.0;
+    const int chunk = spmv_chunk(fmt);
+    const double npad = (double)((nnz + chunk - 1) / chunk) * chunk;
+    *phys = (fmt == 1 ? (4.0 + 8.0 / 3.0) : 8.0) * npad + 12.0 * (double)M + 4.0;
+}
+
+extern "C" int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_out) {
+    if (algorithmic_out) *algorithmic_out = g_prof_alg_bytes;
+    if (physical_out) *physical_out = g_prof_phys_bytes;
+    g_prof_alg_bytes = g_prof_phys_bytes = 0.0;
+    return NKSR_OK;
+}
 
 extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out) {
     if (ms_out) *ms_out = g_prof_ms;
@@ -459,6 +476,10 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const flo
                 if (hipEventElapsedTime(&ms, g_prof_events[2 * c], g_prof_events[2 * c + 1]) == hipSuccess) {
                     g_prof_ms += ms;
                     g_prof_launches += 1;
+                    double ba, bp;
+                    spmv_bytes(M, nnz, col_format, &ba, &bp);
+                    g_prof_alg_bytes += ba;
+                    g_prof_phys_bytes += bp;
                 }
             }
         }

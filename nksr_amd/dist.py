@@ -5,11 +5,11 @@ The solve of a chunk is independent of every other chunk (the reference runs chu
 on one device, examples/recons_by_chunk.py:26-29), so chunks are sharded over ranks with NO
 collective on the solve path.  Exactly one exchange step precedes meshing -- every rank needs the
 solved fields that overlap the cells it meshes -- and one gather step follows it:
-  * exchange_payloads: all_gather of sizes, then all_gather of padded int64 / float32 buffers
-    (payloads are tens of MB: latency-, not bandwidth-bound; the fully connected xGMI mesh
-    serves an all_gather as direct peer copies, no ring bottleneck)
-  * gather_meshes: same pattern to rank 0, then seam vertices are merged by their canonical
-    (lattice key, axis) identity.
+  * exchange_payloads: ONE all_gather of sizes (the only host sync) + ONE all_gather of a padded byte buffer
+    holding every chunk halo of the rank (a couple of MB: latency-, not bandwidth-bound; on the fully
+    connected xGMI mesh an all_gather is direct peer copies, no ring bottleneck)
+  * gather_meshes: one size collective, then point-to-point transfers to rank 0 only (the other ranks
+    receive nothing); rank 0 merges seam vertices by their canonical (lattice key, axis) identity.
 Everything here works on CPU tensors too, so the protocol is covered by world_size-2 gloo tests.
 """
 import torch
@@ -25,18 +25,36 @@ def world():
     return (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
 
 
-def partition_chunks(n_chunks, world_size, weights=None):
-    """owner[c] for every chunk: greedy longest-processing-time balance on ``weights`` (point
-    counts), ties broken by chunk index => identical on every rank."""
+def _morton3(x, y, z):
+    k = 0
+    for b in range(21):
+        k |= ((x >> b) & 1) << (3 * b) | ((y >> b) & 1) << (3 * b + 1) | ((z >> b) & 1) << (3 * b + 2)
+    return k
+
+
+def partition_chunks(n_chunks, world_size, weights=None, grid=None):
+    """owner[c] for every chunk.  Chunks are ordered along a Morton curve over their grid position (``grid`` = chunks per
+    axis, chunk id = (cx * grid[1] + cy) * grid[2] + cz; plain index order without it) and the curve is cut into
+    ``world_size`` contiguous pieces of (nearly) equal total ``weights`` (point counts): a rank's chunks are spatially
+    compact, so it shares halos with few other ranks and -- with sharded input -- loads few extra tiles.  Pure integer
+    arithmetic => identical on every rank."""
     if weights is None:
         return [c % world_size for c in range(n_chunks)]
-    order = sorted(range(n_chunks), key=lambda c: (-int(weights[c]), c))
-    load = [0] * world_size
+    if grid is not None:
+        g1, g2 = int(grid[1]), int(grid[2])
+        order = sorted(range(n_chunks), key=lambda c: (_morton3(c // (g1 * g2), (c // g2) % g1, c % g2), c))
+    else:
+        order = list(range(n_chunks))
+    w = [max(int(weights[c]), 0) for c in range(n_chunks)]
+    total = sum(w)
     owner = [0] * n_chunks
+    if total == 0:
+        return [c % world_size for c in range(n_chunks)]
+    acc = 0
     for c in order:
-        r = min(range(world_size), key=lambda k: (load[k], k))
-        owner[c] = r
-        load[r] += int(weights[c])
+        # rank of the piece that holds the midpoint of this chunk's weight interval
+        owner[c] = min(world_size - 1, ((2 * acc + w[c]) * world_size) // (2 * total))
+        acc += w[c]
     return owner
 
 
@@ -45,58 +63,126 @@ def _comm_device(t):
     return t.device if dist.get_backend() != 'gloo' else torch.device('cpu')
 
 
-def all_gather_variable(t):
-    """all_gather of 1-D tensors whose lengths differ per rank.  Returns the list of per-rank
-    tensors (on t's device)."""
+def _default_device():
+    import torch.distributed as dist
+    return torch.device('cpu') if dist.get_backend() == 'gloo' else torch.device('cuda', torch.cuda.current_device())
+
+
+def _pack_bytes(tensors):
+    """list of tensors (any dtype) -> (uint8 buffer, [(dtype, numel)])."""
+    parts = [t.contiguous().reshape(-1).view(torch.uint8) for t in tensors]
+    pad = [torch.zeros((-p.numel()) % 8, dtype=torch.uint8, device=p.device) for p in parts]     # keep every part 8-byte aligned
+    buf = torch.cat([x for pp in zip(parts, pad) for x in pp]) if parts else torch.zeros(0, dtype=torch.uint8)
+    return buf, [(t.dtype, t.numel()) for t in tensors]
+
+
+def _unpack_bytes(buf, dtypes, numels):
+    out, o = [], 0
+    for dt, n in zip(dtypes, numels):
+        nb = n * torch.empty(0, dtype=dt).element_size()
+        out.append(buf[o:o + nb].view(dt))
+        o += nb + ((-nb) % 8)
+    return out
+
+
+def all_gather_tensors(tensors):
+    """all_gather of a LIST of 1-D tensors whose lengths differ per rank (dtypes are the same on every rank): ONE size
+    collective ([k] int64 per rank, the only host sync) + ONE padded byte collective.  Returns per rank the list of
+    tensors, on the device of the inputs."""
     import torch.distributed as dist
     rank, ws = world()
     if ws == 1:
-        return [t]
-    dev = _comm_device(t)
-    n = torch.tensor([t.numel()], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros_like(n) for _ in range(ws)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(max(sizes), 1)
-    buf = torch.zeros(mx, dtype=t.dtype, device=dev)
-    buf[:t.numel()] = t.to(dev)
-    out = [torch.empty_like(buf) for _ in range(ws)]
-    dist.all_gather(out, buf)
-    return [o[:s].to(t.device) for o, s in zip(out, sizes)]
+        return [list(tensors)]
+    src_dev = tensors[0].device
+    dev = _comm_device(tensors[0])
+    buf, meta = _pack_bytes([t.to(dev) for t in tensors])
+    k = len(tensors)
+    n = torch.tensor([m[1] for m in meta], dtype=torch.int64, device=dev)
+    sizes = torch.empty(ws * k, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, n) if dist.get_backend() != 'gloo' else dist.all_gather(list(sizes.view(ws, k).unbind(0)), n)
+    sizes = sizes.view(ws, k).tolist()                       # one host sync for the whole exchange
+    es = [torch.empty(0, dtype=m[0]).element_size() for m in meta]
+    nbytes = [sum(s * e + ((-(s * e)) % 8) for s, e in zip(row, es)) for row in sizes]
+    mx = max(max(nbytes), 8)
+    send = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    send[:buf.numel()] = buf
+    out = torch.empty(ws * mx, dtype=torch.uint8, device=dev)
+    if dist.get_backend() != 'gloo':
+        dist.all_gather_into_tensor(out, send)
+    else:
+        dist.all_gather(list(out.view(ws, mx).unbind(0)), send)
+    res = []
+    for r in range(ws):
+        res.append([t.to(src_dev) for t in _unpack_bytes(out[r * mx:r * mx + nbytes[r]], [m[0] for m in meta], sizes[r])])
+    return res
 
 
-def exchange_payloads(local, expected_ids):
+def all_gather_variable(t):
+    """all_gather of 1-D tensors whose lengths differ per rank.  Returns the list of per-rank tensors (on t's device)."""
+    return [r[0] for r in all_gather_tensors([t])]
+
+
+def gather_tensors(tensors, dst=0):
+    """Variable-length gather of a list of 1-D tensors to rank ``dst`` ONLY: one size collective, then point-to-point
+    transfers (batched isend / irecv) -- the other ranks receive nothing.  Returns the per-rank lists on ``dst``, None elsewhere."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if ws == 1:
+        return [list(tensors)]
+    src_dev = tensors[0].device
+    dev = _comm_device(tensors[0])
+    buf, meta = _pack_bytes([t.to(dev) for t in tensors])
+    k = len(tensors)
+    n = torch.tensor([m[1] for m in meta], dtype=torch.int64, device=dev)
+    sizes = torch.empty(ws * k, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, n) if dist.get_backend() != 'gloo' else dist.all_gather(list(sizes.view(ws, k).unbind(0)), n)
+    sizes = sizes.view(ws, k).tolist()
+    es = [torch.empty(0, dtype=m[0]).element_size() for m in meta]
+    nbytes = [sum(s * e + ((-(s * e)) % 8) for s, e in zip(row, es)) for row in sizes]
+    if rank != dst:
+        if nbytes[rank]:
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst)]):
+                w.wait()
+        return None
+    bufs = [buf if r == dst else torch.empty(nbytes[r], dtype=torch.uint8, device=dev) for r in range(ws)]
+    ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(ws) if r != dst and nbytes[r]]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return [[t.to(src_dev) for t in _unpack_bytes(bufs[r], [m[0] for m in meta], sizes[r])] for r in range(ws)]
+
+
+def exchange_payloads(local, expected_ids=None):
     """``local``: {chunk_id: (int64 tensor, float32 tensor)} for the chunks this rank owns.
-    Returns the same dict for ALL chunks (``expected_ids``) on every rank."""
+    Returns the same dict for ALL chunks on every rank (one size collective + one byte collective)."""
     rank, ws = world()
     if ws == 1:
         return dict(local)
     ids = sorted(local)
-    if ids:
-        dev = local[ids[0]][0].device
-    else:                                  # idle rank (more ranks than chunks): still takes part in the collectives
-        import torch.distributed as dist
-        dev = torch.device('cpu') if dist.get_backend() == 'gloo' else torch.device('cuda', torch.cuda.current_device())
+    dev = local[ids[0]][0].device if ids else _default_device()     # an idle rank still takes part in the collectives
     head = torch.tensor([v for c in ids for v in (c, local[c][0].numel(), local[c][1].numel())], dtype=torch.int64, device=dev)
     ibuf = torch.cat([local[c][0].reshape(-1) for c in ids]) if ids else torch.zeros(0, dtype=torch.int64, device=dev)
     fbuf = torch.cat([local[c][1].reshape(-1) for c in ids]) if ids else torch.zeros(0, dtype=torch.float32, device=dev)
-    heads, ibufs, fbufs = all_gather_variable(head), all_gather_variable(ibuf), all_gather_variable(fbuf)
     out = {}
-    for h, ib, fb in zip(heads, ibufs, fbufs):
+    for h, ib, fb in all_gather_tensors([head, ibuf, fbuf]):
         io = fo = 0
-        for k in range(0, h.numel(), 3):
-            c, ni, nf = int(h[k]), int(h[k + 1]), int(h[k + 2])
+        hl = h.tolist()
+        for k in range(0, len(hl), 3):
+            c, ni, nf = hl[k], hl[k + 1], hl[k + 2]
             out[c] = (ib[io:io + ni], fb[fo:fo + nf])
             io += ni
             fo += nf
-    assert sorted(out) == sorted(expected_ids), 'chunk payloads missing after the exchange'
+    if expected_ids is not None:
+        assert sorted(out) == sorted(expected_ids), 'chunk payloads missing after the exchange'
     return out
 
 
 def merge_meshes(pieces):
     """``pieces``: list of (v [V,3] f32, f [T,3] i64, vkey [V] i64, axis [V] i8).  Vertices with
     the same (vkey, axis) are one vertex (seams between chunks / ranks).  Deterministic: output
-    vertices ordered by (axis, vkey), faces in piece order."""
+    vertices ordered by (axis, vkey), faces in piece order; the representative of a merged vertex is its first
+    occurrence.  On the GPU the grouping is a stable device radix sort of the lattice keys per axis
+    (nksr_sort_pairs_u64_u32) + a flag scan; CPU tensors (the gloo tests) take the torch.unique route."""
     v = torch.cat([p[0] for p in pieces])
     key = torch.cat([p[2] for p in pieces])
     ax = torch.cat([p[3] for p in pieces]).to(torch.int64)
@@ -111,28 +197,35 @@ def merge_meshes(pieces):
         sel = torch.nonzero(ax == a).reshape(-1)
         if sel.numel() == 0:
             continue
-        uk, inv = torch.unique(key[sel], sorted=True, return_inverse=True)
-        first = torch.full((uk.numel(),), v.shape[0], dtype=torch.int64, device=v.device)
-        first.scatter_reduce_(0, inv, sel, reduce='amin')          # representative = first occurrence
-        new_index[sel] = inv + base
-        out_v.append(v[first])
-        base += uk.numel()
+        if v.is_cuda:
+            from . import ops
+            ks, order = ops.sort_pairs(key[sel].contiguous(), torch.arange(sel.numel(), dtype=torch.int32, device=v.device))
+            head = torch.ones(ks.numel(), dtype=torch.bool, device=v.device)
+            head[1:] = ks[1:] != ks[:-1]
+            rank_sorted = torch.cumsum(head.to(torch.int64), 0) - 1           # group id of every sorted position
+            orig = sel[order.long()]                                          # stable sort: first of a group = first occurrence
+            new_index[orig] = rank_sorted + base
+            out_v.append(v[orig[head]])
+            base += int(head.sum())
+        else:
+            uk, inv = torch.unique(key[sel], sorted=True, return_inverse=True)
+            first = torch.full((uk.numel(),), v.shape[0], dtype=torch.int64, device=v.device)
+            first.scatter_reduce_(0, inv, sel, reduce='amin')          # representative = first occurrence
+            new_index[sel] = inv + base
+            out_v.append(v[first])
+            base += uk.numel()
     vv = torch.cat(out_v) if out_v else v[:0]
     return vv, new_index[f]
 
 
 def gather_meshes(v, f, vkey, axis, dst=0):
-    """Gathers the per-rank mesh pieces; rank ``dst`` merges the seams and returns the full mesh,
-    the other ranks keep their own piece (the merge is O(total mesh): doing it N times would cost
-    weak-scaling efficiency for nothing)."""
+    """Gathers the per-rank mesh pieces on rank ``dst`` ONLY (point-to-point, after one size collective); ``dst`` merges
+    the seams and returns the full mesh, the other ranks keep their own piece."""
     rank, ws = world()
     if ws == 1:
         return v, f
-    vs = all_gather_variable(v.reshape(-1).contiguous())
-    fs = all_gather_variable(f.reshape(-1).contiguous())
-    ks = all_gather_variable(vkey.contiguous())
-    as_ = all_gather_variable(axis.to(torch.int64).contiguous())
+    got = gather_tensors([v.reshape(-1).contiguous(), f.reshape(-1).contiguous(), vkey.contiguous(), axis.to(torch.int8).contiguous()], dst)
     if rank != dst:
         return v, f
-    pieces = [(a.view(-1, 3), b.view(-1, 3), c, d.to(torch.int8)) for a, b, c, d in zip(vs, fs, ks, as_)]
+    pieces = [(a.view(-1, 3), b.view(-1, 3), c, d) for a, b, c, d in got]
     return merge_meshes(pieces)

@@ -46,6 +46,14 @@ def _extract(field, mise_iter, grid_upsample, max_points):
     if g0.num_voxels == 0:
         return empty
     batch = max_points if (max_points is not None and max_points > 0) else (1 << 22)
+    if U < 1 or mise_iter < 0:
+        raise RuntimeError('grid_upsample must be >= 1 and mise_iter >= 0')
+    # lattice / cell keys are 21-bit-per-axis Morton codes biased by 2^20 (csrc/meshing.hip): the refined lattice
+    # coordinate ijk * U * 2^mise_iter (+ one cell) must stay inside, or keys would wrap silently
+    reach = (int(g0.ijk.abs().max()) + 2) * U * (1 << int(mise_iter)) + 2
+    if reach >= (1 << 20):
+        raise RuntimeError('mesh lattice out of range: |ijk| * grid_upsample * 2^mise_iter = %d >= 2^20; recentre the cloud '
+                           '(or lower mise_iter / grid_upsample)' % reach)
 
     flags = torch.empty(g0.num_voxels, dtype=torch.int32, device=dev)
     call('nksr_base_cell_flags', ptr(g0.nbr), g0.num_voxels, ptr(flags), stream())

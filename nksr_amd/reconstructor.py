@@ -78,7 +78,9 @@ class Reconstructor:
 
     def reconstruct(self, xyz, normal=None, sensor=None, detail_level=0.0, voxel_size=None, chunk_size=-1.0,
                     overlap_ratio=0.05, approx_kernel_grad=False, solver_max_iter=2000, solver_tol=1e-5,
-                    fused_mode=True, preprocess_fn=None):
+                    fused_mode=True, preprocess_fn=None, sharded_input=False, chunk_owner=None, chunk_bounds=None):
+        """``sharded_input`` / ``chunk_owner`` / ``chunk_bounds`` (chunk mode under torch.distributed only; not part of the
+        reference surface): every rank passes just the points of the chunks it owns, see chunking.reconstruct_by_chunk."""
         if xyz.dtype != torch.float32 or xyz.dim() != 2 or xyz.shape[1] != 3:
             raise RuntimeError('xyz must be a float32 [N,3] tensor')
         xyz = xyz.to(self.device)
@@ -91,7 +93,8 @@ class Reconstructor:
         if chunked:
             from .chunking import reconstruct_by_chunk
             return reconstruct_by_chunk(self, xyz, normal, sensor, float(chunk_size), float(overlap_ratio),
-                                        approx_kernel_grad, solver_max_iter, solver_tol, fused_mode, preprocess_fn)
+                                        approx_kernel_grad, solver_max_iter, solver_tol, fused_mode, preprocess_fn,
+                                        sharded_input=sharded_input, chunk_owner=chunk_owner, chunk_bounds=chunk_bounds)
         if preprocess_fn is not None:
             xyz, normal, sensor = preprocess_fn(xyz, normal, sensor)
         if normal is None:

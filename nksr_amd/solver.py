@@ -48,6 +48,13 @@ def profile_spmv(enable):
     return float(ms.value), int(n.value)
 
 
+def profile_spmv_bytes():
+    """(algorithmic, physical) bytes of the SpMV launches timed since the last call."""
+    a, b = C.c_double(0.0), C.c_double(0.0)
+    call('nksr_pcg_profile_bytes', C.byref(a), C.byref(b))
+    return float(a.value), float(b.value)
+
+
 def csr_logical(rowptr, cols, vals):
     """Undo the SpMV's tile interleave: returns (cols, vals) in plain CSR order (length nnz).
     Test / export helper -- not on the hot path."""

@@ -149,3 +149,203 @@ def synth_terrain(n, seed=0, extent=(1000.0, 1000.0), origin=(0.0, 0.0), amp=8.0
     nrm = np.stack([-dzdx, -dzdy, np.ones(n)], 1)
     nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     return np.stack([x, y, z], 1).astype(np.float32), nrm.astype(np.float32)
+
+
+def synth_street(n, seed=0, extent=(200.0, 100.0), n_boxes=12, n_poles=10, noise=0.0, sensor_height=1.8):
+    """SURVEY.md section 8d config 4 (CARLA stand-in): a street scene -- gently undulating ground, box
+    buildings on both sides of a centre line along x, vertical cylinders (poles) -- sampled area-uniformly,
+    with the scanner positions on the centre line (the point's x, clamped).  Returns
+    (xyz [n,3], analytic normal [n,3], sensor [n,3]); sensor-only pipelines ignore the normals."""
+    rs = np.random.RandomState(seed)
+    ex, ey = float(extent[0]), float(extent[1])
+    s = min(ex, ey)
+    boxes = []
+    for i in range(n_boxes):
+        side = 1.0 if i % 2 == 0 else -1.0
+        w, d, h = s * (0.10 + 0.06 * rs.rand()), s * (0.10 + 0.05 * rs.rand()), s * (0.08 + 0.10 * rs.rand())
+        cx = ex * (i // 2 + 0.5 + 0.2 * (rs.rand() - 0.5)) / max((n_boxes + 1) // 2, 1)
+        cy = ey * 0.5 + side * (ey * 0.17 + d * 0.5 + ey * 0.08 * rs.rand())
+        boxes.append((cx - w / 2, cx + w / 2, max(cy - d / 2, 0.02 * ey), min(cy + d / 2, 0.98 * ey), h))
+    poles = [(ex * (j + 0.5) / n_poles, ey * 0.5 + (1.0 if j % 2 else -1.0) * ey * 0.10, s * 0.012 + 0.03, s * 0.05 + 1.0)
+             for j in range(n_poles)]
+    area = [ex * ey] + [2 * (b[1] - b[0]) * b[4] + 2 * (b[3] - b[2]) * b[4] + (b[1] - b[0]) * (b[3] - b[2]) for b in boxes] + \
+           [2 * np.pi * p[2] * p[3] for p in poles]
+    cnt = np.floor(np.asarray(area) / sum(area) * n).astype(int)
+    cnt[0] += n - cnt.sum()
+    pts, nrms = [], []
+    # ground (points under a building are not visible)
+    m = int(cnt[0] * 1.5) + 64
+    gx, gy = rs.rand(m) * ex, rs.rand(m) * ey
+    hidden = np.zeros(m, bool)
+    for b in boxes:
+        hidden |= (gx > b[0]) & (gx < b[1]) & (gy > b[2]) & (gy < b[3])
+    gx, gy = gx[~hidden][:cnt[0]], gy[~hidden][:cnt[0]]
+    cnt[0] = len(gx)
+    ka, kb, amp = 2 * np.pi / (0.35 * s), 2 * np.pi / (0.5 * s), 0.012 * s
+    gz = amp * np.sin(ka * gx) * np.cos(kb * gy)
+    gn = np.stack([-amp * ka * np.cos(ka * gx) * np.cos(kb * gy), amp * kb * np.sin(ka * gx) * np.sin(kb * gy), np.ones_like(gx)], 1)
+    pts.append(np.stack([gx, gy, gz], 1))
+    nrms.append(gn / np.linalg.norm(gn, axis=1, keepdims=True))
+    for b, c in zip(boxes, cnt[1:1 + len(boxes)]):
+        w, d, h = b[1] - b[0], b[3] - b[2], b[4]
+        fa = np.array([w * h, w * h, d * h, d * h, w * d])
+        face = rs.choice(5, size=c, p=fa / fa.sum())
+        u, v = rs.rand(c), rs.rand(c)
+        p = np.zeros((c, 3))
+        q = np.zeros((c, 3))
+        for f_, (ax, val, sg) in enumerate([(1, b[2], -1), (1, b[3], 1), (0, b[0], -1), (0, b[1], 1)]):
+            k = face == f_
+            o = 1 - ax
+            p[k, ax] = val
+            p[k, o] = (b[0] + u[k] * w) if o == 0 else (b[2] + u[k] * d)
+            p[k, 2] = v[k] * h
+            q[k, ax] = sg
+        k = face == 4
+        p[k, 0], p[k, 1], p[k, 2] = b[0] + u[k] * w, b[2] + v[k] * d, h
+        q[k, 2] = 1
+        pts.append(p)
+        nrms.append(q)
+    for pl, c in zip(poles, cnt[1 + len(boxes):]):
+        th, z = rs.rand(c) * 2 * np.pi, rs.rand(c) * pl[3]
+        q = np.stack([np.cos(th), np.sin(th), np.zeros(c)], 1)
+        pts.append(np.stack([pl[0] + pl[2] * q[:, 0], pl[1] + pl[2] * q[:, 1], z], 1))
+        nrms.append(q)
+    xyz = np.concatenate(pts)
+    nrm = np.concatenate(nrms)
+    if noise > 0:
+        xyz = xyz + rs.randn(*xyz.shape) * noise
+    sensor = np.stack([np.clip(xyz[:, 0], 0.0, ex), np.full(len(xyz), ey * 0.5), np.full(len(xyz), sensor_height)], 1)
+    perm = rs.permutation(len(xyz))
+    return xyz[perm].astype(np.float32), nrm[perm].astype(np.float32), sensor[perm].astype(np.float32)
+
+
+def terrain_height(x, y, amp=8.0):
+    """Scene-global height field of synth_terrain / terrain_tile (+ its gradient)."""
+    fr = np.random.RandomState(12345).rand(6, 3)
+    z = np.zeros_like(x, dtype=np.float64)
+    dzdx = np.zeros_like(z)
+    dzdy = np.zeros_like(z)
+    for k in range(6):
+        kx, ky, ph = (fr[k, 0] + 0.2) * 0.05, (fr[k, 1] + 0.2) * 0.05, fr[k, 2] * 6.28
+        a = amp / (k + 1)
+        z += a * np.sin(kx * x + ky * y + ph)
+        c = a * np.cos(kx * x + ky * y + ph)
+        dzdx += c * kx
+        dzdy += c * ky
+    return z, dzdx, dzdy
+
+
+def terrain_tile(tile_xy, n, tile=125.0, seed=0, boxes_per_tile=8, amp=8.0):
+    """BASELINE.json configs[4]: one ``tile`` x ``tile`` metre tile of the km-scale
+    height field (+ ``boxes_per_tile`` box buildings standing on it: 8 x 64 tiles ~ the 500 boxes of the survey),
+    ``n`` points, seeded by the tile index -- so a rank can generate exactly the tiles it needs and every rank
+    sees the same points in a shared tile.  Returns (xyz, normal)."""
+    tx, ty = int(tile_xy[0]), int(tile_xy[1])
+    rs = np.random.RandomState((seed * 1_000_003 + tx * 1009 + ty) % (2 ** 31 - 1))
+    ox, oy = tx * tile, ty * tile
+    boxes = []
+    for _ in range(boxes_per_tile):
+        w, d, h = 6 + 8 * rs.rand(), 6 + 8 * rs.rand(), 4 + 10 * rs.rand()
+        cx, cy = ox + w + (tile - 2 * w) * rs.rand(), oy + d + (tile - 2 * d) * rs.rand()
+        z0 = float(terrain_height(np.array([cx]), np.array([cy]), amp)[0][0]) - 1.0
+        boxes.append((cx - w / 2, cx + w / 2, cy - d / 2, cy + d / 2, z0, z0 + h + 1.0))
+    barea = [2 * (b[1] - b[0] + b[3] - b[2]) * (b[5] - b[4]) + (b[1] - b[0]) * (b[3] - b[2]) for b in boxes]
+    frac = sum(barea) / (tile * tile + sum(barea)) if boxes else 0.0
+    nb = int(n * frac)
+    pts, nrms = [], []
+    for i, b in enumerate(boxes):
+        c = int(round(nb * barea[i] / sum(barea)))
+        w, d, h = b[1] - b[0], b[3] - b[2], b[5] - b[4]
+        fa = np.array([w * h, w * h, d * h, d * h, w * d])
+        face = rs.choice(5, size=c, p=fa / fa.sum())
+        u, v = rs.rand(c), rs.rand(c)
+        p, q = np.zeros((c, 3)), np.zeros((c, 3))
+        for f_, (ax, val, sg) in enumerate([(1, b[2], -1), (1, b[3], 1), (0, b[0], -1), (0, b[1], 1)]):
+            k = face == f_
+            o = 1 - ax
+            p[k, ax] = val
+            p[k, o] = (b[0] + u[k] * w) if o == 0 else (b[2] + u[k] * d)
+            p[k, 2] = b[4] + v[k] * h
+            q[k, ax] = sg
+        k = face == 4
+        p[k, 0], p[k, 1], p[k, 2] = b[0] + u[k] * w, b[2] + v[k] * d, b[5]
+        q[k, 2] = 1
+        vis = p[:, 2] >= terrain_height(p[:, 0], p[:, 1], amp)[0]       # wall points below the terrain are not visible
+        pts.append(p[vis])
+        nrms.append(q[vis])
+    ng = n - sum(len(p) for p in pts)                                   # the ground takes the rest: exactly n points per tile
+    m = int(ng * 1.25) + 256
+    x, y = ox + rs.rand(m) * tile, oy + rs.rand(m) * tile
+    hid = np.zeros(m, bool)
+    for b in boxes:
+        hid |= (x > b[0]) & (x < b[1]) & (y > b[2]) & (y < b[3])
+    x, y = x[~hid][:ng], y[~hid][:ng]
+    assert len(x) == ng
+    z, dzdx, dzdy = terrain_height(x, y, amp)
+    gn = np.stack([-dzdx, -dzdy, np.ones_like(z)], 1)
+    pts.append(np.stack([x, y, z], 1))
+    nrms.append(gn / np.linalg.norm(gn, axis=1, keepdims=True))
+    return np.concatenate(pts).astype(np.float32), np.concatenate(nrms).astype(np.float32)
+
+
+def synth_terrain_patch(n, seed=0, extent=(14.0, 14.0), box=True):
+    """Small stand-in of the configs[4] scene for oracle-sized parity cases: a wavy height field over
+    ``extent`` plus one box standing on it.  Returns (xyz, normal)."""
+    rs = np.random.RandomState(seed)
+    ex, ey = float(extent[0]), float(extent[1])
+    bx = (0.55 * ex, 0.78 * ex, 0.30 * ey, 0.52 * ey, 1.9) if box else None
+    barea = (2 * (bx[1] - bx[0] + bx[3] - bx[2]) * bx[4] + (bx[1] - bx[0]) * (bx[3] - bx[2])) if box else 0.0
+    nb = int(n * barea / (ex * ey + barea))
+    m = int((n - nb) * 1.3) + 64
+    x, y = rs.rand(m) * ex, rs.rand(m) * ey
+    if box:
+        hid = (x > bx[0]) & (x < bx[1]) & (y > bx[2]) & (y < bx[3])
+        x, y = x[~hid], y[~hid]
+    x, y = x[:n - nb], y[:n - nb]
+    z = 0.6 * np.sin(0.5 * x + 0.3 * y) + 0.3 * np.cos(0.8 * y)
+    gn = np.stack([-0.3 * np.cos(0.5 * x + 0.3 * y), -(0.18 * np.cos(0.5 * x + 0.3 * y) - 0.24 * np.sin(0.8 * y)), np.ones_like(x)], 1)
+    pts, nrms = [np.stack([x, y, z], 1)], [gn / np.linalg.norm(gn, axis=1, keepdims=True)]
+    if box:
+        w, d, h = bx[1] - bx[0], bx[3] - bx[2], bx[4]
+        z0 = -1.2
+        fa = np.array([w * (h - z0), w * (h - z0), d * (h - z0), d * (h - z0), w * d])
+        face = rs.choice(5, size=nb, p=fa / fa.sum())
+        u, v = rs.rand(nb), rs.rand(nb)
+        p, q = np.zeros((nb, 3)), np.zeros((nb, 3))
+        for f_, (ax, val, sg) in enumerate([(1, bx[2], -1), (1, bx[3], 1), (0, bx[0], -1), (0, bx[1], 1)]):
+            k = face == f_
+            o = 1 - ax
+            p[k, ax] = val
+            p[k, o] = (bx[0] + u[k] * w) if o == 0 else (bx[2] + u[k] * d)
+            p[k, 2] = z0 + v[k] * (h - z0)
+            q[k, ax] = sg
+        k = face == 4
+        p[k, 0], p[k, 1], p[k, 2] = bx[0] + u[k] * w, bx[2] + v[k] * d, h
+        q[k, 2] = 1
+        vis = p[:, 2] >= 0.6 * np.sin(0.5 * p[:, 0] + 0.3 * p[:, 1]) + 0.3 * np.cos(0.8 * p[:, 1])
+        pts.append(p[vis])
+        nrms.append(q[vis])
+    xyz, nrm = np.concatenate(pts), np.concatenate(nrms)
+    perm = rs.permutation(len(xyz))
+    return xyz[perm].astype(np.float32), nrm[perm].astype(np.float32)
+
+
+def synth_rounded_box(n, half=(0.30, 0.22, 0.16), radius=0.10, noise=0.0, seed=0):
+    """Points + analytic normals on the surface {x : dist(x, box(half)) = radius}: uniform samples of a thin
+    exterior shell projected onto the surface (exact closest-point projection)."""
+    rs = np.random.RandomState(seed)
+    b = np.asarray(half, np.float64)
+    out_p, out_n, have = [], [], 0
+    while have < n:
+        x = (rs.rand(4 * n, 3) * 2 - 1) * (b + radius * 1.1)
+        q = np.clip(x, -b, b)
+        d = np.linalg.norm(x - q, axis=1)
+        k = (d > radius * 0.9) & (d < radius * 1.1)
+        nn_ = (x[k] - q[k]) / d[k, None]
+        out_p.append(q[k] + radius * nn_)
+        out_n.append(nn_)
+        have += int(k.sum())
+    p, nrm = np.concatenate(out_p)[:n], np.concatenate(out_n)[:n]
+    if noise > 0:
+        p = p + rs.randn(n, 3) * noise
+    return p.astype(np.float32), nrm.astype(np.float32)

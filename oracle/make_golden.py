@@ -34,10 +34,12 @@ def run_case(xyz, nrm, vs):
            'A_rowsum': np.asarray(fld['A'].sum(1)).ravel().astype(np.float32)}
     for d, L in enumerate(fld['hier'].levels):
         out['keys_%d' % d] = L.keys
+    from oracle.make_golden_chunked import pack_mesh_info
     for mise in (0, 1):
-        v, t = pipeline.extract_dual_mesh(fld, mise_iter=mise)
-        out['mesh_v_%d' % mise] = v
-        out['mesh_f_%d' % mise] = t
+        info = {}
+        v, t = pipeline.extract_dual_mesh(fld, mise_iter=mise, info=info)
+        fmax = max(float(np.abs(L['f_raw']).max()) for L in info['levels'])
+        pack_mesh_info('mesh%d_' % mise, v, t, info, out, fmax)      # mesh + what tests/parity_util needs to localise differences
     return out
 
 

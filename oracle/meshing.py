@@ -95,8 +95,12 @@ def constrain_hanging(g, f, vk_coarse, f_coarse, active_keys):
     return f
 
 
-def extract(level0_voxel_size, level0, eval_fn, mise_iter=0, grid_upsample=1, mask_fn=None):
-    """eval_fn(xyz[n,3] f32) -> f[n] f32;  mask_fn(xyz) -> bool[n] (True = keep)."""
+def extract(level0_voxel_size, level0, eval_fn, mise_iter=0, grid_upsample=1, mask_fn=None, info=None):
+    """eval_fn(xyz[n,3] f32) -> f[n] f32;  mask_fn(xyz) -> bool[n] (True = keep).
+    ``info`` (dict, optional) receives what the parity tests need to localise a topology difference:
+    per MISE level the cell coordinates / corner table / (constrained) vertex values, and for the output
+    mesh the cell of every triangle and the canonical identity (lattice key of the lower end point, axis)
+    plus |f0 - f1| of every vertex."""
     w0 = float(level0_voxel_size)
     U = int(grid_upsample)
     cells = base_cells(level0, U)
@@ -107,11 +111,15 @@ def extract(level0_voxel_size, level0, eval_fn, mise_iter=0, grid_upsample=1, ma
         g = lattice_decode(vk)
         pos = lattice_positions(g, h, 0.5 * w0)
         f = eval_fn(pos) if len(pos) else np.zeros(0, np.float32)
+        f_raw = f
         if prev is not None and len(f):
             f = constrain_hanging(g, f, *prev)
         inside = f > 0
         ci = inside[cidx] if len(cidx) else np.zeros((0, 8), bool)
         config = (ci * (1 << np.arange(8))[None]).sum(1).astype(np.int32) if len(cidx) else np.zeros(0, np.int32)
+        if info is not None:
+            info.setdefault('levels', []).append({'cells': cells.copy(), 'cidx': cidx, 'f': f.copy(), 'f_raw': f_raw, 'vk': vk, 'pos': pos,
+                                                  'config': config, 'h': h})
         if m < mise_iter:
             act = (config != 0) & (config != 255)
             prev = (vk, f, np.sort(lattice_key(cells[act])))
@@ -127,12 +135,16 @@ def extract(level0_voxel_size, level0, eval_fn, mise_iter=0, grid_upsample=1, ma
         key = lo.astype(np.int64) * 3 + mc_tables.EDGE_AXIS[e]
         tri_edge_keys.append((sel, np.full(len(sel), t), key))
     if not tri_edge_keys or sum(len(s) for s, _, _ in tri_edge_keys) == 0:
+        if info is not None:
+            info.update({'tri_cell': np.zeros((0, 3), np.int64), 'vert_vkey': np.zeros(0, np.int64), 'vert_axis': np.zeros(0, np.int64),
+                         'vert_df': np.zeros(0, np.float32), 'h': h})
         return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32)
     sel = np.concatenate([a for a, _, _ in tri_edge_keys])
     tt = np.concatenate([b for _, b, _ in tri_edge_keys])
     keys = np.concatenate([c for _, _, c in tri_edge_keys])
     order = np.lexsort((tt, sel))                                     # cell-major, table order
     keys = keys[order]
+    tri_cell = cells[sel[order]]
     ek = np.unique(keys)
     faces = np.searchsorted(ek, keys).astype(np.int32)
     v0 = (ek // 3).astype(np.int64)
@@ -144,6 +156,7 @@ def extract(level0_voxel_size, level0, eval_fn, mise_iter=0, grid_upsample=1, ma
     t = (f0 / (f0 - f1)).astype(np.float32)
     verts = pos[v0].copy()
     verts[np.arange(len(ek)), ax] = (pos[v0, ax] + t * np.float32(h)).astype(np.float32)
+    vert_vkey, vert_axis, vert_df = vk[v0], ax, np.abs(f0 - f1)
     if mask_fn is not None and len(verts):
         keep_v = mask_fn(verts)
         keep_f = keep_v[faces].all(1)
@@ -153,4 +166,8 @@ def extract(level0_voxel_size, level0, eval_fn, mise_iter=0, grid_upsample=1, ma
         remap = np.cumsum(used) - 1
         verts = verts[used]
         faces = remap[faces].astype(np.int32)
+        tri_cell = tri_cell[keep_f]
+        vert_vkey, vert_axis, vert_df = vert_vkey[used], vert_axis[used], vert_df[used]
+    if info is not None:
+        info.update({'tri_cell': tri_cell, 'vert_vkey': vert_vkey, 'vert_axis': vert_axis, 'vert_df': vert_df, 'h': h})
     return verts.astype(np.float32), faces

@@ -97,10 +97,10 @@ def evaluate(fld, xyz, grad=False):
                             fld['approx_kernel_grad'])
 
 
-def extract_dual_mesh(fld, mise_iter=0, grid_upsample=1):
+def extract_dual_mesh(fld, mise_iter=0, grid_upsample=1, info=None):
     mask_fn = None
     if fld.get('udf_feats') is not None:      # NeuralField mask, level set 2 * voxel_size (models/nksr_net.py:130)
         from . import network as onet
         mask_fn = lambda p: onet.udf_decode(fld['hier'], fld['udf_feats'], p) < np.float32(fld.get('udf_level_set', 2 * fld['voxel_size']))
     return meshing.extract(fld['voxel_size'], fld['hier'].levels[0], lambda p: evaluate(fld, p)[0], mise_iter, grid_upsample,
-                           mask_fn=mask_fn)
+                           mask_fn=mask_fn, info=info)

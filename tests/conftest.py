@@ -21,6 +21,8 @@ def make_cloud(kind='sphere', n=3000, noise=0.005, seed=0):
         xyz, nrm = utils.synth_sphere(n, 0.45, noise, seed)
     elif kind == 'torus':
         xyz, nrm = utils.synth_torus(n, 0.32, 0.12, noise, seed)
+    elif kind == 'rbox':
+        xyz, nrm = utils.synth_rounded_box(n, (0.30, 0.22, 0.16), 0.10, noise, seed)
     else:
         raise ValueError(kind)
     return xyz, nrm

@@ -1,0 +1,206 @@
+"""Helpers of the GPU parity tests: unconditional topology comparison and measured-error reporting.
+
+Topology bar (BASELINE.json north_star: "index-exact for voxel/triangle topology"):
+the HIP mesh and the oracle mesh must hold the SAME triangles -- compared through the canonical identity
+of their vertices, (lattice key of the lower end point of the crossed lattice edge, axis), so vertex
+numbering does not matter -- EXCEPT inside cells where fp32 noise can legitimately flip a sign decision.
+That set is computed on the ORACLE side only:
+  * level m of the MISE refinement: a lattice vertex is *ambiguous* when |f| < eps, a cell is ambiguous when one
+    of its 8 corners is; ambiguity spreads to the 26 neighbouring cells (the hanging-vertex rule couples a cell's
+    refined face values to whether its neighbour was refined) and to every descendant at finer levels;
+  * eps = 10 x the measured max |f_hip - f_oracle| over the oracle's lattice vertices (itself asserted <= the
+    1e-4 contract of SURVEY.md section 8c), so the test calibrates itself and cannot hide a regression.
+Every differing triangle must lie in a tainted cell; the tainted fraction is bounded and printed.
+"""
+import numpy as np
+
+from oracle import meshing as omesh
+
+
+def report(name, **kv):
+    """One line per test with the measured errors (pytest -s / captured output shows it on failure, and
+    tests/ collects them in gpurun_out/parity_report.txt when NKSR_PARITY_REPORT is set)."""
+    import os
+    line = '[parity] %s: ' % name + ' '.join('%s=%s' % (k, ('%.3e' % v) if isinstance(v, float) else v) for k, v in kv.items())
+    print(line)
+    path = os.environ.get('NKSR_PARITY_REPORT')
+    if path:
+        with open(path, 'a') as f:
+            f.write(line + '\n')
+
+
+def check(name, measured, bound):
+    """Tolerance check that always REPORTS the measured value next to its bound.  NKSR_PARITY_CALIBRATE=1 turns the
+    assertion off (used once per round on the GPU box to read all measured errors in one pass)."""
+    import os
+    measured, bound = float(measured), float(bound)
+    report(name, measured=measured, bound=bound, ok=bool(measured <= bound))
+    if not os.environ.get('NKSR_PARITY_CALIBRATE'):
+        assert measured <= bound, '%s: measured %.3e > bound %.3e' % (name, measured, bound)
+
+
+def _rows_view(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.dtype((np.void, a.dtype.itemsize * a.shape[1]))).ravel()
+
+
+def canonical_triangles(faces, vkey, axis):
+    """[T, 3] vertex indices -> [T, 6] canonical ids (3 lattice keys, 3 axes), corner order preserved.
+    (Lattice keys are 63-bit Morton codes: key and axis cannot share one int64.)"""
+    f = faces.astype(np.int64)
+    return np.concatenate([vkey.astype(np.int64)[f], axis.astype(np.int64)[f]], 1)
+
+
+def triangle_cells(tri_ids):
+    """Lattice cell(s) of triangles given by canonical vertex ids.  An edge (lower vertex g, axis a) lies in the
+    cells c with c[a] == g[a] and c[b] in {g[b] - 1, g[b]} for b != a; the three edges of a marching-cubes
+    triangle pin the cell, unless all three lie in one lattice face (then both cells sharing it qualify).
+    Returns (lo [T,3], hi [T,3]) inclusive candidate ranges (lo == hi when unique)."""
+    vk, ax = tri_ids[:, :3], tri_ids[:, 3:]
+    g = omesh.lattice_decode(vk.reshape(-1)).astype(np.int64).reshape(vk.shape + (3,))     # [T,3 corners,3 xyz]
+    lo = np.full((tri_ids.shape[0], 3), -(1 << 40), np.int64)
+    hi = np.full((tri_ids.shape[0], 3), (1 << 40), np.int64)
+    for k in range(3):
+        for b in range(3):
+            on_axis = ax[:, k] == b
+            l = np.where(on_axis, g[:, k, b], g[:, k, b] - 1)
+            h = g[:, k, b]
+            lo[:, b] = np.maximum(lo[:, b], l)
+            hi[:, b] = np.minimum(hi[:, b], h)
+    return lo, hi
+
+
+def ref_from_info(ov, of, info):
+    """Reference mesh record from a live oracle run (oracle.meshing.extract(..., info=))."""
+    levels = []
+    for L in info['levels']:
+        cmin = np.abs(L['f'])[L['cidx']].min(1) if len(L['cidx']) else np.zeros(0, np.float32)
+        levels.append((L['cells'].astype(np.int64), cmin, len(L['cells'])))
+    return {'v': ov, 'f': of, 'vert_vkey': info['vert_vkey'], 'vert_axis': info['vert_axis'], 'vert_df': info['vert_df'],
+            'h': float(info['h']), 'levels': levels,
+            'probes': [(L['pos'], L['f_raw']) for L in info['levels']]}
+
+
+def ref_from_golden(g, prefix='mesh_', w0=0.1):
+    """Same record from a committed fixture (oracle/make_golden_chunked.py: only the near-threshold cells and a
+    sample of the lattice vertices are stored)."""
+    nl = int(g[prefix + 'nlevels'])
+    levels = [(g[prefix + 'near_cells_%d' % m].astype(np.int64), g[prefix + 'near_minabs_%d' % m], int(g[prefix + 'ncells_%d' % m]))
+              for m in range(nl)]
+    probes = []
+    for m in range(nl):
+        gk = omesh.lattice_decode(g[prefix + 'probe_vk_%d' % m])
+        probes.append((omesh.lattice_positions(gk, float(g[prefix + 'lat_h_%d' % m]), 0.5 * w0), g[prefix + 'probe_f_%d' % m]))
+    return {'v': g[prefix + 'v'], 'f': g[prefix + 'f'], 'vert_vkey': g[prefix + 'vert_vkey'], 'vert_axis': g[prefix + 'vert_axis'],
+            'vert_df': g[prefix + 'vert_df'], 'h': float(g[prefix + 'h']), 'levels': levels, 'probes': probes}
+
+
+def tainted_cells(levels, eps):
+    """Per MISE level: sorted lattice keys of the tainted cells at that level (see module docstring).
+    ``levels``: [(cell coords [k,3], min |f| over the cell's corners [k], number of cells)]."""
+    out = []
+    carried = None              # tainted cells of the previous level, as coords
+    for cells, cmin, _ in levels:
+        seeds = cells[cmin < eps]
+        if len(seeds):
+            off = np.array([[a, b, c] for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)], np.int64)
+            seeds = (seeds[:, None, :] + off[None]).reshape(-1, 3)
+        if carried is not None and len(carried):
+            ch = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], np.int64)
+            kids = (carried[:, None, :] * 2 + ch[None]).reshape(-1, 3)
+            seeds = np.concatenate([seeds, kids]) if len(seeds) else kids
+        keys = np.unique(omesh.lattice_key(seeds)) if len(seeds) else np.zeros(0, np.int64)
+        out.append(keys)
+        carried = omesh.lattice_decode(keys).astype(np.int64) if len(keys) else None
+    return out
+
+
+def compare_meshes(name, gv, gf, gvkey, gaxis, ref, delta_f, w0=0.1, max_tainted_frac=0.02, eps=None):
+    """Unconditional topology + vertex-position comparison (positions in model units) of a HIP mesh against a
+    reference record (ref_from_info / ref_from_golden).  ``delta_f``: measured max |f_hip - f_oracle| at the
+    oracle's lattice vertices.  Returns a stats dict."""
+    eps = 10.0 * float(delta_f) if eps is None else float(eps)
+    ov, of = ref['v'], ref['f']
+    taint = tainted_cells(ref['levels'], eps)[-1]
+    n_final = ref['levels'][-1][2]
+    n_taint = len(taint)            # counts dilated (possibly non-existing) cells too: an over-estimate
+    tg = canonical_triangles(gf, gvkey, gaxis)
+    to = canonical_triangles(of, ref['vert_vkey'], ref['vert_axis'])
+    vg, vo = _rows_view(tg), _rows_view(to)
+    only_g = ~np.isin(vg, vo)
+    only_o = ~np.isin(vo, vg)
+    bad = 0
+    for tri in (tg[only_g], to[only_o]):
+        if len(tri):
+            lo, hi = triangle_cells(tri)
+            ok = np.isin(omesh.lattice_key(lo), taint) | np.isin(omesh.lattice_key(hi), taint)
+            bad += int((~ok).sum())
+    # vertex positions of the common vertices
+    idg = _rows_view(np.stack([gvkey.astype(np.int64), gaxis.astype(np.int64)], 1))
+    ido = _rows_view(np.stack([ref['vert_vkey'].astype(np.int64), ref['vert_axis'].astype(np.int64)], 1))
+    common, ig, io = np.intersect1d(idg, ido, return_indices=True)
+    dv = np.abs(gv[ig].astype(np.float64) - ov[io].astype(np.float64)).max(1) if len(common) else np.zeros(0)
+    h = ref['h']
+    bound = np.maximum(1e-4 * w0, 2.0 * h * float(delta_f) / np.maximum(ref['vert_df'][io].astype(np.float64), 1e-30))
+    n_over_plain = int((dv > 1e-4 * w0).sum())
+    stats = {'T_hip': len(tg), 'T_oracle': len(to), 'only_hip': int(only_g.sum()), 'only_oracle': int(only_o.sum()),
+             'outside_tainted': bad, 'tainted_cells': n_taint, 'final_cells': n_final, 'eps': eps,
+             'common_vertices': len(common), 'max_dv_voxel': float(dv.max() / w0) if len(dv) else 0.0,
+             'vertices_over_1e-4_voxel': n_over_plain}
+    report(name, **stats)
+    import os
+    if os.environ.get('NKSR_PARITY_CALIBRATE'):
+        stats['exact'] = not only_g.any() and not only_o.any()
+        return stats
+    assert bad == 0, '%s: %d differing triangles lie outside the near-threshold cells' % (name, bad)
+    assert n_taint <= max(64, max_tainted_frac * n_final), '%s: tainted set too large (%d of %d cells)' % (name, n_taint, n_final)
+    exact = not only_g.any() and not only_o.any()
+    if exact:   # identical triangle sets: the ORDER must be identical too (cell-major, table order) => index-exact faces
+        assert np.array_equal(tg, to), '%s: same triangles in a different order' % name
+        assert np.array_equal(np.asarray(gf, np.int64), np.asarray(of, np.int64)), '%s: face indices differ' % name
+    assert (dv <= bound).all(), '%s: vertex off by %.3e voxel' % (name, float((dv / w0).max()))
+    stats['exact'] = exact
+    return stats
+
+
+def lattice_delta(field_eval, ref):
+    """max |f_hip - f_oracle| over the oracle's lattice vertices of every MISE level (raw evaluations, before the
+    hanging-vertex rule) and the largest |f| there.  ``field_eval(pos [n,3] f32 model units) -> f [n] np``."""
+    d, fmax = 0.0, 0.0
+    for pos, f_raw in ref['probes']:
+        if len(pos) == 0:
+            continue
+        fg = field_eval(np.ascontiguousarray(pos, np.float32))
+        d = max(d, float(np.abs(fg - f_raw).max()))
+        fmax = max(fmax, float(np.abs(f_raw).max()))
+    return d, fmax
+
+
+def mesh_arrays(mesh, scale=1.0):
+    """(v in model units, f, edge_vkey, edge_axis) numpy arrays of a nksr_amd MeshingResult."""
+    return (mesh.v.cpu().numpy() * np.float32(scale), mesh.f.cpu().numpy(), mesh.edge_vkey.cpu().numpy(),
+            mesh.edge_axis.cpu().numpy().astype(np.int64))
+
+
+def assert_closed(faces, name='mesh'):
+    e = np.sort(np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]), 1)
+    _, cnt = np.unique(e, axis=0, return_counts=True)
+    assert (cnt == 2).all(), '%s is not closed' % name
+    return len(cnt)
+
+
+def mesh_parity(name, fld, ofl, mise_iter, scale=1.0, grid_upsample=1, w0=0.1):
+    """HIP field ``fld`` (KernelField, global scale ``scale``) against the live oracle field ``ofl`` (oracle.pipeline dict):
+    lattice field values within 1e-4 of max|f|, then the unconditional mesh comparison."""
+    import torch
+    from oracle import pipeline
+    info = {}
+    ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=mise_iter, grid_upsample=grid_upsample, info=info)
+    ref = ref_from_info(ov, of, info)
+    dev = fld.device
+    ev = lambda p: fld._evaluate_f_model(torch.from_numpy(p).to(dev), False).value.cpu().numpy()
+    delta, fmax = lattice_delta(ev, ref)
+    check(name + ':lattice_f_rel', delta / max(fmax, 1e-30), 1e-4)
+    mesh = fld.extract_dual_mesh(mise_iter=mise_iter, grid_upsample=grid_upsample)
+    st = compare_meshes(name, *mesh_arrays(mesh, scale), ref, delta_f=delta, w0=w0)
+    return st, mesh, (ov, of)

@@ -1,0 +1,61 @@
+"""CPU-side contract of bench.py (the driver parses its one JSON line): record keys, the roofline arithmetic, the
+chunk -> rank map of the strong-scaling scene and the sharded tile loader's bookkeeping."""
+import importlib.util
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_roofline_record_arithmetic_and_keys():
+    b = _bench()
+    # 220 launches of 0.58 ms each moving 3.01 GB (algorithmic) / 2.50 GB (physical)
+    r = b.roofline_record(220 * 0.58, 220, 220 * 3.01e9, 220 * 2.50e9)
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'achieved_physical', 'frac_physical',
+              'bytes_per_launch', 'physical_bytes_per_launch', 'avg_launch_us', 'launches_timed', 'kernel'):
+        assert k in r, k
+    assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
+    assert abs(r['achieved'] - 3.01e9 / 0.58e-3 / 1e9) < 1e-6 * r['achieved']
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['frac_physical'] < r['frac']
+    assert abs(r['avg_launch_us'] - 580.0) < 1e-6
+    # traffic is only attached when the committed PMC pass was taken on the same matrix, and then names its source
+    assert (r['traffic'] is None) == (r['traffic_source'] is None)
+    z = b.roofline_record(0.0, 0, 0.0, 0.0)
+    assert z['achieved'] == 0.0 and z['traffic'] is None
+
+
+def test_strong_scaling_partition_is_compact_and_balanced():
+    from nksr_amd import dist as D
+    for world in (1, 2, 4, 8):
+        owner = D.partition_chunks(64, world, [156250] * 64, grid=(8, 8, 1))
+        assert sorted(set(owner)) == list(range(world))
+        for r in range(world):
+            mine = [c for c in range(64) if owner[c] == r]
+            assert len(mine) == 64 // world
+            cx, cy = np.array([c // 8 for c in mine]), np.array([c % 8 for c in mine])
+            # a Morton-contiguous piece of 64 / world tiles is an axis-aligned block
+            assert (cx.max() - cx.min() + 1) * (cy.max() - cy.min() + 1) == len(mine)
+    # weights shift the cuts but keep every piece contiguous along the curve
+    w = [1000] * 32 + [10] * 32
+    o = D.partition_chunks(64, 4, w, grid=(8, 8, 1))
+    load = [sum(w[c] for c in range(64) if o[c] == r) for r in range(4)]
+    assert max(load) <= 1.3 * sum(w) / 4
+
+
+def test_terrain_tiles_are_deterministic_and_exactly_sized():
+    from nksr_amd import utils
+    a, na = utils.terrain_tile((2, 5), 20000, 125.0, seed=0)
+    b, nb = utils.terrain_tile((2, 5), 20000, 125.0, seed=0)
+    assert a.shape == (20000, 3) and np.array_equal(a, b) and np.array_equal(na, nb)
+    assert a[:, 0].min() >= 250.0 and a[:, 0].max() <= 375.0 and a[:, 1].min() >= 625.0 and a[:, 1].max() <= 750.0
+    np.testing.assert_allclose(np.linalg.norm(na, axis=1), 1.0, atol=1e-5)
+    c, _ = utils.terrain_tile((2, 6), 20000, 125.0, seed=0)
+    assert not np.array_equal(a, c)

@@ -6,8 +6,10 @@ import pytest
 import torch
 
 from conftest import make_cloud
+import parity_util as pu
 
 pytestmark = pytest.mark.gpu
+ALPHA_TOL = 1e-4      # see tests/test_gpu_parity.py
 
 
 def _run(prune):
@@ -95,8 +97,9 @@ def test_reconstruct_with_active_heads_matches_oracle_pipeline():
     fo, go = pipeline.evaluate(ofl, xs, grad=True)
     res = fld.evaluate_f(torch.from_numpy(xyz).to(dev), grad=True)
     ref = np.abs(ofl['alpha']).max()
-    assert np.abs(res.value.cpu().numpy() - fo).max() <= 3e-3 * ref
-    assert np.abs(res.gradient.cpu().numpy() / 2.0 - go).max() <= 3e-3 * np.abs(go).max()
+    pu.check('active_heads:f_at_inputs', np.abs(res.value.cpu().numpy() - fo).max() / ref, 1e-4)
+    pu.check('active_heads:grad_rel', np.abs(res.gradient.cpu().numpy() / 2.0 - go).max() / np.abs(go).max(), 1e-4)
+    pu.mesh_parity('active_heads[mise=1]', fld, ofl, 1, fld.scale)
 
 
 def test_shapenet_3k_noise_config():
@@ -115,13 +118,11 @@ def test_shapenet_3k_noise_config():
     for d in range(4):
         assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
     ref = np.abs(ofl['alpha']).max()
-    assert np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() <= 3e-3 * ref
+    pu.check('shapenet3k:alpha_rel', np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() / ref, ALPHA_TOL)
     fo, _ = pipeline.evaluate(ofl, xyz)
     fg = fld.evaluate_f(torch.from_numpy(xyz).to(dev)).value.cpu().numpy()
-    assert np.abs(fg - fo).max() <= 3e-3 * ref
-    mesh = fld.extract_dual_mesh(mise_iter=0)
-    ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=0)
-    assert abs(mesh.f.shape[0] - len(of)) <= max(4, 0.01 * len(of))
+    pu.check('shapenet3k:f_at_inputs', np.abs(fg - fo).max() / ref, 1e-4)
+    pu.mesh_parity('shapenet3k[mise=0]', fld, ofl, 0, fld.scale, w0=rec.hparams.voxel_size)
 
 
 def _open_sheet(n, seed):
@@ -167,9 +168,7 @@ def test_udf_mask_branch_matches_oracle():
     np.testing.assert_allclose(got[~far], ref[~far], atol=2e-5)
     assert np.median(got[:2000]) < 0.02            # on the sheet: distance ~ 0 (model units, voxel = 0.1)
     # meshes: same trimming; the trimmed mesh stays within 2 voxels of the data plane estimate
-    mesh = fld.extract_dual_mesh(mise_iter=0)
-    ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=0)
-    assert abs(mesh.f.shape[0] - len(of)) <= max(4, 0.01 * len(of))
+    _, mesh, _ = pu.mesh_parity('udf[level_set=0.2]', fld, ofl, 0, fld.scale)
     d_v = rec.network.udf_decoder(mesh.v.to(dev) * fld.scale, fld.svh, ofl_feats_to_torch(ofl, dev))
     assert float(d_v.max()) < 0.2 + 1e-6
     # a tight level set actually trims (noise-free sheet: vertices farther than 0.004 from the plane estimate)
@@ -178,7 +177,15 @@ def test_udf_mask_branch_matches_oracle():
     tight = fld.extract_dual_mesh(mise_iter=0)
     tv, tf = pipeline.extract_dual_mesh(ofl, mise_iter=0)
     assert 0 < tight.f.shape[0] < mesh.f.shape[0]
-    assert abs(tight.f.shape[0] - len(tf)) <= max(8, 0.03 * len(tf))
+    # the trim threshold (udf < level set) is a second fp32 decision per vertex: triangle sets may differ where a
+    # vertex's decoded distance sits at the level set; everything else must be the same triangles
+    tg = pu.canonical_triangles(tight.f.cpu().numpy(), tight.edge_vkey.cpu().numpy(), tight.edge_axis.cpu().numpy().astype(np.int64))
+    info_t = {}
+    tv, tf = pipeline.extract_dual_mesh(ofl, mise_iter=0, info=info_t)
+    to = pu.canonical_triangles(tf, info_t['vert_vkey'], info_t['vert_axis'])
+    diff = int((~np.isin(pu._rows_view(tg), pu._rows_view(to))).sum() + (~np.isin(pu._rows_view(to), pu._rows_view(tg))).sum())
+    pu.report('udf[tight]', T_hip=len(tg), T_oracle=len(to), differing=diff)
+    assert diff <= max(8, 0.005 * len(to))
     fld.to_('cpu')                                  # the mask's features travel with the field
     assert fld.mask_field.features[0].device.type == 'cpu'
 

@@ -6,8 +6,15 @@ import pytest
 import torch
 
 from conftest import make_cloud
+import parity_util as pu
 
 pytestmark = pytest.mark.gpu
+
+
+# alpha solves an ill-conditioned system to a relative RESIDUAL of 1e-6 on both sides: the coefficient vectors agree to
+# cond(A) x that, the field they define agrees to 1e-6 (measured values are printed by every test; bound = max(1e-4
+# contract of SURVEY.md section 8c, 10 x measured on MI355X in round 2))
+ALPHA_TOL = 1e-4
 
 
 def _dev():
@@ -205,26 +212,14 @@ def test_end_to_end_mesh(kind, vs):
     # field values at the input points agree (both solved to 1e-6)
     fo, _ = pipeline.evaluate(ofl, (xyz * np.float32(scale)).astype(np.float32))
     fg = fld.evaluate_f(torch.from_numpy(xyz).to(_dev())).value.cpu().numpy()
-    ref = np.abs(ofl['alpha']).max()
-    assert abs(fg - fo).max() <= 2e-3 * ref
+    pu.check('e2e[%s]:f_at_inputs' % kind, np.abs(fg - fo).max() / np.abs(ofl['alpha']).max(), 1e-4)
+    pu.check('e2e[%s]:alpha_rel' % kind, np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() / np.abs(ofl['alpha']).max(), ALPHA_TOL)
     for mise in (0, 1, 2):
-        mesh = fld.extract_dual_mesh(mise_iter=mise)
-        ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=mise)
+        # topology: index-exact outside the near-threshold cells, vertices within 1e-4 voxel (tests/parity_util.py)
+        st, mesh, _ = pu.mesh_parity('e2e[%s,mise=%d]' % (kind, mise), fld, ofl, mise, scale)
         gv, gf = mesh.v.cpu().numpy() * scale, mesh.f.cpu().numpy()
-        if gf.shape == of.shape and np.array_equal(gf, of):
-            np.testing.assert_allclose(gv, ov, rtol=0, atol=1e-3 * 0.1)   # <= 1e-3 voxel
-        else:
-            # near-threshold sign flips change local topology; then require near-identical size + geometry
-            assert abs(len(gf) - len(of)) <= 0.01 * len(of)
-            from scipy.spatial import cKDTree
-            d, _ = cKDTree(ov).query(gv)
-            assert d.max() <= 0.02 * 0.1
-        if True:   # closed at every MISE level (hanging-vertex constraint)
-            e = np.sort(np.concatenate([gf[:, [0, 1]], gf[:, [1, 2]], gf[:, [2, 0]]]), 1)
-            _, cnt = np.unique(e, axis=0, return_counts=True)
-            assert (cnt == 2).all(), 'mesh is not closed'
-            V, E, F = len(gv), len(cnt), len(gf)
-            assert V - E + F == (2 if kind == 'sphere' else 0)
+        E = pu.assert_closed(gf, 'mesh')          # closed at every MISE level (hanging-vertex constraint)
+        assert len(gv) - E + len(gf) == (2 if kind == 'sphere' else 0)
 
 
 @pytest.mark.parametrize('name', ['bunny_2k', 'sphere_3k'])
@@ -246,20 +241,21 @@ def test_against_committed_golden(name):
     for d in range(4):
         assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), g['keys_%d' % d])      # voxel sets: exact
     amax = abs(g['alpha']).max()
-    np.testing.assert_allclose(fld.alpha.cpu().numpy(), g['alpha'], rtol=0, atol=2e-3 * amax)
+    pu.check('golden[%s]:alpha_rel' % name, np.abs(fld.alpha.cpu().numpy() - g['alpha']).max() / amax, ALPHA_TOL)
     np.testing.assert_allclose(fld.rhs.cpu().numpy(), g['b'], rtol=1e-4, atol=1e-5 * abs(g['b']).max())
     np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), g['A_diag'], rtol=1e-4)
     res = fld.evaluate_f(torch.from_numpy(xyz).to(_dev()), grad=True)
-    np.testing.assert_allclose(res.value.cpu().numpy(), g['f_at_points'], rtol=0, atol=2e-3 * amax)
+    pu.check('golden[%s]:f_at_inputs' % name, np.abs(res.value.cpu().numpy() - g['f_at_points']).max() / amax, 1e-4)
     scale = 0.1 / vs
-    np.testing.assert_allclose(res.gradient.cpu().numpy() / scale, g['grad_at_points'], rtol=0,
-                               atol=2e-3 * abs(g['grad_at_points']).max())
-    mesh = fld.extract_dual_mesh(mise_iter=0)
-    gf, gv = mesh.f.cpu().numpy(), mesh.v.cpu().numpy() * scale
-    if gf.shape == g['mesh_f_0'].shape and np.array_equal(gf, g['mesh_f_0']):                # topology: exact
-        np.testing.assert_allclose(gv, g['mesh_v_0'], rtol=0, atol=1e-3 * 0.1)
-    else:
-        assert abs(len(gf) - len(g['mesh_f_0'])) <= 0.01 * len(g['mesh_f_0'])
+    pu.check('golden[%s]:grad_at_inputs_rel' % name, np.abs(res.gradient.cpu().numpy() / scale - g['grad_at_points']).max()
+             / abs(g['grad_at_points']).max(), 1e-4)
+    for mise in (0, 1):
+        ref = pu.ref_from_golden(g, 'mesh%d_' % mise)
+        ev = lambda p: fld._evaluate_f_model(torch.from_numpy(p).to(_dev()), False).value.cpu().numpy()
+        delta, fmax = pu.lattice_delta(ev, ref)
+        pu.check('golden[%s,mise=%d]:lattice_f_rel' % (name, mise), delta / fmax, 1e-4)
+        mesh = fld.extract_dual_mesh(mise_iter=mise)
+        pu.compare_meshes('golden[%s,mise=%d]' % (name, mise), *pu.mesh_arrays(mesh, scale), ref, delta_f=delta)
 
 
 def test_sorted_builders_equal_point_builders():
@@ -312,11 +308,9 @@ def test_tree_depth_5_matches_oracle():
     for d in range(5):
         assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
     ref = np.abs(ofl['alpha']).max()
-    assert np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() <= 3e-3 * ref
+    pu.check('depth5:alpha_rel', np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() / ref, ALPHA_TOL)
     np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), ofl['A'].diagonal(), rtol=1e-4)
-    mesh = fld.extract_dual_mesh(mise_iter=1)
-    ov, of = pipeline.extract_dual_mesh(ofl, mise_iter=1)
-    assert abs(mesh.f.shape[0] - len(of)) <= max(4, 0.01 * len(of))
+    pu.mesh_parity('depth5[mise=1]', fld, ofl, 1, fld.scale)
 
 
 def test_build_adaptive_normal_variation_matches_oracle():
@@ -360,8 +354,9 @@ def test_other_tree_depths_match_oracle(depth):
         assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
     np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), ofl['A'].diagonal(), rtol=1e-4)
     ref = np.abs(ofl['alpha']).max()
-    assert np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() <= 3e-3 * ref
+    pu.check('depth%d:alpha_rel' % depth, np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() / ref, ALPHA_TOL)
     q = (xs[:500] + np.float32(0.03)).astype(np.float32)
-    f_gpu = fld.evaluate_f(torch.from_numpy(q / np.float32(fld.scale)).to(_dev())).value.cpu().numpy()
+    f_gpu = fld._evaluate_f_model(torch.from_numpy(q).to(_dev()), False).value.cpu().numpy()
     f_ref = pipeline.evaluate(ofl, q)[0]
-    assert np.abs(f_gpu - f_ref).max() <= 3e-3 * max(np.abs(f_ref).max(), 1e-6)
+    pu.check('depth%d:f_rel' % depth, np.abs(f_gpu - f_ref).max() / max(np.abs(f_ref).max(), 1e-6), 1e-4)
+    pu.mesh_parity('depth%d[mise=1]' % depth, fld, ofl, 1, fld.scale)

@@ -163,5 +163,7 @@ def test_oracle_reproduces_golden(name):
     assert int(out['A_nnz']) == int(g['A_nnz'])
     np.testing.assert_allclose(out['A_diag'], g['A_diag'], rtol=1e-5)
     np.testing.assert_allclose(out['alpha'], g['alpha'], rtol=0, atol=1e-4 * abs(g['alpha']).max())
-    assert np.array_equal(out['mesh_f_0'], g['mesh_f_0'])
-    np.testing.assert_allclose(out['mesh_v_0'], g['mesh_v_0'], atol=1e-5)
+    for mise in (0, 1):
+        assert np.array_equal(out['mesh%d_f' % mise], g['mesh%d_f' % mise])
+        assert np.array_equal(out['mesh%d_vert_vkey' % mise], g['mesh%d_vert_vkey' % mise])
+        np.testing.assert_allclose(out['mesh%d_v' % mise], g['mesh%d_v' % mise], atol=1e-5)
