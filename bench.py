@@ -257,7 +257,7 @@ def main():
         crop = os.path.join(tempfile.gettempdir(), 'nksr_bench_crop_%d.npz' % os.getpid())
         np.savez(crop, xyz=(xyz_np[idx] * np.float32(scale)).astype(np.float32), normal=nrm_np[idx], mise_iter=args.mise_iter)
         try:
-            cb = waymo_cpu.measure(cores=os.cpu_count(), repeats=4, crop=crop)
+            cb = waymo_cpu.measure(cores=min(os.cpu_count() or 1, 64), repeats=4, crop=crop)
         finally:
             if os.path.exists(crop):
                 os.remove(crop)

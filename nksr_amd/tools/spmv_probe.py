@@ -25,11 +25,17 @@ def main():
     fmt = solver.col_format(cols)
     call('nksr_spmv_plan', ptr(rowptr), M, nnz, fmt, ptr(ws), stream())
     print('M=%d nnz=%d nnz/row=%.1f bytes=%.3f GB col_format=%d' % (M, nnz, nnz / M, B / 1e9, fmt))
+    y_ref = None
     for v in variants:
         call('nksr_spmv_set_variant', v)
         for _ in range(3):
             call('nksr_spmv_csr', ptr(rowptr), ptr(cols), ptr(vals), M, nnz, fmt, ptr(x), ptr(y), ptr(ws), stream())
         torch.cuda.synchronize()
+        if v in (0, 2):      # real products: every variant must give the bits of variant 0 (same order of additions)
+            if y_ref is None:
+                y_ref = y.clone()
+            else:
+                print('variant %d vs variant %d: max |dy| = %.3e (max |y| = %.3e)' % (v, variants[0], float((y - y_ref).abs().max()), float(y_ref.abs().max())))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20
         e0.record()
