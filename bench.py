@@ -110,6 +110,8 @@ def main():
     ap.add_argument('--mise-iter', type=int, default=1)
     ap.add_argument('--detail-level', type=float, default=1.0)
     ap.add_argument('--cpu-sample', type=int, default=10000, help='points of the configs[2] crop every CPU worker solves')
+    ap.add_argument('--cpu-cores', type=int, default=0, help='CPU baseline worker processes (0 = all host cores, at most 64)')
+    ap.add_argument('--cpu-repeats', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scale-scene', action='store_true')
     ap.add_argument('--scene', choices=['auto', 'cloud', 'terrain'], default='auto',
@@ -257,7 +259,7 @@ def main():
         crop = os.path.join(tempfile.gettempdir(), 'nksr_bench_crop_%d.npz' % os.getpid())
         np.savez(crop, xyz=(xyz_np[idx] * np.float32(scale)).astype(np.float32), normal=nrm_np[idx], mise_iter=args.mise_iter)
         try:
-            cb = waymo_cpu.measure(cores=min(os.cpu_count() or 1, 64), repeats=4, crop=crop)
+            cb = waymo_cpu.measure(cores=args.cpu_cores or min(os.cpu_count() or 1, 64), repeats=args.cpu_repeats, crop=crop)
         finally:
             if os.path.exists(crop):
                 os.remove(crop)

@@ -8,9 +8,12 @@
 // holds a few times k points); cells are contiguous point ranges found through the voxel hash.
 // EXACT selection without a per-thread heap: the k-th smallest squared distance is found by a
 // 32-step bisection on the float bit pattern (positive floats order like their bit patterns), each
-// step re-counting the candidates (L1/L2 resident); the covariance is then accumulated over all
-// candidates within that radius.  One thread per query, queries in Morton order (neighbouring lanes
-// scan the same cells).
+// step re-counting the candidates (L1/L2 resident).  fp32 distances decide everything except the few
+// candidates within a couple of ulps of that radius: those are ranked by their fp64 distance, so the
+// neighbour SET is the one an fp64 kd-tree search returns (an fp32-only rule swaps near-equidistant
+// neighbours against it: normals off by ~1e-3 at a few points, measured in round 2).  The covariance
+// is then accumulated in fp64 over that set.  One thread per query, queries in Morton order
+// (neighbouring lanes scan the same cells).
 #include "common.h"
 
 struct KnnGrid {
@@ -117,7 +120,39 @@ __global__ void __launch_bounds__(128) k_knn_pca_normals(KnnGrid g, int64_t n, i
         if (count_within(g, q, c, R, __uint_as_float(mid)) >= k) hi = mid; else lo = mid + 1;
     }
     const float r2 = __uint_as_float(lo);
-    // mean and covariance of the neighbours within r2 (ties included)
+    // candidates with an fp32 distance well below r2 are neighbours; the ones within a few ulps of it are ranked in fp64
+    const float r2_lo = r2 * (1.0f - 2e-6f), r2_hi = r2 * (1.0f + 2e-6f);
+    constexpr int AMB = 12;
+    double amb[AMB];
+    int n_amb = 0, n_in = 0;
+    for (int dx = -R; dx <= R; ++dx)
+        for (int dy = -R; dy <= R; ++dy)
+            for (int dz = -R; dz <= R; ++dz) {
+                const int ci = hash_find(g.hkeys, g.hvals, g.hcap, morton_biased(c[0] + dx, c[1] + dy, c[2] + dz, NKSR_BIAS0));
+                if (ci < 0) continue;
+                for (int kk = g.start[ci]; kk < g.end[ci]; ++kk) {
+                    const float px = g.xyz[kk * 3], py = g.xyz[kk * 3 + 1], pz = g.xyz[kk * 3 + 2];
+                    const float ex = px - q[0], ey = py - q[1], ez = pz - q[2];
+                    const float d32 = ex * ex + ey * ey + ez * ez;
+                    if (d32 < r2_lo) { ++n_in; continue; }
+                    if (d32 > r2_hi) continue;
+                    const double fx = (double)px - (double)q[0], fy = (double)py - (double)q[1], fz = (double)pz - (double)q[2];
+                    double d64 = fx * fx + fy * fy + fz * fz;
+                    if (n_amb < AMB) {          // insertion into the (tiny) ascending list
+                        int j = n_amb++;
+                        while (j > 0 && amb[j - 1] > d64) { amb[j] = amb[j - 1]; --j; }
+                        amb[j] = d64;
+                    } else if (d64 < amb[AMB - 1]) {
+                        int j = AMB - 1;
+                        while (j > 0 && amb[j - 1] > d64) { amb[j] = amb[j - 1]; --j; }
+                        amb[j] = d64;
+                    }
+                }
+            }
+    int need = k - n_in;                         // how many of the near-threshold candidates belong to the k nearest
+    if (need > n_amb) need = n_amb;
+    const double thr64 = need > 0 ? amb[need - 1] : -1.0;
+    // mean and covariance of the neighbour set
     double m[3] = {0, 0, 0};
     int cnt = 0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -130,7 +165,12 @@ __global__ void __launch_bounds__(128) k_knn_pca_normals(KnnGrid g, int64_t n, i
                     for (int kk = g.start[ci]; kk < g.end[ci]; ++kk) {
                         const float px = g.xyz[kk * 3], py = g.xyz[kk * 3 + 1], pz = g.xyz[kk * 3 + 2];
                         const float ex = px - q[0], ey = py - q[1], ez = pz - q[2];
-                        if (ex * ex + ey * ey + ez * ez > r2) continue;
+                        const float d32 = ex * ex + ey * ey + ez * ez;
+                        if (d32 > r2_hi) continue;
+                        if (d32 >= r2_lo) {
+                            const double fx = (double)px - (double)q[0], fy = (double)py - (double)q[1], fz = (double)pz - (double)q[2];
+                            if (fx * fx + fy * fy + fz * fz > thr64) continue;
+                        }
                         if (pass == 0) { m[0] += px; m[1] += py; m[2] += pz; ++cnt; }
                         else {
                             const double d0 = px - m[0], d1 = py - m[1], d2 = pz - m[2];

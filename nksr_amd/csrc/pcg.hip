@@ -198,91 +198,6 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spmv(const int32_t* __restrict__ 
     }
 }
 
-// ---- variant 2 (format 1 only): the (col, val) stream goes HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging VGPRs.
-// The CU's vector-memory pipe is the binding resource of k_spmv (~10 B/clk/CU of register loads + ~16 clk per 64-lane x
-// gather: MI355X_MICROARCH.md; that model predicts the measured 4.2-4.4 TB/s); the DMA path sustains 12-13 B/clk/CU and the
-// next chunk's stream is requested as soon as every thread has copied the current one to registers, so it lands behind the
-// gathers and the row reduction.  LDS image = linear copy of the chunk's two streams (DMA writes wave-uniform base + lane x 16).
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef const __attribute__((address_space(1))) void glb_void_t;
-
-template <int VARIANT>
-__global__ void __launch_bounds__(PCG_BLOCK) k_spmv_dma(const int32_t* __restrict__ rowptr, const void* __restrict__ cols_,
-                                                        const float* __restrict__ vals, int M, int nnz, int nchunks,
-                                                        const int32_t* __restrict__ chunk_row, const float* __restrict__ x,
-                                                        float* __restrict__ y, float* __restrict__ carry,
-                                                        int32_t* __restrict__ carry_row, const int* __restrict__ done) {
-    if (done && *done) return;
-    typedef SpmvFmt<3> F;
-    constexpr int COL_BYTES = F::CHUNK / 3 * 8, VAL_BYTES = F::CHUNK * 4;       // 12288 + 18432 per chunk
-    constexpr int NDMA = (COL_BYTES + VAL_BYTES) / 1024;                        // 1 KiB per wave instruction
-    static_assert(COL_BYTES % 1024 == 0 && VAL_BYTES % 1024 == 0, "chunk streams must be whole KiB");
-    __shared__ __attribute__((aligned(16))) unsigned long long s_cols[F::CHUNK / 3];
-    __shared__ __attribute__((aligned(16))) float s_vals[F::CHUNK];
-    __shared__ __attribute__((aligned(16))) float prod[F::CHUNK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    auto issue = [&](int b) {
-        const char* gc = reinterpret_cast<const char*>(cols_) + (int64_t)b * COL_BYTES;
-        const char* gv = reinterpret_cast<const char*>(vals) + (int64_t)b * VAL_BYTES;
-        for (int i = wave; i < NDMA; i += PCG_BLOCK / 64) {
-            const bool is_col = i < COL_BYTES / 1024;
-            const char* g = is_col ? gc + i * 1024 : gv + (i - COL_BYTES / 1024) * 1024;
-            char* l = is_col ? reinterpret_cast<char*>(s_cols) + i * 1024 : reinterpret_cast<char*>(s_vals) + (i - COL_BYTES / 1024) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(g + lane * 16), (lds_void_t*)l, 16, 0, 0);
-        }
-    };
-    int b = blockIdx.x;
-    if (b < nchunks) issue(b);
-    for (; b < nchunks; b += gridDim.x) {
-        const int base = b * F::CHUNK;
-        const int end = (base + F::CHUNK < nnz) ? base + F::CHUNK : nnz;
-        const int r_first = chunk_row[b], r_lim = chunk_row[b + 1];
-        int pre0 = 0x7fffffff, pre1 = 0x7fffffff;
-        {
-            const int r = r_first + wave + (PCG_BLOCK / 64) * lane;
-            if (r <= r_lim && r < M) { pre0 = rowptr[r]; pre1 = rowptr[r + 1]; }
-        }
-        __syncthreads();                    // this chunk's stream has landed in LDS (the barrier drains the DMA queue)
-        int c[F::QUADS][3];
-        float v[F::QUADS][3];
-#pragma unroll
-        for (int q = 0; q < F::QUADS; ++q) {
-            const unsigned long long pk = s_cols[q * PCG_BLOCK + tid];
-            const f32x3_u vi = reinterpret_cast<const f32x3_u*>(s_vals)[q * PCG_BLOCK + tid];
-            c[q][0] = (int)(pk & 0x1FFFFFull); c[q][1] = (int)((pk >> 21) & 0x1FFFFFull); c[q][2] = (int)((pk >> 42) & 0x1FFFFFull);
-            v[q][0] = vi.x; v[q][1] = vi.y; v[q][2] = vi.z;
-        }
-        __syncthreads();                    // every thread holds its entries: the stream buffer is free again
-        if (b + (int)gridDim.x < nchunks) issue(b + gridDim.x);
-#pragma unroll
-        for (int q = 0; q < F::QUADS; ++q) {
-            float* pt = prod + q * F::QUAD + wave * F::TILE + lane;
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                pt[64 * j] = v[q][j] * (VARIANT == 1 ? (float)c[q][j] : x[c[q][j]]);
-        }
-        __syncthreads();
-        if (tid == 0 && pre0 >= base) carry_row[b] = -1;
-        int j = 0;
-        for (int r = r_first + wave; r <= r_lim && r < M; r += PCG_BLOCK / 64, ++j) {
-            int p0, p1;
-            if (j < 64) { p0 = __builtin_amdgcn_readlane(pre0, j); p1 = __builtin_amdgcn_readlane(pre1, j); }
-            else { p0 = rowptr[r]; p1 = rowptr[r + 1]; }
-            if (p0 >= end) break;
-            const int k0 = p0 > base ? p0 : base, k1 = p1 < end ? p1 : end;
-            float s = 0.f;
-            for (int k = k0 + lane; k < k1; k += 64) s += prod[k - base];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) {
-                if (p0 >= base) y[r] = s;
-                else { carry[b] = s; carry_row[b] = r; }
-            }
-        }
-        // the next iteration's first barrier separates these prod reads from the next products
-    }
-}
-
 // three int32 columns (< 2^21) of one lane slot -> one 64-bit word (format 1)
 __global__ void k_pack_cols21(const int32_t* __restrict__ cols32, int64_t nslots, unsigned long long* __restrict__ out) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -464,14 +379,7 @@ static int launch_spmv(const int32_t* rowptr, const void* cols, const float* val
                        const float* x, float* y, const int* done, hipStream_t st) {
 #define SPMV_LAUNCH(E, V) hipLaunchKernelGGL((k_spmv<E, V>), dim3(spmv_grid(p.nchunks)), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, (int)nnz, \
                        p.nchunks, p.chunk_row, x, y, p.carry, p.carry_row, done)
-    if (fmt == 1 && g_spmv_variant >= 2) {
-        // LDS-DMA variant: 48 KiB of LDS per workgroup => 3 workgroups per CU; 768 resident workgroups deal the chunks round-robin
-        const int grid = p.nchunks < 768 ? p.nchunks : 768;
-        if (g_spmv_variant == 3)
-            hipLaunchKernelGGL((k_spmv_dma<1>), dim3(grid), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, (int)nnz, p.nchunks, p.chunk_row, x, y, p.carry, p.carry_row, done);
-        else
-            hipLaunchKernelGGL((k_spmv_dma<0>), dim3(grid), dim3(PCG_BLOCK), 0, st, rowptr, cols, vals, M, (int)nnz, p.nchunks, p.chunk_row, x, y, p.carry, p.carry_row, done);
-    } else if (fmt == 1) { if (g_spmv_variant == 1) SPMV_LAUNCH(3, 1); else SPMV_LAUNCH(3, 0); }
+    if (fmt == 1) { if (g_spmv_variant == 1) SPMV_LAUNCH(3, 1); else SPMV_LAUNCH(3, 0); }
     else { if (g_spmv_variant == 1) SPMV_LAUNCH(4, 1); else SPMV_LAUNCH(4, 0); }
     hipLaunchKernelGGL(k_spmv_fixup, dim3(nksr_blocks(p.nchunks, 256)), dim3(256), 0, st, p.nchunks, p.carry, p.carry_row, y, done);
     return 0;

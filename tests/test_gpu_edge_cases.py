@@ -124,7 +124,8 @@ def test_bench_contract_line():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '1', '--warmup', '1',
-                          '--points', '60000', '--cpu-sample', '1500'], capture_output=True, text=True, timeout=600)
+                          '--points', '60000', '--cpu-sample', '1500', '--scene-points', '640000', '--cpu-cores', '2', '--cpu-repeats', '1'],
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
@@ -134,10 +135,18 @@ def test_bench_contract_line():
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 1 and d['higher_is_better'] is True and d['vs_baseline'] is None
     assert 'workload' in d['config'] and d['value'] > 0
+    assert 'configs[2]' in d['config']['workload'] and d['scaling'] == 'weak'
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    for k in ('traffic', 'traffic_source', 'achieved_physical', 'frac_physical', 'bytes_per_launch', 'avg_launch_us'):
+        assert k in r, k
+    assert (r['traffic'] is None) == (r['traffic_source'] is None)
     c = d['cpu_baseline']
-    assert c['kind'] == 'port' and c['cores'] == 1 and c['value'] > 0 and 'sample' in c
+    assert c['kind'] == 'port' and c['cores'] == 2 and c['value'] > 0 and 'recons_waymo_cpu.py' in c['sample']
+    assert c['gpu_same_input']['value'] > 0 and c['workload_crop']['value'] > 0
+    s = d['scale_scene']           # the N=1 point of the configs[4] strong-scaling curve
+    assert 'configs[4]' in s['config']['workload'] and s['value'] > 0 and s['config']['chunks'] == 64
+    assert s['config']['tree_depth'] == 5 and s['roofline']['launches_timed'] > 0
 
 
 def test_reconstruct_is_bitwise_deterministic():

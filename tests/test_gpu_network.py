@@ -9,7 +9,6 @@ from conftest import make_cloud
 import parity_util as pu
 
 pytestmark = pytest.mark.gpu
-ALPHA_TOL = 1e-4      # see tests/test_gpu_parity.py
 
 
 def _run(prune):
@@ -118,7 +117,7 @@ def test_shapenet_3k_noise_config():
     for d in range(4):
         assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
     ref = np.abs(ofl['alpha']).max()
-    pu.check('shapenet3k:alpha_rel', np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() / ref, ALPHA_TOL)
+    pu.check_alpha('shapenet3k', fld.alpha.cpu().numpy(), ofl, 1e-6)
     fo, _ = pipeline.evaluate(ofl, xyz)
     fg = fld.evaluate_f(torch.from_numpy(xyz).to(dev)).value.cpu().numpy()
     pu.check('shapenet3k:f_at_inputs', np.abs(fg - fo).max() / ref, 1e-4)

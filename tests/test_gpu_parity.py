@@ -11,12 +11,6 @@ import parity_util as pu
 pytestmark = pytest.mark.gpu
 
 
-# alpha solves an ill-conditioned system to a relative RESIDUAL of 1e-6 on both sides: the coefficient vectors agree to
-# cond(A) x that, the field they define agrees to 1e-6 (measured values are printed by every test; bound = max(1e-4
-# contract of SURVEY.md section 8c, 10 x measured on MI355X in round 2))
-ALPHA_TOL = 1e-4
-
-
 def _dev():
     return torch.device('cuda:0')
 
@@ -213,7 +207,7 @@ def test_end_to_end_mesh(kind, vs):
     fo, _ = pipeline.evaluate(ofl, (xyz * np.float32(scale)).astype(np.float32))
     fg = fld.evaluate_f(torch.from_numpy(xyz).to(_dev())).value.cpu().numpy()
     pu.check('e2e[%s]:f_at_inputs' % kind, np.abs(fg - fo).max() / np.abs(ofl['alpha']).max(), 1e-4)
-    pu.check('e2e[%s]:alpha_rel' % kind, np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() / np.abs(ofl['alpha']).max(), ALPHA_TOL)
+    pu.check_alpha('e2e[%s]' % kind, fld.alpha.cpu().numpy(), ofl, 1e-6)
     for mise in (0, 1, 2):
         # topology: index-exact outside the near-threshold cells, vertices within 1e-4 voxel (tests/parity_util.py)
         st, mesh, _ = pu.mesh_parity('e2e[%s,mise=%d]' % (kind, mise), fld, ofl, mise, scale)
@@ -241,7 +235,7 @@ def test_against_committed_golden(name):
     for d in range(4):
         assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), g['keys_%d' % d])      # voxel sets: exact
     amax = abs(g['alpha']).max()
-    pu.check('golden[%s]:alpha_rel' % name, np.abs(fld.alpha.cpu().numpy() - g['alpha']).max() / amax, ALPHA_TOL)
+    pu.check('golden[%s]:alpha_rel' % name, np.abs(fld.alpha.cpu().numpy() - g['alpha']).max() / amax, pu.ALPHA_TOL)
     np.testing.assert_allclose(fld.rhs.cpu().numpy(), g['b'], rtol=1e-4, atol=1e-5 * abs(g['b']).max())
     np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), g['A_diag'], rtol=1e-4)
     res = fld.evaluate_f(torch.from_numpy(xyz).to(_dev()), grad=True)
@@ -308,7 +302,7 @@ def test_tree_depth_5_matches_oracle():
     for d in range(5):
         assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
     ref = np.abs(ofl['alpha']).max()
-    pu.check('depth5:alpha_rel', np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() / ref, ALPHA_TOL)
+    pu.check_alpha('depth5', fld.alpha.cpu().numpy(), ofl, 1e-6)
     np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), ofl['A'].diagonal(), rtol=1e-4)
     pu.mesh_parity('depth5[mise=1]', fld, ofl, 1, fld.scale)
 
@@ -354,7 +348,7 @@ def test_other_tree_depths_match_oracle(depth):
         assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
     np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), ofl['A'].diagonal(), rtol=1e-4)
     ref = np.abs(ofl['alpha']).max()
-    pu.check('depth%d:alpha_rel' % depth, np.abs(fld.alpha.cpu().numpy() - ofl['alpha']).max() / ref, ALPHA_TOL)
+    pu.check_alpha('depth%d' % depth, fld.alpha.cpu().numpy(), ofl, 1e-6)
     q = (xs[:500] + np.float32(0.03)).astype(np.float32)
     f_gpu = fld._evaluate_f_model(torch.from_numpy(q).to(_dev()), False).value.cpu().numpy()
     f_ref = pipeline.evaluate(ofl, q)[0]
