@@ -55,15 +55,27 @@ def load_traffic(bytes_per_launch):
     return best
 
 
-def roofline_record(ms, launches, alg, phys):
+def roofline_record(ms, launches, alg, phys, fused=False):
+    """The CG operator application ("SpMV") measured live with HIP events on the solve stream.
+    assembled CSR : achieved = the algorithmic CSR bytes of SURVEY.md section 8d (8 nnz + 12 M + 4) / time; achieved_physical
+                    counts what the packed layout streams (6.67 B per entry).
+    matrix-free   : the dense-slot rows hold no column indices, so the survey's matrix-free figure (8 bytes per stored entry of
+                    G and Q in each direction) would credit bytes that do not exist: achieved = the bytes the operator really
+                    moves (4 B per slot per direction + its vectors), the survey figure is kept as achieved_survey_formula."""
     avg_s = (ms / max(launches, 1)) * 1e-3
     a = alg / max(launches, 1)
     p = phys / max(launches, 1)
-    ach = a / avg_s if avg_s > 0 else 0.0
+    rate = lambda b: (b / avg_s if avg_s > 0 else 0.0)
+    if fused:
+        return {'bound': 'hbm', 'kernel': 'k_fz_forward + k_fz_tsum + k_fz_transposed + k_fz_gather (matrix-free normal-equation operator '
+                                          'inside the PCG loop, fused_mode=True)',
+                'achieved': rate(p) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(p) / HBM_PEAK,
+                'achieved_survey_formula': rate(a) / 1e9, 'traffic': None, 'traffic_source': None,
+                'bytes_per_launch': p, 'survey_formula_bytes_per_launch': a, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
     traffic, src = load_traffic(a) if launches else (None, None)
-    return {'bound': 'hbm', 'kernel': 'k_spmv<3,0> + k_spmv_fixup (packed-column CSR SpMV inside the PCG loop)',
-            'achieved': ach / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': ach / HBM_PEAK,
-            'achieved_physical': (p / avg_s if avg_s > 0 else 0.0) / 1e9, 'frac_physical': (p / avg_s if avg_s > 0 else 0.0) / HBM_PEAK,
+    return {'bound': 'hbm', 'kernel': 'k_spmv<3,0> + k_spmv_fixup (packed-column CSR SpMV inside the PCG loop, fused_mode=False)',
+            'achieved': rate(a) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(a) / HBM_PEAK,
+            'achieved_physical': rate(p) / 1e9, 'frac_physical': rate(p) / HBM_PEAK,
             'traffic': traffic, 'traffic_source': src if traffic is not None else None,
             'bytes_per_launch': a, 'physical_bytes_per_launch': p, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
 
@@ -114,6 +126,8 @@ def main():
     ap.add_argument('--cpu-repeats', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scale-scene', action='store_true')
+    ap.add_argument('--no-other-mode', action='store_true')
+    ap.add_argument('--non-fused', action='store_true', help='headline through the assembled CSR solve (fused_mode=False)')
     ap.add_argument('--scene', choices=['auto', 'cloud', 'terrain'], default='auto',
                     help="'terrain' runs configs[4] as the headline at N=1 too")
     args = ap.parse_args()
@@ -175,7 +189,7 @@ def main():
                 acc[k] = acc.get(k, 0.0) + v
 
     # ---- configs[4]: strong-scaling scene ----------------------------------------------------------------------------
-    def run_terrain(steps, warmup):
+    def run_terrain(steps, warmup, fused):
         rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', tree_depth=5))
         rec.sync_timing = True
         xyz, nrm, scale, owner, bounds, n_scene, ntiles = terrain_setup(rec, dev, args.scene_points, rank, world)
@@ -183,7 +197,7 @@ def main():
 
         def step(acc):
             field = rec.reconstruct(xyz, nrm, detail_level=None, chunk_size=chunk_size, sharded_input=True, chunk_owner=owner,
-                                    chunk_bounds=bounds)
+                                    chunk_bounds=bounds, fused_mode=fused)
             t0 = time.perf_counter()
             mesh = field.extract_dual_mesh(mise_iter=args.mise_iter)
             torch.cuda.synchronize()
@@ -195,7 +209,7 @@ def main():
         infos = [f.solve_info for f in field.fields.values() if f.solve_info]
         cfg = {'workload': 'configs[4]: synthetic %d-point km-scale terrain + boxes (8x8 tiles of 125 m), tree_depth=5, chunk_size=125 m '
                            '(64 chunks), reconstruct(chunk_size=)+extract_dual_mesh(mise_iter=%d), STRONG scaling' % (n_scene, args.mise_iter),
-               'scene_points': n_scene, 'tree_depth': 5, 'kernel_dim': rec.hparams.kernel_dim, 'global_scale': scale,
+               'scene_points': n_scene, 'fused_mode': fused, 'tree_depth': 5, 'kernel_dim': rec.hparams.kernel_dim, 'global_scale': scale,
                'chunks': TILES * TILES, 'chunks_this_rank': sum(1 for c in owner if c == rank), 'tiles_loaded_this_rank': ntiles,
                'points_resident_this_rank': int(xyz.shape[0]),
                'unknowns_M_per_chunk': int(np.mean([i['M'] for i in infos])) if infos else 0,
@@ -207,14 +221,14 @@ def main():
         return dt, n_scene, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}
 
     # ---- configs[2]: the roofline workload ---------------------------------------------------------------------------
-    def run_cloud(steps, warmup):
+    def run_cloud(steps, warmup, fused):
         rec = nksr_amd.Reconstructor(dev)
         rec.sync_timing = True
         xyz_np, nrm_np = utils.synth_scene(args.points, seed=0, extent=(40.0, 40.0, 10.0), noise=0.01)
         xyz, nrm = torch.from_numpy(xyz_np).to(dev), torch.from_numpy(nrm_np).to(dev)
 
         def step(acc):
-            field = rec.reconstruct(xyz, nrm, detail_level=args.detail_level)
+            field = rec.reconstruct(xyz, nrm, detail_level=args.detail_level, fused_mode=fused)
             t0 = time.perf_counter()
             mesh = field.extract_dual_mesh(mise_iter=args.mise_iter)
             torch.cuda.synchronize()
@@ -226,30 +240,37 @@ def main():
         info = field.solve_info
         cfg = {'workload': 'configs[2]: synthetic %d-point oriented cloud (8 spheres/tori in a 40x40x10 box, sigma=0.01), '
                            'detail_level=%.1f, reconstruct()+extract_dual_mesh(mise_iter=%d)' % (args.points, args.detail_level, args.mise_iter),
-               'points': args.points, 'tree_depth': rec.hparams.tree_depth, 'kernel_dim': rec.hparams.kernel_dim,
-               'unknowns_M': info['M'], 'nnz_A': info['nnz'], 'pcg_iters': info['iters'], 'pcg_rel_residual': info['rel_residual'],
+               'points': args.points, 'fused_mode': fused, 'tree_depth': rec.hparams.tree_depth, 'kernel_dim': rec.hparams.kernel_dim,
+               'unknowns_M': info['M'], 'nnz_A': info['nnz'], 'kernel_row_slots': info.get('kernel_row_slots'), 'pcg_iters': info['iters'], 'pcg_rel_residual': info['rel_residual'],
                'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]), 'global_scale': field.scale,
                'parallelism': 'none'}
         return dt, args.points, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}, (rec, xyz_np, nrm_np, field.scale)
 
     terrain_headline = world > 1 or args.scene == 'terrain'
     extra = None
+    fused = not args.non_fused            # the API default (and what the reference's examples pass): fused_mode=True
     if terrain_headline:
-        dt, npts, cfg, prof, stages = run_terrain(args.steps, args.warmup)
+        dt, npts, cfg, prof, stages = run_terrain(args.steps, args.warmup, fused)
     else:
-        dt, npts, cfg, prof, stages, extra = run_cloud(args.steps, args.warmup)
+        dt, npts, cfg, prof, stages, extra = run_cloud(args.steps, args.warmup, fused)
     out = {
         'metric': 'reconstructed points/sec (solve+mesh)', 'value': npts * args.steps / dt, 'unit': 'points/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'strong' if terrain_headline else 'weak', 'vs_baseline': None, 'dtype': 'f32',
-        'data': 'synthetic', 'config': cfg, 'roofline': roofline_record(*prof), 'stages_s_per_step': stages,
+        'data': 'synthetic', 'config': cfg, 'roofline': roofline_record(*prof, fused=fused), 'stages_s_per_step': stages,
     }
+    if not terrain_headline and not args.no_other_mode:
+        # the same workload through the other solve: assembled CSR + streaming SpMV (solve_non_fused, the path training needs)
+        odt, _, ocfg, oprof, ostages, _ = run_cloud(2, 1, not fused)
+        out['other_solve_mode'] = {'fused_mode': not fused, 'value': npts * 2 / odt, 'unit': 'points/s', 'ms_per_step': odt / 2 * 1e3, 'steps': 2,
+                                   'warmup': 1, 'unknowns_M': ocfg['unknowns_M'], 'nnz_A': ocfg['nnz_A'], 'pcg_iters': ocfg['pcg_iters'],
+                                   'roofline': roofline_record(*oprof, fused=not fused), 'stages_s_per_step': ostages}
     if not terrain_headline and not args.no_scale_scene:
         # the same scene the N > 1 runs solve, on this one GPU (1 warm-up + 2 timed steps): the N=1 point of the curve
         torch.cuda.empty_cache()
-        sdt, sn, scfg, sprof, sstages = run_terrain(2, 1)
+        sdt, sn, scfg, sprof, sstages = run_terrain(2, 1, fused)
         out['scale_scene'] = {'value': sn * 2 / sdt, 'unit': 'points/s', 'ms_per_step': sdt / 2 * 1e3, 'steps': 2, 'warmup': 1,
-                              'config': scfg, 'roofline': roofline_record(*sprof), 'stages_s_per_step': sstages}
+                              'config': scfg, 'roofline': roofline_record(*sprof, fused=fused), 'stages_s_per_step': sstages}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and extra is not None:
         from oracle import waymo_cpu
         rec, xyz_np, nrm_np, scale = extra

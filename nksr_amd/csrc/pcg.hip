@@ -7,6 +7,7 @@
 // turns the remaining launches of a chunk into no-ops, so the host only syncs every
 // `check_every` iterations.
 #include "common.h"
+#include "pcg_core.h"
 
 #define PCG_BLOCK 256
 #define PCG_MAX_BLOCKS 2048
@@ -32,6 +33,7 @@ static size_t pcg_vector_bytes(int32_t M) {
     size_t vec = align_up((size_t)M * sizeof(float), 256);
     return 4 * vec + 3 * PCG_MAX_BLOCKS * sizeof(double) + 256;
 }
+size_t nksr_pcg_vector_bytes(int32_t M) { return pcg_vector_bytes(M); }
 extern "C" size_t nksr_spmv_workspace_bytes(int64_t nnz);
 extern "C" size_t nksr_pcg_workspace_bytes(int32_t M, int64_t nnz) {
     return pcg_vector_bytes(M) + nksr_spmv_workspace_bytes(nnz);
@@ -429,18 +431,12 @@ extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_ou
     return NKSR_OK;
 }
 
-extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, const float* diag, int32_t M,
-                              int64_t nnz, int col_format, const float* b, float* x, float tol, int max_iter, int check_every,
-                              void* workspace, double* info_out, void* stream) {
+int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, float* x, float tol, int max_iter, int check_every,
+                 void* vector_workspace, double* info_out, hipStream_t st) {
     if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
-    if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
+    if (!vector_workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     if (check_every < 1) check_every = 1;
-    hipStream_t st = (hipStream_t)stream;
-    PcgWork w = carve(workspace, M);
-    void* spmv_ws = (char*)workspace + pcg_vector_bytes(M);
-    int rc = nksr_spmv_plan(rowptr, M, nnz, col_format, spmv_ws, stream);
-    if (rc) return rc;
-    SpmvPlan plan = carve_spmv(spmv_ws, nnz, col_format);
+    PcgWork w = carve(vector_workspace, M);
     const int nbv = nksr_blocks(M, PCG_BLOCK) > PCG_MAX_BLOCKS ? PCG_MAX_BLOCKS : nksr_blocks(M, PCG_BLOCK);
     hipLaunchKernelGGL(k_pcg_init, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, b, diag, w, x);
     hipLaunchKernelGGL(k_pcg_init_finish, dim3(1), dim3(PCG_BLOCK), 0, st, w, nbv);
@@ -459,9 +455,9 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const flo
         int chunk = check_every < (max_iter - launched) ? check_every : (max_iter - launched);
         for (int c = 0; c < chunk; ++c) {
             const int parity = (launched + c) & 1;
-            if (prof) hipEventRecord(g_prof_events[2 * c], st);
-            launch_spmv(rowptr, cols, vals, M, nnz, col_format, plan, w.p, w.y, &w.sc->done, st);
-            if (prof) hipEventRecord(g_prof_events[2 * c + 1], st);
+            if (prof) (void)hipEventRecord(g_prof_events[2 * c], st);
+            if (int rc = A.apply(w.p, w.y, &w.sc->done, st)) return rc;
+            if (prof) (void)hipEventRecord(g_prof_events[2 * c + 1], st);
             hipLaunchKernelGGL(k_pcg_dot, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w);
             hipLaunchKernelGGL(k_pcg_update, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, diag, w, x, nbv, parity);
             hipLaunchKernelGGL(k_pcg_pupdate, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w, nbv, parity, tol);
@@ -470,14 +466,14 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const flo
         NKSR_CHECK_HIP(hipMemcpyAsync(&host, w.sc, sizeof(host), hipMemcpyDeviceToHost, st));
         NKSR_CHECK_HIP(hipStreamSynchronize(st));
         if (prof) {
-            // only launches that did real work (the done flag turns later ones into no-ops)
+            // only applications that did real work (the done flag turns later ones into no-ops)
+            double ba, bp;
+            A.bytes(&ba, &bp);
             for (int c = 0; c < chunk && launched + c < host.iter; ++c) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, g_prof_events[2 * c], g_prof_events[2 * c + 1]) == hipSuccess) {
                     g_prof_ms += ms;
                     g_prof_launches += 1;
-                    double ba, bp;
-                    spmv_bytes(M, nnz, col_format, &ba, &bp);
                     g_prof_alg_bytes += ba;
                     g_prof_phys_bytes += bp;
                 }
@@ -491,4 +487,27 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const flo
         info_out[1] = host.rel;
     }
     return NKSR_OK;
+}
+
+struct CsrOperator : PcgOperator {
+    const int32_t* rowptr; const void* cols; const float* vals; int M; int64_t nnz; int fmt; SpmvPlan plan;
+    int apply(const float* p, float* y, const int* done, hipStream_t st) override {
+        launch_spmv(rowptr, cols, vals, M, nnz, fmt, plan, p, y, done, st);
+        return NKSR_OK;
+    }
+    void bytes(double* a, double* ph) override { spmv_bytes(M, nnz, fmt, a, ph); }
+};
+
+extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, const float* diag, int32_t M,
+                              int64_t nnz, int col_format, const float* b, float* x, float tol, int max_iter, int check_every,
+                              void* workspace, double* info_out, void* stream) {
+    if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
+    if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
+    void* spmv_ws = (char*)workspace + pcg_vector_bytes(M);
+    int rc = nksr_spmv_plan(rowptr, M, nnz, col_format, spmv_ws, stream);
+    if (rc) return rc;
+    CsrOperator A;
+    A.rowptr = rowptr; A.cols = cols; A.vals = vals; A.M = M; A.nnz = nnz; A.fmt = col_format;
+    A.plan = carve_spmv(spmv_ws, nnz, col_format);
+    return nksr_pcg_run(A, diag, M, b, x, tol, max_iter, check_every, workspace, info_out, (hipStream_t)stream);
 }

@@ -17,7 +17,7 @@ import time
 import torch
 
 from .. import _lib, ops
-from .._lib import HierT, SiteSetT, call, ptr, stream
+from .._lib import FusedSetT, HierT, SiteSetT, call, ptr, stream
 from .base_field import BaseField, EvaluationResult
 
 
@@ -67,13 +67,15 @@ class KernelField(BaseField):
         return h
 
     # ---- kernel rows ---------------------------------------------------------------------------------
-    def kernel_rows(self, xyz, grad, scale=1.0, values=True):
+    def kernel_rows(self, xyz, grad, scale=1.0, values=True, level_major=False):
         """Dense-slot rows: val [n, L, 27] (``None`` with values=False) and (grad) dval [n, 3, L, 27]
-        (model units), times ``scale``."""
+        (model units), times ``scale``.  ``level_major``: val [L, n, 27], dval [L, n, 3, 27] (matrix-free solve)."""
         n, L = xyz.shape[0], self.svh.depth
-        val = torch.empty((n, L, 27), dtype=torch.float32, device=self.device) if values else None
-        dval = torch.empty((n, 3, L, 27), dtype=torch.float32, device=self.device) if grad else None
-        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), ptr(val), ptr(dval), stream())
+        vs, ds = ((L, n, 27), (L, n, 3, 27)) if level_major else ((n, L, 27), (n, 3, L, 27))
+        val = torch.empty(vs, dtype=torch.float32, device=self.device) if values else None
+        dval = torch.empty(ds, dtype=torch.float32, device=self.device) if grad else None
+        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), int(level_major),
+             ptr(val), ptr(dval), stream())
         return val, dval
 
     def _sorted_sites(self, xyz):
@@ -146,8 +148,8 @@ class KernelField(BaseField):
         n_up, n_mir = [int(v) for v in counts[:2].sum(dim=1, dtype=torch.int64).tolist()]
         nnz = 2 * n_up + M
         if nnz >= 2 ** 31 - 4096:
-            raise RuntimeError('system too large for one chunk (M=%d, nnz=%d >= 2^31): pass chunk_size= to '
-                               'reconstruct() (examples/recons_by_chunk.py)' % (M, nnz))
+            raise RuntimeError('assembled system too large for one chunk (M=%d, nnz=%d >= 2^31): use the matrix-free solve '
+                               '(fused_mode=True) or pass chunk_size= to reconstruct() (examples/recons_by_chunk.py)' % (M, nnz))
         rowlen = indeg + samelow + rowcount + 1     # [cross-level mirrors][same-level lower][own upper][diagonal]
         rowlen[M] = 0
         rowptr = ops.exclusive_sum_i32(rowlen)
@@ -202,7 +204,7 @@ class KernelField(BaseField):
         t2 = time.perf_counter()
         self.alpha = x
         self.matrix = (rowptr, cols, vals, diag)
-        self.rhs = b
+        self.rhs, self.diag = b, diag
         self.solve_info = {'iters': iters, 'rel_residual': rel, 'M': int(b.numel()), 'nnz': int(self.nnz),
                            't_assemble': t1 - t0, 't_pcg': t2 - t1}
         if self.solver_config.get('verbose'):
@@ -210,11 +212,108 @@ class KernelField(BaseField):
                 b.numel(), self.nnz, iters, rel, t1 - t0, t2 - t1))
         return self
 
+    # ---- matrix-free ("fused") solve ---------------------------------------------------------------------
+    def fused_operator(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, pos_sorted_keys=None, normal_sorted_keys=None):
+        """Everything the matrix-free operator needs (csrc/fused.hip): level-major kernel rows of both site sets
+        (pre-multiplied by sqrt(weight)), their per-cell site ranges and the work items.  Returns a dict; ``keep`` holds
+        the buffers the C structs point into."""
+        dev = self.device
+        if self.svh.num_unknowns == 0:
+            raise RuntimeError('empty hierarchy')
+        keep = []
+        sets = (FusedSetT * 2)()
+        nsets = 0
+        for xyz, target, weight, ncomp, pre in ((pos_xyz, None, pos_weight, 1, pos_sorted_keys),
+                                                 (normal_xyz, normal_value, normal_weight, 3, normal_sorted_keys)):
+            if xyz is None or xyz.shape[0] == 0:
+                continue
+            xyz = xyz.to(dev, torch.float32).contiguous()
+            if pre is not None:
+                ks, perm, xs = pre, None, xyz
+            else:
+                ks, perm = self._sorted_sites(xyz)
+                xs = xyz[perm].contiguous()
+            if not float(weight) >= 0.0:
+                raise RuntimeError('solver weights must be >= 0')
+            sw = float(weight) ** 0.5
+            val, dval = self.kernel_rows(xs, grad=(ncomp == 3), scale=sw, values=(ncomp == 1), level_major=True)
+            rows = val if ncomp == 1 else dval
+            st, en = self._site_ranges(ks)
+            S = sets[nsets]
+            S.n, S.ncomp, S.rows = xs.shape[0], ncomp, ptr(rows)
+            tgt = None
+            if target is not None:
+                tgt = target.to(dev, torch.float32)
+                tgt = ((tgt[perm] if perm is not None else tgt) * sw).contiguous()      # [n, 3] == rows order (site, component)
+                S.target = ptr(tgt)
+            for d in range(self.svh.depth):
+                S.start[d], S.end[d] = ptr(st[d]), ptr(en[d])
+            keep += [xs, rows, st, en, tgt, ks]
+            nsets += 1
+        if nsets == 0:
+            raise RuntimeError('no constraint sites')
+        ncells = int(_lib.lib.nksr_fused_cells(C.byref(self._hier), nsets))
+        counts = torch.empty(ncells + 1, dtype=torch.int32, device=dev)
+        call('nksr_fused_item_counts', C.byref(self._hier), sets, nsets, ptr(counts), stream())
+        offsets = ops.exclusive_sum_i32(counts)
+        nitems = int(offsets[ncells].item())
+        items = torch.empty((max(nitems, 1), 4), dtype=torch.int32, device=dev)
+        call('nksr_fused_items', C.byref(self._hier), sets, nsets, ptr(offsets), ptr(items), stream())
+        ws = torch.empty(int(_lib.lib.nksr_fused_workspace_bytes(C.byref(self._hier), sets, nsets, nitems)), dtype=torch.uint8, device=dev)
+        rows_total = sum(int(sets[i].n) * int(sets[i].ncomp) for i in range(nsets))
+        return {'sets': sets, 'nsets': nsets, 'offsets': offsets, 'items': items, 'nitems': nitems, 'ws': ws, 'keep': keep,
+                'rows_total': rows_total}
+
+    def fused_apply(self, op, x, reg_weight=1.0):
+        """y = (w_p G^T G + w_n Q^T Q + reg I) x without the matrix (test / export helper)."""
+        y = torch.empty_like(x)
+        call('nksr_fused_apply', C.byref(self._hier), op['sets'], op['nsets'], ptr(op['offsets']), ptr(op['items']), op['nitems'],
+             float(reg_weight), ptr(op['ws']), ptr(x.contiguous()), ptr(y), stream())
+        return y
+
+    def solve_fused(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0,
+                    pos_sorted_keys=None, normal_sorted_keys=None):
+        """Matrix-free Jacobi-PCG on the normal equations: no assembly, ~8 bytes per dense kernel-row slot per
+        iteration (examples/recons_waymo.py:33 ``fused_mode=True``).  Same system, same stopping rule as
+        solve_non_fused; the iterates agree to fp32 rounding (different summation order)."""
+        t0 = time.perf_counter()
+        op = self.fused_operator(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, pos_sorted_keys, normal_sorted_keys)
+        dev = self.device
+        M = self.svh.num_unknowns
+        b = torch.empty(M, dtype=torch.float32, device=dev)
+        diag = torch.empty(M, dtype=torch.float32, device=dev)
+        call('nksr_fused_rhs_diag', C.byref(self._hier), op['sets'], op['nsets'], ptr(op['offsets']), ptr(op['items']), op['nitems'],
+             float(reg_weight), ptr(op['ws']), ptr(b), ptr(diag), stream())
+        if self.solver_config.get('verbose') or self.solver_config.get('sync_timing'):
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        x = torch.empty(M, dtype=torch.float32, device=dev)
+        pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=dev)
+        info = (C.c_double * 2)()
+        call('nksr_pcg_solve_fused', C.byref(self._hier), op['sets'], op['nsets'], ptr(op['offsets']), ptr(op['items']), op['nitems'],
+             float(reg_weight), ptr(diag), ptr(b), ptr(x), float(self.solver_config['tol']), int(self.solver_config['max_iter']),
+             int(self.solver_config['check_every']), ptr(op['ws']), ptr(pws), info, stream())
+        t2 = time.perf_counter()
+        self.alpha = x
+        self.matrix = None
+        self.rhs, self.diag = b, diag
+        self.nnz = 0
+        self.solve_info = {'iters': int(info[0]), 'rel_residual': float(info[1]), 'M': int(M), 'nnz': 0, 'fused': True,
+                           'kernel_row_slots': 27 * self.svh.depth * op['rows_total'], 'work_items': op['nitems'],
+                           't_assemble': t1 - t0, 't_pcg': t2 - t1}
+        if self.solver_config.get('verbose'):
+            print('[KernelField] fused: M=%d rows=%d iters=%d rel=%.3e rows+rhs=%.3fs pcg=%.3fs' % (
+                M, op['rows_total'], int(info[0]), float(info[1]), t1 - t0, t2 - t1))
+        return self
+
     def solve(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0, fused_mode=True,
               pos_sorted_keys=None, normal_sorted_keys=None):
-        """``fused_mode`` selects the reference's memory-lean operator; on a 288 GB MI355X the
-        materialised CSR is both smaller than G (nnz(A) < nnz(G) at >= 2 points/voxel) and the
-        faster SpMV, so both modes run the CSR path."""
+        """``fused_mode=True`` (the reference's memory-lean operator, examples/recons_waymo.py:33): matrix-free solve,
+        no assembly; ``False``: assemble the CSR and stream it (solve_non_fused -- the path the training code needs,
+        models/nksr_net.py:105-112).  DESIGN.md section 3.5 has the cost model of the two."""
+        if fused_mode:
+            return self.solve_fused(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight,
+                                    pos_sorted_keys, normal_sorted_keys)
         return self.solve_non_fused(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight,
                                     pos_sorted_keys, normal_sorted_keys)
 

@@ -138,9 +138,13 @@ def test_bench_contract_line():
     assert 'configs[2]' in d['config']['workload'] and d['scaling'] == 'weak'
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
-    for k in ('traffic', 'traffic_source', 'achieved_physical', 'frac_physical', 'bytes_per_launch', 'avg_launch_us'):
+    for k in ('traffic', 'traffic_source', 'bytes_per_launch', 'avg_launch_us', 'launches_timed', 'kernel'):
         assert k in r, k
     assert (r['traffic'] is None) == (r['traffic_source'] is None)
+    assert d['config']['fused_mode'] is True and 'k_fz_forward' in r['kernel'] and 'achieved_survey_formula' in r
+    o = d['other_solve_mode']          # the assembled CSR solve on the same workload, with the CSR SpMV roofline
+    assert o['fused_mode'] is False and o['value'] > 0 and 'k_spmv' in o['roofline']['kernel'] and o['nnz_A'] > 0
+    assert 'achieved_physical' in o['roofline'] and o['roofline']['frac_physical'] <= o['roofline']['frac']
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] == 2 and c['value'] > 0 and 'recons_waymo_cpu.py' in c['sample']
     assert c['gpu_same_input']['value'] > 0 and c['workload_crop']['value'] > 0
@@ -158,13 +162,14 @@ def test_reconstruct_is_bitwise_deterministic():
     xyz, nrm = utils.synth_scene(120000, seed=3, extent=(12.0, 12.0, 6.0), n_objects=4)
     xyz, nrm = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
     rec = nksr_amd.Reconstructor(dev)
-    runs = []
-    for _ in range(2):
-        fld = rec.reconstruct(xyz, nrm, detail_level=1.0)
-        mesh = fld.extract_dual_mesh(mise_iter=1)
-        runs.append((fld.alpha.clone(), fld.matrix[1].clone(), fld.matrix[2].clone(), fld.rhs.clone(), mesh.v.clone(), mesh.f.clone(),
-                     fld.solve_info['iters']))
-    a, b = runs
-    assert a[6] == b[6]
-    for u, v in zip(a[:6], b[:6]):
-        assert torch.equal(u, v)
+    for fused in (False, True):         # assembled CSR solve / matrix-free solve
+        runs = []
+        for _ in range(2):
+            fld = rec.reconstruct(xyz, nrm, detail_level=1.0, fused_mode=fused)
+            mesh = fld.extract_dual_mesh(mise_iter=1)
+            mat = (fld.matrix[1].clone(), fld.matrix[2].clone()) if not fused else (fld.diag.clone(), fld.diag.clone())
+            runs.append((fld.alpha.clone(), mat[0], mat[1], fld.rhs.clone(), mesh.v.clone(), mesh.f.clone(), fld.solve_info['iters']))
+        a, b = runs
+        assert a[6] == b[6]
+        for u, v in zip(a[:6], b[:6]):
+            assert torch.equal(u, v)

@@ -14,7 +14,7 @@ def big():
     xyz, nrm = utils.synth_scene(1_000_000, seed=0)
     xyz, nrm = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
     rec = nksr_amd.Reconstructor(dev)
-    fld = rec.reconstruct(xyz, nrm, detail_level=1.0)
+    fld = rec.reconstruct(xyz, nrm, detail_level=1.0, fused_mode=False)      # the assembled system is inspected below
     return rec, fld, xyz, nrm
 
 
@@ -74,6 +74,24 @@ def test_solution_satisfies_the_system(big):
     rel = float(res.norm() / fld.rhs.double().norm())
     assert rel <= 2e-5, rel                                       # solver_tol 1e-5, independent residual
     assert fld.solve_info['rel_residual'] <= 1e-5 and fld.solve_info['iters'] < 200
+
+
+def test_matrix_free_solve_agrees_at_full_size(big):
+    """fused_mode=True on the 1M-point cloud: the operator equals the assembled matrix on a random vector, the solve
+    reaches the tolerance against the ASSEMBLED system (independent residual) and defines the same field."""
+    from nksr_amd import solver
+    rec, fld, xyz, nrm = big
+    ff = rec.reconstruct(xyz, nrm, detail_level=1.0, fused_mode=True)
+    assert ff.solve_info['fused'] and ff.solve_info['rel_residual'] <= 1e-5 and ff.matrix is None
+    rowptr, cols_p, vals_p, diag = fld.matrix
+    assert float(((ff.diag - diag).abs() / diag).max()) <= 1e-5
+    assert float((ff.rhs - fld.rhs).abs().max()) <= 1e-5 * float(fld.rhs.abs().max())
+    res = fld.rhs.double() - solver.spmv(rowptr, cols_p, vals_p, ff.alpha).double()
+    assert float(res.norm() / fld.rhs.double().norm()) <= 3e-5
+    sel = torch.randperm(xyz.shape[0], device=xyz.device)[:100000]
+    q = (xyz[sel] + 0.02).contiguous()
+    fa, fb = fld.evaluate_f(q).value, ff.evaluate_f(q).value
+    assert float((fa - fb).abs().max()) <= 1e-3 * float(fa.abs().max())          # both solved to 1e-5
 
 
 def test_field_fits_the_input(big):

@@ -138,6 +138,63 @@ def test_assembly_and_spmv():
     assert float((s1[0] - s0[0]).abs().max()) <= 1e-4 * float(s1[0].abs().max())
 
 
+@pytest.mark.parametrize('approx', [False, True])
+def test_fused_operator_matches_the_assembled_matrix(approx):
+    """fused_mode=True (examples/recons_waymo.py:33): the matrix-free operator, its right-hand side and diagonal against
+    the assembled CSR of the same system and against the oracle's matrix; fixed-iteration PCG iterates of the two solves."""
+    import scipy.sparse as sp
+    from nksr_amd import solver
+    from nksr_amd.fields import KernelField
+    from oracle import solve
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=3000)
+    fld = KernelField(svh, net.interpolators, [torch.from_numpy(f) for f in feats], approx_kernel_grad=approx)
+    t = lambda a: torch.from_numpy(a).to(_dev())
+    nxyz = np.concatenate([oh.levels[0].centers(), oh.levels[1].centers()])          # normal sites on two levels (adaptive_depth 2)
+    nval = np.random.RandomState(5).randn(len(nxyz), 3).astype(np.float32)
+    wp, wn = 1e4 / len(xyz), 1e4 / len(nxyz) * 0.01
+    A, b, _, _, _ = solve.assemble(oh, feats, ointerps, xyz, nxyz, nval, wp, wn, 1.0, approx)
+    rowptr, cols, vals, diag, gb = fld.assemble(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
+    op = fld.fused_operator(t(xyz), t(nxyz), t(nval), wp, wn)
+    M = A.shape[0]
+    fb, fd = torch.empty(M, device=_dev()), torch.empty(M, device=_dev())
+    import ctypes as C
+    from nksr_amd._lib import call, ptr, stream
+    call('nksr_fused_rhs_diag', C.byref(fld._hier), op['sets'], op['nsets'], ptr(op['offsets']), ptr(op['items']), op['nitems'], 1.0,
+         ptr(op['ws']), ptr(fb), ptr(fd), stream())
+    pu.check('fused:rhs_rel', np.abs(fb.cpu().numpy() - b).max() / np.abs(b).max(), 1e-5)
+    pu.check('fused:diag_rel', (np.abs(fd.cpu().numpy() - A.diagonal()) / A.diagonal()).max(), 1e-5)
+    pu.check('fused:diag_vs_csr_rel', float(((fd - diag).abs() / diag).max()), 1e-5)
+    rs = np.random.RandomState(1)
+    A64 = A.astype(np.float64)
+    for trial in range(3):
+        x = rs.randn(M).astype(np.float32)
+        yf = fld.fused_apply(op, t(x)).cpu().numpy()
+        yc = solver.spmv(rowptr, cols, vals, t(x)).cpu().numpy()
+        bound = abs(A64) @ abs(x).astype(np.float64)                                  # |A||x|: the fp32 rounding scale of one product
+        pu.check('fused:apply_vs_oracle[%d]' % trial, (np.abs(yf - A64 @ x.astype(np.float64)) / bound).max(), 1e-5)
+        pu.check('fused:apply_vs_csr[%d]' % trial, (np.abs(yf - yc) / bound).max(), 1e-5)
+    # same PCG, two operators: iterates after a fixed number of iterations
+    fld.solver_config.update({'tol': 0.0, 'max_iter': 6, 'check_every': 2})
+    x_csr = solver.pcg_solve(rowptr, cols, vals, diag, gb, tol=0.0, max_iter=6, check_every=2)[0]
+    fld.solve_fused(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
+    assert fld.solve_info['iters'] == 6 and fld.solve_info['fused']
+    pu.check('fused:iterate6_vs_csr', float((fld.alpha - x_csr).abs().max() / x_csr.abs().max()), 1e-5)
+    # converged: both reach the tolerance, the fields agree
+    fld.solver_config.update({'tol': 1e-6, 'max_iter': 2000, 'check_every': 16})
+    fld.solve_fused(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
+    a_f, it_f = fld.alpha.clone(), fld.solve_info['iters']
+    assert fld.solve_info['rel_residual'] <= 1e-6
+    fld.solve_non_fused(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
+    assert abs(fld.solve_info['iters'] - it_f) <= max(3, it_f // 10)
+    r = b.astype(np.float64) - A64 @ a_f.cpu().numpy().astype(np.float64)
+    pu.check('fused:residual_in_oracle_system', np.linalg.norm(r) / np.linalg.norm(b), 1e-5)
+    q = t((xyz[:1500] + np.float32(0.02)).astype(np.float32))
+    f_csr = fld.evaluate_f(q).value
+    fld.alpha = a_f
+    f_fused = fld.evaluate_f(q).value
+    pu.check('fused:field_vs_csr', float((f_fused - f_csr).abs().max() / f_csr.abs().max()), 1e-4)
+
+
 def test_pcg_matches_oracle_and_scipy():
     import scipy.sparse as sp
     import scipy.sparse.linalg as sla
@@ -199,7 +256,10 @@ def test_end_to_end_mesh(kind, vs):
     from oracle import pipeline
     xyz, nrm = make_cloud(kind, 3000, 0.005, 0)
     rec = nksr_amd.Reconstructor(_dev())
-    fld = rec.reconstruct(torch.from_numpy(xyz).to(_dev()), torch.from_numpy(nrm).to(_dev()), voxel_size=vs, solver_tol=1e-6)
+    # sphere: the default matrix-free solve (fused_mode=True); torus: the assembled CSR solve
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(_dev()), torch.from_numpy(nrm).to(_dev()), voxel_size=vs, solver_tol=1e-6,
+                          fused_mode=(kind == 'sphere'))
+    assert bool(fld.solve_info.get('fused', False)) == (kind == 'sphere')
     scale = 0.1 / vs
     ofl = pipeline.reconstruct((xyz * np.float32(scale)).astype(np.float32), nrm, tol=1e-6)
     assert fld.solve_info['M'] == ofl['A'].shape[0]
@@ -237,7 +297,7 @@ def test_against_committed_golden(name):
     amax = abs(g['alpha']).max()
     pu.check('golden[%s]:alpha_rel' % name, np.abs(fld.alpha.cpu().numpy() - g['alpha']).max() / amax, pu.ALPHA_TOL)
     np.testing.assert_allclose(fld.rhs.cpu().numpy(), g['b'], rtol=1e-4, atol=1e-5 * abs(g['b']).max())
-    np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), g['A_diag'], rtol=1e-4)
+    np.testing.assert_allclose(fld.diag.cpu().numpy(), g['A_diag'], rtol=1e-4)
     res = fld.evaluate_f(torch.from_numpy(xyz).to(_dev()), grad=True)
     pu.check('golden[%s]:f_at_inputs' % name, np.abs(res.value.cpu().numpy() - g['f_at_points']).max() / amax, 1e-4)
     scale = 0.1 / vs
@@ -303,7 +363,7 @@ def test_tree_depth_5_matches_oracle():
         assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
     ref = np.abs(ofl['alpha']).max()
     pu.check_alpha('depth5', fld.alpha.cpu().numpy(), ofl, 1e-6)
-    np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), ofl['A'].diagonal(), rtol=1e-4)
+    np.testing.assert_allclose(fld.diag.cpu().numpy(), ofl['A'].diagonal(), rtol=1e-4)
     pu.mesh_parity('depth5[mise=1]', fld, ofl, 1, fld.scale)
 
 
@@ -346,7 +406,7 @@ def test_other_tree_depths_match_oracle(depth):
     assert fld.svh.depth == depth and fld.solve_info['M'] == ofl['A'].shape[0]
     for d in range(depth):
         assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), ofl['hier'].levels[d].keys)
-    np.testing.assert_allclose(fld.matrix[3].cpu().numpy(), ofl['A'].diagonal(), rtol=1e-4)
+    np.testing.assert_allclose(fld.diag.cpu().numpy(), ofl['A'].diagonal(), rtol=1e-4)
     ref = np.abs(ofl['alpha']).max()
     pu.check_alpha('depth%d' % depth, fld.alpha.cpu().numpy(), ofl, 1e-6)
     q = (xs[:500] + np.float32(0.03)).astype(np.float32)
