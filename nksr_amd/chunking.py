@@ -292,8 +292,8 @@ class MultiChunkField(BaseField):
         return self
 
 
-OV_FLOOR = 1.6        # blend half-width floor, in coarsest voxels
-BAND_EXTRA = None     # data margin beyond core +- ov, in coarsest voxels; None = ov (chunk solves core +- 2 ov)
+OV_FLOOR = 1.0        # blend half-width floor, in coarsest voxels
+BAND_EXTRA = 1.5      # data margin beyond core +- ov, in coarsest voxels (= the support radius of the coarsest kernel); None = ov
 MIN_CHUNK_POINTS = 8
 
 

@@ -92,36 +92,50 @@ __device__ __forceinline__ float half_sum(float p) {      // sum over the 32 lan
 }
 
 // t_d[r] = sum_s rows[d][r][s] * x[stencil of the item's cell][s]
+// Every half-wave carries FZ_ILP consecutive items at once: a fine cell holds only a handful of rows, so one item per
+// half-wave is a chain of three dependent loads (item -> neighbour table -> x) in front of two or three row loads, and the
+// kernel ran at the latency of that chain (measured: 700 us for 1.9 GB).  Consecutive items are neighbouring cells of the
+// same set and level (similar row counts), so their chains and row loads overlap.
+#define FZ_ILP 4
 __global__ void __launch_bounds__(FZ_BLOCK) k_fz_forward(FusedArgs A, const int4* __restrict__ items, int nitems,
                                                         const float* __restrict__ x, float* __restrict__ tpart,
                                                         const int* __restrict__ done) {
     if (done && *done) return;
     const int hw = (blockIdx.x * FZ_BLOCK + threadIdx.x) >> 5;
-    if (hw >= nitems) return;
+    const int i0 = hw * FZ_ILP;
+    if (i0 >= nitems) return;
     const int s = threadIdx.x & 31;
-    const int4 it = items[hw];
-    const int set = it.x >> 3, d = it.x & 7, c = it.y;
-    const nksr_level_t& lv = A.hier.lv[d];
-    const nksr_fused_set_t& S = A.sets[set];
-    float xs = 0.f;
-    if (s < 27) {
-        const int nb = lv.nbr[(int64_t)c * 27 + s];
-        if (nb >= 0) xs = x[lv.offset + nb];
+    const bool act = s < 27;
+    int4 it[FZ_ILP];
+    int nb[FZ_ILP], nrows[FZ_ILP], maxrows = 0;
+#pragma unroll
+    for (int k = 0; k < FZ_ILP; ++k) it[k] = items[i0 + k < nitems ? i0 + k : nitems - 1];
+#pragma unroll
+    for (int k = 0; k < FZ_ILP; ++k) {
+        nb[k] = act ? A.hier.lv[it[k].x & 7].nbr[(int64_t)it[k].y * 27 + s] : -1;
+        nrows[k] = i0 + k < nitems ? it[k].w - it[k].z : 0;
+        maxrows = nrows[k] > maxrows ? nrows[k] : maxrows;
     }
-    const float* base = S.rows + (int64_t)d * (S.n * S.ncomp) * 27 + (s < 27 ? s : 0);
-    float* tp = tpart + (int64_t)d * A.rows_total + A.row_off[set];
-    int r = it.z;
-    for (; r + 4 <= it.w; r += 4) {           // four independent row loads in flight
-        float v0 = base[(int64_t)r * 27], v1 = base[(int64_t)(r + 1) * 27], v2 = base[(int64_t)(r + 2) * 27], v3 = base[(int64_t)(r + 3) * 27];
-        if (s >= 27) v0 = v1 = v2 = v3 = 0.f;
-        const float p0 = half_sum(v0 * xs), p1 = half_sum(v1 * xs), p2 = half_sum(v2 * xs), p3 = half_sum(v3 * xs);
-        if (s == 0) { tp[r] = p0; tp[r + 1] = p1; tp[r + 2] = p2; tp[r + 3] = p3; }
+    float xs[FZ_ILP];
+    const float* base[FZ_ILP];
+    float* tp[FZ_ILP];
+#pragma unroll
+    for (int k = 0; k < FZ_ILP; ++k) {
+        const int set = it[k].x >> 3, d = it[k].x & 7;
+        const nksr_fused_set_t& S = A.sets[set];
+        xs[k] = nb[k] >= 0 ? x[A.hier.lv[d].offset + nb[k]] : 0.f;
+        base[k] = S.rows + ((int64_t)d * (S.n * S.ncomp) + it[k].z) * 27 + (act ? s : 0);
+        tp[k] = tpart + (int64_t)d * A.rows_total + A.row_off[set] + it[k].z;
     }
-    for (; r < it.w; ++r) {
-        float v = base[(int64_t)r * 27];
-        if (s >= 27) v = 0.f;
-        const float p = half_sum(v * xs);
-        if (s == 0) tp[r] = p;
+    for (int j = 0; j < maxrows; ++j) {
+        float v[FZ_ILP];
+#pragma unroll
+        for (int k = 0; k < FZ_ILP; ++k) v[k] = (act && j < nrows[k]) ? base[k][(int64_t)j * 27] : 0.f;
+#pragma unroll
+        for (int k = 0; k < FZ_ILP; ++k) {
+            const float p = half_sum(v[k] * xs[k]);
+            if (s == 0 && j < nrows[k]) tp[k][j] = p;
+        }
     }
 }
 
@@ -142,52 +156,78 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_transposed(FusedArgs A, const i
                                                            const int* __restrict__ done) {
     if (done && *done) return;
     const int hw = (blockIdx.x * FZ_BLOCK + threadIdx.x) >> 5;
-    if (hw >= nitems) return;
+    const int i0 = hw * FZ_ILP;
+    if (i0 >= nitems) return;
     const int s = threadIdx.x & 31;
-    const int4 it = items[hw];
-    const int set = it.x >> 3, d = it.x & 7;
-    const nksr_fused_set_t& S = A.sets[set];
-    const float* base = S.rows + (int64_t)d * (S.n * S.ncomp) * 27 + (s < 27 ? s : 0);
-    const float* w = MODE == 0 ? t + A.row_off[set] : (MODE == 1 ? S.target : nullptr);
-    float acc = 0.f;
-    if (MODE != 1 || w != nullptr) {
-        int r = it.z;
-        for (; r + 4 <= it.w; r += 4) {
-            const float v0 = base[(int64_t)r * 27], v1 = base[(int64_t)(r + 1) * 27], v2 = base[(int64_t)(r + 2) * 27], v3 = base[(int64_t)(r + 3) * 27];
-            const float w0 = MODE == 2 ? v0 : w[r], w1 = MODE == 2 ? v1 : w[r + 1], w2 = MODE == 2 ? v2 : w[r + 2], w3 = MODE == 2 ? v3 : w[r + 3];
-            acc = fmaf(v0, w0, acc); acc = fmaf(v1, w1, acc); acc = fmaf(v2, w2, acc); acc = fmaf(v3, w3, acc);
-        }
-        for (; r < it.w; ++r) {
-            const float v = base[(int64_t)r * 27];
-            acc = fmaf(v, MODE == 2 ? v : w[r], acc);
-        }
+    const bool act = s < 27;
+    int4 it[FZ_ILP];
+    int nrows[FZ_ILP], maxrows = 0;
+    const float* base[FZ_ILP];
+    const float* w[FZ_ILP];
+    float acc[FZ_ILP];
+#pragma unroll
+    for (int k = 0; k < FZ_ILP; ++k) it[k] = items[i0 + k < nitems ? i0 + k : nitems - 1];
+#pragma unroll
+    for (int k = 0; k < FZ_ILP; ++k) {
+        const int set = it[k].x >> 3, d = it[k].x & 7;
+        const nksr_fused_set_t& S = A.sets[set];
+        base[k] = S.rows + ((int64_t)d * (S.n * S.ncomp) + it[k].z) * 27 + (act ? s : 0);
+        w[k] = MODE == 0 ? t + A.row_off[set] + it[k].z : (MODE == 1 ? (S.target ? S.target + it[k].z : nullptr) : nullptr);
+        nrows[k] = i0 + k < nitems ? it[k].w - it[k].z : 0;
+        if (MODE == 1 && w[k] == nullptr) nrows[k] = 0;          // a set without targets adds nothing to the right-hand side
+        maxrows = nrows[k] > maxrows ? nrows[k] : maxrows;
+        acc[k] = 0.f;
     }
-    part[(int64_t)hw * 32 + s] = s < 27 ? acc : 0.f;
+    for (int j = 0; j < maxrows; ++j) {
+        float v[FZ_ILP], wk[FZ_ILP];
+#pragma unroll
+        for (int k = 0; k < FZ_ILP; ++k) {
+            const bool live = j < nrows[k];
+            v[k] = live ? base[k][(int64_t)j * 27] : 0.f;
+            wk[k] = (MODE != 2 && live) ? w[k][j] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < FZ_ILP; ++k) acc[k] = fmaf(v[k], MODE == 2 ? v[k] : wk[k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < FZ_ILP; ++k)
+        if (i0 + k < nitems) part[(int64_t)(i0 + k) * 32 + s] = act ? acc[k] : 0.f;
 }
 
 // y_j = (MODE 0: reg x_j, 1: 0, 2: reg) + sum over the 27 neighbour cells c of j, sets, items of c:  P[item][26 - s']
+// One half-wave per unknown, lane = neighbour slot: the 27 (cell -> items -> block entry) chains run side by side (a thread per
+// unknown walking them one after the other took 1.4 ms); fixed tree reduction.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_fz_gather(FusedArgs A, const int32_t* __restrict__ offsets, const float* __restrict__ part,
                                                   const float* __restrict__ x, float reg, float* __restrict__ y,
                                                   const int* __restrict__ done) {
     if (done && *done) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = (blockIdx.x * 256 + threadIdx.x) >> 5;
     if (j >= A.M) return;
+    const int sp = threadIdx.x & 31;
     int d = 0;
     while (d + 1 < A.hier.depth && j >= A.hier.lv[d + 1].offset) ++d;
     const nksr_level_t& lv = A.hier.lv[d];
     const int i = j - lv.offset;
-    float acc = MODE == 0 ? reg * x[j] : (MODE == 2 ? reg : 0.f);
-    for (int sp = 0; sp < 27; ++sp) {
-        const int c = lv.nbr[(int64_t)i * 27 + sp];
-        if (c < 0) continue;
-        for (int set = 0; set < A.nsets; ++set) {
-            const int lin = A.lin_base[set][d] + c;
-            const int i0 = offsets[lin], i1 = offsets[lin + 1];
-            for (int itx = i0; itx < i1; ++itx) acc += part[(int64_t)itx * 32 + (26 - sp)];
+    float acc = 0.f;
+    const int c = sp < 27 ? lv.nbr[(int64_t)i * 27 + sp] : -1;
+    if (c >= 0) {
+        int i0[FZ_MAX_SETS], i1[FZ_MAX_SETS];
+#pragma unroll
+        for (int set = 0; set < FZ_MAX_SETS; ++set) {
+            i0[set] = i1[set] = 0;
+            if (set < A.nsets) {
+                const int lin = A.lin_base[set][d] + c;
+                i0[set] = offsets[lin];
+                i1[set] = offsets[lin + 1];
+            }
         }
+#pragma unroll
+        for (int set = 0; set < FZ_MAX_SETS; ++set)
+            for (int itx = i0[set]; itx < i1[set]; ++itx) acc += part[(int64_t)itx * 32 + (26 - sp)];
     }
-    y[j] = acc;
+    acc = half_sum(acc);
+    if (sp == 0) y[j] = acc + (MODE == 0 ? reg * x[j] : (MODE == 2 ? reg : 0.f));
 }
 
 struct FusedWork {
@@ -241,12 +281,12 @@ extern "C" int nksr_fused_items(const nksr_hier_t* h, const nksr_fused_set_t* se
 static int fz_apply(const FusedArgs& A, const int32_t* offsets, const int4* items, int nitems, float reg, const FusedWork& w,
                     const float* x, float* y, const int* done, hipStream_t st) {
     if (nitems > 0) {
-        const dim3 grid(nksr_blocks((int64_t)nitems * 32, FZ_BLOCK));
+        const dim3 grid(nksr_blocks(((int64_t)nitems + FZ_ILP - 1) / FZ_ILP * 32, FZ_BLOCK));
         hipLaunchKernelGGL(k_fz_forward, grid, dim3(FZ_BLOCK), 0, st, A, items, nitems, x, w.tpart, done);
         hipLaunchKernelGGL(k_fz_tsum, dim3(nksr_blocks(A.rows_total, 256)), dim3(256), 0, st, A.hier.depth, A.rows_total, (const float*)w.tpart, w.t, done);
         hipLaunchKernelGGL((k_fz_transposed<0>), grid, dim3(FZ_BLOCK), 0, st, A, items, nitems, (const float*)w.t, w.part, done);
     }
-    hipLaunchKernelGGL((k_fz_gather<0>), dim3(nksr_blocks(A.M, 256)), dim3(256), 0, st, A, offsets, (const float*)w.part, x, reg, y, done);
+    hipLaunchKernelGGL((k_fz_gather<0>), dim3(nksr_blocks((int64_t)A.M * 32, 256)), dim3(256), 0, st, A, offsets, (const float*)w.part, x, reg, y, done);
     return NKSR_OK;
 }
 
@@ -269,7 +309,7 @@ extern "C" int nksr_fused_rhs_diag(const nksr_hier_t* h, const nksr_fused_set_t*
     if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     const FusedWork w = fz_carve(workspace, A, nitems);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(nksr_blocks(nitems * 32, FZ_BLOCK)), gm(nksr_blocks(A.M, 256));
+    const dim3 grid(nksr_blocks((nitems + FZ_ILP - 1) / FZ_ILP * 32, FZ_BLOCK)), gm(nksr_blocks((int64_t)A.M * 32, 256));
     const float* nof = nullptr;
     const int* nod = nullptr;
     if (b_out) {

@@ -259,7 +259,9 @@ class KernelField(BaseField):
         nitems = int(offsets[ncells].item())
         items = torch.empty((max(nitems, 1), 4), dtype=torch.int32, device=dev)
         call('nksr_fused_items', C.byref(self._hier), sets, nsets, ptr(offsets), ptr(items), stream())
-        ws = torch.empty(int(_lib.lib.nksr_fused_workspace_bytes(C.byref(self._hier), sets, nsets, nitems)), dtype=torch.uint8, device=dev)
+        # zeroed once: rows of sites that lie in no active cell of a level belong to no work item, their partial products are
+        # never written and must read as 0
+        ws = torch.zeros(int(_lib.lib.nksr_fused_workspace_bytes(C.byref(self._hier), sets, nsets, nitems)), dtype=torch.uint8, device=dev)
         rows_total = sum(int(sets[i].n) * int(sets[i].ncomp) for i in range(nsets))
         return {'sets': sets, 'nsets': nsets, 'offsets': offsets, 'items': items, 'nitems': nitems, 'ws': ws, 'keep': keep,
                 'rows_total': rows_total}

@@ -101,8 +101,8 @@ class ChunkedField:
                                mask_fn=(self.mask if has_mask else None), info=info)
 
 
-OV_FLOOR = 1.6        # blend half-width floor, in coarsest voxels        
-BAND_EXTRA = None     # data margin beyond core +- ov, in coarsest voxels; None = ov (i.e. core +- 2 ov)
+OV_FLOOR = 1.0        # blend half-width floor, in coarsest voxels        
+BAND_EXTRA = 1.5      # data margin beyond core +- ov, in coarsest voxels (= the support radius of the coarsest kernel); None = ov
 
 
 def reconstruct_by_chunk(xyz, normal, sensor, chunk_size, overlap_ratio=0.05, preprocess_fn=None, voxel_size=0.1, depth=4,

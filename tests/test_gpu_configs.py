@@ -88,8 +88,11 @@ def _gt(kind, n=200000):
     return make_cloud(kind, n, 0.0, 12345)
 
 
-# bounds = 1.5 x the values measured on MI355X in round 2 (profiles/README.md), unit cube, ShapeNet-3K recipe
-QUALITY = {'sphere': (0.0040, 0.97, 0.985), 'torus': (0.0045, 0.95, 0.975), 'rbox': (0.0045, 0.95, 0.97)}
+# (chamfer-L1 <=, F-score@0.01 >=, normal consistency >=): chamfer bound = 1.5 x the value measured on MI355X in round 2
+# (sphere 3.08e-3 / 0.990 / 0.993, torus 2.40e-3 / 0.999 / 0.993, rounded box 2.72e-3 / 0.995 / 0.994), unit cube, ShapeNet-3K recipe.
+# At 3000 points and 0.02 voxels the cloud is sparser than one point per voxel: the level-0 band has gaps, the mesh has
+# boundary edges (reported) -- the metrics score what is there against the complete analytic surface
+QUALITY = {'sphere': (0.0046, 0.975, 0.985), 'torus': (0.0036, 0.985, 0.985), 'rbox': (0.0041, 0.98, 0.985)}
 
 
 @pytest.mark.parametrize('kind', ['sphere', 'torus', 'rbox'])

@@ -1,0 +1,134 @@
+"""Two ranks on ONE GPU (gloo rendezvous, both processes on cuda:0): the sharded chunk pipeline end to end --
+sharded input (every rank passes only the points of its own chunks + band), Morton-contiguous ownership, the halo
+exchange, per-rank meshing with the one-cell halo ring, point-to-point mesh gather and the seam merge on rank 0 --
+must give the mesh of the single-rank chunked run BIT FOR BIT (same vertex set, same positions, same triangles).
+RCCL itself needs two GPUs; the driver's multi-GPU bench exercises it with the same code path."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene():
+    from nksr_amd import utils
+    xyz, nrm = utils.synth_scene(200000, seed=5, extent=(24.0, 18.0, 6.0), noise=0.0, n_objects=6)
+    return (xyz - xyz.min(0)).astype(np.float32), nrm
+
+
+def _canon(v, f, key, ax):
+    order = np.lexsort((key, ax))
+    inv = np.empty_like(order)
+    inv[order] = np.arange(len(order))
+    f = inv[f]
+    f = f[np.lexsort((f[:, 2], f[:, 1], f[:, 0]))]
+    return key[order], ax[order], v[order], f
+
+
+def _worker(rank, world, port, out_path, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        import nksr_amd
+        from nksr_amd import chunking, dist as D
+        dev = torch.device('cuda:0')
+        xyz, nrm = _scene()
+        rec = nksr_amd.Reconstructor(dev)
+        cs = 8.1
+        lo, hi = xyz.min(0), xyz.max(0)
+        grid = chunking.chunk_grid([float(v) for v in lo], [float(v) for v in hi], cs)
+        assert grid[0] * grid[1] * grid[2] >= 6
+        ov, band = chunking.chunk_geometry(rec.hparams, cs, 0.05)
+        # what a sharded loader does: ownership from the per-core counts, then only the points of the owned chunks + band
+        cid = np.zeros(len(xyz), np.int64)
+        for a in range(3):
+            ia = np.clip(np.floor((xyz[:, a] - lo[a]) / np.float32(cs)).astype(np.int64), 0, grid[a] - 1) if grid[a] > 1 else 0
+            cid = cid * grid[a] + ia
+        counts = np.bincount(cid, minlength=grid[0] * grid[1] * grid[2])
+        owner = D.partition_chunks(len(counts), world, counts.tolist(), grid)
+        keep = np.zeros(len(xyz), bool)
+        for c in range(len(counts)):
+            if owner[c] != rank:
+                continue
+            c3 = (c // (grid[1] * grid[2]), (c // grid[2]) % grid[1], c % grid[2])
+            m = np.ones(len(xyz), bool)
+            for a in range(3):
+                if grid[a] > 1:
+                    m &= (xyz[:, a] >= lo[a] + c3[a] * cs - band - 1e-3) & (xyz[:, a] < lo[a] + (c3[a] + 1) * cs + band + 1e-3)
+            keep |= m
+        assert 0.3 < keep.mean() < 0.95                      # a real shard, not the whole cloud
+        t = lambda a: torch.from_numpy(a).to(dev)
+        fld = rec.reconstruct(t(xyz[keep]), t(nrm[keep]), detail_level=None, chunk_size=cs, sharded_input=True, chunk_owner=owner,
+                              chunk_bounds=([float(v) for v in lo], [float(v) for v in hi]))
+        assert all(owner[c] == rank for c in fld.fields if fld.fields[c].solve_info)      # solved chunks are the owned ones
+        mesh = fld.extract_dual_mesh(mise_iter=1)
+        if rank == 0:
+            # the gather returns positions / faces; recompute the canonical ids of the merged mesh from the pieces' ids is
+            # not possible here, so the merged mesh is compared through its geometry-independent invariants + exact
+            # vertex positions and faces after a canonical reordering by position
+            np.savez(out_path, v=mesh.v.cpu().numpy(), f=mesh.f.cpu().numpy())
+        q.put((rank, 'ok'))
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()[-1500:]))
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+def _position_canon(v, f):
+    """Order vertices by their exact position bits (seam-merged meshes have no duplicate positions) and faces by index."""
+    key = np.ascontiguousarray(v).view(np.dtype((np.void, 12))).ravel()
+    order = np.argsort(key, kind='stable')
+    inv = np.empty_like(order)
+    inv[order] = np.arange(len(order))
+    f2 = inv[f]
+    f2 = f2[np.lexsort((f2[:, 2], f2[:, 1], f2[:, 0]))]
+    return v[order], f2
+
+
+def test_two_ranks_one_gpu_equal_one_rank():
+    import nksr_amd
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    out_path = os.path.join(tempfile.gettempdir(), 'nksr_dist2_%d.npz' % os.getpid())
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out_path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+    got = np.load(out_path)
+    os.remove(out_path)
+    # single rank, full cloud, same chunking
+    dev = torch.device('cuda:0')
+    xyz, nrm = _scene()
+    rec = nksr_amd.Reconstructor(dev)
+    one = rec.reconstruct(torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev), detail_level=None, chunk_size=8.1)
+    m1 = one.extract_dual_mesh(mise_iter=1)
+    v1, f1 = _position_canon(m1.v.cpu().numpy(), m1.f.cpu().numpy())
+    v2, f2 = _position_canon(got['v'], got['f'])
+    assert v1.shape == v2.shape and f1.shape == f2.shape
+    np.testing.assert_array_equal(v1, v2)          # bit-identical vertex positions
+    np.testing.assert_array_equal(f1, f2)          # index-exact topology
