@@ -255,6 +255,10 @@ int nksr_nearest_index(const float* xyz_sorted, const int32_t* start, const int3
 int nksr_base_cell_flags(const int32_t* nbr, int32_t n, int32_t* flags, void* stream);
 /* expand selected base voxels into U^3 lattice cell keys */
 int nksr_base_cell_keys(const int32_t* ijk, const int32_t* sel, int64_t nsel, int upsample, int64_t* cell_keys, void* stream);
+/* Lattice cells covered by the dual cells of the selected level-`level` voxels ((upsample << level)^3 keys each): the part of
+ * the dual grid that comes from levels 1 .. adaptive_depth-1 where the finest level is absent
+ * (LayerField(dec_svh, adaptive_depth), models/nksr_net.py:132; adaptive_depth 2: configs/carla/train.yaml:6). */
+int nksr_level_cell_keys(const int32_t* ijk, const int32_t* sel, int64_t nsel, int level, int upsample, int64_t* cell_keys, void* stream);
 /* 8 corner lattice keys per cell */
 int nksr_cell_corner_keys(const int64_t* cell_keys, int64_t ncell, int64_t* corner_keys, void* stream);
 /* lattice key -> position x = g*h + half_w0 */

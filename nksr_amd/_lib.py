@@ -110,6 +110,7 @@ _PROTOS = {
     'nksr_nearest_index': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, _vp, _vp],
     'nksr_base_cell_flags': [_vp, _i32, _vp, _vp],
     'nksr_base_cell_keys': [_vp, _vp, _i64, C.c_int, _vp, _vp],
+    'nksr_level_cell_keys': [_vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp],
     'nksr_cell_corner_keys': [_vp, _i64, _vp, _vp],
     'nksr_lattice_positions': [_vp, _i64, _f32, _f32, _vp, _vp],
     'nksr_cell_config': [_vp, _vp, _i64, _vp, _vp, _vp],

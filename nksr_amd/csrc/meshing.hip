@@ -77,6 +77,24 @@ __global__ void k_base_cell_keys(const int32_t* __restrict__ ijk, const int32_t*
     keys[t] = morton_biased(x, y, z, NKSR_BIAS0);
 }
 
+// lattice cells covered by the dual cell of a level-`level` voxel (level >= 1): the dual cell spans the centres
+// (i + 1/2) w_d .. (i + 3/2) w_d, i.e. fine-lattice coordinates 2^d i + 2^(d-1) - 1/2 .. + 2^d; the S = U 2^d lattice cells per axis
+// whose centre lies inside start at (2^d i + 2^(d-1) - 1) U.  level 0 reproduces k_base_cell_keys.
+__global__ void k_level_cell_keys(const int32_t* __restrict__ ijk, const int32_t* __restrict__ sel, int64_t nsel, int level, int U,
+                                  int64_t* __restrict__ keys) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int S = U << level;
+    const int64_t S3 = (int64_t)S * S * S;
+    if (t >= nsel * S3) return;
+    const int64_t c = t / S3;
+    const int r = (int)(t % S3);
+    const int i = sel[c];
+    const int off = level == 0 ? 0 : (1 << (level - 1)) - 1;
+    const int x = ((ijk[i * 3] << level) + off) * U + r / (S * S), y = ((ijk[i * 3 + 1] << level) + off) * U + (r / S) % S,
+              z = ((ijk[i * 3 + 2] << level) + off) * U + r % S;
+    keys[t] = morton_biased(x, y, z, NKSR_BIAS0);
+}
+
 __global__ void k_cell_corner_keys(const int64_t* __restrict__ cell_keys, int64_t ncell, int64_t* __restrict__ ck) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ncell * 8) return;
@@ -179,6 +197,13 @@ extern "C" int nksr_base_cell_flags(const int32_t* nbr, int32_t n, int32_t* flag
 extern "C" int nksr_base_cell_keys(const int32_t* ijk, const int32_t* sel, int64_t nsel, int upsample, int64_t* cell_keys, void* stream) {
     if (upsample < 1 || upsample > 8) return nksr_set_error(NKSR_ERR_ARG, "grid_upsample must be in [1,8]");
     LAUNCH1D(k_base_cell_keys, nsel * upsample * upsample * upsample, stream, ijk, sel, nsel, upsample, cell_keys);
+    return NKSR_OK;
+}
+extern "C" int nksr_level_cell_keys(const int32_t* ijk, const int32_t* sel, int64_t nsel, int level, int upsample, int64_t* cell_keys, void* stream) {
+    if (upsample < 1 || upsample > 8) return nksr_set_error(NKSR_ERR_ARG, "grid_upsample must be in [1,8]");
+    if (level < 0 || level >= NKSR_MAX_DEPTH || (upsample << level) > 64) return nksr_set_error(NKSR_ERR_ARG, "bad level / upsample");
+    const int64_t S = (int64_t)upsample << level;
+    LAUNCH1D(k_level_cell_keys, nsel * S * S * S, stream, ijk, sel, nsel, level, upsample, cell_keys);
     return NKSR_OK;
 }
 extern "C" int nksr_cell_corner_keys(const int64_t* cell_keys, int64_t ncell, int64_t* corner_keys, void* stream) {

@@ -32,6 +32,7 @@ class BaseField:
         self.scale = 1.0          # world -> model units (Reconstructor's global scale)
         self.mask_field = None
         self.texture_field = None
+        self.meshing_depth = 1     # levels whose dual cells are meshed (Reconstructor sets hparams.adaptive_depth)
 
     @property
     def device(self):

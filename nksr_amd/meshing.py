@@ -50,7 +50,7 @@ def _extract(field, mise_iter, grid_upsample, max_points):
         raise RuntimeError('grid_upsample must be >= 1 and mise_iter >= 0')
     # lattice / cell keys are 21-bit-per-axis Morton codes biased by 2^20 (csrc/meshing.hip): the refined lattice
     # coordinate ijk * U * 2^mise_iter (+ one cell) must stay inside, or keys would wrap silently
-    reach = (int(g0.ijk.abs().max()) + 2) * U * (1 << int(mise_iter)) + 2
+    reach = (int(g0.ijk.abs().max()) + 4) * U * (1 << int(mise_iter)) + 2
     if reach >= (1 << 20):
         raise RuntimeError('mesh lattice out of range: |ijk| * grid_upsample * 2^mise_iter = %d >= 2^20; recentre the cloud '
                            '(or lower mise_iter / grid_upsample)' % reach)
@@ -61,10 +61,27 @@ def _extract(field, mise_iter, grid_upsample, max_points):
     if owned_only:      # distributed fields: cells this rank owns + a one-cell halo (evaluated, not meshed)
         flags = (flags * field.base_cell_halo_mask(g0.ijk).to(torch.int32)).contiguous()
     sel = ops.compact(flags)
-    if sel.numel() == 0:
-        return empty
     raw = torch.empty(sel.numel() * U ** 3, dtype=torch.int64, device=dev)
-    call('nksr_base_cell_keys', ptr(g0.ijk), ptr(sel), sel.numel(), U, ptr(raw), stream())
+    if sel.numel():
+        call('nksr_base_cell_keys', ptr(g0.ijk), ptr(sel), sel.numel(), U, ptr(raw), stream())
+    # dual cells of the coarser levels below adaptive_depth cover what the finest level leaves open (a structure head that
+    # stops at level 1, or input sparser than the finest voxels): their extent, at the SAME lattice resolution -- one
+    # uniform lattice over the adaptive support, so there are no level transitions to stitch
+    adaptive = 1 if owned_only else min(int(getattr(field, 'meshing_depth', 1)), svh.depth)
+    for d in range(1, adaptive):
+        gd = svh.level(d)
+        if gd.num_voxels == 0:
+            continue
+        fl = torch.empty(gd.num_voxels, dtype=torch.int32, device=dev)
+        call('nksr_base_cell_flags', ptr(gd.nbr), gd.num_voxels, ptr(fl), stream())
+        sd = ops.compact(fl)
+        if sd.numel():
+            S = U << d
+            rd = torch.empty(sd.numel() * S ** 3, dtype=torch.int64, device=dev)
+            call('nksr_level_cell_keys', ptr(gd.ijk), ptr(sd), sd.numel(), d, U, ptr(rd), stream())
+            raw = torch.cat([raw, rd])
+    if raw.numel() == 0:
+        return empty
 
     h = w0 / U
     prev = None          # (vertex keys, values, active cell keys) of the coarser MISE level

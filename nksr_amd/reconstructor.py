@@ -72,6 +72,7 @@ class Reconstructor:
         else:
             mask = LayerField(dec_svh, hp.adaptive_depth)
         field.set_mask_field(mask)
+        field.meshing_depth = int(hp.adaptive_depth)
         t.update({k: v for k, v in field.solve_info.items() if k.startswith('t_')})
         self.timing = t
         return field

@@ -35,17 +35,23 @@ def lattice_positions(g, h, half_w0):
     return (g.astype(np.float32) * np.float32(h) + np.float32(half_w0)).astype(np.float32)
 
 
-def base_cells(level0, upsample):
-    nbr = level0.nbr
-    ok = np.ones(level0.n, bool)
-    for co in spec.CORNER_OFFSETS:
-        s = (co[0] + 1) * 9 + (co[1] + 1) * 3 + (co[2] + 1)
-        ok &= nbr[:, s] >= 0
-    base = level0.ijk[ok].astype(np.int64)
-    U = upsample
-    sub = np.array([[a, b, c] for a in range(U) for b in range(U) for c in range(U)], np.int64)
-    cells = (base[:, None, :] * U + sub[None]).reshape(-1, 3)
-    return cells
+def base_cells(level0, upsample, coarser=()):
+    """Lattice cells of the meshing domain: the dual cells of level 0 (8 mutually adjacent active centres) and -- for the
+    levels 1 .. adaptive_depth-1 in ``coarser`` -- the extent of their dual cells at the same lattice resolution (the
+    (U 2^d)^3 cells whose centre lies inside a level-d dual cell start at (2^d i + 2^(d-1) - 1) U)."""
+    out = []
+    for d, lev in [(0, level0)] + [(L.level, L) for L in coarser]:
+        nbr = lev.nbr
+        ok = np.ones(lev.n, bool)
+        for co in spec.CORNER_OFFSETS:
+            s = (co[0] + 1) * 9 + (co[1] + 1) * 3 + (co[2] + 1)
+            ok &= nbr[:, s] >= 0
+        base = lev.ijk[ok].astype(np.int64)
+        S = upsample << d
+        off = 0 if d == 0 else (1 << (d - 1)) - 1
+        sub = np.array([[a, b, c] for a in range(S) for b in range(S) for c in range(S)], np.int64)
+        out.append((((base << d) + off)[:, None, :] * upsample + sub[None]).reshape(-1, 3))
+    return np.concatenate(out) if out else np.zeros((0, 3), np.int64)
 
 
 def cell_vertices(cells):
@@ -95,7 +101,7 @@ def constrain_hanging(g, f, vk_coarse, f_coarse, active_keys):
     return f
 
 
-def extract(level0_voxel_size, level0, eval_fn, mise_iter=0, grid_upsample=1, mask_fn=None, info=None):
+def extract(level0_voxel_size, level0, eval_fn, mise_iter=0, grid_upsample=1, mask_fn=None, info=None, coarser=()):
     """eval_fn(xyz[n,3] f32) -> f[n] f32;  mask_fn(xyz) -> bool[n] (True = keep).
     ``info`` (dict, optional) receives what the parity tests need to localise a topology difference:
     per MISE level the cell coordinates / corner table / (constrained) vertex values, and for the output
@@ -103,7 +109,7 @@ def extract(level0_voxel_size, level0, eval_fn, mise_iter=0, grid_upsample=1, ma
     plus |f0 - f1| of every vertex."""
     w0 = float(level0_voxel_size)
     U = int(grid_upsample)
-    cells = base_cells(level0, U)
+    cells = base_cells(level0, U, coarser)
     h = w0 / U
     prev = None
     for m in range(mise_iter + 1):

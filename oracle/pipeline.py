@@ -89,7 +89,8 @@ def reconstruct(xyz, normal, voxel_size=0.1, depth=4, adaptive_depth=1, kernel_d
                        'M': A.shape[0], 'nnz': A.nnz})
     return {'hier': hier, 'feats': feats, 'interps': interps, 'psis': psis, 'alpha': alpha, 'A': A, 'b': b,
             'iters': iters, 'rel': rel, 'normal_xyz': nxyz, 'normal_value': nval,
-            'approx_kernel_grad': approx_kernel_grad, 'voxel_size': voxel_size, 'udf_feats': udf_feats}
+            'approx_kernel_grad': approx_kernel_grad, 'voxel_size': voxel_size, 'udf_feats': udf_feats,
+            'adaptive_depth': adaptive_depth}
 
 
 def evaluate(fld, xyz, grad=False):
@@ -103,4 +104,4 @@ def extract_dual_mesh(fld, mise_iter=0, grid_upsample=1, info=None):
         from . import network as onet
         mask_fn = lambda p: onet.udf_decode(fld['hier'], fld['udf_feats'], p) < np.float32(fld.get('udf_level_set', 2 * fld['voxel_size']))
     return meshing.extract(fld['voxel_size'], fld['hier'].levels[0], lambda p: evaluate(fld, p)[0], mise_iter, grid_upsample,
-                           mask_fn=mask_fn, info=info)
+                           mask_fn=mask_fn, info=info, coarser=fld['hier'].levels[1:fld.get('adaptive_depth', 1)])

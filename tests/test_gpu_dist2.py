@@ -96,14 +96,13 @@ def _worker(rank, world, port, out_path, q):
 
 
 def _position_canon(v, f):
-    """Order vertices by their exact position bits (seam-merged meshes have no duplicate positions) and faces by index."""
-    key = np.ascontiguousarray(v).view(np.dtype((np.void, 12))).ravel()
-    order = np.argsort(key, kind='stable')
-    inv = np.empty_like(order)
-    inv[order] = np.arange(len(order))
-    f2 = inv[f]
-    f2 = f2[np.lexsort((f2[:, 2], f2[:, 1], f2[:, 0]))]
-    return v[order], f2
+    """Index-free form of a mesh: the sorted unique vertex positions and the triangles as sorted rows of 9 position floats
+    (corner order kept).  Distinct vertices may share a position bit for bit (a zero of f exactly on a lattice vertex puts
+    the vertices of its three edges there), so faces are compared through positions, not through a position-sorted index."""
+    vb = np.ascontiguousarray(v).view(np.dtype((np.void, 12))).ravel()
+    tri = np.ascontiguousarray(v[f].reshape(len(f), 9))
+    tb = tri.view(np.dtype((np.void, 36))).ravel()
+    return v[np.argsort(vb, kind='stable')], tri[np.argsort(tb, kind='stable')]
 
 
 def test_two_ranks_one_gpu_equal_one_rank():

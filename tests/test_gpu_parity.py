@@ -367,6 +367,39 @@ def test_tree_depth_5_matches_oracle():
     pu.mesh_parity('depth5[mise=1]', fld, ofl, 1, fld.scale)
 
 
+def test_adaptive_depth_meshing_covers_what_the_finest_level_leaves_open():
+    """adaptive_depth 2 (configs/carla/train.yaml:6; LayerField(dec_svh, adaptive_depth), models/nksr_net.py:132): where the
+    finest level is absent (input sparser than the finest voxels) the dual cells of level 1 are meshed too, on the same
+    lattice -- the level-0-only mesh has holes, the adaptive one is closed, and it equals the oracle's index for index."""
+    import nksr_amd
+    from nksr_amd import configs
+    from oracle import network as onet, pipeline
+    xyz, nrm = make_cloud('sphere', 500, 0.0, 0)
+    vs = 0.04
+    hp = configs.get_hparams('ks', adaptive_depth=2)
+    rec = nksr_amd.Reconstructor(_dev(), hparams=hp)
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(_dev()), torch.from_numpy(nrm).to(_dev()), voxel_size=vs, solver_tol=1e-6)
+    assert fld.meshing_depth == 2
+    scale = 0.1 / vs
+    ofl = pipeline.reconstruct((xyz * np.float32(scale)).astype(np.float32), nrm, adaptive_depth=2, tol=1e-6,
+                               net_params=onet.export_params(rec.network))
+    assert fld.solve_info['M'] == ofl['A'].shape[0]
+
+    def open_edges(f):
+        e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1)
+        _, cnt = np.unique(e, axis=0, return_counts=True)
+        return int((cnt == 1).sum()), len(cnt)
+    for mise in (0, 1):
+        st, mesh, _ = pu.mesh_parity('adaptive2[mise=%d]' % mise, fld, ofl, mise, scale)
+        gf = mesh.f.cpu().numpy()
+        n_open, E = open_edges(gf)
+        assert n_open == 0 and mesh.v.shape[0] - E + len(gf) == 2, 'adaptive mesh is not a closed sphere'
+    fld.meshing_depth = 1
+    n_open0, _ = open_edges(fld.extract_dual_mesh(mise_iter=0).f.cpu().numpy())
+    pu.report('adaptive2', open_edges_level0_only=n_open0)
+    assert n_open0 > 0, 'the case does not exercise the coarse-level cells'
+
+
 def test_build_adaptive_normal_variation_matches_oracle():
     """Training-GT hierarchy (models/nksr_net.py:175-179): flat regions stop at a coarse level."""
     from nksr_amd import SparseFeatureHierarchy
