@@ -14,11 +14,12 @@
 // deterministic.  No assembly: the solve starts right after the kernel rows.
 #include "common.h"
 #include "pcg_core.h"
+#include <stdlib.h>
 
 #define FZ_RC 32
 #define FZ_BLOCK 256
 #define FZ_MAX_SETS 2
-#define FZ_ILP 4
+#define FZ_DEFAULT_VARIANT 0
 
 struct FusedArgs {
     nksr_hier_t hier;
@@ -27,6 +28,8 @@ struct FusedArgs {
     int M;
     int64_t row_off[FZ_MAX_SETS];                     // first row of the set in the concatenated t vector
     int64_t rows_total;
+    int32_t lin_base[FZ_MAX_SETS][NKSR_MAX_DEPTH];    // index of (set, level, cell 0) in the per-cell item offsets
+    int32_t lin_total;
 };
 
 static int fz_args(FusedArgs& A, const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets) {
@@ -36,62 +39,49 @@ static int fz_args(FusedArgs& A, const nksr_hier_t* h, const nksr_fused_set_t* s
     A.hier = *h;
     A.nsets = nsets;
     A.M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
-    int64_t rows = 0;
+    int64_t lin = 0, rows = 0;
     for (int s = 0; s < nsets; ++s) {
         if (sets[s].ncomp != 1 && sets[s].ncomp != 3) return nksr_set_error(NKSR_ERR_ARG, "ncomp must be 1 or 3");
         if (sets[s].n * sets[s].ncomp >= ((int64_t)1 << 31)) return nksr_set_error(NKSR_ERR_CAPACITY, "site set too large");
         A.sets[s] = sets[s];
         A.row_off[s] = rows;
         rows += sets[s].n * sets[s].ncomp;
+        for (int d = 0; d < h->depth; ++d) { A.lin_base[s][d] = (int32_t)lin; lin += h->lv[d].n; }
     }
+    if (lin >= ((int64_t)1 << 31) - 1) return nksr_set_error(NKSR_ERR_CAPACITY, "too many cells");
     A.rows_total = rows;
+    A.lin_total = (int32_t)lin;
     return NKSR_OK;
 }
 
-__device__ __forceinline__ int fz_level(const nksr_hier_t& h, int j) {
-    int d = 0;
-    while (d + 1 < h.depth && j >= h.lv[d + 1].offset) ++d;
-    return d;
-}
-
-// Work items: the rows of ALL site sets inside one cell (= one unknown's voxel), sets in order, cut into pieces of <= FZ_RC rows.
-// record = { level | rows of set 0 << 4 | rows of set 1 << 12,  cell,  first row in set 0,  first row in set 1 }
-__device__ __forceinline__ void fz_cell_rows(const FusedArgs& A, int d, int c, int r0[FZ_MAX_SETS], int n[FZ_MAX_SETS]) {
-#pragma unroll
-    for (int s = 0; s < FZ_MAX_SETS; ++s) {
-        r0[s] = n[s] = 0;
-        if (s < A.nsets) {
-            const nksr_fused_set_t& S = A.sets[s];
-            r0[s] = S.start[d][c] * S.ncomp;
-            n[s] = (S.end[d][c] - S.start[d][c]) * S.ncomp;
-        }
-    }
+__device__ __forceinline__ void fz_decode_lin(const FusedArgs& A, int lin, int& set, int& d, int& c) {
+    set = 0; d = 0;
+    for (int s = 0; s < A.nsets; ++s)
+        for (int l = 0; l < A.hier.depth; ++l)
+            if (lin >= A.lin_base[s][l]) { set = s; d = l; }
+    c = lin - A.lin_base[set][d];
 }
 
 __global__ void k_fz_item_counts(FusedArgs A, int32_t* __restrict__ counts) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > A.M) return;
-    if (j == A.M) { counts[j] = 0; return; }
-    const int d = fz_level(A.hier, j);
-    int r0[FZ_MAX_SETS], n[FZ_MAX_SETS];
-    fz_cell_rows(A, d, j - A.hier.lv[d].offset, r0, n);
-    counts[j] = (n[0] + n[1] + FZ_RC - 1) / FZ_RC;
+    const int lin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin > A.lin_total) return;
+    if (lin == A.lin_total) { counts[lin] = 0; return; }
+    int set, d, c;
+    fz_decode_lin(A, lin, set, d, c);
+    const nksr_fused_set_t& S = A.sets[set];
+    const int nrows = (S.end[d][c] - S.start[d][c]) * S.ncomp;
+    counts[lin] = (nrows + FZ_RC - 1) / FZ_RC;
 }
 
 __global__ void k_fz_item_fill(FusedArgs A, const int32_t* __restrict__ offsets, int4* __restrict__ items) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= A.M) return;
-    const int d = fz_level(A.hier, j), c = j - A.hier.lv[d].offset;
-    int r0[FZ_MAX_SETS], n[FZ_MAX_SETS];
-    fz_cell_rows(A, d, c, r0, n);
-    const int total = n[0] + n[1];
-    int it = offsets[j];
-    for (int q = 0; q < total; q += FZ_RC, ++it) {          // piece = rows [q, q + FZ_RC) of the sequence (set 0 rows, set 1 rows)
-        const int e = q + FZ_RC < total ? q + FZ_RC : total;
-        const int a0 = q < n[0] ? q : n[0], a1 = e < n[0] ? e : n[0];
-        const int b0 = q > n[0] ? q - n[0] : 0, b1 = e > n[0] ? e - n[0] : 0;
-        items[it] = make_int4(d | ((a1 - a0) << 4) | ((b1 - b0) << 12), c, r0[0] + a0, r0[1] + b0);
-    }
+    const int lin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin >= A.lin_total) return;
+    int set, d, c;
+    fz_decode_lin(A, lin, set, d, c);
+    const nksr_fused_set_t& S = A.sets[set];
+    const int r0 = S.start[d][c] * S.ncomp, r1 = S.end[d][c] * S.ncomp;
+    int it = offsets[lin];
+    for (int r = r0; r < r1; r += FZ_RC, ++it) items[it] = make_int4(set * 8 + d, c, r, r + FZ_RC < r1 ? r + FZ_RC : r1);
 }
 
 __device__ __forceinline__ float half_sum(float p) {      // sum over the 32 lanes of this half-wave, fixed tree
@@ -103,79 +93,55 @@ __device__ __forceinline__ float half_sum(float p) {      // sum over the 32 lan
     return p;
 }
 
-// one item of a half-wave's bundle, decoded
-struct FzItem {
-    const float* base[FZ_MAX_SETS];     // first row of the item in set s (this lane's slot)
-    int64_t trow[FZ_MAX_SETS];          // index of that row in the concatenated t vector
-    int n[FZ_MAX_SETS];
-    int d, c;
-};
-__device__ __forceinline__ FzItem fz_decode(const FusedArgs& A, const int4 it, bool valid, int s) {
-    FzItem I;
-    I.d = it.x & 15;
-    I.c = it.y;
-    I.n[0] = valid ? (it.x >> 4) & 255 : 0;
-    I.n[1] = valid ? (it.x >> 12) & 255 : 0;
-    const int r0[FZ_MAX_SETS] = {it.z, it.w};
-#pragma unroll
-    for (int q = 0; q < FZ_MAX_SETS; ++q) {
-        const nksr_fused_set_t& S = A.sets[q];
-        I.base[q] = q < A.nsets ? S.rows + ((int64_t)I.d * (S.n * S.ncomp) + r0[q]) * 27 + (s < 27 ? s : 0) : nullptr;
-        I.trow[q] = A.row_off[q] + r0[q];
-    }
-    return I;
-}
-
 // t_d[r] = sum_s rows[d][r][s] * x[stencil of the item's cell][s]
 // Every half-wave carries FZ_ILP consecutive items at once: a fine cell holds only a handful of rows, so one item per
-// half-wave is a chain of three dependent loads (item -> neighbour table -> x) in front of a few row loads, and the kernel
-// ran at the latency of that chain.  Consecutive items are neighbouring cells (similar row counts): their chains and row
-// loads overlap.
+// half-wave is a chain of three dependent loads (item -> neighbour table -> x) in front of two or three row loads, and the
+// kernel ran at the latency of that chain (measured: 700 us for 1.9 GB).  Consecutive items are neighbouring cells of the
+// same set and level (similar row counts), so their chains and row loads overlap.
+template <int ILP, int RU>
 __global__ void __launch_bounds__(FZ_BLOCK) k_fz_forward(FusedArgs A, const int4* __restrict__ items, int nitems,
                                                         const float* __restrict__ x, float* __restrict__ tpart,
                                                         const int* __restrict__ done) {
     if (done && *done) return;
     const int hw = (blockIdx.x * FZ_BLOCK + threadIdx.x) >> 5;
-    const int i0 = hw * FZ_ILP;
+    const int i0 = hw * ILP;
     if (i0 >= nitems) return;
     const int s = threadIdx.x & 31;
     const bool act = s < 27;
-    int4 it[FZ_ILP];
+    int4 it[ILP];
+    int nb[ILP], nrows[ILP], maxrows = 0;
 #pragma unroll
-    for (int k = 0; k < FZ_ILP; ++k) it[k] = items[i0 + k < nitems ? i0 + k : nitems - 1];
-    FzItem I[FZ_ILP];
-    int nb[FZ_ILP], maxrows = 0;
+    for (int k = 0; k < ILP; ++k) it[k] = items[i0 + k < nitems ? i0 + k : nitems - 1];
 #pragma unroll
-    for (int k = 0; k < FZ_ILP; ++k) {
-        I[k] = fz_decode(A, it[k], i0 + k < nitems, s);
-        nb[k] = act ? A.hier.lv[I[k].d].nbr[(int64_t)I[k].c * 27 + s] : -1;
-        const int tot = I[k].n[0] + I[k].n[1];
-        maxrows = tot > maxrows ? tot : maxrows;
+    for (int k = 0; k < ILP; ++k) {
+        nb[k] = act ? A.hier.lv[it[k].x & 7].nbr[(int64_t)it[k].y * 27 + s] : -1;
+        nrows[k] = i0 + k < nitems ? it[k].w - it[k].z : 0;
+        maxrows = nrows[k] > maxrows ? nrows[k] : maxrows;
     }
-    float xs[FZ_ILP];
+    float xs[ILP];
+    const float* base[ILP];
+    float* tp[ILP];
 #pragma unroll
-    for (int k = 0; k < FZ_ILP; ++k) xs[k] = nb[k] >= 0 ? x[A.hier.lv[I[k].d].offset + nb[k]] : 0.f;
-    for (int j = 0; j < maxrows; ++j) {
-        float v[FZ_ILP];
+    for (int k = 0; k < ILP; ++k) {
+        const int set = it[k].x >> 3, d = it[k].x & 7;
+        const nksr_fused_set_t& S = A.sets[set];
+        xs[k] = nb[k] >= 0 ? x[A.hier.lv[d].offset + nb[k]] : 0.f;
+        base[k] = S.rows + ((int64_t)d * (S.n * S.ncomp) + it[k].z) * 27 + (act ? s : 0);
+        tp[k] = tpart + (int64_t)d * A.rows_total + A.row_off[set] + it[k].z;
+    }
+    for (int j = 0; j < maxrows; j += RU) {
+        float v[ILP][RU];
 #pragma unroll
-        for (int k = 0; k < FZ_ILP; ++k) {
-            const int jb = j - I[k].n[0];
-            v[k] = 0.f;
-            if (act) {
-                if (j < I[k].n[0]) v[k] = I[k].base[0][(int64_t)j * 27];
-                else if (jb < I[k].n[1]) v[k] = I[k].base[1][(int64_t)jb * 27];
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) v[k][u] = (act && j + u < nrows[k]) ? base[k][(int64_t)(j + u) * 27] : 0.f;
+#pragma unroll
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) {
+                const float p = half_sum(v[k][u] * xs[k]);
+                if (s == 0 && j + u < nrows[k]) tp[k][j + u] = p;
             }
-        }
-#pragma unroll
-        for (int k = 0; k < FZ_ILP; ++k) {
-            const float p = half_sum(v[k] * xs[k]);
-            const int jb = j - I[k].n[0];
-            if (s == 0) {
-                float* tp = tpart + (int64_t)I[k].d * A.rows_total;
-                if (j < I[k].n[0]) tp[I[k].trow[0] + j] = p;
-                else if (jb < I[k].n[1]) tp[I[k].trow[1] + jb] = p;
-            }
-        }
     }
 }
 
@@ -190,64 +156,57 @@ __global__ void k_fz_tsum(int depth, int64_t rows_total, const float* __restrict
 }
 
 // P[item][s] = sum_{r in item} rows[d][r][s] * w[r];  MODE 0: w = t (operator), 1: w = target (right-hand side), 2: w = the row value itself (diagonal)
-template <int MODE>
+template <int MODE, int ILP, int RU>
 __global__ void __launch_bounds__(FZ_BLOCK) k_fz_transposed(FusedArgs A, const int4* __restrict__ items, int nitems,
                                                            const float* __restrict__ t, float* __restrict__ part,
                                                            const int* __restrict__ done) {
     if (done && *done) return;
     const int hw = (blockIdx.x * FZ_BLOCK + threadIdx.x) >> 5;
-    const int i0 = hw * FZ_ILP;
+    const int i0 = hw * ILP;
     if (i0 >= nitems) return;
     const int s = threadIdx.x & 31;
     const bool act = s < 27;
-    int4 it[FZ_ILP];
+    int4 it[ILP];
+    int nrows[ILP], maxrows = 0;
+    const float* base[ILP];
+    const float* w[ILP];
+    float acc[ILP];
 #pragma unroll
-    for (int k = 0; k < FZ_ILP; ++k) it[k] = items[i0 + k < nitems ? i0 + k : nitems - 1];
-    FzItem I[FZ_ILP];
-    const float* w[FZ_ILP][FZ_MAX_SETS];
-    float acc[FZ_ILP];
-    int maxrows = 0;
+    for (int k = 0; k < ILP; ++k) it[k] = items[i0 + k < nitems ? i0 + k : nitems - 1];
 #pragma unroll
-    for (int k = 0; k < FZ_ILP; ++k) {
-        I[k] = fz_decode(A, it[k], i0 + k < nitems, s);
-#pragma unroll
-        for (int q = 0; q < FZ_MAX_SETS; ++q) {
-            w[k][q] = MODE == 0 ? t + I[k].trow[q] : nullptr;
-            if (MODE == 1) {      // a set without targets adds nothing to the right-hand side
-                const float* tg = q < A.nsets ? A.sets[q].target : nullptr;
-                w[k][q] = tg ? tg + (I[k].trow[q] - A.row_off[q]) : nullptr;
-                if (!tg) I[k].n[q] = (q == 0) ? -I[k].n[q] : 0;       // set 0 rows are skipped but still counted in the row sequence
-            }
-        }
-        const int tot = (I[k].n[0] < 0 ? -I[k].n[0] : I[k].n[0]) + I[k].n[1];
-        maxrows = tot > maxrows ? tot : maxrows;
+    for (int k = 0; k < ILP; ++k) {
+        const int set = it[k].x >> 3, d = it[k].x & 7;
+        const nksr_fused_set_t& S = A.sets[set];
+        base[k] = S.rows + ((int64_t)d * (S.n * S.ncomp) + it[k].z) * 27 + (act ? s : 0);
+        w[k] = MODE == 0 ? t + A.row_off[set] + it[k].z : (MODE == 1 ? (S.target ? S.target + it[k].z : nullptr) : nullptr);
+        nrows[k] = i0 + k < nitems ? it[k].w - it[k].z : 0;
+        if (MODE == 1 && w[k] == nullptr) nrows[k] = 0;          // a set without targets adds nothing to the right-hand side
+        maxrows = nrows[k] > maxrows ? nrows[k] : maxrows;
         acc[k] = 0.f;
     }
-    for (int j = 0; j < maxrows; ++j) {
-        float v[FZ_ILP], wk[FZ_ILP];
+    for (int j = 0; j < maxrows; j += RU) {
+        float v[ILP][RU], wk[ILP][RU];
 #pragma unroll
-        for (int k = 0; k < FZ_ILP; ++k) {
-            const int na = I[k].n[0] < 0 ? -I[k].n[0] : I[k].n[0];
-            const int jb = j - na;
-            v[k] = wk[k] = 0.f;
-            if (j < na) {
-                if (I[k].n[0] > 0) { v[k] = I[k].base[0][(int64_t)j * 27]; wk[k] = MODE == 2 ? v[k] : w[k][0][j]; }
-            } else if (jb < I[k].n[1]) {
-                v[k] = I[k].base[1][(int64_t)jb * 27];
-                wk[k] = MODE == 2 ? v[k] : w[k][1][jb];
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) {
+                const bool live = j + u < nrows[k];
+                v[k][u] = live ? base[k][(int64_t)(j + u) * 27] : 0.f;
+                wk[k][u] = (MODE != 2 && live) ? w[k][j + u] : 0.f;
             }
-        }
 #pragma unroll
-        for (int k = 0; k < FZ_ILP; ++k) acc[k] = fmaf(v[k], wk[k], acc[k]);
+        for (int u = 0; u < RU; ++u)
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) acc[k] = fmaf(v[k][u], MODE == 2 ? v[k][u] : wk[k][u], acc[k]);
     }
 #pragma unroll
-    for (int k = 0; k < FZ_ILP; ++k)
+    for (int k = 0; k < ILP; ++k)
         if (i0 + k < nitems) part[(int64_t)(i0 + k) * 32 + s] = act ? acc[k] : 0.f;
 }
 
-// y_j = (MODE 0: reg x_j, 1: 0, 2: reg) + sum over the 27 neighbour cells c of j and the items of c:  P[item][26 - s']
-// One half-wave per unknown, lane = neighbour slot: the 27 (cell -> items -> block entry) chains run side by side; fixed tree
-// reduction.  The item offsets are indexed by the cell's own unknown index.
+// y_j = (MODE 0: reg x_j, 1: 0, 2: reg) + sum over the 27 neighbour cells c of j, sets, items of c:  P[item][26 - s']
+// One half-wave per unknown, lane = neighbour slot: the 27 (cell -> items -> block entry) chains run side by side (a thread per
+// unknown walking them one after the other took 1.4 ms); fixed tree reduction.
 template <int MODE>
 __global__ void __launch_bounds__(256) k_fz_gather(FusedArgs A, const int32_t* __restrict__ offsets, const float* __restrict__ part,
                                                   const float* __restrict__ x, float reg, float* __restrict__ y,
@@ -256,14 +215,26 @@ __global__ void __launch_bounds__(256) k_fz_gather(FusedArgs A, const int32_t* _
     const int j = (blockIdx.x * 256 + threadIdx.x) >> 5;
     if (j >= A.M) return;
     const int sp = threadIdx.x & 31;
-    const int d = fz_level(A.hier, j);
+    int d = 0;
+    while (d + 1 < A.hier.depth && j >= A.hier.lv[d + 1].offset) ++d;
     const nksr_level_t& lv = A.hier.lv[d];
     const int i = j - lv.offset;
     float acc = 0.f;
     const int c = sp < 27 ? lv.nbr[(int64_t)i * 27 + sp] : -1;
     if (c >= 0) {
-        const int i0 = offsets[lv.offset + c], i1 = offsets[lv.offset + c + 1];
-        for (int itx = i0; itx < i1; ++itx) acc += part[(int64_t)itx * 32 + (26 - sp)];
+        int i0[FZ_MAX_SETS], i1[FZ_MAX_SETS];
+#pragma unroll
+        for (int set = 0; set < FZ_MAX_SETS; ++set) {
+            i0[set] = i1[set] = 0;
+            if (set < A.nsets) {
+                const int lin = A.lin_base[set][d] + c;
+                i0[set] = offsets[lin];
+                i1[set] = offsets[lin + 1];
+            }
+        }
+#pragma unroll
+        for (int set = 0; set < FZ_MAX_SETS; ++set)
+            for (int itx = i0[set]; itx < i1[set]; ++itx) acc += part[(int64_t)itx * 32 + (26 - sp)];
     }
     acc = half_sum(acc);
     if (sp == 0) y[j] = acc + (MODE == 0 ? reg * x[j] : (MODE == 2 ? reg : 0.f));
@@ -293,16 +264,15 @@ extern "C" size_t nksr_fused_workspace_bytes(const nksr_hier_t* h, const nksr_fu
 }
 
 extern "C" int64_t nksr_fused_cells(const nksr_hier_t* h, int nsets) {
-    (void)nsets;                     // one entry per unknown (= cell): the rows of all site sets inside it share its work items
     int64_t n = 0;
     for (int d = 0; d < h->depth; ++d) n += h->lv[d].n;
-    return n;
+    return n * nsets;
 }
 
 extern "C" int nksr_fused_item_counts(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, int32_t* counts_out, void* stream) {
     FusedArgs A;
     if (int rc = fz_args(A, h, sets, nsets)) return rc;
-    hipLaunchKernelGGL(k_fz_item_counts, dim3(nksr_blocks((int64_t)A.M + 1, 256)), dim3(256), 0, (hipStream_t)stream, A, counts_out);
+    hipLaunchKernelGGL(k_fz_item_counts, dim3(nksr_blocks((int64_t)A.lin_total + 1, 256)), dim3(256), 0, (hipStream_t)stream, A, counts_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -311,20 +281,39 @@ extern "C" int nksr_fused_items(const nksr_hier_t* h, const nksr_fused_set_t* se
                                 void* stream) {
     FusedArgs A;
     if (int rc = fz_args(A, h, sets, nsets)) return rc;
-    if (A.M > 0) {
-        hipLaunchKernelGGL(k_fz_item_fill, dim3(nksr_blocks(A.M, 256)), dim3(256), 0, (hipStream_t)stream, A, offsets, (int4*)items_out);
+    if (A.lin_total > 0) {
+        hipLaunchKernelGGL(k_fz_item_fill, dim3(nksr_blocks(A.lin_total, 256)), dim3(256), 0, (hipStream_t)stream, A, offsets, (int4*)items_out);
         NKSR_CHECK_LAUNCH();
     }
     return NKSR_OK;
 }
 
+// (items per half-wave, rows per trip): probe variants, NKSR_FZ_VARIANT = 0..3; the default is the fastest one measured
+static int g_fz_variant = -1;
+static int fz_variant() {
+    if (g_fz_variant < 0) {
+        const char* e = getenv("NKSR_FZ_VARIANT");
+        g_fz_variant = e ? atoi(e) : FZ_DEFAULT_VARIANT;
+        if (g_fz_variant < 0 || g_fz_variant > 3) g_fz_variant = FZ_DEFAULT_VARIANT;
+    }
+    return g_fz_variant;
+}
+static dim3 fz_grid(int64_t nitems, int ilp) { return dim3(nksr_blocks((nitems + ilp - 1) / ilp * 32, FZ_BLOCK)); }
+
 static int fz_apply(const FusedArgs& A, const int32_t* offsets, const int4* items, int nitems, float reg, const FusedWork& w,
                     const float* x, float* y, const int* done, hipStream_t st) {
     if (nitems > 0) {
-        const dim3 grid(nksr_blocks(((int64_t)nitems + FZ_ILP - 1) / FZ_ILP * 32, FZ_BLOCK));
-        hipLaunchKernelGGL(k_fz_forward, grid, dim3(FZ_BLOCK), 0, st, A, items, nitems, x, w.tpart, done);
-        hipLaunchKernelGGL(k_fz_tsum, dim3(nksr_blocks(A.rows_total, 256)), dim3(256), 0, st, A.hier.depth, A.rows_total, (const float*)w.tpart, w.t, done);
-        hipLaunchKernelGGL((k_fz_transposed<0>), grid, dim3(FZ_BLOCK), 0, st, A, items, nitems, (const float*)w.t, w.part, done);
+        const dim3 blk(FZ_BLOCK), gs(nksr_blocks(A.rows_total, 256));
+#define FZ_APPLY(I, R)                                                                                                          \
+        hipLaunchKernelGGL((k_fz_forward<I, R>), fz_grid(nitems, I), blk, 0, st, A, items, nitems, x, w.tpart, done);          \
+        hipLaunchKernelGGL(k_fz_tsum, gs, dim3(256), 0, st, A.hier.depth, A.rows_total, (const float*)w.tpart, w.t, done);     \
+        hipLaunchKernelGGL((k_fz_transposed<0, I, R>), fz_grid(nitems, I), blk, 0, st, A, items, nitems, (const float*)w.t, w.part, done)
+        switch (fz_variant()) {
+            case 0: { FZ_APPLY(4, 1); break; }
+            case 1: { FZ_APPLY(8, 1); break; }
+            case 2: { FZ_APPLY(4, 2); break; }
+            default: { FZ_APPLY(8, 2); break; }
+        }
     }
     hipLaunchKernelGGL((k_fz_gather<0>), dim3(nksr_blocks((int64_t)A.M * 32, 256)), dim3(256), 0, st, A, offsets, (const float*)w.part, x, reg, y, done);
     return NKSR_OK;
@@ -349,15 +338,15 @@ extern "C" int nksr_fused_rhs_diag(const nksr_hier_t* h, const nksr_fused_set_t*
     if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     const FusedWork w = fz_carve(workspace, A, nitems);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(nksr_blocks((nitems + FZ_ILP - 1) / FZ_ILP * 32, FZ_BLOCK)), gm(nksr_blocks((int64_t)A.M * 32, 256));
+    const dim3 grid = fz_grid(nitems, 4), gm(nksr_blocks((int64_t)A.M * 32, 256));
     const float* nof = nullptr;
     const int* nod = nullptr;
     if (b_out) {
-        if (nitems > 0) hipLaunchKernelGGL((k_fz_transposed<1>), grid, dim3(FZ_BLOCK), 0, st, A, (const int4*)items, (int)nitems, nof, w.part, nod);
+        if (nitems > 0) hipLaunchKernelGGL((k_fz_transposed<1, 4, 1>), grid, dim3(FZ_BLOCK), 0, st, A, (const int4*)items, (int)nitems, nof, w.part, nod);
         hipLaunchKernelGGL((k_fz_gather<1>), gm, dim3(256), 0, st, A, offsets, (const float*)w.part, nof, reg, b_out, nod);
     }
     if (diag_out) {
-        if (nitems > 0) hipLaunchKernelGGL((k_fz_transposed<2>), grid, dim3(FZ_BLOCK), 0, st, A, (const int4*)items, (int)nitems, nof, w.part, nod);
+        if (nitems > 0) hipLaunchKernelGGL((k_fz_transposed<2, 4, 1>), grid, dim3(FZ_BLOCK), 0, st, A, (const int4*)items, (int)nitems, nof, w.part, nod);
         hipLaunchKernelGGL((k_fz_gather<2>), gm, dim3(256), 0, st, A, offsets, (const float*)w.part, nof, reg, diag_out, nod);
     }
     NKSR_CHECK_LAUNCH();

@@ -1,0 +1,67 @@
+"""HBM traffic of the matrix-free operator's kernels from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over
+tools/fused_probe.py.  Run on the GPU box:  python -m nksr_amd.tools.fused_pmc <out.json> [points]
+Same corrections as tools/spmv_pmc.py (MI355X_MICROARCH.md, HBM / rocprofv3 section): KiB units, FETCH_SIZE doubled on gfx950.
+Launches that the PCG's done flag turned into no-ops are excluded (duration < 20 us)."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+KERNELS = ('k_fz_forward', 'k_fz_tsum', 'k_fz_transposedILi0', 'k_fz_gatherILi0')
+
+
+def run_pass(counter, points, tag):
+    out = '/tmp/pmc_%s' % tag
+    subprocess.run(['rm', '-rf', out])
+    env = dict(os.environ, TMPDIR='/tmp')
+    cmd = ['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out, '--',
+           sys.executable, '-m', 'nksr_amd.tools.fused_probe', str(points), '10']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=os.environ.get('GRAFT_REPO_ROOT', os.getcwd()))
+    desc = [l for l in r.stdout.splitlines() if l.startswith('M=')]
+    dur = {}
+    for f in glob.glob(out + '/**/*kernel_trace.csv', recursive=True):
+        for row in csv.DictReader(open(f)):
+            dur[row.get('Dispatch_Id')] = (row.get('Kernel_Name', ''), (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3)
+    vals = {k: [] for k in KERNELS}
+    durs = {k: [] for k in KERNELS}
+    for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get('Counter_Name') != counter:
+                continue
+            name = row.get('Kernel_Name', '')
+            for k in KERNELS:
+                if k in name:
+                    d = dur.get(row.get('Dispatch_Id'), (name, 1e9))[1]
+                    if d >= 20.0:
+                        vals[k].append(float(row['Counter_Value']))
+                        durs[k].append(d)
+    return vals, durs, (desc[0] if desc else '')
+
+
+def main():
+    out = sys.argv[1]
+    points = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+    fv, fd, desc = run_pass('FETCH_SIZE', points, 'ffetch')
+    wv, wd, _ = run_pass('WRITE_SIZE', points, 'fwrite')
+    rec = {'probe': 'python -m nksr_amd.tools.fused_probe %d 10' % points, 'system': desc,
+           'correction': 'KiB units; gfx950 FETCH_SIZE counts the 128-B requests of a coalesced stream at 64 B: doubled; WRITE_SIZE uncorrected',
+           'kernels': {}}
+    tot = 0.0
+    for k in KERNELS:
+        if not fv[k] or not wv[k]:
+            continue
+        fetch = 2.0 * 1024.0 * sum(fv[k]) / len(fv[k])
+        write = 1024.0 * sum(wv[k]) / len(wv[k])
+        us = sum(fd[k]) / len(fd[k])
+        rec['kernels'][k] = {'launches': len(fv[k]), 'fetch_bytes': fetch, 'write_bytes': write, 'avg_us_under_pmc': us,
+                             'hbm_TBps_under_pmc': (fetch + write) / us / 1e6}
+        tot += fetch + write
+    rec['hbm_bytes_per_application'] = tot
+    json.dump(rec, open(out, 'w'), indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == '__main__':
+    main()

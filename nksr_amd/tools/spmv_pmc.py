@@ -10,12 +10,15 @@ import subprocess
 import sys
 
 
-def run_pass(counter, points, tag):
+PROBE = 'nksr_amd.tools.spmv_probe'
+
+
+def run_pass(counter, points, tag, probe_args=('0',)):
     out = '/tmp/pmc_%s' % tag
     subprocess.run(['rm', '-rf', out])
     env = dict(os.environ, TMPDIR='/tmp')
     cmd = ['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', out, '--',
-           sys.executable, '-m', 'nksr_amd.tools.spmv_probe', str(points), '0']
+           sys.executable, '-m', PROBE, str(points)] + list(probe_args)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=os.environ.get('GRAFT_REPO_ROOT', os.getcwd()))
     line = [l for l in r.stdout.splitlines() if l.startswith('M=')]
     vals, durs = [], []

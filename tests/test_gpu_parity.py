@@ -374,7 +374,13 @@ def test_adaptive_depth_meshing_covers_what_the_finest_level_leaves_open():
     import nksr_amd
     from nksr_amd import configs
     from oracle import network as onet, pipeline
-    xyz, nrm = make_cloud('sphere', 500, 0.0, 0)
+    # evenly spaced samples (Fibonacci sphere), spacing ~1.5 finest voxels: too sparse for the level-0 band (+-1 voxel around
+    # every sample) to be gap-free, dense enough for level 1
+    n = 700
+    k = np.arange(n) + 0.5
+    phi, z = np.pi * (1 + 5 ** 0.5) * k, 1 - 2 * k / n
+    nrm = np.stack([np.cos(phi) * np.sqrt(1 - z * z), np.sin(phi) * np.sqrt(1 - z * z), z], 1).astype(np.float32)
+    xyz = (nrm * np.float32(0.45)).astype(np.float32)
     vs = 0.04
     hp = configs.get_hparams('ks', adaptive_depth=2)
     rec = nksr_amd.Reconstructor(_dev(), hparams=hp)
