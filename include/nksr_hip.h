@@ -127,9 +127,11 @@ int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden, const flo
 /* Dense-slot kernel rows at arbitrary sites.  val [n, L, 27] (may be NULL when only the gradient rows are
  * wanted); dval [n, 3, L, 27] (may be NULL).  approx!=0 drops the d(phi)/dx term (approx_kernel_grad, recons_waymo.py:33).  Every output is
  * multiplied by row_scale (the assembly takes rows pre-multiplied by sqrt(set weight), see nksr_assemble). */
-int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, int level_major,
+int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, int64_t level_stride,
                      float* val, float* dval, void* stream);
-/* level_major != 0: val [L, n, 27], dval [L, n, 3, 27] -- the layout of the matrix-free solve (nksr_fused_set_t.rows) */
+/* level_stride > 0: LEVEL-MAJOR output, row (site i, component a) of level d at val / dval + ((d * level_stride + i * ncomp + a) * 27)
+ * (ncomp = 1 for val, 3 for dval) -- the layout of the matrix-free solve (nksr_fused_op_t.rows_all; pass the pointer of the
+ * set's first row) */
 /* f(x) (and gradient if grad_out != NULL): field.evaluate_f, models/loss.py:189-198. */
 int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx,
                     float* f_out, float* grad_out, void* stream);
@@ -208,32 +210,38 @@ int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_out);
 /* ---- matrix-free ("fused") operator and solve: reconstruct(..., fused_mode=True), examples/recons_waymo.py:33,
  *      recons_waymo_cpu.py:58, gis_app.py:40; KernelField.solve (csrc/fused.hip).  The system matrix is never built:
  *      y = (sum_s R_s^T R_s + reg I) x is applied from the dense-slot kernel rows, cell by cell. ------------------ */
-typedef struct {
-    int64_t n;                 /* sites                                                                    */
+typedef struct {               /* a site set, as far as the work-item builder needs it */
+    int64_t n;                 /* sites (Morton-sorted)                                                     */
     int32_t ncomp;             /* rows per site: 1 (position rows, G) or 3 (gradient rows, Q)               */
-    const float* rows;         /* LEVEL-MAJOR dense-slot rows [L][n * ncomp][27], pre-multiplied by sqrt(w)  */
-    const float* target;       /* [n * ncomp] right-hand side values (pre-multiplied by sqrt(w)) or NULL    */
-    const int32_t* start[NKSR_MAX_DEPTH]; /* per level: [n_d] site range per voxel (sites Morton-sorted)    */
+    const int32_t* start[NKSR_MAX_DEPTH]; /* per level: [n_d] site range of every voxel                     */
     const int32_t* end[NKSR_MAX_DEPTH];
 } nksr_fused_set_t;
-/* Work items (set, level, cell, <= 32 rows): counts_out [cells + 1] (cells = nsets * sum_d n_d, last entry 0) ->
- * exclusive scan = offsets -> items_out [nitems, 4] int32. */
+typedef struct {
+    int32_t depth, nsets, M, reserved;
+    int64_t rows_total;        /* rows of all sets (set 0 first); also the level stride of rows_all         */
+    const float* rows_all;     /* LEVEL-MAJOR dense-slot rows [depth][rows_total][27], pre-multiplied by sqrt(w) (nksr_kernel_rows, level_stride) */
+    const float* targets_all;  /* [rows_total] right-hand side values pre-multiplied by sqrt(w) (0 for rows without a target); may be NULL if unused */
+    const int32_t* nbr_all;    /* [M, 27] GLOBAL unknown index of every neighbour voxel, or -1               */
+    const int32_t* offsets;    /* [nsets * M + 1] first work item of (set, cell)                            */
+    const int32_t* items;      /* [nitems, 4] work items (nksr_fused_items)                                 */
+    int64_t nitems;
+    void* workspace;           /* nksr_fused_workspace_bytes, zero-initialised once                         */
+} nksr_fused_op_t;
+/* Work items (set, cell, <= 32 rows): counts_out [nsets * M + 1] (last entry 0) -> exclusive scan = offsets ->
+ * items_out [nitems, 4] int32. */
 int64_t nksr_fused_cells(const nksr_hier_t* h, int nsets);
 int nksr_fused_item_counts(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, int32_t* counts_out, void* stream);
 int nksr_fused_items(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, const int32_t* offsets, int32_t* items_out,
                      void* stream);
-size_t nksr_fused_workspace_bytes(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, int64_t nitems);
+size_t nksr_fused_workspace_bytes(int32_t depth, int64_t rows_total, int64_t nitems);
 /* b = sum_s R_s^T t_s and diag = reg + sum_s diag(R_s^T R_s) (either may be NULL). */
-int nksr_fused_rhs_diag(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, const int32_t* offsets, const int32_t* items,
-                        int64_t nitems, float reg, void* workspace, float* b_out, float* diag_out, void* stream);
+int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* b_out, float* diag_out, void* stream);
 /* y = (sum_s R_s^T R_s + reg I) x */
-int nksr_fused_apply(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, const int32_t* offsets, const int32_t* items,
-                     int64_t nitems, float reg, void* workspace, const float* x, float* y, void* stream);
+int nksr_fused_apply(const nksr_fused_op_t* op, float reg, const float* x, float* y, void* stream);
 /* Jacobi-PCG with that operator; pcg_workspace: nksr_pcg_vector_workspace_bytes(M).  Syncs like nksr_pcg_solve. */
 size_t nksr_pcg_vector_workspace_bytes(int32_t M);
-int nksr_pcg_solve_fused(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, const int32_t* offsets, const int32_t* items,
-                         int64_t nitems, float reg, const float* diag, const float* b, float* x, float tol, int max_iter,
-                         int check_every, void* workspace, void* pcg_workspace, double* info_out, void* stream);
+int nksr_pcg_solve_fused(const nksr_fused_op_t* op, float reg, const float* diag, const float* b, float* x, float tol, int max_iter,
+                         int check_every, void* pcg_workspace, double* info_out, void* stream);
 
 /* ---- grid-hash nearest neighbours (csrc/knn.hip) ----------------------------------------------------
  * Points Morton-sorted by a uniform grid of size `cell` (keys from nksr_point_keys with inv_w0 =

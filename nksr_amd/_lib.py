@@ -24,7 +24,12 @@ class HierT(C.Structure):
 
 
 class FusedSetT(C.Structure):
-    _fields_ = [('n', _i64), ('ncomp', _i32), ('rows', _vp), ('target', _vp), ('start', _vp * MAX_DEPTH), ('end', _vp * MAX_DEPTH)]
+    _fields_ = [('n', _i64), ('ncomp', _i32), ('start', _vp * MAX_DEPTH), ('end', _vp * MAX_DEPTH)]
+
+
+class FusedOpT(C.Structure):
+    _fields_ = [('depth', _i32), ('nsets', _i32), ('M', _i32), ('reserved', _i32), ('rows_total', _i64), ('rows_all', _vp),
+                ('targets_all', _vp), ('nbr_all', _vp), ('offsets', _vp), ('items', _vp), ('nitems', _i64), ('workspace', _vp)]
 
 
 class SiteSetT(C.Structure):
@@ -55,7 +60,7 @@ lib.nksr_assemble_workspace_bytes.argtypes = [C.POINTER(HierT)]
 lib.nksr_spmv_workspace_bytes.restype = _sz
 lib.nksr_spmv_workspace_bytes.argtypes = [_i64]
 lib.nksr_fused_workspace_bytes.restype = _sz
-lib.nksr_fused_workspace_bytes.argtypes = [C.POINTER(HierT), C.POINTER(FusedSetT), C.c_int, _i64]
+lib.nksr_fused_workspace_bytes.argtypes = [_i32, _i64, _i64]
 lib.nksr_pcg_vector_workspace_bytes.restype = _sz
 lib.nksr_pcg_vector_workspace_bytes.argtypes = [_i32]
 lib.nksr_fused_cells.restype = _i64
@@ -88,7 +93,7 @@ _PROTOS = {
     'nksr_splat_plane': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp],
     'nksr_udf_decode': [_P(LevelT), C.c_int, _vp, _vp, _i64, _f32, _f32, C.c_int, _vp, _vp],
     'nksr_voxel_psi': [_vp, _i32, C.c_int, C.c_int, _vp, _vp, _vp],
-    'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _f32, C.c_int, _vp, _vp, _vp],
+    'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _f32, _i64, _vp, _vp, _vp],
     'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, _vp, _vp, _vp],
     'nksr_assemble_count': [_P(HierT), _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -100,10 +105,9 @@ _PROTOS = {
     'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
     'nksr_fused_item_counts': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp],
     'nksr_fused_items': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp, _vp],
-    'nksr_fused_rhs_diag': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp],
-    'nksr_fused_apply': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp],
-    'nksr_pcg_solve_fused': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _vp,
-                             _P(C.c_double), _vp],
+    'nksr_fused_rhs_diag': [_P(FusedOpT), _f32, _vp, _vp, _vp],
+    'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
+    'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
     'nksr_pcg_profile_bytes': [_P(C.c_double), _P(C.c_double)],
     'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp],

@@ -160,7 +160,7 @@ __device__ __forceinline__ void store_row27(float* __restrict__ p, const float v
 // grid.y = level; one thread per site.
 template <int K, int H, bool GRAD, bool JAC>
 __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float row_scale,
-                              int level_major, float* __restrict__ val, float* __restrict__ dval) {
+                              int64_t level_stride, float* __restrict__ val, float* __restrict__ dval) {
     const int d = blockIdx.y, L = hier.depth;
     const nksr_level_t& lv = hier.lv[d];
     __shared__ float w[MlpView<K, H>::SIZE];
@@ -170,11 +170,11 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
     if (i >= n) return;
     float x[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
     SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
-    // site-major [n, (3,) L, 27] for the assembly, level-major [L, n, (3,) 27] for the matrix-free solve
-    float* vrow = val + (level_major ? ((int64_t)d * n + i) * 27 : (i * L + d) * 27);
+    // site-major [n, (3,) L, 27] for the assembly, level-major [L, stride, 27] (row = site * ncomp + component) for the matrix-free solve
+    float* vrow = val + (level_stride ? ((int64_t)d * level_stride + i) * 27 : (i * L + d) * 27);
     float* grow[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) grow[a] = dval + (level_major ? (((int64_t)d * n + i) * 3 + a) * 27 : ((i * 3 + a) * L + d) * 27);
+    for (int a = 0; a < 3; ++a) grow[a] = dval + (level_stride ? ((int64_t)d * level_stride + i * 3 + a) * 27 : ((i * 3 + a) * L + d) * 27);
     if (sc.cell < 0) {
         if (val)
             for (int s = 0; s < 27; ++s) vrow[s] = 0.f;
@@ -305,16 +305,16 @@ extern "C" int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden
     return NKSR_OK;
 }
 
-extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, int level_major,
+extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, int64_t level_stride,
                                 float* val, float* dval, void* stream) {
     if (n <= 0) return NKSR_OK;
     if (!val && !dval) return nksr_set_error(NKSR_ERR_ARG, "val and dval are both NULL");
     if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
     dim3 grid(nksr_blocks(n, 128), h->depth), block(128);
     DISPATCH_KH(h->kdim, h->hidden, {
-        if (!dval) hipLaunchKernelGGL((k_kernel_rows<K, H, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_major, val, dval);
-        else if (approx) hipLaunchKernelGGL((k_kernel_rows<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_major, val, dval);
-        else hipLaunchKernelGGL((k_kernel_rows<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_major, val, dval);
+        if (!dval) hipLaunchKernelGGL((k_kernel_rows<K, H, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, val, dval);
+        else if (approx) hipLaunchKernelGGL((k_kernel_rows<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, val, dval);
+        else hipLaunchKernelGGL((k_kernel_rows<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, val, dval);
     })
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;

@@ -17,7 +17,7 @@ import time
 import torch
 
 from .. import _lib, ops
-from .._lib import FusedSetT, HierT, SiteSetT, call, ptr, stream
+from .._lib import FusedOpT, FusedSetT, HierT, SiteSetT, call, ptr, stream
 from .base_field import BaseField, EvaluationResult
 
 
@@ -67,16 +67,20 @@ class KernelField(BaseField):
         return h
 
     # ---- kernel rows ---------------------------------------------------------------------------------
-    def kernel_rows(self, xyz, grad, scale=1.0, values=True, level_major=False):
+    def kernel_rows(self, xyz, grad, scale=1.0, values=True):
         """Dense-slot rows: val [n, L, 27] (``None`` with values=False) and (grad) dval [n, 3, L, 27]
-        (model units), times ``scale``.  ``level_major``: val [L, n, 27], dval [L, n, 3, 27] (matrix-free solve)."""
+        (model units), times ``scale``."""
         n, L = xyz.shape[0], self.svh.depth
-        vs, ds = ((L, n, 27), (L, n, 3, 27)) if level_major else ((n, L, 27), (n, 3, L, 27))
-        val = torch.empty(vs, dtype=torch.float32, device=self.device) if values else None
-        dval = torch.empty(ds, dtype=torch.float32, device=self.device) if grad else None
-        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), int(level_major),
-             ptr(val), ptr(dval), stream())
+        val = torch.empty((n, L, 27), dtype=torch.float32, device=self.device) if values else None
+        dval = torch.empty((n, 3, L, 27), dtype=torch.float32, device=self.device) if grad else None
+        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), 0, ptr(val), ptr(dval), stream())
         return val, dval
+
+    def kernel_rows_level_major(self, xyz, grad, scale, out, level_stride):
+        """Rows of the sites ``xyz`` written LEVEL-MAJOR into ``out`` (a flat view starting at the set's first row of the
+        [L, level_stride, 27] array): position rows (grad=False, one per site) or gradient rows (three per site)."""
+        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), xyz.shape[0], int(self.approx_kernel_grad), float(scale), int(level_stride),
+             None if grad else ptr(out), ptr(out) if grad else None, stream())
 
     def _sorted_sites(self, xyz):
         """Permutation that Morton-sorts sites by their level-0 cell + the sorted keys."""
@@ -214,44 +218,52 @@ class KernelField(BaseField):
 
     # ---- matrix-free ("fused") solve ---------------------------------------------------------------------
     def fused_operator(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, pos_sorted_keys=None, normal_sorted_keys=None):
-        """Everything the matrix-free operator needs (csrc/fused.hip): level-major kernel rows of both site sets
-        (pre-multiplied by sqrt(weight)), their per-cell site ranges and the work items.  Returns a dict; ``keep`` holds
-        the buffers the C structs point into."""
+        """Everything the matrix-free operator needs (csrc/fused.hip, nksr_fused_op_t): the level-major kernel rows of both
+        site sets in one array (pre-multiplied by sqrt(weight)), their targets, the global neighbour table and the work
+        items.  Returns a dict; ``keep`` holds the buffers the C struct points into."""
         dev = self.device
-        if self.svh.num_unknowns == 0:
+        svh = self.svh
+        M, L = svh.num_unknowns, svh.depth
+        if M == 0:
             raise RuntimeError('empty hierarchy')
-        keep = []
-        sets = (FusedSetT * 2)()
-        nsets = 0
+        specs = []
         for xyz, target, weight, ncomp, pre in ((pos_xyz, None, pos_weight, 1, pos_sorted_keys),
                                                  (normal_xyz, normal_value, normal_weight, 3, normal_sorted_keys)):
             if xyz is None or xyz.shape[0] == 0:
                 continue
+            if not float(weight) >= 0.0:
+                raise RuntimeError('solver weights must be >= 0')
             xyz = xyz.to(dev, torch.float32).contiguous()
             if pre is not None:
                 ks, perm, xs = pre, None, xyz
             else:
                 ks, perm = self._sorted_sites(xyz)
                 xs = xyz[perm].contiguous()
-            if not float(weight) >= 0.0:
-                raise RuntimeError('solver weights must be >= 0')
-            sw = float(weight) ** 0.5
-            val, dval = self.kernel_rows(xs, grad=(ncomp == 3), scale=sw, values=(ncomp == 1), level_major=True)
-            rows = val if ncomp == 1 else dval
-            st, en = self._site_ranges(ks)
-            S = sets[nsets]
-            S.n, S.ncomp, S.rows = xs.shape[0], ncomp, ptr(rows)
-            tgt = None
+            specs.append((xs, ks, perm, target, float(weight) ** 0.5, ncomp))
+        if not specs:
+            raise RuntimeError('no constraint sites')
+        nsets = len(specs)
+        rows_total = sum(sp[0].shape[0] * sp[5] for sp in specs)
+        rows_all = torch.empty(L * rows_total * 27, dtype=torch.float32, device=dev)
+        targets_all = torch.zeros(rows_total, dtype=torch.float32, device=dev)
+        sets = (FusedSetT * 2)()
+        keep = [rows_all, targets_all]
+        off = 0
+        for i, (xs, ks, perm, target, sw, ncomp) in enumerate(specs):
+            self.kernel_rows_level_major(xs, ncomp == 3, sw, rows_all[off * 27:], rows_total)
             if target is not None:
                 tgt = target.to(dev, torch.float32)
-                tgt = ((tgt[perm] if perm is not None else tgt) * sw).contiguous()      # [n, 3] == rows order (site, component)
-                S.target = ptr(tgt)
-            for d in range(self.svh.depth):
-                S.start[d], S.end[d] = ptr(st[d]), ptr(en[d])
-            keep += [xs, rows, st, en, tgt, ks]
-            nsets += 1
-        if nsets == 0:
-            raise RuntimeError('no constraint sites')
+                tgt = (tgt[perm] if perm is not None else tgt) * sw                       # [n, 3] == row order (site, component)
+                targets_all[off:off + xs.shape[0] * ncomp] = tgt.reshape(-1)
+            st, en = self._site_ranges(ks)
+            sets[i].n, sets[i].ncomp = xs.shape[0], ncomp
+            for d in range(L):
+                sets[i].start[d], sets[i].end[d] = ptr(st[d]), ptr(en[d])
+            keep += [xs, ks, st, en]
+            off += xs.shape[0] * ncomp
+        # neighbour table of all levels with GLOBAL unknown indices
+        offs = svh.offsets
+        nbr_all = torch.cat([torch.where(svh.level(d).nbr >= 0, svh.level(d).nbr + offs[d], svh.level(d).nbr) for d in range(L)]).contiguous()
         ncells = int(_lib.lib.nksr_fused_cells(C.byref(self._hier), nsets))
         counts = torch.empty(ncells + 1, dtype=torch.int32, device=dev)
         call('nksr_fused_item_counts', C.byref(self._hier), sets, nsets, ptr(counts), stream())
@@ -261,16 +273,25 @@ class KernelField(BaseField):
         call('nksr_fused_items', C.byref(self._hier), sets, nsets, ptr(offsets), ptr(items), stream())
         # zeroed once: rows of sites that lie in no active cell of a level belong to no work item, their partial products are
         # never written and must read as 0
-        ws = torch.zeros(int(_lib.lib.nksr_fused_workspace_bytes(C.byref(self._hier), sets, nsets, nitems)), dtype=torch.uint8, device=dev)
-        rows_total = sum(int(sets[i].n) * int(sets[i].ncomp) for i in range(nsets))
-        return {'sets': sets, 'nsets': nsets, 'offsets': offsets, 'items': items, 'nitems': nitems, 'ws': ws, 'keep': keep,
-                'rows_total': rows_total}
+        ws = torch.zeros(int(_lib.lib.nksr_fused_workspace_bytes(L, rows_total, nitems)), dtype=torch.uint8, device=dev)
+        op = FusedOpT()
+        op.depth, op.nsets, op.M, op.rows_total, op.nitems = L, nsets, M, rows_total, nitems
+        op.rows_all, op.targets_all, op.nbr_all = ptr(rows_all), ptr(targets_all), ptr(nbr_all)
+        op.offsets, op.items, op.workspace = ptr(offsets), ptr(items), ptr(ws)
+        keep += [nbr_all, offsets, items, ws]
+        return {'op': op, 'nsets': nsets, 'nitems': nitems, 'rows_total': rows_total, 'keep': keep}
+
+    def fused_rhs_diag(self, op, reg_weight=1.0):
+        M = self.svh.num_unknowns
+        b = torch.empty(M, dtype=torch.float32, device=self.device)
+        diag = torch.empty(M, dtype=torch.float32, device=self.device)
+        call('nksr_fused_rhs_diag', C.byref(op['op']), float(reg_weight), ptr(b), ptr(diag), stream())
+        return b, diag
 
     def fused_apply(self, op, x, reg_weight=1.0):
         """y = (w_p G^T G + w_n Q^T Q + reg I) x without the matrix (test / export helper)."""
         y = torch.empty_like(x)
-        call('nksr_fused_apply', C.byref(self._hier), op['sets'], op['nsets'], ptr(op['offsets']), ptr(op['items']), op['nitems'],
-             float(reg_weight), ptr(op['ws']), ptr(x.contiguous()), ptr(y), stream())
+        call('nksr_fused_apply', C.byref(op['op']), float(reg_weight), ptr(x.contiguous()), ptr(y), stream())
         return y
 
     def solve_fused(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0,
@@ -282,19 +303,15 @@ class KernelField(BaseField):
         op = self.fused_operator(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, pos_sorted_keys, normal_sorted_keys)
         dev = self.device
         M = self.svh.num_unknowns
-        b = torch.empty(M, dtype=torch.float32, device=dev)
-        diag = torch.empty(M, dtype=torch.float32, device=dev)
-        call('nksr_fused_rhs_diag', C.byref(self._hier), op['sets'], op['nsets'], ptr(op['offsets']), ptr(op['items']), op['nitems'],
-             float(reg_weight), ptr(op['ws']), ptr(b), ptr(diag), stream())
+        b, diag = self.fused_rhs_diag(op, reg_weight)
         if self.solver_config.get('verbose') or self.solver_config.get('sync_timing'):
             torch.cuda.synchronize()
         t1 = time.perf_counter()
         x = torch.empty(M, dtype=torch.float32, device=dev)
         pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=dev)
         info = (C.c_double * 2)()
-        call('nksr_pcg_solve_fused', C.byref(self._hier), op['sets'], op['nsets'], ptr(op['offsets']), ptr(op['items']), op['nitems'],
-             float(reg_weight), ptr(diag), ptr(b), ptr(x), float(self.solver_config['tol']), int(self.solver_config['max_iter']),
-             int(self.solver_config['check_every']), ptr(op['ws']), ptr(pws), info, stream())
+        call('nksr_pcg_solve_fused', C.byref(op['op']), float(reg_weight), ptr(diag), ptr(b), ptr(x), float(self.solver_config['tol']),
+             int(self.solver_config['max_iter']), int(self.solver_config['check_every']), ptr(pws), info, stream())
         t2 = time.perf_counter()
         self.alpha = x
         self.matrix = None

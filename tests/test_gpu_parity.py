@@ -156,11 +156,7 @@ def test_fused_operator_matches_the_assembled_matrix(approx):
     rowptr, cols, vals, diag, gb = fld.assemble(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
     op = fld.fused_operator(t(xyz), t(nxyz), t(nval), wp, wn)
     M = A.shape[0]
-    fb, fd = torch.empty(M, device=_dev()), torch.empty(M, device=_dev())
-    import ctypes as C
-    from nksr_amd._lib import call, ptr, stream
-    call('nksr_fused_rhs_diag', C.byref(fld._hier), op['sets'], op['nsets'], ptr(op['offsets']), ptr(op['items']), op['nitems'], 1.0,
-         ptr(op['ws']), ptr(fb), ptr(fd), stream())
+    fb, fd = fld.fused_rhs_diag(op, 1.0)
     pu.check('fused:rhs_rel', np.abs(fb.cpu().numpy() - b).max() / np.abs(b).max(), 1e-5)
     pu.check('fused:diag_rel', (np.abs(fd.cpu().numpy() - A.diagonal()) / A.diagonal()).max(), 1e-5)
     pu.check('fused:diag_vs_csr_rel', float(((fd - diag).abs() / diag).max()), 1e-5)
