@@ -127,7 +127,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scale-scene', action='store_true')
     ap.add_argument('--no-other-mode', action='store_true')
-    ap.add_argument('--non-fused', action='store_true', help='headline through the assembled CSR solve (fused_mode=False)')
+    ap.add_argument('--non-fused', action='store_true', help='configs[2] headline through the assembled CSR solve (fused_mode=False)')
+    ap.add_argument('--fused-scene', action='store_true', help='configs[4] through the matrix-free solve (default: assembled CSR)')
     ap.add_argument('--scene', choices=['auto', 'cloud', 'terrain'], default='auto',
                     help="'terrain' runs configs[4] as the headline at N=1 too")
     args = ap.parse_args()
@@ -248,7 +249,11 @@ def main():
 
     terrain_headline = world > 1 or args.scene == 'terrain'
     extra = None
-    fused = not args.non_fused            # the API default (and what the reference's examples pass): fused_mode=True
+    # configs[2] runs through the API default, fused_mode=True (what the reference's examples pass): 11 PCG iterations, the
+    # matrix-free solve skips a 21 ms assembly.  configs[4] needs ~47 iterations per chunk (tree_depth 5, open terrain): there the
+    # assembled CSR amortises (its SpMV is ~2x cheaper per iteration), so the scene is solved with fused_mode=False; the other
+    # mode is measured and reported next to each (DESIGN.md section 3.5 has the cost model).
+    fused = (not args.non_fused) if not terrain_headline else bool(args.fused_scene)
     if terrain_headline:
         dt, npts, cfg, prof, stages = run_terrain(args.steps, args.warmup, fused)
     else:
@@ -268,9 +273,16 @@ def main():
     if not terrain_headline and not args.no_scale_scene:
         # the same scene the N > 1 runs solve, on this one GPU (1 warm-up + 2 timed steps): the N=1 point of the curve
         torch.cuda.empty_cache()
-        sdt, sn, scfg, sprof, sstages = run_terrain(2, 1, fused)
+        sf = bool(args.fused_scene)
+        sdt, sn, scfg, sprof, sstages = run_terrain(2, 1, sf)
         out['scale_scene'] = {'value': sn * 2 / sdt, 'unit': 'points/s', 'ms_per_step': sdt / 2 * 1e3, 'steps': 2, 'warmup': 1,
-                              'config': scfg, 'roofline': roofline_record(*sprof, fused=fused), 'stages_s_per_step': sstages}
+                              'config': scfg, 'roofline': roofline_record(*sprof, fused=sf), 'stages_s_per_step': sstages}
+        if not args.no_other_mode:
+            torch.cuda.empty_cache()
+            odt, _, ocfg, oprof, ostages = run_terrain(1, 1, not sf)
+            out['scale_scene']['other_solve_mode'] = {'fused_mode': not sf, 'value': sn / odt, 'unit': 'points/s', 'ms_per_step': odt * 1e3,
+                                                      'steps': 1, 'warmup': 1, 'pcg_iters_per_chunk': ocfg['pcg_iters_per_chunk'],
+                                                      'roofline': roofline_record(*oprof, fused=not sf), 'stages_s_per_step': ostages}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and extra is not None:
         from oracle import waymo_cpu
         rec, xyz_np, nrm_np, scale = extra

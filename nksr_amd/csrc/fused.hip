@@ -105,11 +105,31 @@ __device__ __forceinline__ float half_sum(float p) {      // sum over the 32 lan
     return p;
 }
 
+// sums of FOUR rows over the 32 lanes of a half-wave in 6 lane exchanges instead of 4 x 5: a transposing butterfly -- after the
+// xor-16 step a lane keeps two of the four rows (its own + its partner's share), after xor-8 one, then 3 plain steps.
+// Returns, in every lane, the total of row  2 * bit4(lane) + bit3(lane).
+// lane exchanges inside a 16-lane row as DPP modifiers of a VALU move (no LDS crossbar): quad_perm [1,0,3,2] (xor 1),
+// [2,3,0,1] (xor 2), row_half_mirror (l -> 7 - l: the other quad of an 8-lane group once quads are uniform), row_ror:8 (xor 8)
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float half_sum4(float p0, float p1, float p2, float p3, int lane) {
+    const bool hi = (lane >> 4) & 1, b = (lane >> 3) & 1;
+    const float r0 = __shfl_xor(hi ? p0 : p2, 16, 32), r1 = __shfl_xor(hi ? p1 : p3, 16, 32);       // the only two crossbar trips
+    const float q0 = (hi ? p2 : p0) + r0, q1 = (hi ? p3 : p1) + r1;          // rows {2,3} in the upper 16 lanes, {0,1} in the lower
+    float r = (b ? q1 : q0) + dpp_move<0x128>(b ? q0 : q1);                  // row_ror:8
+    r += dpp_move<0xB1>(r);                                                  // xor 1
+    r += dpp_move<0x4E>(r);                                                  // xor 2
+    r += dpp_move<0x141>(r);                                                 // row_half_mirror: the other quad
+    return r;
+}
+
 // t_d[r] = sum_s rows[d][r][s] * x[stencil of the item's cell][s]
-// Every half-wave carries ILP consecutive items at once (their load chains item -> neighbour row -> x overlap) and RU rows per
-// trip.  The vector-memory pipe spends ~16 clocks per wavefront instruction whatever it moves: the row sums are not stored one
-// 4-byte store per row -- lane j keeps the sum of row j and every item leaves as one coalesced store of <= 32 floats.
-template <int ILP, int RU>
+// Every half-wave carries ILP consecutive items at once (their load chains item -> neighbour row -> x overlap), four rows per
+// trip.  The row sums leave through 4 lanes per trip (16 contiguous bytes): one store instruction per four rows, and the
+// cross-lane exchanges -- the LDS crossbar was this kernel's bottleneck at one 5-step reduction per row -- drop 3.3x.
+template <int ILP>
 __global__ void __launch_bounds__(FZ_BLOCK) k_fz_forward(FusedArgs A, const float* __restrict__ x, float* __restrict__ tpart,
                                                         const int* __restrict__ done) {
     if (done && *done) return;
@@ -128,31 +148,28 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_forward(FusedArgs A, const floa
         nrows[k] = i0 + k < A.nitems ? (it[k].z & 255) : 0;
         maxrows = nrows[k] > maxrows ? nrows[k] : maxrows;
     }
-    float xs[ILP], keep[ILP];
+    float xs[ILP];
     const float* base[ILP];
+    float* tp[ILP];
 #pragma unroll
     for (int k = 0; k < ILP; ++k) {
         xs[k] = nb[k] >= 0 ? x[nb[k]] : 0.f;
         base[k] = A.rows_all + ((int64_t)(it[k].z >> 8) * A.rows_total + it[k].x) * 27 + (act ? s : 0);
-        keep[k] = 0.f;
+        tp[k] = tpart + (int64_t)(it[k].z >> 8) * A.rows_total + it[k].x;
     }
-    for (int j = 0; j < maxrows; j += RU) {
-        float v[ILP][RU];
+    const int myrow = 2 * ((s >> 4) & 1) + ((s >> 3) & 1);         // the row of a trip whose total this lane ends up with
+    for (int j = 0; j < maxrows; j += 4) {
+        float v[ILP][4];
 #pragma unroll
-        for (int u = 0; u < RU; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int k = 0; k < ILP; ++k) v[k][u] = (act && j + u < nrows[k]) ? base[k][(int64_t)(j + u) * 27] : 0.f;
 #pragma unroll
-        for (int u = 0; u < RU; ++u)
-#pragma unroll
-            for (int k = 0; k < ILP; ++k) {
-                const float p = half_sum(v[k][u] * xs[k]);       // every lane of the half holds the sum
-                if (s == j + u) keep[k] = p;
-            }
+        for (int k = 0; k < ILP; ++k) {
+            const float r = half_sum4(v[k][0] * xs[k], v[k][1] * xs[k], v[k][2] * xs[k], v[k][3] * xs[k], s);
+            if ((s & 7) == 0 && j + myrow < nrows[k]) tp[k][j + myrow] = r;
+        }
     }
-#pragma unroll
-    for (int k = 0; k < ILP; ++k)
-        if (s < nrows[k]) tpart[(int64_t)(it[k].z >> 8) * A.rows_total + it[k].x + s] = keep[k];
 }
 
 __global__ void k_fz_tsum(int depth, int64_t rows_total, const float* __restrict__ tpart, float* __restrict__ t,
@@ -202,7 +219,13 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_transposed(FusedArgs A, const f
         for (int u = 0; u < RU; ++u)
 #pragma unroll
             for (int k = 0; k < ILP; ++k) {
-                const float wk = MODE == 2 ? v[k][u] : __shfl(wreg[k], (j + u) & 31, 32);
+                // row j + u is the same lane of both halves' items: two scalar lane reads + a select, no crossbar
+                float wk = v[k][u];
+                if (MODE != 2) {
+                    const float wl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[k]), (j + u) & 31)),
+                                wh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[k]), 32 + ((j + u) & 31)));
+                    wk = (threadIdx.x & 32) ? wh : wl;
+                }
                 acc[k] = fmaf(v[k][u], wk, acc[k]);
             }
     }
@@ -315,7 +338,7 @@ static int fz_apply(const FusedArgs& A, float reg, const FusedWork& w, const flo
     if (A.nitems > 0) {
         const dim3 blk(FZ_BLOCK), gs(nksr_blocks(A.rows_total, 256));
 #define FZ_APPLY(I, R)                                                                                                      \
-        hipLaunchKernelGGL((k_fz_forward<I, R>), fz_grid(A.nitems, I), blk, 0, st, A, x, w.tpart, done);                   \
+        hipLaunchKernelGGL((k_fz_forward<I>), fz_grid(A.nitems, I), blk, 0, st, A, x, w.tpart, done);                      \
         hipLaunchKernelGGL(k_fz_tsum, gs, dim3(256), 0, st, A.depth, A.rows_total, (const float*)w.tpart, w.t, done);      \
         hipLaunchKernelGGL((k_fz_transposed<0, I, R>), fz_grid(A.nitems, I), blk, 0, st, A, (const float*)w.t, w.part, done)
         switch (fz_variant()) {
