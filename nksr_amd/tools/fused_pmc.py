@@ -9,7 +9,16 @@ import os
 import subprocess
 import sys
 
-KERNELS = ('k_fz_forward', 'k_fz_tsum', 'k_fz_transposedILi0', 'k_fz_gatherILi0')
+KERNELS = ('k_fz_forward', 'k_fz_tsum', 'k_fz_transposed', 'k_fz_gather')
+
+
+def _match(k, name):
+    """operator instantiations only (MODE 0), mangled or demangled kernel names"""
+    if k not in name:
+        return False
+    if k in ('k_fz_transposed', 'k_fz_gather'):
+        return (k + 'ILi0') in name or (k + '<0') in name
+    return True
 
 
 def run_pass(counter, points, tag):
@@ -32,7 +41,7 @@ def run_pass(counter, points, tag):
                 continue
             name = row.get('Kernel_Name', '')
             for k in KERNELS:
-                if k in name:
+                if _match(k, name):
                     d = dur.get(row.get('Dispatch_Id'), (name, 1e9))[1]
                     if d >= 20.0:
                         vals[k].append(float(row['Counter_Value']))

@@ -15,7 +15,7 @@ def main():
     dev = torch.device('cuda:0')
     xyz, nrm = utils.synth_scene(n, seed=0)
     rec = nksr_amd.Reconstructor(dev)
-    f = rec.reconstruct(torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev), detail_level=1.0)
+    f = rec.reconstruct(torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev), detail_level=1.0, fused_mode=False)
     rowptr, cols, vals, diag = f.matrix
     M, nnz = rowptr.numel() - 1, f.nnz
     B = 8.0 * nnz + 12.0 * M + 4
