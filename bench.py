@@ -55,6 +55,22 @@ def load_traffic(bytes_per_launch):
     return best
 
 
+def load_traffic_fused(bytes_per_launch):
+    """Same for the matrix-free operator (profiles/*_fused_pmc.json, matched on the operator's physical bytes)."""
+    best = (None, None)
+    pdir = os.path.join(ROOT, 'profiles')
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith('_fused_pmc.json'):
+                try:
+                    rec = json.load(open(os.path.join(pdir, f)))
+                    if abs(rec.get('physical_bytes_per_application', 0) - bytes_per_launch) < 0.02 * bytes_per_launch:
+                        best = (rec.get('hbm_bytes_per_application'), 'profiles/' + f)
+                except Exception:
+                    pass
+    return best
+
+
 def roofline_record(ms, launches, alg, phys, fused=False):
     """The CG operator application ("SpMV") measured live with HIP events on the solve stream.
     assembled CSR : achieved = the algorithmic CSR bytes of SURVEY.md section 8d (8 nnz + 12 M + 4) / time; achieved_physical
@@ -67,10 +83,11 @@ def roofline_record(ms, launches, alg, phys, fused=False):
     p = phys / max(launches, 1)
     rate = lambda b: (b / avg_s if avg_s > 0 else 0.0)
     if fused:
+        traffic, src = load_traffic_fused(p) if launches else (None, None)
         return {'bound': 'hbm', 'kernel': 'k_fz_forward + k_fz_tsum + k_fz_transposed + k_fz_gather (matrix-free normal-equation operator '
                                           'inside the PCG loop, fused_mode=True)',
                 'achieved': rate(p) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(p) / HBM_PEAK,
-                'achieved_survey_formula': rate(a) / 1e9, 'traffic': None, 'traffic_source': None,
+                'achieved_survey_formula': rate(a) / 1e9, 'traffic': traffic, 'traffic_source': src if traffic is not None else None,
                 'bytes_per_launch': p, 'survey_formula_bytes_per_launch': a, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
     traffic, src = load_traffic(a) if launches else (None, None)
     return {'bound': 'hbm', 'kernel': 'k_spmv<3,0> + k_spmv_fixup (packed-column CSR SpMV inside the PCG loop, fused_mode=False)',

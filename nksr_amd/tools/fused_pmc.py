@@ -68,6 +68,11 @@ def main():
                              'hbm_TBps_under_pmc': (fetch + write) / us / 1e6}
         tot += fetch + write
     rec['hbm_bytes_per_application'] = tot
+    import re
+    m = re.search(r'M=(\d+) rows=(\d+) items=(\d+)', desc)
+    if m:      # same formula as csrc/fused.hip FusedOperator::bytes (depth 4 on the probe workload)
+        M, rows, items = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        rec['physical_bytes_per_application'] = 2 * 4 * 27 * 4 * rows + (2 * 4 + 3) * 4 * rows + 504 * items + 8 * M
     json.dump(rec, open(out, 'w'), indent=1)
     print(json.dumps(rec))
 
