@@ -208,16 +208,19 @@ class KernelField(BaseField):
         t2 = time.perf_counter()
         self.alpha = x
         self.matrix = (rowptr, cols, vals, diag)
+        self._fused_op = None
         self.rhs, self.diag = b, diag
         self.solve_info = {'iters': iters, 'rel_residual': rel, 'M': int(b.numel()), 'nnz': int(self.nnz),
                            't_assemble': t1 - t0, 't_pcg': t2 - t1}
+        self._attach_autograd(normal_xyz, normal_value, normal_weight, reg_weight)
         if self.solver_config.get('verbose'):
             print('[KernelField] M=%d nnz=%d iters=%d rel=%.3e assemble=%.3fs pcg=%.3fs' % (
                 b.numel(), self.nnz, iters, rel, t1 - t0, t2 - t1))
         return self
 
     # ---- matrix-free ("fused") solve ---------------------------------------------------------------------
-    def fused_operator(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, pos_sorted_keys=None, normal_sorted_keys=None):
+    def fused_operator(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, pos_sorted_keys=None, normal_sorted_keys=None,
+                       pos_value=None):
         """Everything the matrix-free operator needs (csrc/fused.hip, nksr_fused_op_t): the level-major kernel rows of both
         site sets in one array (pre-multiplied by sqrt(weight)), their targets, the global neighbour table and the work
         items.  Returns a dict; ``keep`` holds the buffers the C struct points into."""
@@ -227,7 +230,7 @@ class KernelField(BaseField):
         if M == 0:
             raise RuntimeError('empty hierarchy')
         specs = []
-        for xyz, target, weight, ncomp, pre in ((pos_xyz, None, pos_weight, 1, pos_sorted_keys),
+        for xyz, target, weight, ncomp, pre in ((pos_xyz, pos_value, pos_weight, 1, pos_sorted_keys),
                                                  (normal_xyz, normal_value, normal_weight, 3, normal_sorted_keys)):
             if xyz is None or xyz.shape[0] == 0:
                 continue
@@ -252,8 +255,8 @@ class KernelField(BaseField):
         for i, (xs, ks, perm, target, sw, ncomp) in enumerate(specs):
             self.kernel_rows_level_major(xs, ncomp == 3, sw, rows_all[off * 27:], rows_total)
             if target is not None:
-                tgt = target.to(dev, torch.float32)
-                tgt = (tgt[perm] if perm is not None else tgt) * sw                       # [n, 3] == row order (site, component)
+                tgt = target.detach().to(dev, torch.float32)
+                tgt = (tgt[perm] if perm is not None else tgt) * sw                       # [n] / [n, 3] == row order (site, component)
                 targets_all[off:off + xs.shape[0] * ncomp] = tgt.reshape(-1)
             st, en = self._site_ranges(ks)
             sets[i].n, sets[i].ncomp = xs.shape[0], ncomp
@@ -315,6 +318,7 @@ class KernelField(BaseField):
         t2 = time.perf_counter()
         self.alpha = x
         self.matrix = None
+        self._fused_op, self._fused_reg = op, float(reg_weight)
         self.rhs, self.diag = b, diag
         self.nnz = 0
         self.solve_info = {'iters': int(info[0]), 'rel_residual': float(info[1]), 'M': int(M), 'nnz': 0, 'fused': True,
@@ -323,7 +327,36 @@ class KernelField(BaseField):
         if self.solver_config.get('verbose'):
             print('[KernelField] fused: M=%d rows=%d iters=%d rel=%.3e rows+rhs=%.3fs pcg=%.3fs' % (
                 M, op['rows_total'], int(info[0]), float(info[1]), t1 - t0, t2 - t1))
+        if not (torch.is_grad_enabled() and torch.is_tensor(normal_value) and normal_value.requires_grad):
+            self._fused_op = None          # only the backward pass needs the operator again: do not pin ~2 GB of rows
+        self._attach_autograd(normal_xyz, normal_value, normal_weight, reg_weight)
         return self
+
+    # ---- differentiable solve (training path, models/nksr_net.py:105-112) ---------------------------------------
+    def _solve_system(self, rhs):
+        """A^-1 rhs with the system of the last solve (assembled CSR or matrix-free operator), same tolerance."""
+        from .. import solver
+        cfg = self.solver_config
+        if self.matrix is not None:
+            rowptr, cols, vals, diag = self.matrix
+            return solver.pcg_solve(rowptr, cols, vals, diag, rhs.contiguous(), tol=cfg['tol'], max_iter=cfg['max_iter'], check_every=cfg['check_every'])[0]
+        if getattr(self, '_fused_op', None) is None:
+            raise RuntimeError('the system of the last solve is gone: call solve*() under torch.enable_grad() with normal_value.requires_grad')
+        M = self.svh.num_unknowns
+        x = torch.empty(M, dtype=torch.float32, device=self.device)
+        pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=self.device)
+        info = (C.c_double * 2)()
+        call('nksr_pcg_solve_fused', C.byref(self._fused_op['op']), self._fused_reg, ptr(self.diag), ptr(rhs.contiguous()), ptr(x), float(cfg['tol']),
+             int(cfg['max_iter']), int(cfg['check_every']), ptr(pws), info, stream())
+        return x
+
+    def _attach_autograd(self, normal_xyz, normal_value, normal_weight, reg_weight):
+        """Under autograd, alpha becomes a differentiable function of the normal targets (implicit differentiation: one more
+        PCG solve with the same system in backward).  Gradients w.r.t. the basis features / interpolator weights (the
+        dA/dtheta terms) are NOT implemented: DESIGN.md section 6."""
+        if not (torch.is_grad_enabled() and torch.is_tensor(normal_value) and normal_value.requires_grad):
+            return
+        self.alpha = _SolveFunction.apply(self, self.alpha, normal_xyz.detach(), normal_value, float(normal_weight))
 
     def solve(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0, fused_mode=True,
               pos_sorted_keys=None, normal_sorted_keys=None):
@@ -338,8 +371,15 @@ class KernelField(BaseField):
 
     # ---- evaluation -------------------------------------------------------------------------------------
     def _evaluate_f_model(self, xyz, grad, max_points=1 << 22):
+        if torch.is_grad_enabled() and self.alpha.requires_grad:
+            f, g = _EvaluateFunction.apply(self, self.alpha, xyz.detach(), bool(grad), max_points)
+            return EvaluationResult(f, g if grad else None)
+        return self._evaluate_raw(self.alpha, xyz, grad, max_points)
+
+    def _evaluate_raw(self, alpha, xyz, grad, max_points=1 << 22):
         n = xyz.shape[0]
         xyz = xyz.to(self.device)
+        alpha = alpha.detach().contiguous()
         f = torch.empty(n, dtype=torch.float32, device=self.device)
         g = torch.empty((n, 3), dtype=torch.float32, device=self.device) if grad else None
         for s in range(0, n, max_points):
@@ -347,7 +387,7 @@ class KernelField(BaseField):
             xs = xyz[s:e].contiguous()
             fs = f[s:e]
             gs = g[s:e] if grad else None
-            call('nksr_evaluate_f', C.byref(self._hier), ptr(self.alpha), ptr(xs), e - s, int(self.approx_kernel_grad),
+            call('nksr_evaluate_f', C.byref(self._hier), ptr(alpha), ptr(xs), e - s, int(self.approx_kernel_grad),
                  ptr(fs), ptr(gs), stream())
         return EvaluationResult(f, g)
 
@@ -364,6 +404,48 @@ class KernelField(BaseField):
         if self.mask_field is not None:
             self.mask_field.to_(device)
         return self
+
+
+class _SolveFunction(torch.autograd.Function):
+    """alpha(normal targets) for the system of the field's last solve.  (w_p G^T G + w_n Q^T Q + reg I) alpha = w_n Q^T n  =>
+    dL/dn = w_n Q lambda with A lambda = dL/dalpha, and (Q lambda)[k, a] is d/dx_a of the kernel field with coefficients lambda
+    at normal site k -- one PCG solve and one gradient evaluation."""
+
+    @staticmethod
+    def forward(ctx, field, alpha, normal_xyz, normal_value, normal_weight):
+        ctx.field, ctx.normal_xyz, ctx.normal_weight = field, normal_xyz, normal_weight
+        return alpha.clone()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_alpha):
+        fld = ctx.field
+        lam = fld._solve_system(g_alpha.to(torch.float32))
+        q_lam = fld._evaluate_raw(lam, ctx.normal_xyz, True).gradient
+        return None, None, None, ctx.normal_weight * q_lam, None
+
+
+class _EvaluateFunction(torch.autograd.Function):
+    """f(x) and grad f(x) as functions of alpha (linear): dL/dalpha = G_x^T g_f + Q_x^T g_grad, the transposed pass of the
+    matrix-free operator over the kernel rows of the query points.  Query points are not differentiated; points outside every
+    active cell of a level contribute nothing at that level here (evaluate_f itself looks their neighbours up in the hash)."""
+
+    @staticmethod
+    def forward(ctx, field, alpha, xyz, want_grad, max_points):
+        ctx.field, ctx.xyz, ctx.want_grad = field, xyz, want_grad
+        res = field._evaluate_raw(alpha, xyz, want_grad, max_points)
+        g = res.gradient if want_grad else torch.zeros((0, 3), dtype=torch.float32, device=res.value.device)
+        return res.value, g
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_f, g_grad):
+        fld = ctx.field
+        use_g = ctx.want_grad and g_grad is not None and g_grad.numel() > 0
+        op = fld.fused_operator(ctx.xyz, ctx.xyz if use_g else None, g_grad if use_g else None, 1.0, 1.0,
+                                pos_value=g_f if g_f is not None else torch.zeros(ctx.xyz.shape[0], device=fld.device))
+        b, _ = fld.fused_rhs_diag(op, 0.0)
+        return None, b, None, None, None
 
 
 class _PackedInterpolator:

@@ -191,6 +191,53 @@ def test_fused_operator_matches_the_assembled_matrix(approx):
     pu.check('fused:field_vs_csr', float((f_fused - f_csr).abs().max() / f_csr.abs().max()), 1e-4)
 
 
+@pytest.mark.parametrize('fused', [False, True])
+def test_solve_is_differentiable_wrt_the_normal_targets(fused):
+    """SURVEY.md section 8(f)-4, the part that is built: under autograd, solve*() makes alpha a differentiable function of
+    ``normal_value`` (models/nksr_net.py:105-112 passes the normal head's output there) by implicit differentiation -- one more PCG
+    solve with the same system -- and evaluate_f is differentiable in alpha (transposed pass of the matrix-free operator).
+    Checked against EXACT directional derivatives from the oracle: alpha is linear in the targets, so a loss that is linear /
+    quadratic in (f, grad f) has exact first / central differences."""
+    import scipy.sparse.linalg as sla
+    from nksr_amd.fields import KernelField
+    from oracle import field as ofield, solve
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=1500, init_scale=0.3)
+    fld = KernelField(svh, net.interpolators, [torch.from_numpy(f) for f in feats])
+    fld.solver_config.update({'tol': 1e-7, 'max_iter': 4000})
+    t = lambda a: torch.from_numpy(a).to(_dev())
+    nxyz = oh.levels[0].centers()
+    rs = np.random.RandomState(3)
+    nval = rs.randn(len(nxyz), 3).astype(np.float32)
+    wp, wn = 1e4 / len(xyz), 1e4 / len(nxyz) * 0.01
+    A, b, G, Q, psis = solve.assemble(oh, feats, ointerps, xyz, nxyz, nval, wp, wn, 1.0)
+    lu = sla.splu(A.astype(np.float64).tocsc())
+    q = (xyz[:400] + rs.randn(400, 3).astype(np.float32) * np.float32(0.02)).astype(np.float32)
+    c1, c3 = rs.randn(400), rs.randn(400, 3)
+
+    def oracle_loss(nv):
+        rhs = wn * (Q.astype(np.float64).T @ np.concatenate([nv[:, a] for a in range(3)]).astype(np.float64))
+        alpha = lu.solve(rhs).astype(np.float32)
+        f, g = ofield.evaluate_f(oh, feats, ointerps, psis, alpha, q, True, False)
+        return float((c1 * f).sum() + (c3 * g).sum() + 0.5 * (f.astype(np.float64) ** 2).sum())
+
+    nv_t = t(nval).requires_grad_(True)
+    (fld.solve if fused else fld.solve_non_fused)(t(xyz), t(nxyz), nv_t, wp, wn, 1.0)
+    assert fld.alpha.requires_grad and bool(fld.solve_info.get('fused', False)) == fused
+    res = fld.evaluate_f(t(q), grad=True)
+    loss = (t(c1.astype(np.float32)) * res.value).sum() + (t(c3.astype(np.float32)) * res.gradient).sum() + 0.5 * (res.value ** 2).sum()
+    pu.check('autograd[fused=%s]:loss_rel' % fused, abs(float(loss) - oracle_loss(nval)) / abs(oracle_loss(nval)), 1e-4)
+    loss.backward()
+    g = nv_t.grad.cpu().numpy().astype(np.float64)
+    assert g.shape == nval.shape and np.isfinite(g).all() and np.abs(g).max() > 0
+    for trial in range(3):                # exact central differences of the (quadratic) loss along random directions
+        v = rs.randn(*nval.shape).astype(np.float32)
+        fd = 0.5 * (oracle_loss(nval + v) - oracle_loss(nval - v))
+        pu.check('autograd[fused=%s]:directional_derivative[%d]' % (fused, trial), abs((g * v).sum() - fd) / max(abs(fd), 1e-12), 2e-3)
+    # no autograd, no graph: the plain solve keeps returning a leaf
+    fld.solve_non_fused(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
+    assert not fld.alpha.requires_grad
+
+
 def test_pcg_matches_oracle_and_scipy():
     import scipy.sparse as sp
     import scipy.sparse.linalg as sla
