@@ -142,6 +142,7 @@ def main():
     ap.add_argument('--cpu-cores', type=int, default=0, help='CPU baseline worker processes (0 = all host cores, at most 64)')
     ap.add_argument('--cpu-repeats', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--chunk-streams', type=int, default=0, help='concurrent chunk streams in chunk mode (0 = the Reconstructor default)')
     ap.add_argument('--no-scale-scene', action='store_true')
     ap.add_argument('--no-other-mode', action='store_true')
     ap.add_argument('--non-fused', action='store_true', help='configs[2] headline through the assembled CSR solve (fused_mode=False)')
@@ -210,6 +211,8 @@ def main():
     def run_terrain(steps, warmup, fused):
         rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', tree_depth=5))
         rec.sync_timing = True
+        if args.chunk_streams > 0:
+            rec.chunk_streams = args.chunk_streams
         xyz, nrm, scale, owner, bounds, n_scene, ntiles = terrain_setup(rec, dev, args.scene_points, rank, world)
         chunk_size = TILE * scale
 
@@ -228,7 +231,7 @@ def main():
         cfg = {'workload': 'configs[4]: synthetic %d-point km-scale terrain + boxes (8x8 tiles of 125 m), tree_depth=5, chunk_size=125 m '
                            '(64 chunks), reconstruct(chunk_size=)+extract_dual_mesh(mise_iter=%d), STRONG scaling' % (n_scene, args.mise_iter),
                'scene_points': n_scene, 'fused_mode': fused, 'tree_depth': 5, 'kernel_dim': rec.hparams.kernel_dim, 'global_scale': scale,
-               'chunks': TILES * TILES, 'chunks_this_rank': sum(1 for c in owner if c == rank), 'tiles_loaded_this_rank': ntiles,
+               'chunks': TILES * TILES, 'chunk_streams': rec.chunk_streams, 'chunks_this_rank': sum(1 for c in owner if c == rank), 'tiles_loaded_this_rank': ntiles,
                'points_resident_this_rank': int(xyz.shape[0]),
                'unknowns_M_per_chunk': int(np.mean([i['M'] for i in infos])) if infos else 0,
                'nnz_A_per_chunk': int(np.mean([i['nnz'] for i in infos])) if infos else 0,

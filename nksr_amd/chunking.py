@@ -366,11 +366,8 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
         owner = [int(o) for o in chunk_owner]
     else:
         owner = D.partition_chunks(nchunk, ws, counts, grid)
-    local = {}
-    timing = {}
-    for c in range(nchunk):
-        if owner[c] != rank or counts[c] == 0:
-            continue
+    def solve_chunk(c):
+        """select -> (preprocess) -> solve one chunk on the CURRENT stream; returns (c, field or None)"""
         if sharded_input and local_counts[c] != counts[c]:
             raise RuntimeError('sharded input: rank %d owns chunk %d but holds %d of its %d core points' % (rank, c, local_counts[c], counts[c]))
         clo, chi = cores[c]
@@ -387,22 +384,50 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
                 cx_, cn_, cs_ = preprocess_fn(cx_, cn_, cs_)
             except RuntimeError as e:
                 if 'need at least' in str(e):     # too few points for the normal estimator: treat the chunk as empty
-                    continue
+                    return c, None
                 raise
         if cn_ is None:
             raise RuntimeError('oriented input required (normal= or sensor= with a normal-estimating preprocess_fn)')
         if cx_.shape[0] < MIN_CHUNK_POINTS:       # a handful of stray points: nothing to solve, neighbours cover the band
-            continue
+            return c, None
         if not bool(torch.isfinite(cn_).all()):
             raise RuntimeError('non-finite normals in the input')
         fld = rec._reconstruct_single(cx_.contiguous(), cn_.to(torch.float32).contiguous(), approx_kernel_grad,
                                       solver_max_iter, solver_tol, fused_mode)
-        for k, v in rec.timing.items():
-            timing[k] = timing.get(k, 0.0) + v
         fld.matrix = None                 # the CSR is not needed after the solve
+        fld._fused_op = None
         if rec.chunk_tmp_device != dev and ws == 1 and sim is None:
             fld.to_(rec.chunk_tmp_device)  # reference semantics: park solved chunks elsewhere
-        local[c] = fld
+        return c, fld
+
+    jobs = [c for c in range(nchunk) if owner[c] == rank and counts[c] > 0]
+    nstreams = max(1, min(int(getattr(rec, 'chunk_streams', 1)), len(jobs)))
+    if nstreams > 1:
+        # Chunks are independent: solve them on several HIP streams, one host thread each.  A chunk of a few 100 k points is a chain
+        # of ~100 short kernels with host round trips for sizes in between (unique counts, nnz, PCG convergence checks); with
+        # one stream the GPU idles through those, with several the gaps of one chunk are filled by another.  Results do not depend
+        # on the interleaving (no float atomics, every chunk has its own buffers): bit-identical to the sequential run.
+        from concurrent.futures import ThreadPoolExecutor
+        torch.cuda.synchronize(dev)               # inputs (and anything still using memory the workers may be handed) are settled
+        streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+
+        def worker(i):
+            out = []
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[i]):
+                for c in jobs[i::nstreams]:
+                    out.append(solve_chunk(c))
+                streams[i].synchronize()
+            return out
+        with ThreadPoolExecutor(max_workers=nstreams) as ex:
+            results = [r for part in ex.map(worker, range(nstreams)) for r in part]
+    else:
+        results = [solve_chunk(c) for c in jobs]
+    local = {c: f for c, f in sorted(results, key=lambda r: r[0]) if f is not None}
+    timing = {}
+    for f in local.values():              # per-stage host time summed over chunks (they overlap when chunk_streams > 1)
+        for k, v in getattr(f, 'timing', {}).items():
+            timing[k] = timing.get(k, 0.0) + v
     rec.timing = timing
     if ws > 1 and sim is None:
         # the exchange carries the halo of every chunk (the voxels other ranks can touch), not the whole field; which

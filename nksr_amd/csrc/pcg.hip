@@ -399,12 +399,16 @@ extern "C" int nksr_spmv_csr(const int32_t* rowptr, const void* cols, const floa
 }
 
 // ---- optional live profiling of the SpMV launches (bench.py's roofline leg) ---------------------
+#include <mutex>
 #include <vector>
 static int g_prof_enable = 0;
 static double g_prof_ms = 0.0;
 static long long g_prof_launches = 0;
 static double g_prof_alg_bytes = 0.0, g_prof_phys_bytes = 0.0;
-static std::vector<hipEvent_t> g_prof_events;
+// several host threads may run solves at once (chunks on separate streams): every thread times with its own event pool and
+// adds to the shared accumulators under a lock
+static thread_local std::vector<hipEvent_t> g_prof_events;
+static std::mutex g_prof_mutex;
 
 // bytes one SpMV launch moves: algorithmic CSR figure of SURVEY.md section 8d (8 nnz + 12 M + 4) and what the physical
 // layout actually streams (values + packed / int32 columns over the padded storage + row pointers + x + y)
@@ -416,6 +420,7 @@ static void spmv_bytes(int M, int64_t nnz, int fmt, double* alg, double* phys) {
 }
 
 extern "C" int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_out) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     if (algorithmic_out) *algorithmic_out = g_prof_alg_bytes;
     if (physical_out) *physical_out = g_prof_phys_bytes;
     g_prof_alg_bytes = g_prof_phys_bytes = 0.0;
@@ -423,6 +428,7 @@ extern "C" int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_
 }
 
 extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     if (ms_out) *ms_out = g_prof_ms;
     if (launches_out) *launches_out = g_prof_launches;
     g_prof_ms = 0.0;
@@ -469,6 +475,7 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
             // only applications that did real work (the done flag turns later ones into no-ops)
             double ba, bp;
             A.bytes(&ba, &bp);
+            std::lock_guard<std::mutex> lock(g_prof_mutex);
             for (int c = 0; c < chunk && launched + c < host.iter; ++c) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, g_prof_events[2 * c], g_prof_events[2 * c + 1]) == hipSuccess) {

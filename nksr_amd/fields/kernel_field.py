@@ -201,7 +201,7 @@ class KernelField(BaseField):
         rowptr, cols, vals, diag, b = self.assemble(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight,
                                                     pos_sorted_keys, normal_sorted_keys)
         if self.solver_config.get('verbose') or self.solver_config.get('sync_timing'):
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
         x, iters, rel = solver.pcg_solve(rowptr, cols, vals, diag, b, tol=self.solver_config['tol'],
                                          max_iter=self.solver_config['max_iter'], check_every=self.solver_config['check_every'])
@@ -308,7 +308,7 @@ class KernelField(BaseField):
         M = self.svh.num_unknowns
         b, diag = self.fused_rhs_diag(op, reg_weight)
         if self.solver_config.get('verbose') or self.solver_config.get('sync_timing'):
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
         x = torch.empty(M, dtype=torch.float32, device=dev)
         pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=dev)

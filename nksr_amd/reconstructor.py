@@ -26,7 +26,8 @@ class Reconstructor:
         self.network.eval()
         self.chunk_tmp_device = self.device
         self.timing = {}
-        self.sync_timing = False   # insert device syncs so that per-stage wall times are exact
+        self.sync_timing = False   # insert stream syncs so that per-stage wall times are exact
+        self.chunk_streams = 3     # chunk mode: chunks solved concurrently on this many HIP streams (one host thread each)
 
     # ---- scale selection (NKSR-USAGE.md:129-137) ---------------------------------------------------
     def _global_scale(self, xyz, detail_level, voxel_size):
@@ -59,7 +60,7 @@ class Reconstructor:
         normal_xyz = torch.cat([dec_svh.get_voxel_centers(d) for d in range(hp.adaptive_depth)])
         normal_value = torch.cat([feat.normal_features[d] for d in range(hp.adaptive_depth)])
         if self.sync_timing:
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
         t['t_network'] = time.perf_counter() - tic
         field.solve(pos_xyz=enc.xyz, normal_xyz=normal_xyz, normal_value=-normal_value,
                     pos_weight=hp.solver.pos_weight / xyz.shape[0],
@@ -75,6 +76,7 @@ class Reconstructor:
         field.meshing_depth = int(hp.adaptive_depth)
         t.update({k: v for k, v in field.solve_info.items() if k.startswith('t_')})
         self.timing = t
+        field.timing = t           # chunk mode solves several chunks at once: the per-field copy is the race-free one
         return field
 
     def reconstruct(self, xyz, normal=None, sensor=None, detail_level=0.0, voxel_size=None, chunk_size=-1.0,

@@ -21,16 +21,20 @@ def run_pass(counter, points, tag, probe_args=('0',)):
            sys.executable, '-m', PROBE, str(points)] + list(probe_args)
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd=os.environ.get('GRAFT_REPO_ROOT', os.getcwd()))
     line = [l for l in r.stdout.splitlines() if l.startswith('M=')]
+    is_spmv = lambda n: 'k_spmv' in n and 'fixup' not in n and 'plan' not in n
+    dur = {}
+    for f in glob.glob(out + '/**/*kernel_trace.csv', recursive=True):
+        for row in csv.DictReader(open(f)):
+            if is_spmv(row.get('Kernel_Name', '')):
+                dur[row.get('Dispatch_Id')] = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3
     vals, durs = [], []
     for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
         for row in csv.DictReader(open(f)):
-            if 'k_spmv' in row.get('Kernel_Name', '') and 'fixup' not in row['Kernel_Name'] and 'plan' not in row['Kernel_Name'] \
-                    and row.get('Counter_Name') == counter:
-                vals.append(float(row['Counter_Value']))
-    for f in glob.glob(out + '/**/*kernel_trace.csv', recursive=True):
-        for row in csv.DictReader(open(f)):
-            if 'k_spmv' in row.get('Kernel_Name', '') and 'fixup' not in row['Kernel_Name'] and 'plan' not in row['Kernel_Name']:
-                durs.append((int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3)
+            if is_spmv(row.get('Kernel_Name', '')) and row.get('Counter_Name') == counter:
+                d = dur.get(row.get('Dispatch_Id'), 1e9)
+                if d >= 20.0:       # launches the PCG's done flag turned into no-ops move nothing: not part of the average
+                    vals.append(float(row['Counter_Value']))
+                    durs.append(d)
     return vals, durs, (line[0] if line else '')
 
 
@@ -52,7 +56,7 @@ def main():
         'kernel': 'k_spmv<0> (tools/spmv_probe.py, bench matrix: M=%d nnz=%d)' % (M, nnz),
         'command': 'rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python -m nksr_amd.tools.spmv_probe %d 0  '
                    '(second pass: --pmc WRITE_SIZE); driver: python -m nksr_amd.tools.spmv_pmc' % points,
-        'FETCH_SIZE_KB_per_launch': fetch_kb, 'WRITE_SIZE_KB_per_launch': write_kb, 'launches': len(fv),
+        'FETCH_SIZE_KB_per_launch': fetch_kb, 'WRITE_SIZE_KB_per_launch': write_kb, 'launches': len(fv), 'note': 'no-op launches (< 20 us: the done flag of the probe\'s own PCG) excluded',
         'correction': 'gfx950 rocprofv3 FETCH_SIZE counts 128-B requests of a wide coalesced stream at 64 B: doubled '
                       '(MI355X_MICROARCH.md section HBM); WRITE_SIZE uncorrected',
         'hbm_bytes_per_launch': hbm, 'algorithmic_bytes_per_launch': alg,

@@ -129,6 +129,29 @@ def test_simulated_two_ranks_equal_one_rank(scene):
     assert np.array_equal(fm, f1)                                                  # index-exact topology
 
 
+def test_concurrent_chunk_streams_are_bit_identical():
+    """Reconstructor.chunk_streams: chunks solved concurrently on several HIP streams (one host thread each) give exactly the
+    fields and the mesh of the sequential run."""
+    import nksr_amd
+    dev = torch.device('cuda:0')
+    xyz, nrm = _wide_scene()
+    rec = nksr_amd.Reconstructor(dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ext = float(xyz[:, 0].max() - xyz[:, 0].min())
+    out = {}
+    for k in (1, 3):
+        rec.chunk_streams = k
+        fld = rec.reconstruct(t(xyz), t(nrm), detail_level=None, chunk_size=ext / 4 + 1e-3)
+        assert len(fld.fields) >= 4
+        out[k] = (fld, fld.extract_dual_mesh(mise_iter=1))
+    a, b = out[1], out[3]
+    assert sorted(a[0].fields) == sorted(b[0].fields)
+    for c in a[0].fields:
+        assert torch.equal(a[0].fields[c].alpha, b[0].fields[c].alpha), 'chunk %d' % c
+        assert all(torch.equal(a[0].fields[c].svh.level(d).keys, b[0].fields[c].svh.level(d).keys) for d in range(4))
+    assert torch.equal(a[1].v, b[1].v) and torch.equal(a[1].f, b[1].f)
+
+
 def test_chunked_udf_mask_travels_with_the_chunks():
     """udf.enabled in chunk mode: per-chunk NeuralField masks are OR-ed over the blend support, and the
     packed payload (rank exchange / save_field) carries the mask features."""
