@@ -27,7 +27,10 @@ class Reconstructor:
         self.chunk_tmp_device = self.device
         self.timing = {}
         self.sync_timing = False   # insert stream syncs so that per-stage wall times are exact
-        self.chunk_streams = 3     # chunk mode: chunks solved concurrently on this many HIP streams (one host thread each)
+        # chunk mode: chunks can be solved concurrently on this many HIP streams (one host thread each; bit-identical results).
+        # Measured on configs[4] (64 chunks of ~260 k points, one MI355X): 1 stream 1.96 s, 2 streams 1.90 s, 3 streams 2.32 s,
+        # 4 streams 6.0 s -- the chunks are GPU-bound, the host threads contend (GIL, allocator pools per stream): default 1
+        self.chunk_streams = 1
 
     # ---- scale selection (NKSR-USAGE.md:129-137) ---------------------------------------------------
     def _global_scale(self, xyz, detail_level, voxel_size):
