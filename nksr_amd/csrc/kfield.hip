@@ -16,11 +16,15 @@ struct MlpView {
 };
 
 // phi = t + W3 relu(W2 relu(W1 t + b1) + b2) + b3 ; optional forward-mode tangents J[K][3]
+// Layers 2 and 3 are fused: every hidden unit g of layer 2 (value + 3 tangents) is folded into the K outputs as soon as it
+// exists, so only layer 1 (h1, d1) and the outputs are live -- 4 (H + K) instead of 8 H + 8 K registers with tangents (the
+// K=16 / H=32 instantiations spilled to scratch and the K=4 / H=16 one sat at 196 VGPRs when all three layers were arrays).
+// phi / J may alias t / Jt.
 template <int K, int H, bool JAC>
 __device__ __forceinline__ void mlp_residual(const MlpView<K, H>& m, const float t[K], const float Jt[K][3],
                                              float phi[K], float J[K][3]) {
-    float h1[H], h2[H];
-    float d1[JAC ? H : 1][3], d2[JAC ? H : 1][3];
+    float h1[H];
+    float d1[JAC ? H : 1][3];
 #pragma unroll
     for (int h = 0; h < H; ++h) {
         float a = m.b1[h];
@@ -35,7 +39,15 @@ __device__ __forceinline__ void mlp_residual(const MlpView<K, H>& m, const float
         h1[h] = on ? a : 0.f;
         if (JAC) { d1[h][0] = on ? da[0] : 0.f; d1[h][1] = on ? da[1] : 0.f; d1[h][2] = on ? da[2] : 0.f; }
     }
+    float out[K], Jo[JAC ? K : 1][3];
 #pragma unroll
+    for (int k = 0; k < K; ++k) {
+        out[k] = t[k] + m.b3[k];
+        if (JAC) { Jo[k][0] = Jt[k][0]; Jo[k][1] = Jt[k][1]; Jo[k][2] = Jt[k][2]; }
+    }
+    // kept as a LOOP when tangents are carried: fully unrolled, the compiler hoists the H*H + K*H weight reads of both layers and the
+    // kernel needs ~400 registers (AGPR copies, scratch for H = 32); rolled, one row of W2 and one column of W3 are live at a time
+#pragma unroll 1
     for (int g = 0; g < H; ++g) {
         float a = m.b2[g];
         float da[3] = {0.f, 0.f, 0.f};
@@ -45,22 +57,20 @@ __device__ __forceinline__ void mlp_residual(const MlpView<K, H>& m, const float
             a = fmaf(w, h1[h], a);
             if (JAC) { da[0] = fmaf(w, d1[h][0], da[0]); da[1] = fmaf(w, d1[h][1], da[1]); da[2] = fmaf(w, d1[h][2], da[2]); }
         }
-        bool on = a > 0.f;
-        h2[g] = on ? a : 0.f;
-        if (JAC) { d2[g][0] = on ? da[0] : 0.f; d2[g][1] = on ? da[1] : 0.f; d2[g][2] = on ? da[2] : 0.f; }
+        const bool on = a > 0.f;
+        const float h2 = on ? a : 0.f;
+        const float e0 = on ? da[0] : 0.f, e1 = on ? da[1] : 0.f, e2 = on ? da[2] : 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float w = m.W3[k * H + g];
+            out[k] = fmaf(w, h2, out[k]);
+            if (JAC) { Jo[k][0] = fmaf(w, e0, Jo[k][0]); Jo[k][1] = fmaf(w, e1, Jo[k][1]); Jo[k][2] = fmaf(w, e2, Jo[k][2]); }
+        }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        float a = m.b3[k];
-        float da[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < H; ++g) {
-            float w = m.W3[k * H + g];
-            a = fmaf(w, h2[g], a);
-            if (JAC) { da[0] = fmaf(w, d2[g][0], da[0]); da[1] = fmaf(w, d2[g][1], da[1]); da[2] = fmaf(w, d2[g][2], da[2]); }
-        }
-        phi[k] = t[k] + a;
-        if (JAC) { J[k][0] = Jt[k][0] + da[0]; J[k][1] = Jt[k][1] + da[1]; J[k][2] = Jt[k][2] + da[2]; }
+        phi[k] = out[k];
+        if (JAC) { J[k][0] = Jo[k][0]; J[k][1] = Jo[k][1]; J[k][2] = Jo[k][2]; }
     }
 }
 
