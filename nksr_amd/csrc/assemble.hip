@@ -44,13 +44,6 @@ __device__ __forceinline__ int row_level(const nksr_hier_t& h, int row) {
     return d;
 }
 
-__device__ __forceinline__ int rel_slot(int cx, int cy, int cz, int ix, int iy, int iz, int dd, int s) {
-    int rx = ((cx >> dd) + s / 9 - 1) - (ix >> dd) + 2;
-    int ry = ((cy >> dd) + (s / 3) % 3 - 1) - (iy >> dd) + 2;
-    int rz = ((cz >> dd) + s % 3 - 1) - (iz >> dd) + 2;
-    return dd * 125 + (rx * 5 + ry) * 5 + rz;
-}
-
 // physical CSR layout (see csrc/pcg.hip): tiles of 64 EPL entries, logical entry m of a tile at
 // EPL (m % 64) + m / 64;  EPL = 4 (col_format 0, 256-entry tiles) or 3 (col_format 1, 192-entry tiles)
 __device__ __forceinline__ int64_t csr_phys(int64_t k, int fmt) {
@@ -141,21 +134,6 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
     }
 }
 
-// ---- structural test shared by count and fill -----------------------------------------------------
-// slot t of row i (level d, coords ix,iy,iz): column voxel index (global) or -1
-__device__ __forceinline__ int slot_column(const nksr_hier_t& h, int d, int ix, int iy, int iz, int t) {
-    const int dd = t / 125, r = t % 125;
-    const nksr_level_t& lc = h.lv[d + dd];
-    const int x = (ix >> dd) + r / 25 - 2, y = (iy >> dd) + (r / 5) % 5 - 2, z = (iz >> dd) + r % 5 - 2;
-    // B-spline supports overlap  <=>  |(2I+1) - (2J+1) 2^dd| < 3 (1 + 2^dd)  on every axis
-    const int lim = 3 * (1 + (1 << dd));
-    const int ax = (2 * ix + 1) - ((2 * x + 1) << dd), ay = (2 * iy + 1) - ((2 * y + 1) << dd),
-              az = (2 * iz + 1) - ((2 * z + 1) << dd);
-    if (abs(ax) >= lim || abs(ay) >= lim || abs(az) >= lim) return -1;
-    const int j = hash_find(lc.hkeys, lc.hvals, lc.hcap, morton_biased(x, y, z, NKSR_BIAS0 >> (d + dd)));
-    return j < 0 ? -1 : lc.offset + j;
-}
-
 // ---- phase 2a: structure.  colmap[row slot] = column of every structural slot ---------------------------
 // One wavefront walks RC_RUN Morton-consecutive rows.  Such rows share their coarse ancestors, hence the
 // 5^3 column frames of the coarser levels: a frame (125 hash lookups) is fetched when the ancestor changes
@@ -163,6 +141,9 @@ __device__ __forceinline__ int slot_column(const nksr_hier_t& h, int d, int ix, 
 // run that coupled to them, which becomes ONE global integer atomic per touched column when the frame is
 // retired (instead of one per structural entry).  No LDS, no barriers, no float atomics; integer
 // atomics are order-independent, so the result is deterministic.
+// Frame slots run x fastest (slot = (z * 5 + y) * 5 + x): the unknowns of a level are Morton-ordered with x in the lowest bit, so the
+// voxels (2k, y, z), (2k + 1, y, z) have CONSECUTIVE indices and land on adjacent frame slots -- a row's entries then come out with
+// consecutive columns next to each other (the SpMV's x gathers of one 64-entry group then touch fewer 64-byte segments).
 // colmap encoding: upper neighbour -> column, same-level lower neighbour -> -2 - column (emitted by the
 // row itself: bitwise equal to the transposed entry), diagonal / absent / non-overlapping -> -1.
 #define RC_RUN 32
@@ -204,8 +185,8 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_count(AsmArgs A, int32_t
             }
             const nksr_level_t& lc = h.lv[d + dd];
             const int bias = NKSR_BIAS0 >> (d + dd);
-            int j0 = hash_find(lc.hkeys, lc.hvals, lc.hcap, morton_biased(ax + lane / 25 - 2, ay + (lane / 5) % 5 - 2, az + lane % 5 - 2, bias));
-            int j1 = has1 ? hash_find(lc.hkeys, lc.hvals, lc.hcap, morton_biased(ax + r1 / 25 - 2, ay + (r1 / 5) % 5 - 2, az + r1 % 5 - 2, bias)) : -1;
+            int j0 = hash_find(lc.hkeys, lc.hvals, lc.hcap, morton_biased(ax + lane % 5 - 2, ay + (lane / 5) % 5 - 2, az + lane / 25 - 2, bias));
+            int j1 = has1 ? hash_find(lc.hkeys, lc.hvals, lc.hcap, morton_biased(ax + r1 % 5 - 2, ay + (r1 / 5) % 5 - 2, az + r1 / 25 - 2, bias)) : -1;
             cf[f][0] = j0 < 0 ? -1 : lc.offset + j0;
             cf[f][1] = j1 < 0 ? -1 : lc.offset + j1;
             nf[f][0] = nf[f][1] = 0;
@@ -221,7 +202,7 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_count(AsmArgs A, int32_t
         for (int u = 0; u < 2; ++u) {
             const int r = u == 0 ? lane : r1;
             const bool on = u == 0 || has1;
-            const int dx = r / 25 - 2, dy = (r / 5) % 5 - 2, dz = r % 5 - 2;
+            const int dx = r % 5 - 2, dy = (r / 5) % 5 - 2, dz = r / 25 - 2;          // frame slot r = (z, y, x), x fastest
             const int ex = dx < -1 ? -1 : (dx > 1 ? 1 : dx), ey = dy < -1 ? -1 : (dy > 1 ? 1 : dy), ez = dz < -1 ? -1 : (dz > 1 ? 1 : dz);
             const int n1 = __shfl(nb_lane, (ex + 1) * 9 + (ey + 1) * 3 + (ez + 1));
             int col = -1;
@@ -248,7 +229,7 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_count(AsmArgs A, int32_t
             for (int u = 0; u < 2; ++u) {
                 const int r = u == 0 ? lane : r1;
                 const bool on = u == 0 || has1;
-                const int x = (ix >> dd) + r / 25 - 2, y = (iy >> dd) + (r / 5) % 5 - 2, z = (iz >> dd) + r % 5 - 2;
+                const int x = (ix >> dd) + r % 5 - 2, y = (iy >> dd) + (r / 5) % 5 - 2, z = (iz >> dd) + r / 25 - 2;
                 const int ox = (2 * ix + 1) - ((2 * x + 1) << dd), oy = (2 * iy + 1) - ((2 * y + 1) << dd),
                           oz = (2 * iz + 1) - ((2 * z + 1) << dd);
                 int col = -1;
@@ -361,7 +342,7 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_row_fill(AsmArgs A, const in
                     const int dd = edd[q];
                     const int rx = ((cx >> dd) + esx[q]) - (ix >> dd) + 2, ry = ((cy >> dd) + esy[q]) - (iy >> dd) + 2,
                               rz = ((cz >> dd) + esz[q]) - (iz >> dd) + 2;
-                    acc[dd * 125 + (rx * 5 + ry) * 5 + rz] += vb[buf][u][q];
+                    acc[dd * 125 + (rz * 5 + ry) * 5 + rx] += vb[buf][u][q];
                 }
             }
         }

@@ -31,6 +31,7 @@ class Reconstructor:
         # Measured on configs[4] (64 chunks of ~260 k points, one MI355X): 1 stream 1.96 s, 2 streams 1.90 s, 3 streams 2.32 s,
         # 4 streams 6.0 s -- the chunks are GPU-bound, the host threads contend (GIL, allocator pools per stream): default 1
         self.chunk_streams = 1
+        self.col_format = 1        # physical layout of the assembled matrix (include/nksr_hip.h); int32 columns when M > 2^21
 
     # ---- scale selection (NKSR-USAGE.md:129-137) ---------------------------------------------------
     def _global_scale(self, xyz, detail_level, voxel_size):
@@ -59,7 +60,8 @@ class Reconstructor:
             raise RuntimeError('empty decoder hierarchy')
         field = KernelField(svh=dec_svh, interpolator=self.network.interpolators, features=feat.basis_features,
                             approx_kernel_grad=approx_kernel_grad)
-        field.solver_config.update({'max_iter': int(solver_max_iter), 'tol': float(solver_tol), 'sync_timing': self.sync_timing})
+        field.solver_config.update({'max_iter': int(solver_max_iter), 'tol': float(solver_tol), 'sync_timing': self.sync_timing,
+                                    'col_format': self.col_format})
         normal_xyz = torch.cat([dec_svh.get_voxel_centers(d) for d in range(hp.adaptive_depth)])
         normal_value = torch.cat([feat.normal_features[d] for d in range(hp.adaptive_depth)])
         if self.sync_timing:
