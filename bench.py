@@ -13,9 +13,10 @@ N > 1   : BASELINE.json configs[4] -- the north_star scaling scene: synthetic 10
           125 m, tree_depth=5), recons_by_chunk over 64 chunks, STRONG scaling: the same scene on 1/2/4/8 ranks.  Every
           rank generates only the tiles of its own chunks and their neighbours (sharded input), solves its chunks with no
           collective, exchanges chunk halos once (RCCL), meshes its cells; rank 0 gathers + stitches the mesh.
-roofline: the CG SpMV (csrc/pcg.hip k_spmv).  achieved = ALGORITHMIC bytes (8 nnz + 12 M + 4 per launch, SURVEY.md
-          section 8d) / average launch duration, measured live with HIP events on the solve stream inside the timed
-          region; ``achieved_physical`` counts the bytes the packed layout really streams.
+roofline: the operator application inside the PCG loop.  achieved = ALGORITHMIC bytes per application (SURVEY.md section 8d:
+          assembled CSR 8 nnz + 12 M + 4; matrix-free 2 x 8 bytes per stored entry of G and Q + 12 M + 4) / average duration,
+          measured live with HIP events on the solve stream inside the timed region; ``achieved_physical`` counts the bytes
+          the layout really moves (packed columns / index-free rows read once).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -73,22 +74,24 @@ def load_traffic_fused(bytes_per_launch):
 
 def roofline_record(ms, launches, alg, phys, fused=False):
     """The CG operator application ("SpMV") measured live with HIP events on the solve stream.
-    assembled CSR : achieved = the algorithmic CSR bytes of SURVEY.md section 8d (8 nnz + 12 M + 4) / time; achieved_physical
-                    counts what the packed layout streams (6.67 B per entry).
-    matrix-free   : the dense-slot rows hold no column indices, so the survey's matrix-free figure (8 bytes per stored entry of
-                    G and Q in each direction) would credit bytes that do not exist: achieved = the bytes the operator really
-                    moves (4 B per slot per direction + its vectors), the survey figure is kept as achieved_survey_formula."""
+    achieved / frac   = ALGORITHMIC bytes of SURVEY.md section 8d / time:  assembled CSR 8 nnz + 12 M + 4;  matrix-free operator
+                        G and Q once in each direction at 8 bytes per stored entry (2 x 8 x non-zero slots) + 12 M + 4.
+    achieved_physical = the bytes the implementation really moves: packed 21-bit columns (6.67 B per entry) for the CSR; for the
+                        matrix-free operator 4 B per dense slot ONCE (no column indices, one pass serves both products) + the
+                        partial blocks + tables.  It moves ~2.3x fewer bytes than the algorithmic figure, so ``frac`` can
+                        exceed what the HBM could stream: read frac_physical for how busy the memory system is."""
     avg_s = (ms / max(launches, 1)) * 1e-3
     a = alg / max(launches, 1)
     p = phys / max(launches, 1)
     rate = lambda b: (b / avg_s if avg_s > 0 else 0.0)
     if fused:
         traffic, src = load_traffic_fused(p) if launches else (None, None)
-        return {'bound': 'hbm', 'kernel': 'k_fz_forward + k_fz_tsum + k_fz_transposed + k_fz_gather (matrix-free normal-equation operator '
-                                          'inside the PCG loop, fused_mode=True)',
-                'achieved': rate(p) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(p) / HBM_PEAK,
-                'achieved_survey_formula': rate(a) / 1e9, 'traffic': traffic, 'traffic_source': src if traffic is not None else None,
-                'bytes_per_launch': p, 'survey_formula_bytes_per_launch': a, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
+        return {'bound': 'hbm', 'kernel': 'k_fz_sweep + k_fz_cellsum + k_fz_gather (matrix-free normal-equation operator inside the PCG loop, '
+                                          'fused_mode=True)',
+                'achieved': rate(a) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(a) / HBM_PEAK,
+                'achieved_physical': rate(p) / 1e9, 'frac_physical': rate(p) / HBM_PEAK,
+                'traffic': traffic, 'traffic_source': src if traffic is not None else None,
+                'bytes_per_launch': a, 'physical_bytes_per_launch': p, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
     traffic, src = load_traffic(a) if launches else (None, None)
     return {'bound': 'hbm', 'kernel': 'k_spmv<3,0> + k_spmv_fixup (packed-column CSR SpMV inside the PCG loop, fused_mode=False)',
             'achieved': rate(a) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(a) / HBM_PEAK,
@@ -146,7 +149,7 @@ def main():
     ap.add_argument('--no-scale-scene', action='store_true')
     ap.add_argument('--no-other-mode', action='store_true')
     ap.add_argument('--non-fused', action='store_true', help='configs[2] headline through the assembled CSR solve (fused_mode=False)')
-    ap.add_argument('--fused-scene', action='store_true', help='configs[4] through the matrix-free solve (default: assembled CSR)')
+    ap.add_argument('--assembled-scene', action='store_true', help='configs[4] through the assembled CSR solve (default: matrix-free, fused_mode=True)')
     ap.add_argument('--scene', choices=['auto', 'cloud', 'terrain'], default='auto',
                     help="'terrain' runs configs[4] as the headline at N=1 too")
     args = ap.parse_args()
@@ -262,18 +265,18 @@ def main():
         cfg = {'workload': 'configs[2]: synthetic %d-point oriented cloud (8 spheres/tori in a 40x40x10 box, sigma=0.01), '
                            'detail_level=%.1f, reconstruct()+extract_dual_mesh(mise_iter=%d)' % (args.points, args.detail_level, args.mise_iter),
                'points': args.points, 'fused_mode': fused, 'tree_depth': rec.hparams.tree_depth, 'kernel_dim': rec.hparams.kernel_dim,
-               'unknowns_M': info['M'], 'nnz_A': info['nnz'], 'kernel_row_slots': info.get('kernel_row_slots'), 'pcg_iters': info['iters'], 'pcg_rel_residual': info['rel_residual'],
+               'unknowns_M': info['M'], 'nnz_A': info['nnz'], 'kernel_row_slots': info.get('kernel_row_slots'),
+               'stored_entries_G_Q': field.stored_entries() if fused else None, 'pcg_iters': info['iters'], 'pcg_rel_residual': info['rel_residual'],
                'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]), 'global_scale': field.scale,
                'parallelism': 'none'}
         return dt, args.points, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}, (rec, xyz_np, nrm_np, field.scale)
 
     terrain_headline = world > 1 or args.scene == 'terrain'
     extra = None
-    # configs[2] runs through the API default, fused_mode=True (what the reference's examples pass): 11 PCG iterations, the
-    # matrix-free solve skips a 21 ms assembly.  configs[4] needs ~47 iterations per chunk (tree_depth 5, open terrain): there the
-    # assembled CSR amortises (its SpMV is ~2x cheaper per iteration), so the scene is solved with fused_mode=False; the other
-    # mode is measured and reported next to each (DESIGN.md section 3.5 has the cost model).
-    fused = (not args.non_fused) if not terrain_headline else bool(args.fused_scene)
+    # Both workloads run through the API default, fused_mode=True (what the reference's examples pass): the matrix-free solve
+    # skips the assembly and its operator (one pass over the index-free kernel rows) is about as fast per application as the CSR
+    # SpMV; the other mode is measured and reported next to each (DESIGN.md section 3.5 has the cost model).
+    fused = (not args.non_fused) if not terrain_headline else (not args.assembled_scene)
     if terrain_headline:
         dt, npts, cfg, prof, stages = run_terrain(args.steps, args.warmup, fused)
     else:
@@ -293,7 +296,7 @@ def main():
     if not terrain_headline and not args.no_scale_scene:
         # the same scene the N > 1 runs solve, on this one GPU (1 warm-up + 2 timed steps): the N=1 point of the curve
         torch.cuda.empty_cache()
-        sf = bool(args.fused_scene)
+        sf = (not args.assembled_scene)
         sdt, sn, scfg, sprof, sstages = run_terrain(2, 1, sf)
         out['scale_scene'] = {'value': sn * 2 / sdt, 'unit': 'points/s', 'ms_per_step': sdt / 2 * 1e3, 'steps': 2, 'warmup': 1,
                               'config': scfg, 'roofline': roofline_record(*sprof, fused=sf), 'stages_s_per_step': sstages}

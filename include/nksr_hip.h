@@ -218,22 +218,24 @@ typedef struct {               /* a site set, as far as the work-item builder ne
 } nksr_fused_set_t;
 typedef struct {
     int32_t depth, nsets, M, reserved;
-    int64_t rows_total;        /* rows of all sets (set 0 first); also the level stride of rows_all         */
+    int64_t rows_total;        /* rows of all sets (set 0 first); also the level stride of rows_all / row_cells */
+    int64_t set_rows[2];       /* rows of each set (sites x ncomp)                                           */
     const float* rows_all;     /* LEVEL-MAJOR dense-slot rows [depth][rows_total][27], pre-multiplied by sqrt(w) (nksr_kernel_rows, level_stride) */
     const float* targets_all;  /* [rows_total] right-hand side values pre-multiplied by sqrt(w) (0 for rows without a target); may be NULL if unused */
-    const int32_t* nbr_all;    /* [M, 27] GLOBAL unknown index of every neighbour voxel, or -1               */
-    const int32_t* offsets;    /* [nsets * M + 1] first work item of (set, cell)                            */
-    const int32_t* items;      /* [nitems, 4] work items (nksr_fused_items)                                 */
-    int64_t nitems;
-    void* workspace;           /* nksr_fused_workspace_bytes, zero-initialised once                         */
+    const int32_t* row_cells;  /* [depth][rows_total] GLOBAL unknown index of the row's level-d cell, -1 = none (nksr_fused_tables) */
+    const int32_t* nbr32;      /* [M, 32]: [0..26] GLOBAL unknown index of every neighbour voxel or -1; [27 + s]: block base of (cell, set s) (nksr_fused_tables) */
+    const int32_t* offsets;    /* [M + 1] partial blocks of a cell = [offsets[j], offsets[j + 1]) (set 0's first)                 */
+    int64_t nblocks;           /* offsets[M]                                                                 */
+    uint64_t* nnz_counter;     /* device counter or NULL: nksr_fused_rhs_diag (diagonal pass) leaves the non-zero slots of rows_all here = the
+                                * stored entries of G and Q (roofline accounting) */
+    void* workspace;           /* nksr_fused_workspace_bytes(M, nblocks)                                     */
 } nksr_fused_op_t;
-/* Work items (set, cell, <= 32 rows): counts_out [nsets * M + 1] (last entry 0) -> exclusive scan = offsets ->
- * items_out [nitems, 4] int32. */
-int64_t nksr_fused_cells(const nksr_hier_t* h, int nsets);
-int nksr_fused_item_counts(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, int32_t* counts_out, void* stream);
-int nksr_fused_items(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, const int32_t* offsets, int32_t* items_out,
-                     void* stream);
-size_t nksr_fused_workspace_bytes(int32_t depth, int64_t rows_total, int64_t nitems);
+/* Work items are runs of 32 consecutive rows of a set; a cell whose rows touch k items owns k partial blocks.
+ * counts_out [M + 1] (last entry 0) -> exclusive scan = offsets; then the tables of the operator. */
+int nksr_fused_block_counts(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, int32_t* counts_out, void* stream);
+int nksr_fused_tables(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, const int32_t* offsets, int32_t* nbr32_out,
+                      int32_t* row_cells_out, void* stream);
+size_t nksr_fused_workspace_bytes(int32_t M, int64_t nblocks);
 /* b = sum_s R_s^T t_s and diag = reg + sum_s diag(R_s^T R_s) (either may be NULL). */
 int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* b_out, float* diag_out, void* stream);
 /* y = (sum_s R_s^T R_s + reg I) x */

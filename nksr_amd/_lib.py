@@ -28,8 +28,9 @@ class FusedSetT(C.Structure):
 
 
 class FusedOpT(C.Structure):
-    _fields_ = [('depth', _i32), ('nsets', _i32), ('M', _i32), ('reserved', _i32), ('rows_total', _i64), ('rows_all', _vp),
-                ('targets_all', _vp), ('nbr_all', _vp), ('offsets', _vp), ('items', _vp), ('nitems', _i64), ('workspace', _vp)]
+    _fields_ = [('depth', _i32), ('nsets', _i32), ('M', _i32), ('reserved', _i32), ('rows_total', _i64), ('set_rows', _i64 * 2),
+                ('rows_all', _vp), ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('offsets', _vp), ('nblocks', _i64),
+                ('nnz_counter', _vp), ('workspace', _vp)]
 
 
 class SiteSetT(C.Structure):
@@ -60,11 +61,9 @@ lib.nksr_assemble_workspace_bytes.argtypes = [C.POINTER(HierT)]
 lib.nksr_spmv_workspace_bytes.restype = _sz
 lib.nksr_spmv_workspace_bytes.argtypes = [_i64]
 lib.nksr_fused_workspace_bytes.restype = _sz
-lib.nksr_fused_workspace_bytes.argtypes = [_i32, _i64, _i64]
+lib.nksr_fused_workspace_bytes.argtypes = [_i32, _i64]
 lib.nksr_pcg_vector_workspace_bytes.restype = _sz
 lib.nksr_pcg_vector_workspace_bytes.argtypes = [_i32]
-lib.nksr_fused_cells.restype = _i64
-lib.nksr_fused_cells.argtypes = [C.POINTER(HierT), C.c_int]
 
 _P = C.POINTER
 _PROTOS = {
@@ -103,8 +102,8 @@ _PROTOS = {
     'nksr_pack_cols21': [_vp, _i64, _vp, _vp],
     'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _vp, _vp],
     'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
-    'nksr_fused_item_counts': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp],
-    'nksr_fused_items': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp, _vp],
+    'nksr_fused_block_counts': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp],
+    'nksr_fused_tables': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp, _vp, _vp],
     'nksr_fused_rhs_diag': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
@@ -132,7 +131,7 @@ for _name, _args in _PROTOS.items():
     _fn.restype = C.c_int
 
 EXPORTED = ['nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
-            'nksr_fused_workspace_bytes', 'nksr_pcg_vector_workspace_bytes', 'nksr_fused_cells'] + sorted(_PROTOS)
+            'nksr_fused_workspace_bytes', 'nksr_pcg_vector_workspace_bytes'] + sorted(_PROTOS)
 
 
 def check(rc):

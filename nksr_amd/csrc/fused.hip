@@ -5,19 +5,21 @@
 // gradient rows per normal site), already multiplied by sqrt(weight), stored LEVEL-MAJOR in ONE array
 // rows_all[d][r][27] (r runs over the rows of set 0, then set 1).
 //
-// Every site of a level-d cell c couples to the same 27 voxels (c's stencil), so both products run cell by cell:
-//   forward     t_d[r]   = sum_s rows[d][r][s] * x[nbr[c][s]]          (x stencil of the cell loaded once, 27 lanes)
-//   transposed  P[c][s]  = sum_{r in c} rows[d][r][s] * t[r],   y_j = reg x_j + sum_{s'} P[nbr[j][s']][26 - s']
-// with t = sum_d t_d.  Work items = (set, level, cell, <= 32 consecutive rows); one item per 32-lane half of a wavefront
-// (27 lanes active), so fine cells (a handful of rows) and coarse cells (thousands of rows, cut into many items) balance.
-// Both passes read every row once (the rows of a cell are contiguous: sites are Morton-sorted): 2 x 4 bytes per dense slot
-// per application and no column indices at all.  Fixed summation orders, no float atomics: deterministic.  No assembly: the
-// solve starts right after the kernel rows.
+// Every site of a level-d cell c couples to the same 27 voxels (c's stencil):
+//   t[r]     = sum_d sum_s rows[d][r][s] * x[nbr[c_d(r)][s]]
+//   P[c][s]  = sum_{r in c} rows[d][r][s] * t[r],          y_j = reg x_j + sum_{s'} P[nbr[j][s']][26 - s']
+// The sites are Morton-sorted, so the rows of a cell are contiguous AT EVERY LEVEL at once.  One pass does both products
+// (k_fz_sweep): a work item = 32 consecutive rows of a set, one item per 32-lane half of a wavefront (lane = stencil slot, 27
+// active).  The half-wave walks its rows four at a time with the x stencil and the running block P of the CURRENT cell of every
+// level in registers; when a row enters another cell of level d the finished block is written out and the new stencil
+// (neighbour row + 27 x values) is fetched.  t[r] needs only the row's own slots, so it is formed (one transposing butterfly
+// per four rows) and used while the row is still in registers: every kernel row is read from HBM ONCE per application, there
+// are no column indices, no t vector in memory and no second pass over the rows.  A cell whose rows span several items gets one
+// partial block per item; k_fz_gather sums, per unknown, the blocks of its 27 neighbour cells in a fixed order.  No float
+// atomics: deterministic.
 //
-// An item record holds everything a half-wave needs (row offset, global index of its cell, row count, level): the kernels
-// index three flat arrays with uniform base pointers.  (The first version looked levels and sets up in the argument
-// struct per item -- per-lane indexing of a kernel argument compiles to ~8 dependent global loads per item and was most of
-// the runtime for cells with 3 rows.)
+// (Round-2 history: the first version ran the two products as separate passes over (level, cell, <= 32 rows) items -- rows read
+// twice, t through memory: 1.05 ms per application at the bench workload.)
 #include "common.h"
 #include "pcg_core.h"
 #include <stdlib.h>
@@ -25,20 +27,19 @@
 #define FZ_RC 32
 #define FZ_BLOCK 256
 #define FZ_MAX_SETS 2
-#define FZ_DEFAULT_VARIANT 2
 
-// ---- work items ------------------------------------------------------------------------------------------------------------
-// item = { trow: first row (index into the concatenated row list of all sets), cell: global unknown index of the cell,
-//          meta: rows | level << 8, 0 };  offsets[set * M + cell] .. [+1] = the items of (set, cell)
-struct ItemArgs {
+// ---- tables ----------------------------------------------------------------------------------------------------------------
+struct SetupArgs {
     nksr_hier_t hier;
     nksr_fused_set_t sets[FZ_MAX_SETS];
     int nsets;
     int M;
     int64_t row_off[FZ_MAX_SETS];
+    int64_t rows_total;
 };
 
-static int fz_item_args(ItemArgs& A, const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets) {
+static int fz_setup_args(SetupArgs& A, const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets) {
+    if (!h || !sets) return nksr_set_error(NKSR_ERR_ARG, "hierarchy / site sets are NULL");
     if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
     if (nsets < 1 || nsets > FZ_MAX_SETS) return nksr_set_error(NKSR_ERR_ARG, "1..%d site sets", FZ_MAX_SETS);
     memset(&A, 0, sizeof(A));
@@ -52,7 +53,8 @@ static int fz_item_args(ItemArgs& A, const nksr_hier_t* h, const nksr_fused_set_
         A.row_off[s] = rows;
         rows += sets[s].n * sets[s].ncomp;
     }
-    if (rows >= ((int64_t)1 << 31) || (int64_t)nsets * A.M >= ((int64_t)1 << 31) - 1) return nksr_set_error(NKSR_ERR_CAPACITY, "site sets too large");
+    A.rows_total = rows;
+    if (rows >= ((int64_t)1 << 31) - 64) return nksr_set_error(NKSR_ERR_CAPACITY, "site sets too large");
     return NKSR_OK;
 }
 
@@ -62,38 +64,73 @@ __device__ __forceinline__ int fz_level(const nksr_hier_t& h, int j) {
     return d;
 }
 
-__global__ void k_fz_item_counts(ItemArgs A, int32_t* __restrict__ counts) {
-    const int lin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin > A.nsets * A.M) return;
-    if (lin == A.nsets * A.M) { counts[lin] = 0; return; }
-    const int set = lin / A.M, j = lin - set * A.M;
-    const int d = fz_level(A.hier, j), c = j - A.hier.lv[d].offset;
-    const nksr_fused_set_t& S = A.sets[set];
-    const int nrows = (S.end[d][c] - S.start[d][c]) * S.ncomp;
-    counts[lin] = (nrows + FZ_RC - 1) / FZ_RC;
+// partial blocks of (cell, set): one per 32-row item its row range [r0, r1) touches
+__device__ __forceinline__ int fz_cell_blocks(const nksr_fused_set_t& S, int d, int c, int& first_item) {
+    const int r0 = S.start[d][c] * S.ncomp, r1 = S.end[d][c] * S.ncomp;
+    first_item = r0 / FZ_RC;
+    return r1 > r0 ? (r1 - 1) / FZ_RC - first_item + 1 : 0;
 }
 
-__global__ void k_fz_item_fill(ItemArgs A, const int32_t* __restrict__ offsets, int4* __restrict__ items) {
-    const int lin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin >= A.nsets * A.M) return;
-    const int set = lin / A.M, j = lin - set * A.M;
+__global__ void k_fz_block_counts(SetupArgs A, int32_t* __restrict__ counts) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > A.M) return;
+    if (j == A.M) { counts[j] = 0; return; }
     const int d = fz_level(A.hier, j), c = j - A.hier.lv[d].offset;
+    int n = 0, fi;
+    for (int s = 0; s < A.nsets; ++s) n += fz_cell_blocks(A.sets[s], d, c, fi);
+    counts[j] = n;
+}
+
+// nbr32[j][0..26]: global unknown index of the neighbour voxels or -1;  [27 + s]: (first block of (j, set s)) - (first item of
+// the cell in set s), so that the block of item i is  nbr32[j][27 + s] + i
+__global__ void k_fz_tables(SetupArgs A, const int32_t* __restrict__ offsets, int32_t* __restrict__ nbr32) {
+    const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin >= (int64_t)A.M * 32) return;
+    const int j = (int)(lin >> 5), s = (int)(lin & 31);
+    const int d = fz_level(A.hier, j), c = j - A.hier.lv[d].offset;
+    int v = 0;
+    if (s < 27) {
+        const int nb = A.hier.lv[d].nbr[(int64_t)c * 27 + s];
+        v = nb >= 0 ? nb + A.hier.lv[d].offset : -1;
+    } else if (s - 27 < A.nsets) {
+        int base = offsets[j], fi;
+        for (int q = 0; q < s - 27; ++q) base += fz_cell_blocks(A.sets[q], d, c, fi);
+        fz_cell_blocks(A.sets[s - 27], d, c, fi);
+        v = base - fi;
+    }
+    nbr32[lin] = v;
+}
+
+// row_cells[d][r]: global unknown index of the level-d cell of row r, -1 where the site lies in no active level-d voxel
+__global__ void k_fz_row_cells(SetupArgs A, int set, int32_t* __restrict__ row_cells) {
     const nksr_fused_set_t& S = A.sets[set];
-    const int r0 = S.start[d][c] * S.ncomp, r1 = S.end[d][c] * S.ncomp;
-    int it = offsets[lin];
-    for (int r = r0; r < r1; r += FZ_RC, ++it)
-        items[it] = make_int4((int)A.row_off[set] + r, j, ((r + FZ_RC < r1 ? FZ_RC : r1 - r)) | (d << 8), 0);
+    const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin >= S.n * A.hier.depth) return;
+    const int d = (int)(lin / S.n), site = (int)(lin - (int64_t)d * S.n);
+    const int n = A.hier.lv[d].n;
+    const int32_t* __restrict__ en = S.end[d];
+    int lo = 0, hi = n;                          // first cell whose range ends after the site (ranges are monotone: Morton order)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (en[mid] > site) hi = mid; else lo = mid + 1;
+    }
+    const int j = (lo < n && S.start[d][lo] <= site) ? A.hier.lv[d].offset + lo : -1;
+    int32_t* out = row_cells + (int64_t)d * A.rows_total + A.row_off[set] + (int64_t)site * S.ncomp;
+    for (int k = 0; k < S.ncomp; ++k) out[k] = j;
 }
 
 // ---- the operator ----------------------------------------------------------------------------------------------------------
 struct FusedArgs {               // uniform scalars and base pointers only
     const float* rows_all;       // [depth][rows_total][27]
     const float* targets_all;    // [rows_total]
-    const int32_t* nbr_all;      // [M,27] global unknown index or -1
-    const int32_t* offsets;      // [nsets * M + 1]
-    const int4* items;
-    int nitems, nsets, M, depth;
-    int64_t rows_total;
+    const int32_t* row_cells;    // [depth][rows_total]
+    const int32_t* nbr32;        // [M][32]
+    const int32_t* offsets;      // [M + 1] blocks of a cell
+    int nsets, M, depth;
+    int hw_set0, hw_total;       // half-waves (items, rounded up to whole wavefronts per set)
+    int64_t rows_total, nblocks;
+    int64_t set_rows[FZ_MAX_SETS], row_off[FZ_MAX_SETS];
+    unsigned long long* nnz_counter;   // MODE 2 adds the non-zero slots it sees (may be NULL)
 };
 
 __device__ __forceinline__ float half_sum(float p) {      // sum over the 32 lanes of this half-wave, fixed tree
@@ -125,189 +162,303 @@ __device__ __forceinline__ float half_sum4(float p0, float p1, float p2, float p
     return r;
 }
 
-// t_d[r] = sum_s rows[d][r][s] * x[stencil of the item's cell][s]
-// Every half-wave carries ILP consecutive items at once (their load chains item -> neighbour row -> x overlap), four rows per
-// trip.  The row sums leave through 4 lanes per trip (16 contiguous bytes): one store instruction per four rows, and the
-// cross-lane exchanges -- the LDS crossbar was this kernel's bottleneck at one 5-step reduction per row -- drop 3.3x.
-template <int ILP>
-__global__ void __launch_bounds__(FZ_BLOCK) k_fz_forward(FusedArgs A, const float* __restrict__ x, float* __restrict__ tpart,
-                                                        const int* __restrict__ done) {
+// lane `l` of the caller's own half-wave, l uniform: two scalar lane reads + a select (no crossbar)
+__device__ __forceinline__ int half_lane_i(int v, int l, bool upper) {
+    const int lo = __builtin_amdgcn_readlane(v, l), hi = __builtin_amdgcn_readlane(v, 32 + l);
+    return upper ? hi : lo;
+}
+__device__ __forceinline__ float half_lane_f(float v, int l, bool upper) { return __int_as_float(half_lane_i(__float_as_int(v), l, upper)); }
+
+// two rows: after the xor-16 step the lower 16 lanes hold row 0, the upper 16 row 1.  Returns the total of row bit4(lane).
+__device__ __forceinline__ float half_sum2(float p0, float p1, int lane) {
+    const bool hi = (lane >> 4) & 1;
+    float r = (hi ? p1 : p0) + __shfl_xor(hi ? p0 : p1, 16, 32);
+    r += dpp_move<0x128>(r);
+    r += dpp_move<0xB1>(r);
+    r += dpp_move<0x4E>(r);
+    r += dpp_move<0x141>(r);
+    return r;
+}
+
+// MODE 0: operator (t from x), 1: right-hand side (t = target), 2: Jacobi diagonal (P += rows^2).
+// U rows per trip.  Levels < NG (the fine ones, where a cell holds a handful of rows) fetch the stencil of EVERY row (neighbour
+// row, then 27 x values: the loads of a trip go out together, nothing to decide); levels >= NG keep the stencil of their current
+// cell in registers and refresh it on the rare trip that crosses a cell boundary -- that trip is processed in two parts, before
+// and after the refresh.  Which rows change cell / have a cell at all is known up front as two 32-bit masks per level.
+template <int MODE, int D, int U, int NG>
+__global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
+                                                      const int* __restrict__ done) {
     if (done && *done) return;
+    constexpr int G = NG < D ? NG : D;                               // levels that gather per row
     const int hw = (blockIdx.x * FZ_BLOCK + threadIdx.x) >> 5;
-    const int i0 = hw * ILP;
-    if (i0 >= A.nitems) return;
+    if (hw >= A.hw_total) return;                                    // whole wavefronts: hw_total is even
+    const int set = hw >= A.hw_set0 ? 1 : 0;                         // uniform per wavefront: hw_set0 is even
+    const int item = hw - (set ? A.hw_set0 : 0);
+    const int64_t rs = (int64_t)item * FZ_RC;
+    const int64_t left = A.set_rows[set] - rs;
+    const int nrows = left >= FZ_RC ? FZ_RC : (left > 0 ? (int)left : 0);
+    const int64_t R0 = A.row_off[set] + rs;
     const int s = threadIdx.x & 31;
-    const bool act = s < 27;
-    int4 it[ILP];
+    const bool act = s < 27, upper = (threadIdx.x & 32) != 0;
+    const int sh = upper ? 32 : 0;
+    // the cells (and targets) of the item's rows, one row per lane: a single coalesced load each
+    int cells[D];
+    unsigned chg[D], pos[D];         // bit l: row l lies in another cell than row l - 1 / lies in a cell at all
 #pragma unroll
-    for (int k = 0; k < ILP; ++k) it[k] = A.items[i0 + k < A.nitems ? i0 + k : A.nitems - 1];
-    int nb[ILP], nrows[ILP], maxrows = 0;
-#pragma unroll
-    for (int k = 0; k < ILP; ++k) {
-        nb[k] = act ? A.nbr_all[(int64_t)it[k].y * 27 + s] : -1;
-        nrows[k] = i0 + k < A.nitems ? (it[k].z & 255) : 0;
-        maxrows = nrows[k] > maxrows ? nrows[k] : maxrows;
+    for (int d = 0; d < D; ++d) {
+        cells[d] = s < nrows ? A.row_cells[(int64_t)d * A.rows_total + R0 + s] : -1;
+        const int before = __shfl_up(cells[d], 1, 32);
+        chg[d] = (unsigned)(__ballot(cells[d] != (s ? before : -1)) >> sh);
+        pos[d] = (unsigned)(__ballot(cells[d] >= 0) >> sh);
     }
-    float xs[ILP];
-    const float* base[ILP];
-    float* tp[ILP];
+    const float tg = (MODE == 1 && s < nrows) ? A.targets_all[R0 + s] : 0.f;
+    int fb[D];
+    float P[D], xs[D];
+    bool have[D];
 #pragma unroll
-    for (int k = 0; k < ILP; ++k) {
-        xs[k] = nb[k] >= 0 ? x[nb[k]] : 0.f;
-        base[k] = A.rows_all + ((int64_t)(it[k].z >> 8) * A.rows_total + it[k].x) * 27 + (act ? s : 0);
-        tp[k] = tpart + (int64_t)(it[k].z >> 8) * A.rows_total + it[k].x;
-    }
-    const int myrow = 2 * ((s >> 4) & 1) + ((s >> 3) & 1);         // the row of a trip whose total this lane ends up with
-    for (int j = 0; j < maxrows; j += 4) {
-        float v[ILP][4];
+    for (int d = 0; d < D; ++d) { fb[d] = 0; P[d] = 0.f; xs[d] = 0.f; have[d] = false; }
+    // coarse levels: the stencils of the item's first row, all levels in one round trip (then one more for x)
+    {
+        int c0[D], nb0[D];
+        float x0[D];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int d = G; d < D; ++d) {
+            c0[d] = half_lane_i(cells[d], 0, upper);
+            nb0[d] = A.nbr32[(int64_t)(c0[d] >= 0 ? c0[d] : 0) * 32 + s];
+        }
 #pragma unroll
-            for (int k = 0; k < ILP; ++k) v[k][u] = (act && j + u < nrows[k]) ? base[k][(int64_t)(j + u) * 27] : 0.f;
+        for (int d = G; d < D; ++d) x0[d] = MODE == 0 ? x[(act && nb0[d] >= 0) ? nb0[d] : 0] : 0.f;
 #pragma unroll
-        for (int k = 0; k < ILP; ++k) {
-            const float r = half_sum4(v[k][0] * xs[k], v[k][1] * xs[k], v[k][2] * xs[k], v[k][3] * xs[k], s);
-            if ((s & 7) == 0 && j + myrow < nrows[k]) tp[k][j + myrow] = r;
+        for (int d = G; d < D; ++d) {
+            have[d] = c0[d] >= 0;
+            fb[d] = __shfl(nb0[d], 27 + set, 32);
+            xs[d] = (have[d] && act && nb0[d] >= 0) ? x0[d] : 0.f;
+            chg[d] &= ~1u;
         }
     }
-}
-
-__global__ void k_fz_tsum(int depth, int64_t rows_total, const float* __restrict__ tpart, float* __restrict__ t,
-                          const int* __restrict__ done) {
-    if (done && *done) return;
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows_total) return;
-    float a = 0.f;
-    for (int d = 0; d < depth; ++d) a += tpart[(int64_t)d * rows_total + r];
-    t[r] = a;
-}
-
-// P[item][s] = sum_{r in item} rows[d][r][s] * w[r];  MODE 0: w = t (operator), 1: w = target (right-hand side), 2: w = the row value itself (diagonal)
-// The <= 32 weights of an item arrive as ONE coalesced load (lane j holds the weight of row j) and are handed out by lane
-// broadcasts, instead of one same-address load per row.
-template <int MODE, int ILP, int RU>
-__global__ void __launch_bounds__(FZ_BLOCK) k_fz_transposed(FusedArgs A, const float* __restrict__ t, float* __restrict__ part,
-                                                           const int* __restrict__ done) {
-    if (done && *done) return;
-    const int hw = (blockIdx.x * FZ_BLOCK + threadIdx.x) >> 5;
-    const int i0 = hw * ILP;
-    if (i0 >= A.nitems) return;
-    const int s = threadIdx.x & 31;
-    const bool act = s < 27;
-    int4 it[ILP];
+    const int nlo = __builtin_amdgcn_readlane(nrows, 0), nhi = __builtin_amdgcn_readlane(nrows, 32);
+    const int nmax = nlo > nhi ? nlo : nhi;
+    int nnz = 0;                                                     // MODE 2: stored entries of G and Q (roofline accounting)
+    // the neighbour rows of the fine levels are requested one trip ahead: with them in hand all loads of a trip (kernel rows, x
+    // stencils, the next trip's neighbour rows) are independent -- one memory round trip per trip instead of two
+    // (all loads of the row loop are UNCONDITIONAL -- clamped addresses, results masked afterwards: a load under a branch makes
+    // the compiler lose count of the outstanding loads and wait for all of them)
+    const int sc = act ? s : 26;
+    const int lastrow = nrows > 0 ? nrows - 1 : 0;
+    int nbn[U][G > 0 ? G : 1];
 #pragma unroll
-    for (int k = 0; k < ILP; ++k) it[k] = A.items[i0 + k < A.nitems ? i0 + k : A.nitems - 1];
-    int nrows[ILP], maxrows = 0;
-    const float* base[ILP];
-    float acc[ILP], wreg[ILP];
-    const float* w = MODE == 0 ? t : A.targets_all;
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-    for (int k = 0; k < ILP; ++k) {
-        nrows[k] = i0 + k < A.nitems ? (it[k].z & 255) : 0;
-        maxrows = nrows[k] > maxrows ? nrows[k] : maxrows;
-        base[k] = A.rows_all + ((int64_t)(it[k].z >> 8) * A.rows_total + it[k].x) * 27 + (act ? s : 0);
-        wreg[k] = (MODE != 2 && s < nrows[k]) ? w[it[k].x + s] : 0.f;
-        acc[k] = 0.f;
-    }
-    for (int j = 0; j < maxrows; j += RU) {
-        float v[ILP][RU];
+        for (int d = 0; d < G; ++d) {
+            const int cj = half_lane_i(cells[d], u, upper);
+            const int v = A.nbr32[(int64_t)(cj >= 0 ? cj : 0) * 32 + s];
+            nbn[u][d] = cj >= 0 ? v : -1;
+        }
+    for (int rr = 0; rr < nmax; rr += U) {
+        float w[U][D], xg[U][G > 0 ? G : 1];
+        int nb[U][G > 0 ? G : 1];
 #pragma unroll
-        for (int u = 0; u < RU; ++u)
+        for (int u = 0; u < U; ++u) {
+            const int row = rr + u < nrows ? rr + u : lastrow;
 #pragma unroll
-            for (int k = 0; k < ILP; ++k) v[k][u] = (j + u < nrows[k]) ? base[k][(int64_t)(j + u) * 27] : 0.f;
+            for (int d = 0; d < D; ++d) w[u][d] = A.rows_all[((int64_t)d * A.rows_total + R0 + row) * 27 + sc];
+        }
 #pragma unroll
-        for (int u = 0; u < RU; ++u)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int k = 0; k < ILP; ++k) {
-                // row j + u is the same lane of both halves' items: two scalar lane reads + a select, no crossbar
-                float wk = v[k][u];
-                if (MODE != 2) {
-                    const float wl = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[k]), (j + u) & 31)),
-                                wh = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[k]), 32 + ((j + u) & 31)));
-                    wk = (threadIdx.x & 32) ? wh : wl;
+            for (int d = 0; d < G; ++d) {
+                nb[u][d] = nbn[u][d];
+                xg[u][d] = MODE == 0 ? x[nb[u][d] >= 0 ? nb[u][d] : 0] : 0.f;
+            }
+        {
+            const int nr = rr + U < 32 ? rr + U : 0;                  // (the last trip's request is a harmless repeat)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int d = 0; d < G; ++d) {
+                    const int cj = half_lane_i(cells[d], (nr + u) & 31, upper);
+                    const int v = A.nbr32[(int64_t)(cj >= 0 ? cj : 0) * 32 + s];
+                    nbn[u][d] = cj >= 0 ? v : -1;
                 }
-                acc[k] = fmaf(v[k][u], wk, acc[k]);
-            }
-    }
-#pragma unroll
-    for (int k = 0; k < ILP; ++k)
-        if (i0 + k < A.nitems) part[(int64_t)(i0 + k) * 32 + s] = act ? acc[k] : 0.f;
-}
-
-// y_j = (MODE 0: reg x_j, 1: 0, 2: reg) + sum over the 27 neighbour cells c of j, sets, items of c:  P[item][26 - s']
-// One half-wave per unknown, lane = neighbour slot: the 27 (cell -> items -> block entry) chains run side by side; fixed tree
-// reduction.
-template <int MODE>
-__global__ void __launch_bounds__(256) k_fz_gather(FusedArgs A, const float* __restrict__ part, const float* __restrict__ x, float reg,
-                                                  float* __restrict__ y, const int* __restrict__ done) {
-    if (done && *done) return;
-    // (giving each XCD a contiguous eighth of the unknowns cut this pass's HBM fetches from 1.51 to 0.35 GB -- the partial blocks
-    // are re-read by all eight L2s -- and still ran 1.5x SLOWER, like the same mapping did for the other two passes: 2x)
-    const int j = (blockIdx.x * 256 + threadIdx.x) >> 5;
-    if (j >= A.M) return;
-    const int sp = threadIdx.x & 31;
-    float acc = 0.f;
-    const int c = sp < 27 ? A.nbr_all[(int64_t)j * 27 + sp] : -1;
-    if (c >= 0) {
-        int i0[FZ_MAX_SETS], i1[FZ_MAX_SETS];
-#pragma unroll
-        for (int set = 0; set < FZ_MAX_SETS; ++set) {
-            i0[set] = i1[set] = 0;
-            if (set < A.nsets) {
-                i0[set] = A.offsets[(int64_t)set * A.M + c];
-                i1[set] = A.offsets[(int64_t)set * A.M + c + 1];
-            }
         }
 #pragma unroll
-        for (int set = 0; set < FZ_MAX_SETS; ++set)
-            for (int itx = i0[set]; itx < i1[set]; ++itx) acc += part[(int64_t)itx * 32 + (26 - sp)];
+        for (int u = 0; u < U; ++u) {
+            const bool ok = rr + u < nrows && act;
+#pragma unroll
+            for (int d = 0; d < D; ++d) w[u][d] = ok ? w[u][d] : 0.f;
+#pragma unroll
+            for (int d = 0; d < G; ++d) xg[u][d] = (ok && nb[u][d] >= 0) ? xg[u][d] : 0.f;
+            if (MODE == 2) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) nnz += __popcll(__ballot(w[u][d] != 0.f));
+            }
+        }
+        // rows of the trip that cross a cell boundary of a level >= NG: the trip is cut there
+        unsigned cut = 0;
+#pragma unroll
+        for (int d = G; d < D; ++d) cut |= chg[d] >> rr;
+        cut &= (1u << U) - 1u;
+        int from = 0;
+        while (true) {
+            // refresh the coarse stencils that change at row `from`
+            if ((cut >> from) & 1u) {
+#pragma unroll
+                for (int d = G; d < D; ++d)
+                    if ((chg[d] >> (rr + from)) & 1u) {
+                        if (have[d]) part[((int64_t)fb[d] + item) * 32 + s] = P[d];
+                        P[d] = 0.f;
+                        xs[d] = 0.f;
+                        have[d] = (pos[d] >> (rr + from)) & 1u;
+                        if (have[d]) {
+                            const int nbv = A.nbr32[(int64_t)__shfl(cells[d], (rr + from) & 31, 32) * 32 + s];      // `from` differs between the halves: no scalar lane read here
+                            fb[d] = __shfl(nbv, 27 + set, 32);
+                            if (MODE == 0 && act && nbv >= 0) xs[d] = x[nbv];
+                        }
+                    }
+                cut &= ~(1u << from);
+            }
+            const int to = cut ? __builtin_ctz(cut) : U;             // rows [from, to) see the same coarse cells
+            float t[U];
+            if (MODE == 0) {
+                float prod[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    prod[u] = 0.f;
+                    const bool in = u >= from && u < to;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) prod[u] = fmaf(in ? w[u][d] : 0.f, d < G ? xg[u][d < G ? d : 0] : xs[d], prod[u]);
+                }
+                if (U == 4) {
+                    const float r = half_sum4(prod[0], prod[1], prod[2 % U], prod[3 % U], s);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) t[u] = half_lane_f(r, 8 * u, upper);
+                } else {
+                    const float r = half_sum2(prod[0], prod[1], s);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) t[u] = half_lane_f(r, 16 * u, upper);
+                }
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) t[u] = half_lane_f(tg, (rr + u) & 31, upper);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = u >= from && u < to && rr + u < nrows;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    if (d < G && in && ((chg[d] >> (rr + u)) & 1u)) {      // fine levels: the block leaves with its cell
+                        if (have[d]) part[((int64_t)fb[d] + item) * 32 + s] = P[d];
+                        P[d] = 0.f;
+                        have[d] = (pos[d] >> (rr + u)) & 1u;
+                        if (have[d]) fb[d] = __shfl(nb[u][d < G ? d : 0], 27 + set, 32);
+                    }
+                    if (in && have[d]) P[d] = MODE == 2 ? fmaf(w[u][d], w[u][d], P[d]) : fmaf(w[u][d], t[u], P[d]);
+                }
+            }
+            if (to >= U) break;
+            from = to;
+        }
     }
-    acc = half_sum(acc);
-    if (sp == 0) y[j] = acc + (MODE == 0 ? reg * x[j] : (MODE == 2 ? reg : 0.f));
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (have[d]) part[((int64_t)fb[d] + item) * 32 + s] = P[d];
+    if (MODE == 2 && A.nnz_counter && (threadIdx.x & 63) == 0 && nnz) atomicAdd(A.nnz_counter, (unsigned long long)nnz);   // integer: order-free
 }
 
-struct FusedWork {
-    float* tpart;   // [depth][rows_total]
-    float* t;       // [rows_total]
-    float* part;    // [nitems][32]
-};
+// C[c][s] = sum of the partial blocks of cell c (a cell has one block per 32-row item its rows touch and per site set: 1.6 on
+// average, hundreds for a coarse cell): one coalesced pass over the blocks, so that the gather below reads exactly one block
+// per neighbour.  A half-wave takes FOUR cells at once (lane = slot): the pass is latency-bound, the first two blocks of the
+// four cells are requested together.  Fixed order.
+#define FZ_GI 4
+__global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __restrict__ part, float* __restrict__ cellp,
+                                                   const int* __restrict__ done) {
+    if (done && *done) return;
+    const int j0 = ((blockIdx.x * 256 + threadIdx.x) >> 5) * FZ_GI;
+    if (j0 >= A.M) return;
+    const int s = threadIdx.x & 31;
+    int b0[FZ_GI], n[FZ_GI];
+#pragma unroll
+    for (int k = 0; k < FZ_GI; ++k) {
+        const int j = j0 + k < A.M ? j0 + k : A.M - 1;
+        b0[k] = A.offsets[j];
+        n[k] = j0 + k < A.M ? A.offsets[j + 1] - b0[k] : 0;
+    }
+    float acc[FZ_GI], a1[FZ_GI];
+#pragma unroll
+    for (int k = 0; k < FZ_GI; ++k) {
+        acc[k] = n[k] > 0 ? part[(int64_t)b0[k] * 32 + s] : 0.f;
+        a1[k] = n[k] > 1 ? part[(int64_t)(b0[k] + 1) * 32 + s] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < FZ_GI; ++k) {
+        acc[k] += a1[k];
+        const float* p = part + (int64_t)(b0[k] + 2) * 32 + s;
+        int b = 2;
+        for (; b + 4 <= n[k]; b += 4, p += 128) acc[k] += (p[0] + p[32]) + (p[64] + p[96]);
+        for (; b < n[k]; ++b, p += 32) acc[k] += p[0];
+        if (j0 + k < A.M) cellp[(int64_t)(j0 + k) * 32 + s] = acc[k];
+    }
+}
+
+// y_j = (MODE 0: reg x_j, 1: 0, 2: reg) + sum over the 27 neighbour cells c of j:  C[c][26 - s']
+// A half-wave takes four consecutive unknowns, lane = neighbour slot; one transposing butterfly sums the four.  Workgroups are
+// dealt to the XCDs round-robin by the hardware: workgroup 8 i + k takes the i-th group of the k-th EIGHTH of the unknowns, so
+// that an XCD's L2 holds one contiguous (Morton-ordered) part of C instead of every XCD fetching all of it.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_fz_gather(FusedArgs A, int per_xcd, const float* __restrict__ cellp, const float* __restrict__ x,
+                                                  float reg, float* __restrict__ y, const int* __restrict__ done) {
+    if (done && *done) return;
+    const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
+    const int local = (grp * 8 + (threadIdx.x >> 5)) * FZ_GI;        // first unknown of this half-wave inside its eighth
+    if (local >= per_xcd) return;
+    const int j0 = xcd * per_xcd + local;
+    if (j0 >= A.M) return;
+    const int sp = threadIdx.x & 31;
+    int c[FZ_GI];
+#pragma unroll
+    for (int k = 0; k < FZ_GI; ++k) c[k] = (sp < 27 && j0 + k < A.M) ? A.nbr32[(int64_t)(j0 + k) * 32 + sp] : -1;
+    float v[FZ_GI];
+#pragma unroll
+    for (int k = 0; k < FZ_GI; ++k) v[k] = c[k] >= 0 ? cellp[(int64_t)c[k] * 32 + (26 - sp)] : 0.f;
+    const float r = half_sum4(v[0], v[1], v[2], v[3], sp);           // lanes 8 k .. 8 k + 7 hold the total of unknown k
+    const int k = sp >> 3;
+    if ((sp & 7) == 0 && j0 + k < A.M) y[j0 + k] = r + (MODE == 0 ? reg * x[j0 + k] : (MODE == 2 ? reg : 0.f));
+}
+static void fz_gather_dims(int M, dim3& grid, int& per_xcd) {
+    per_xcd = ((M + 7) / 8 + 8 * FZ_GI - 1) / (8 * FZ_GI) * (8 * FZ_GI);        // whole workgroups (8 half-waves x FZ_GI unknowns)
+    grid = dim3((unsigned)(per_xcd / (8 * FZ_GI) * 8));
+}
+
 static size_t fz_align(size_t v) { return (v + 255) / 256 * 256; }
-static FusedWork fz_carve(void* ws, int depth, int64_t rows_total) {
+
+struct FusedWork { float* part; float* cellp; };      // [nblocks][32] partial blocks, [M][32] their per-cell sums
+extern "C" size_t nksr_fused_workspace_bytes(int32_t M, int64_t nblocks) {
+    return fz_align((size_t)(nblocks > 0 ? nblocks : 1) * 32 * sizeof(float)) + fz_align((size_t)(M > 0 ? M : 1) * 32 * sizeof(float));
+}
+static FusedWork fz_carve(void* ws, int64_t nblocks) {
     FusedWork w;
-    char* p = (char*)ws;
-    w.tpart = (float*)p; p += fz_align((size_t)depth * rows_total * sizeof(float));
-    w.t = (float*)p; p += fz_align((size_t)rows_total * sizeof(float));
-    w.part = (float*)p;
+    w.part = (float*)ws;
+    w.cellp = (float*)((char*)ws + fz_align((size_t)(nblocks > 0 ? nblocks : 1) * 32 * sizeof(float)));
     return w;
 }
 
-extern "C" size_t nksr_fused_workspace_bytes(int32_t depth, int64_t rows_total, int64_t nitems) {
-    return fz_align((size_t)depth * rows_total * sizeof(float)) + fz_align((size_t)rows_total * sizeof(float)) +
-           fz_align((size_t)nitems * 32 * sizeof(float)) + 256;
-}
-
-extern "C" int64_t nksr_fused_cells(const nksr_hier_t* h, int nsets) {
-    int64_t n = 0;
-    for (int d = 0; d < h->depth; ++d) n += h->lv[d].n;
-    return n * nsets;
-}
-
-extern "C" int nksr_fused_item_counts(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, int32_t* counts_out, void* stream) {
-    ItemArgs A;
-    if (int rc = fz_item_args(A, h, sets, nsets)) return rc;
-    hipLaunchKernelGGL(k_fz_item_counts, dim3(nksr_blocks((int64_t)A.nsets * A.M + 1, 256)), dim3(256), 0, (hipStream_t)stream, A, counts_out);
+extern "C" int nksr_fused_block_counts(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, int32_t* counts_out, void* stream) {
+    SetupArgs A;
+    if (int rc = fz_setup_args(A, h, sets, nsets)) return rc;
+    hipLaunchKernelGGL(k_fz_block_counts, dim3(nksr_blocks((int64_t)A.M + 1, 256)), dim3(256), 0, (hipStream_t)stream, A, counts_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
 
-extern "C" int nksr_fused_items(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, const int32_t* offsets, int32_t* items_out,
-                                void* stream) {
-    ItemArgs A;
-    if (int rc = fz_item_args(A, h, sets, nsets)) return rc;
-    if (A.M > 0) {
-        hipLaunchKernelGGL(k_fz_item_fill, dim3(nksr_blocks((int64_t)A.nsets * A.M, 256)), dim3(256), 0, (hipStream_t)stream, A, offsets, (int4*)items_out);
-        NKSR_CHECK_LAUNCH();
-    }
+extern "C" int nksr_fused_tables(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, const int32_t* offsets, int32_t* nbr32_out,
+                                 int32_t* row_cells_out, void* stream) {
+    SetupArgs A;
+    if (int rc = fz_setup_args(A, h, sets, nsets)) return rc;
+    if (A.M > 0) hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)A.M * 32, 256)), dim3(256), 0, (hipStream_t)stream, A, offsets, nbr32_out);
+    for (int s = 0; s < nsets; ++s)
+        if (A.sets[s].n > 0)
+            hipLaunchKernelGGL(k_fz_row_cells, dim3(nksr_blocks(A.sets[s].n * A.hier.depth, 256)), dim3(256), 0, (hipStream_t)stream, A, s, row_cells_out);
+    NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
 
@@ -315,16 +466,35 @@ static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
     if (!op) return nksr_set_error(NKSR_ERR_ARG, "operator is NULL");
     if (op->depth < 1 || op->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", op->depth);
     if (op->nsets < 1 || op->nsets > FZ_MAX_SETS) return nksr_set_error(NKSR_ERR_ARG, "1..%d site sets", FZ_MAX_SETS);
-    if (op->M > 0 && (!op->rows_all || !op->nbr_all || !op->offsets || !op->workspace || (op->nitems > 0 && !op->items)))
+    if (op->M > 0 && (!op->rows_all || !op->row_cells || !op->nbr32 || !op->offsets || !op->workspace))
         return nksr_set_error(NKSR_ERR_ARG, "operator has NULL arrays");
-    if (op->rows_total >= ((int64_t)1 << 31) || op->nitems >= ((int64_t)1 << 31)) return nksr_set_error(NKSR_ERR_CAPACITY, "operator too large");
-    A.rows_all = op->rows_all; A.targets_all = op->targets_all; A.nbr_all = op->nbr_all; A.offsets = op->offsets;
-    A.items = (const int4*)op->items; A.nitems = (int)op->nitems; A.nsets = op->nsets; A.M = op->M; A.depth = op->depth;
-    A.rows_total = op->rows_total;
+    int64_t rows = 0;
+    for (int s = 0; s < op->nsets; ++s) {
+        if (op->set_rows[s] < 0) return nksr_set_error(NKSR_ERR_ARG, "negative row count");
+        rows += op->set_rows[s];
+    }
+    if (rows != op->rows_total) return nksr_set_error(NKSR_ERR_ARG, "set_rows do not add up to rows_total");
+    if (op->rows_total >= ((int64_t)1 << 31) - 64 || op->nblocks >= ((int64_t)1 << 31) - ((int64_t)1 << 26))
+        return nksr_set_error(NKSR_ERR_CAPACITY, "operator too large");
+    memset(&A, 0, sizeof(A));
+    A.rows_all = op->rows_all; A.targets_all = op->targets_all; A.row_cells = op->row_cells; A.nbr32 = op->nbr32; A.offsets = op->offsets;
+    A.nsets = op->nsets; A.M = op->M; A.depth = op->depth; A.rows_total = op->rows_total; A.nblocks = op->nblocks;
+    A.nnz_counter = (unsigned long long*)op->nnz_counter;
+    int64_t off = 0, hw = 0;
+    for (int s = 0; s < op->nsets; ++s) {
+        A.set_rows[s] = op->set_rows[s];
+        A.row_off[s] = off;
+        off += op->set_rows[s];
+        const int64_t items = (op->set_rows[s] + FZ_RC - 1) / FZ_RC;
+        hw += (items + 1) / 2 * 2;
+        if (s == 0) A.hw_set0 = (int)hw;
+    }
+    A.hw_total = (int)hw;
     return NKSR_OK;
 }
 
-// (items per half-wave, rows per trip): probe variants, NKSR_FZ_VARIANT = 0..3; the default is the fastest one measured
+// (rows per trip, per-row-gather levels): probe variants, NKSR_FZ_VARIANT = 0..3; the default is the fastest one measured
+#define FZ_DEFAULT_VARIANT 0
 static int g_fz_variant = -1;
 static int fz_variant() {
     if (g_fz_variant < 0) {
@@ -334,23 +504,39 @@ static int fz_variant() {
     }
     return g_fz_variant;
 }
-static dim3 fz_grid(int64_t nitems, int ilp) { return dim3(nksr_blocks((nitems + ilp - 1) / ilp * 32, FZ_BLOCK)); }
+
+template <int MODE, int U, int NG>
+static void fz_sweep_v(const FusedArgs& A, const float* x, float* part, const int* done, hipStream_t st) {
+    const dim3 grid(nksr_blocks((int64_t)A.hw_total * 32, FZ_BLOCK)), blk(FZ_BLOCK);
+    switch (A.depth) {
+        case 1: hipLaunchKernelGGL((k_fz_sweep<MODE, 1, U, NG>), grid, blk, 0, st, A, x, part, done); break;
+        case 2: hipLaunchKernelGGL((k_fz_sweep<MODE, 2, U, NG>), grid, blk, 0, st, A, x, part, done); break;
+        case 3: hipLaunchKernelGGL((k_fz_sweep<MODE, 3, U, NG>), grid, blk, 0, st, A, x, part, done); break;
+        case 4: hipLaunchKernelGGL((k_fz_sweep<MODE, 4, U, NG>), grid, blk, 0, st, A, x, part, done); break;
+        case 5: hipLaunchKernelGGL((k_fz_sweep<MODE, 5, U, NG>), grid, blk, 0, st, A, x, part, done); break;
+        default: hipLaunchKernelGGL((k_fz_sweep<MODE, 6, U, NG>), grid, blk, 0, st, A, x, part, done); break;
+    }
+}
+
+template <int MODE>
+static void fz_sweep(const FusedArgs& A, const float* x, float* part, const int* done, hipStream_t st) {
+    if (A.hw_total <= 0) return;
+    if (MODE != 0) { fz_sweep_v<MODE, 4, 1>(A, x, part, done, st); return; }
+    switch (fz_variant()) {
+        case 0: fz_sweep_v<MODE, 4, 1>(A, x, part, done, st); break;
+        case 1: fz_sweep_v<MODE, 2, 1>(A, x, part, done, st); break;
+        case 2: fz_sweep_v<MODE, 4, 2>(A, x, part, done, st); break;
+        default: fz_sweep_v<MODE, 2, 2>(A, x, part, done, st); break;
+    }
+}
 
 static int fz_apply(const FusedArgs& A, float reg, const FusedWork& w, const float* x, float* y, const int* done, hipStream_t st) {
-    if (A.nitems > 0) {
-        const dim3 blk(FZ_BLOCK), gs(nksr_blocks(A.rows_total, 256));
-#define FZ_APPLY(I, R)                                                                                                      \
-        hipLaunchKernelGGL((k_fz_forward<I>), fz_grid(A.nitems, I), blk, 0, st, A, x, w.tpart, done);                      \
-        hipLaunchKernelGGL(k_fz_tsum, gs, dim3(256), 0, st, A.depth, A.rows_total, (const float*)w.tpart, w.t, done);      \
-        hipLaunchKernelGGL((k_fz_transposed<0, I, R>), fz_grid(A.nitems, I), blk, 0, st, A, (const float*)w.t, w.part, done)
-        switch (fz_variant()) {
-            case 0: { FZ_APPLY(4, 1); break; }
-            case 1: { FZ_APPLY(8, 1); break; }
-            case 2: { FZ_APPLY(4, 2); break; }
-            default: { FZ_APPLY(8, 2); break; }
-        }
-    }
-    hipLaunchKernelGGL((k_fz_gather<0>), dim3(nksr_blocks((int64_t)A.M * 32, 256)), dim3(256), 0, st, A, (const float*)w.part, x, reg, y, done);
+    dim3 gg;
+    int per_xcd;
+    fz_gather_dims(A.M, gg, per_xcd);
+    fz_sweep<0>(A, x, w.part, done, st);
+    hipLaunchKernelGGL(k_fz_cellsum, dim3(nksr_blocks(((int64_t)A.M + FZ_GI - 1) / FZ_GI * 32, 256)), dim3(256), 0, st, A, (const float*)w.part, w.cellp, done);
+    hipLaunchKernelGGL((k_fz_gather<0>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.cellp, x, reg, y, done);
     return NKSR_OK;
 }
 
@@ -358,7 +544,7 @@ extern "C" int nksr_fused_apply(const nksr_fused_op_t* op, float reg, const floa
     FusedArgs A;
     if (int rc = fz_args(A, op)) return rc;
     if (A.M <= 0) return NKSR_OK;
-    fz_apply(A, reg, fz_carve(op->workspace, A.depth, A.rows_total), x, y, nullptr, (hipStream_t)stream);
+    fz_apply(A, reg, fz_carve(op->workspace, A.nblocks), x, y, nullptr, (hipStream_t)stream);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -367,19 +553,25 @@ extern "C" int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* 
     FusedArgs A;
     if (int rc = fz_args(A, op)) return rc;
     if (A.M <= 0) return NKSR_OK;
-    const FusedWork w = fz_carve(op->workspace, A.depth, A.rows_total);
+    const FusedWork w = fz_carve(op->workspace, A.nblocks);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid = fz_grid(A.nitems, 4), gm(nksr_blocks((int64_t)A.M * 32, 256));
+    const dim3 gm(nksr_blocks(((int64_t)A.M + FZ_GI - 1) / FZ_GI * 32, 256));
+    dim3 gg;
+    int per_xcd;
+    fz_gather_dims(A.M, gg, per_xcd);
     const float* nof = nullptr;
     const int* nod = nullptr;
     if (b_out) {
         if (!A.targets_all) return nksr_set_error(NKSR_ERR_ARG, "targets_all is NULL");
-        if (A.nitems > 0) hipLaunchKernelGGL((k_fz_transposed<1, 4, 1>), grid, dim3(FZ_BLOCK), 0, st, A, nof, w.part, nod);
-        hipLaunchKernelGGL((k_fz_gather<1>), gm, dim3(256), 0, st, A, (const float*)w.part, nof, reg, b_out, nod);
+        fz_sweep<1>(A, nof, w.part, nod, st);
+        hipLaunchKernelGGL(k_fz_cellsum, gm, dim3(256), 0, st, A, (const float*)w.part, w.cellp, nod);
+        hipLaunchKernelGGL((k_fz_gather<1>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.cellp, nof, reg, b_out, nod);
     }
     if (diag_out) {
-        if (A.nitems > 0) hipLaunchKernelGGL((k_fz_transposed<2, 4, 1>), grid, dim3(FZ_BLOCK), 0, st, A, nof, w.part, nod);
-        hipLaunchKernelGGL((k_fz_gather<2>), gm, dim3(256), 0, st, A, (const float*)w.part, nof, reg, diag_out, nod);
+        if (A.nnz_counter) (void)hipMemsetAsync(A.nnz_counter, 0, sizeof(unsigned long long), st);
+        fz_sweep<2>(A, nof, w.part, nod, st);
+        hipLaunchKernelGGL(k_fz_cellsum, gm, dim3(256), 0, st, A, (const float*)w.part, w.cellp, nod);
+        hipLaunchKernelGGL((k_fz_gather<2>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.cellp, nof, reg, diag_out, nod);
     }
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
@@ -390,11 +582,14 @@ struct FusedOperator : PcgOperator {
     int apply(const float* p, float* y, const int* done, hipStream_t st) override { return fz_apply(A, reg, w, p, y, done, st); }
     void bytes(double* alg, double* phys) override {
         // SURVEY.md section 8d, matrix-free operator: G and Q once in each direction at 8 bytes per stored entry (value + index)
-        // + the vectors.  The dense-slot layout stores no indices: 4 bytes per slot per direction, plus the partial t vectors,
-        // the item records, the per-item stencil (neighbour row + x) and partial-block traffic
+        // + the vectors; stored entries = the non-zero slots (counted by the diagonal pass; all dense slots without a counter).
+        // Physical: every dense slot once (4 bytes, no indices), the row -> cell table, partial blocks written + read, one
+        // neighbour row per block (sweep), the per-cell sums written + read and one neighbour row per unknown (gather), x and y.
         const double slots = 27.0 * A.depth * (double)A.rows_total;
-        *alg = 2.0 * 8.0 * slots + 12.0 * A.M + 4.0;
-        *phys = 2.0 * 4.0 * slots + (2.0 * A.depth + 3.0) * 4.0 * (double)A.rows_total + (2.0 * 16.0 + 2.0 * 108.0 + 2.0 * 128.0) * A.nitems + 8.0 * A.M;
+        unsigned long long nnz = 0;                                  // (only reached with nksr_pcg_profile on, after a stream sync)
+        if (A.nnz_counter) (void)hipMemcpy(&nnz, A.nnz_counter, sizeof(nnz), hipMemcpyDeviceToHost);
+        *alg = 2.0 * 8.0 * (nnz > 0 ? (double)nnz : slots) + 12.0 * A.M + 4.0;
+        *phys = 4.0 * slots + 4.0 * A.depth * (double)A.rows_total + 3.0 * 128.0 * (double)A.nblocks + (3.0 * 128.0 + 8.0 + 12.0) * A.M;
     }
 };
 
@@ -405,7 +600,7 @@ extern "C" int nksr_pcg_solve_fused(const nksr_fused_op_t* opd, float reg, const
     if (op.A.M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
     if (!pcg_workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     op.reg = reg;
-    op.w = fz_carve(opd->workspace, op.A.depth, op.A.rows_total);
+    op.w = fz_carve(opd->workspace, op.A.nblocks);
     return nksr_pcg_run(op, diag, op.A.M, b, x, tol, max_iter, check_every, pcg_workspace, info_out, (hipStream_t)stream);
 }
 

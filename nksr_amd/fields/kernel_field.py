@@ -264,25 +264,27 @@ class KernelField(BaseField):
                 sets[i].start[d], sets[i].end[d] = ptr(st[d]), ptr(en[d])
             keep += [xs, ks, st, en]
             off += xs.shape[0] * ncomp
-        # neighbour table of all levels with GLOBAL unknown indices
-        offs = svh.offsets
-        nbr_all = torch.cat([torch.where(svh.level(d).nbr >= 0, svh.level(d).nbr + offs[d], svh.level(d).nbr) for d in range(L)]).contiguous()
-        ncells = int(_lib.lib.nksr_fused_cells(C.byref(self._hier), nsets))
-        counts = torch.empty(ncells + 1, dtype=torch.int32, device=dev)
-        call('nksr_fused_item_counts', C.byref(self._hier), sets, nsets, ptr(counts), stream())
+        # work items = runs of 32 rows; a cell owns one partial block per item its rows touch
+        counts = torch.empty(M + 1, dtype=torch.int32, device=dev)
+        call('nksr_fused_block_counts', C.byref(self._hier), sets, nsets, ptr(counts), stream())
         offsets = ops.exclusive_sum_i32(counts)
-        nitems = int(offsets[ncells].item())
-        items = torch.empty((max(nitems, 1), 4), dtype=torch.int32, device=dev)
-        call('nksr_fused_items', C.byref(self._hier), sets, nsets, ptr(offsets), ptr(items), stream())
-        # zeroed once: rows of sites that lie in no active cell of a level belong to no work item, their partial products are
-        # never written and must read as 0
-        ws = torch.zeros(int(_lib.lib.nksr_fused_workspace_bytes(L, rows_total, nitems)), dtype=torch.uint8, device=dev)
+        nbr32 = torch.empty((M, 32), dtype=torch.int32, device=dev)
+        row_cells = torch.empty((L, rows_total), dtype=torch.int32, device=dev)
+        call('nksr_fused_tables', C.byref(self._hier), sets, nsets, ptr(offsets), ptr(nbr32), ptr(row_cells), stream())
+        nblocks = int(offsets[M].item())
+        ws = torch.empty(int(_lib.lib.nksr_fused_workspace_bytes(M, nblocks)), dtype=torch.uint8, device=dev)
         op = FusedOpT()
-        op.depth, op.nsets, op.M, op.rows_total, op.nitems = L, nsets, M, rows_total, nitems
-        op.rows_all, op.targets_all, op.nbr_all = ptr(rows_all), ptr(targets_all), ptr(nbr_all)
-        op.offsets, op.items, op.workspace = ptr(offsets), ptr(items), ptr(ws)
-        keep += [nbr_all, offsets, items, ws]
-        return {'op': op, 'nsets': nsets, 'nitems': nitems, 'rows_total': rows_total, 'keep': keep}
+        op.depth, op.nsets, op.M, op.rows_total, op.nblocks = L, nsets, M, rows_total, nblocks
+        for i in range(nsets):
+            op.set_rows[i] = int(sets[i].n) * int(sets[i].ncomp)
+        op.rows_all, op.targets_all, op.row_cells, op.nbr32 = ptr(rows_all), ptr(targets_all), ptr(row_cells), ptr(nbr32)
+        op.offsets, op.workspace = ptr(offsets), ptr(ws)
+        # SURVEY.md section 8d counts the operator's bytes per STORED entry; the dense-slot rows hold structural zeros (absent
+        # neighbours, B-spline support ends): the diagonal pass counts the non-zero slots on its way (read back on demand)
+        nnz_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        op.nnz_counter = ptr(nnz_counter)
+        keep += [nbr32, row_cells, offsets, ws, nnz_counter]
+        return {'op': op, 'nsets': nsets, 'nblocks': nblocks, 'rows_total': rows_total, 'nnz_counter': nnz_counter, 'keep': keep}
 
     def fused_rhs_diag(self, op, reg_weight=1.0):
         M = self.svh.num_unknowns
@@ -290,6 +292,11 @@ class KernelField(BaseField):
         diag = torch.empty(M, dtype=torch.float32, device=self.device)
         call('nksr_fused_rhs_diag', C.byref(op['op']), float(reg_weight), ptr(b), ptr(diag), stream())
         return b, diag
+
+    def stored_entries(self):
+        """Non-zero entries of G and Q of the last matrix-free solve (counted by its diagonal pass; one small device read)."""
+        t = getattr(self, '_stored_entries', None)
+        return int(t.item()) if t is not None else None
 
     def fused_apply(self, op, x, reg_weight=1.0):
         """y = (w_p G^T G + w_n Q^T Q + reg I) x without the matrix (test / export helper)."""
@@ -319,10 +326,11 @@ class KernelField(BaseField):
         self.alpha = x
         self.matrix = None
         self._fused_op, self._fused_reg = op, float(reg_weight)
+        self._stored_entries = op['nnz_counter']
         self.rhs, self.diag = b, diag
         self.nnz = 0
         self.solve_info = {'iters': int(info[0]), 'rel_residual': float(info[1]), 'M': int(M), 'nnz': 0, 'fused': True,
-                           'kernel_row_slots': 27 * self.svh.depth * op['rows_total'], 'work_items': op['nitems'],
+                           'kernel_row_slots': 27 * self.svh.depth * op['rows_total'], 'partial_blocks': op['nblocks'],
                            't_assemble': t1 - t0, 't_pcg': t2 - t1}
         if self.solver_config.get('verbose'):
             print('[KernelField] fused: M=%d rows=%d iters=%d rel=%.3e rows+rhs=%.3fs pcg=%.3fs' % (

@@ -9,14 +9,14 @@ import os
 import subprocess
 import sys
 
-KERNELS = ('k_fz_forward', 'k_fz_tsum', 'k_fz_transposed', 'k_fz_gather')
+KERNELS = ('k_fz_sweep', 'k_fz_cellsum', 'k_fz_gather')
 
 
 def _match(k, name):
     """operator instantiations only (MODE 0), mangled or demangled kernel names"""
     if k not in name:
         return False
-    if k in ('k_fz_transposed', 'k_fz_gather'):
+    if k in ('k_fz_sweep', 'k_fz_gather'):
         return (k + 'ILi0') in name or (k + '<0') in name
     return True
 
@@ -69,10 +69,10 @@ def main():
         tot += fetch + write
     rec['hbm_bytes_per_application'] = tot
     import re
-    m = re.search(r'M=(\d+) rows=(\d+) items=(\d+)', desc)
+    m = re.search(r'M=(\d+) rows=(\d+) partial blocks=(\d+)', desc)
     if m:      # same formula as csrc/fused.hip FusedOperator::bytes (depth 4 on the probe workload)
-        M, rows, items = int(m.group(1)), int(m.group(2)), int(m.group(3))
-        rec['physical_bytes_per_application'] = 2 * 4 * 27 * 4 * rows + (2 * 4 + 3) * 4 * rows + 504 * items + 8 * M
+        M, rows, blocks = int(m.group(1)), int(m.group(2)), int(m.group(3))
+        rec['physical_bytes_per_application'] = 4 * 27 * 4 * rows + 4 * 4 * rows + 3 * 128 * blocks + 404 * M
     json.dump(rec, open(out, 'w'), indent=1)
     print(json.dumps(rec))
 

@@ -1,4 +1,4 @@
-"""Matrix-free operator micro-benchmark on the bench workload: times nksr_fused_apply (forward + tsum + transposed + gather)
+"""Matrix-free operator micro-benchmark on the bench workload: times nksr_fused_apply (sweep + gather)
 with HIP events on the launch stream and compares it with the assembled CSR SpMV on the same system.
 python -m nksr_amd.tools.fused_probe [points] [reps]"""
 import sys
@@ -31,8 +31,8 @@ def main():
     x = torch.randn(M, device=dev)
     y_csr = solver.spmv(rowptr, cols, vals, x)
     y_f = f.fused_apply(op, x)
-    print('M=%d rows=%d items=%d  max|y_fused - y_csr| / max|y| = %.3e' % (M, op['rows_total'], op['nitems'],
-                                                                        float((y_f - y_csr).abs().max() / y_csr.abs().max())))
+    print('M=%d rows=%d partial blocks=%d  max|y_fused - y_csr| / max|y| = %.3e' % (M, op['rows_total'], op['nblocks'],
+                                                                                 float((y_f - y_csr).abs().max() / y_csr.abs().max())))
     for _ in range(3):
         f.fused_apply(op, x)
     torch.cuda.synchronize()
@@ -44,8 +44,11 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     slots = 27 * f.svh.depth * op['rows_total']
-    phys = 2 * 4 * slots
-    print('fused apply: %.1f us  rows streamed twice = %.3f GB -> %.2f TB/s (%.1f%% of 8 TB/s)' % (ms * 1e3, phys / 1e9, phys / ms / 1e9, phys / ms / 1e9 / 8 * 100))
+    phys = 4 * slots + 4 * f.svh.depth * op['rows_total'] + 3 * 128 * op['nblocks'] + 404 * M      # csrc/fused.hip FusedOperator::bytes
+    nnz = int(torch.count_nonzero(op['keep'][0]).item())
+    alg = 16.0 * nnz + 12 * M + 4
+    print('fused apply: %.1f us  physical %.3f GB -> %.2f TB/s (%.1f%% of 8 TB/s);  SURVEY 8d figure (16 B x %d non-zero slots of %d) %.3f GB -> %.2f TB/s'
+          % (ms * 1e3, phys / 1e9, phys / ms / 1e9, phys / ms / 1e9 / 8 * 100, nnz, slots, alg / 1e9, alg / ms / 1e9))
 
 
 if __name__ == '__main__':

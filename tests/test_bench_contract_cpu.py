@@ -28,6 +28,10 @@ def test_roofline_record_arithmetic_and_keys():
     assert abs(r['avg_launch_us'] - 580.0) < 1e-6
     # traffic is only attached when the committed PMC pass was taken on the same matrix, and then names its source
     assert (r['traffic'] is None) == (r['traffic_source'] is None)
+    # the matrix-free record has the same keys and the same definitions (achieved = algorithmic bytes / time)
+    f = b.roofline_record(160 * 0.66, 160, 160 * 5.65e9, 160 * 2.71e9, fused=True)
+    assert set(r) == set(f) and 'k_fz_sweep' in f['kernel']
+    assert abs(f['achieved'] - 5.65e9 / 0.66e-3 / 1e9) < 1e-6 * f['achieved'] and abs(f['achieved_physical'] - 2.71e9 / 0.66e-3 / 1e9) < 1e-6 * f['achieved']
     z = b.roofline_record(0.0, 0, 0.0, 0.0)
     assert z['achieved'] == 0.0 and z['traffic'] is None
 

@@ -141,7 +141,10 @@ def test_bench_contract_line():
     for k in ('traffic', 'traffic_source', 'bytes_per_launch', 'avg_launch_us', 'launches_timed', 'kernel'):
         assert k in r, k
     assert (r['traffic'] is None) == (r['traffic_source'] is None)
-    assert d['config']['fused_mode'] is True and 'k_fz_forward' in r['kernel'] and 'achieved_survey_formula' in r
+    assert d['config']['fused_mode'] is True and 'k_fz_sweep' in r['kernel'] and r['frac_physical'] < r['frac']
+    # algorithmic bytes = 16 per stored entry of G and Q (counted on the device) + the vectors
+    se = d['config']['stored_entries_G_Q']
+    assert 0 < se <= d['config']['kernel_row_slots'] and abs(r['bytes_per_launch'] - (16.0 * se + 12.0 * d['config']['unknowns_M'] + 4)) < 1.0
     o = d['other_solve_mode']          # the assembled CSR solve on the same workload, with the CSR SpMV roofline
     assert o['fused_mode'] is False and o['value'] > 0 and 'k_spmv' in o['roofline']['kernel'] and o['nnz_A'] > 0
     assert 'achieved_physical' in o['roofline'] and o['roofline']['frac_physical'] <= o['roofline']['frac']
