@@ -128,10 +128,11 @@ int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden, const flo
  * wanted); dval [n, 3, L, 27] (may be NULL).  approx!=0 drops the d(phi)/dx term (approx_kernel_grad, recons_waymo.py:33).  Every output is
  * multiplied by row_scale (the assembly takes rows pre-multiplied by sqrt(set weight), see nksr_assemble). */
 int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, int64_t level_stride,
-                     float* val, float* dval, void* stream);
-/* level_stride > 0: LEVEL-MAJOR output, row (site i, component a) of level d at val / dval + ((d * level_stride + i * ncomp + a) * 27)
- * (ncomp = 1 for val, 3 for dval) -- the layout of the matrix-free solve (nksr_fused_op_t.rows_all; pass the pointer of the
- * set's first row) */
+                     const int32_t* row_index, int32_t* row_cells, float* val, float* dval, void* stream);
+/* level_stride > 0: LEVEL-MAJOR output, row (site i, component a) of level d at val / dval + ((d * level_stride + r_i + a) * 27) with
+ * r_i = row_index ? row_index[i] : i * ncomp (ncomp = 1 for val, 3 for dval; ONE of val / dval when row_index is given) -- the layout
+ * of the matrix-free solve (nksr_fused_op_t.rows_all): row_index lets several site sets share one Morton-ordered row list;
+ * row_cells [L, level_stride] (may be NULL) receives the global unknown index of the level-d cell of every row written (-1 = none). */
 /* f(x) (and gradient if grad_out != NULL): field.evaluate_f, models/loss.py:189-198. */
 int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx,
                     float* f_out, float* grad_out, void* stream);
@@ -210,33 +211,30 @@ int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_out);
 /* ---- matrix-free ("fused") operator and solve: reconstruct(..., fused_mode=True), examples/recons_waymo.py:33,
  *      recons_waymo_cpu.py:58, gis_app.py:40; KernelField.solve (csrc/fused.hip).  The system matrix is never built:
  *      y = (sum_s R_s^T R_s + reg I) x is applied from the dense-slot kernel rows, cell by cell. ------------------ */
-typedef struct {               /* a site set, as far as the work-item builder needs it */
-    int64_t n;                 /* sites (Morton-sorted)                                                     */
-    int32_t ncomp;             /* rows per site: 1 (position rows, G) or 3 (gradient rows, Q)               */
-    const int32_t* start[NKSR_MAX_DEPTH]; /* per level: [n_d] site range of every voxel                     */
-    const int32_t* end[NKSR_MAX_DEPTH];
-} nksr_fused_set_t;
 typedef struct {
-    int32_t depth, nsets, M, reserved;
-    int64_t rows_total;        /* rows of all sets (set 0 first); also the level stride of rows_all / row_cells */
-    int64_t set_rows[2];       /* rows of each set (sites x ncomp)                                           */
-    const float* rows_all;     /* LEVEL-MAJOR dense-slot rows [depth][rows_total][27], pre-multiplied by sqrt(w) (nksr_kernel_rows, level_stride) */
+    int32_t depth, M, n_multi, reserved;
+    int64_t rows_total;        /* rows of all site sets in ONE Morton-ordered list (level-0 key of the site; position rows 1 per site,
+                                * gradient rows 3 per site); also the level stride of rows_all / row_cells                   */
+    const float* rows_all;     /* LEVEL-MAJOR dense-slot rows [depth][rows_total][27], pre-multiplied by sqrt(w) (nksr_kernel_rows, level_stride, row_index) */
     const float* targets_all;  /* [rows_total] right-hand side values pre-multiplied by sqrt(w) (0 for rows without a target); may be NULL if unused */
-    const int32_t* row_cells;  /* [depth][rows_total] GLOBAL unknown index of the row's level-d cell, -1 = none (nksr_fused_tables) */
-    const int32_t* nbr32;      /* [M, 32]: [0..26] GLOBAL unknown index of every neighbour voxel or -1; [27 + s]: block base of (cell, set s) (nksr_fused_tables) */
-    const int32_t* offsets;    /* [M + 1] partial blocks of a cell = [offsets[j], offsets[j + 1]) (set 0's first)                 */
-    int64_t nblocks;           /* offsets[M]                                                                 */
-    uint64_t* nnz_counter;     /* device counter or NULL: nksr_fused_rhs_diag (diagonal pass) leaves the non-zero slots of rows_all here = the
+    const int32_t* row_cells;  /* [depth][rows_total] GLOBAL unknown index of the row's level-d cell, -1 = none (nksr_kernel_rows) */
+    const int32_t* nbr32;      /* [M, 32]: [0..26] GLOBAL unknown index of every neighbour voxel or -1; [27] block base, [28] single-block flag (nksr_fused_tables) */
+    const int32_t* offsets;    /* [M + 1] partial blocks of a cell = [offsets[j], offsets[j + 1])                             */
+    const int32_t* multi;      /* [n_multi] the cells with more than one block, ascending                                    */
+    int64_t nblocks;           /* offsets[M]                                                                                 */
+    uint64_t* nnz_counter;     /* device counter or NULL: nksr_fused_rhs_diag leaves the non-zero slots of rows_all here = the
                                 * stored entries of G and Q (roofline accounting) */
-    void* workspace;           /* nksr_fused_workspace_bytes(M, nblocks)                                     */
+    void* workspace;           /* nksr_fused_workspace_bytes(nblocks)                                                        */
+    float* cell_sums;          /* [M, 32] per-cell block sums, ZERO-INITIALISED by the caller                                */
 } nksr_fused_op_t;
-/* Work items are runs of 32 consecutive rows of a set; a cell whose rows touch k items owns k partial blocks.
- * counts_out [M + 1] (last entry 0) -> exclusive scan = offsets; then the tables of the operator. */
-int nksr_fused_block_counts(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, int32_t* counts_out, void* stream);
-int nksr_fused_tables(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, const int32_t* offsets, int32_t* nbr32_out,
-                      int32_t* row_cells_out, void* stream);
-size_t nksr_fused_workspace_bytes(int32_t M, int64_t nblocks);
-/* b = sum_s R_s^T t_s and diag = reg + sum_s diag(R_s^T R_s) (either may be NULL). */
+/* Work items are runs of 32 consecutive rows; a cell whose rows touch k items owns k partial blocks.
+ * nksr_fused_block_counts: span_out [2, M] (first / last row of every cell, -1 = none), counts_out [M + 1] (last entry 0) ->
+ * exclusive scan = offsets -> nksr_fused_tables. */
+int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_total, const int32_t* row_cells, int32_t* span_out, int32_t* counts_out,
+                            void* stream);
+int nksr_fused_tables(const nksr_hier_t* h, const int32_t* offsets, const int32_t* span, int32_t* nbr32_out, void* stream);
+size_t nksr_fused_workspace_bytes(int64_t nblocks);
+/* b = sum_s R_s^T t_s and diag = reg + sum_s diag(R_s^T R_s) (either may be NULL): one sweep over the rows serves both. */
 int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* b_out, float* diag_out, void* stream);
 /* y = (sum_s R_s^T R_s + reg I) x */
 int nksr_fused_apply(const nksr_fused_op_t* op, float reg, const float* x, float* y, void* stream);

@@ -23,14 +23,10 @@ class HierT(C.Structure):
     _fields_ = [('depth', _i32), ('kdim', _i32), ('hidden', _i32), ('inv_w0', _f32), ('lv', LevelT * MAX_DEPTH)]
 
 
-class FusedSetT(C.Structure):
-    _fields_ = [('n', _i64), ('ncomp', _i32), ('start', _vp * MAX_DEPTH), ('end', _vp * MAX_DEPTH)]
-
-
 class FusedOpT(C.Structure):
-    _fields_ = [('depth', _i32), ('nsets', _i32), ('M', _i32), ('reserved', _i32), ('rows_total', _i64), ('set_rows', _i64 * 2),
-                ('rows_all', _vp), ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('offsets', _vp), ('nblocks', _i64),
-                ('nnz_counter', _vp), ('workspace', _vp)]
+    _fields_ = [('depth', _i32), ('M', _i32), ('n_multi', _i32), ('reserved', _i32), ('rows_total', _i64), ('rows_all', _vp),
+                ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('offsets', _vp), ('multi', _vp), ('nblocks', _i64),
+                ('nnz_counter', _vp), ('workspace', _vp), ('cell_sums', _vp)]
 
 
 class SiteSetT(C.Structure):
@@ -61,7 +57,7 @@ lib.nksr_assemble_workspace_bytes.argtypes = [C.POINTER(HierT)]
 lib.nksr_spmv_workspace_bytes.restype = _sz
 lib.nksr_spmv_workspace_bytes.argtypes = [_i64]
 lib.nksr_fused_workspace_bytes.restype = _sz
-lib.nksr_fused_workspace_bytes.argtypes = [_i32, _i64]
+lib.nksr_fused_workspace_bytes.argtypes = [_i64]
 lib.nksr_pcg_vector_workspace_bytes.restype = _sz
 lib.nksr_pcg_vector_workspace_bytes.argtypes = [_i32]
 
@@ -92,7 +88,7 @@ _PROTOS = {
     'nksr_splat_plane': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp],
     'nksr_udf_decode': [_P(LevelT), C.c_int, _vp, _vp, _i64, _f32, _f32, C.c_int, _vp, _vp],
     'nksr_voxel_psi': [_vp, _i32, C.c_int, C.c_int, _vp, _vp, _vp],
-    'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _f32, _i64, _vp, _vp, _vp],
+    'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _f32, _i64, _vp, _vp, _vp, _vp, _vp],
     'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, _vp, _vp, _vp],
     'nksr_assemble_count': [_P(HierT), _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -102,8 +98,8 @@ _PROTOS = {
     'nksr_pack_cols21': [_vp, _i64, _vp, _vp],
     'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _vp, _vp],
     'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
-    'nksr_fused_block_counts': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp],
-    'nksr_fused_tables': [_P(HierT), _P(FusedSetT), C.c_int, _vp, _vp, _vp, _vp],
+    'nksr_fused_block_counts': [_i32, _i32, _i64, _vp, _vp, _vp, _vp],
+    'nksr_fused_tables': [_P(HierT), _vp, _vp, _vp, _vp],
     'nksr_fused_rhs_diag': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],

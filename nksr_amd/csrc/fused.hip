@@ -26,36 +26,26 @@
 
 #define FZ_RC 32
 #define FZ_BLOCK 256
-#define FZ_MAX_SETS 2
 
 // ---- tables ----------------------------------------------------------------------------------------------------------------
-struct SetupArgs {
-    nksr_hier_t hier;
-    nksr_fused_set_t sets[FZ_MAX_SETS];
-    int nsets;
-    int M;
-    int64_t row_off[FZ_MAX_SETS];
-    int64_t rows_total;
-};
+// All they need is row_cells[d][r] (written by nksr_kernel_rows next to the rows): the rows of a cell are one contiguous run.
+// span[0][j] / span[1][j]: first / last row of cell j (-1 = the cell has no rows)
+__global__ void k_fz_spans(int depth, int64_t rows_total, const int32_t* __restrict__ row_cells, int32_t* __restrict__ first,
+                           int32_t* __restrict__ last) {
+    const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lin >= rows_total * depth) return;
+    const int64_t r = lin % rows_total;
+    const int c = row_cells[lin];
+    if (c < 0) return;
+    if (r == 0 || row_cells[lin - 1] != c) first[c] = (int32_t)r;
+    if (r == rows_total - 1 || row_cells[lin + 1] != c) last[c] = (int32_t)r;
+}
 
-static int fz_setup_args(SetupArgs& A, const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets) {
-    if (!h || !sets) return nksr_set_error(NKSR_ERR_ARG, "hierarchy / site sets are NULL");
-    if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
-    if (nsets < 1 || nsets > FZ_MAX_SETS) return nksr_set_error(NKSR_ERR_ARG, "1..%d site sets", FZ_MAX_SETS);
-    memset(&A, 0, sizeof(A));
-    A.hier = *h;
-    A.nsets = nsets;
-    A.M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
-    int64_t rows = 0;
-    for (int s = 0; s < nsets; ++s) {
-        if (sets[s].ncomp != 1 && sets[s].ncomp != 3) return nksr_set_error(NKSR_ERR_ARG, "ncomp must be 1 or 3");
-        A.sets[s] = sets[s];
-        A.row_off[s] = rows;
-        rows += sets[s].n * sets[s].ncomp;
-    }
-    A.rows_total = rows;
-    if (rows >= ((int64_t)1 << 31) - 64) return nksr_set_error(NKSR_ERR_CAPACITY, "site sets too large");
-    return NKSR_OK;
+// partial blocks of a cell: one per 32-row item its rows touch
+__global__ void k_fz_block_counts(int M, const int32_t* __restrict__ first, const int32_t* __restrict__ last, int32_t* __restrict__ counts) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > M) return;
+    counts[j] = (j < M && first[j] >= 0) ? last[j] / FZ_RC - first[j] / FZ_RC + 1 : 0;
 }
 
 __device__ __forceinline__ int fz_level(const nksr_hier_t& h, int j) {
@@ -64,59 +54,24 @@ __device__ __forceinline__ int fz_level(const nksr_hier_t& h, int j) {
     return d;
 }
 
-// partial blocks of (cell, set): one per 32-row item its row range [r0, r1) touches
-__device__ __forceinline__ int fz_cell_blocks(const nksr_fused_set_t& S, int d, int c, int& first_item) {
-    const int r0 = S.start[d][c] * S.ncomp, r1 = S.end[d][c] * S.ncomp;
-    first_item = r0 / FZ_RC;
-    return r1 > r0 ? (r1 - 1) / FZ_RC - first_item + 1 : 0;
-}
-
-__global__ void k_fz_block_counts(SetupArgs A, int32_t* __restrict__ counts) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > A.M) return;
-    if (j == A.M) { counts[j] = 0; return; }
-    const int d = fz_level(A.hier, j), c = j - A.hier.lv[d].offset;
-    int n = 0, fi;
-    for (int s = 0; s < A.nsets; ++s) n += fz_cell_blocks(A.sets[s], d, c, fi);
-    counts[j] = n;
-}
-
-// nbr32[j][0..26]: global unknown index of the neighbour voxels or -1;  [27 + s]: (first block of (j, set s)) - (first item of
-// the cell in set s), so that the block of item i is  nbr32[j][27 + s] + i
-__global__ void k_fz_tables(SetupArgs A, const int32_t* __restrict__ offsets, int32_t* __restrict__ nbr32) {
+// nbr32[j][0..26]: global unknown index of the neighbour voxels or -1;  [27]: (first block of j) - (first item of j), so that the
+// block of item i is nbr32[j][27] + i;  [28]: 1 if the cell owns exactly one block
+__global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__ offsets, const int32_t* __restrict__ first,
+                            int32_t* __restrict__ nbr32) {
     const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin >= (int64_t)A.M * 32) return;
+    if (lin >= (int64_t)M * 32) return;
     const int j = (int)(lin >> 5), s = (int)(lin & 31);
-    const int d = fz_level(A.hier, j), c = j - A.hier.lv[d].offset;
     int v = 0;
     if (s < 27) {
-        const int nb = A.hier.lv[d].nbr[(int64_t)c * 27 + s];
-        v = nb >= 0 ? nb + A.hier.lv[d].offset : -1;
-    } else if (s - 27 < A.nsets) {
-        int base = offsets[j], fi;
-        for (int q = 0; q < s - 27; ++q) base += fz_cell_blocks(A.sets[q], d, c, fi);
-        fz_cell_blocks(A.sets[s - 27], d, c, fi);
-        v = base - fi;
+        const int d = fz_level(hier, j), c = j - hier.lv[d].offset;
+        const int nb = hier.lv[d].nbr[(int64_t)c * 27 + s];
+        v = nb >= 0 ? nb + hier.lv[d].offset : -1;
+    } else if (s == 27) {
+        v = offsets[j] - (first[j] >= 0 ? first[j] / FZ_RC : 0);
+    } else if (s == 28) {
+        v = offsets[j + 1] - offsets[j] == 1;     // the cell's only block: the operator writes it straight into the per-cell sums
     }
     nbr32[lin] = v;
-}
-
-// row_cells[d][r]: global unknown index of the level-d cell of row r, -1 where the site lies in no active level-d voxel
-__global__ void k_fz_row_cells(SetupArgs A, int set, int32_t* __restrict__ row_cells) {
-    const nksr_fused_set_t& S = A.sets[set];
-    const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin >= S.n * A.hier.depth) return;
-    const int d = (int)(lin / S.n), site = (int)(lin - (int64_t)d * S.n);
-    const int n = A.hier.lv[d].n;
-    const int32_t* __restrict__ en = S.end[d];
-    int lo = 0, hi = n;                          // first cell whose range ends after the site (ranges are monotone: Morton order)
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (en[mid] > site) hi = mid; else lo = mid + 1;
-    }
-    const int j = (lo < n && S.start[d][lo] <= site) ? A.hier.lv[d].offset + lo : -1;
-    int32_t* out = row_cells + (int64_t)d * A.rows_total + A.row_off[set] + (int64_t)site * S.ncomp;
-    for (int k = 0; k < S.ncomp; ++k) out[k] = j;
 }
 
 // ---- the operator ----------------------------------------------------------------------------------------------------------
@@ -126,11 +81,11 @@ struct FusedArgs {               // uniform scalars and base pointers only
     const int32_t* row_cells;    // [depth][rows_total]
     const int32_t* nbr32;        // [M][32]
     const int32_t* offsets;      // [M + 1] blocks of a cell
-    int nsets, M, depth;
-    int hw_set0, hw_total;       // half-waves (items, rounded up to whole wavefronts per set)
+    const int32_t* multi;        // cells with more than one block
+    int n_multi, M, depth;
+    int hw_total;                // half-waves = items, rounded up to whole wavefronts
     int64_t rows_total, nblocks;
-    int64_t set_rows[FZ_MAX_SETS], row_off[FZ_MAX_SETS];
-    unsigned long long* nnz_counter;   // MODE 2 adds the non-zero slots it sees (may be NULL)
+    unsigned long long* nnz_counter;   // the set-up pass (MODE 1) adds the non-zero slots it sees (may be NULL)
 };
 
 __device__ __forceinline__ float half_sum(float p) {      // sum over the 32 lanes of this half-wave, fixed tree
@@ -180,24 +135,30 @@ __device__ __forceinline__ float half_sum2(float p0, float p1, int lane) {
     return r;
 }
 
-// MODE 0: operator (t from x), 1: right-hand side (t = target), 2: Jacobi diagonal (P += rows^2).
+// where the block of the current cell goes: the cell's block base (then block = base + item; the base may be negative) or, in
+// MODE 0 for a cell with a single block, the cell's row of the per-cell sums (direct = true, base = the cell)
+template <int MODE>
+__device__ __forceinline__ int fz_block_base(int nbrow, int cell, bool& direct) {
+    direct = MODE == 0 && __shfl(nbrow, 28, 32) != 0;
+    return direct ? cell : __shfl(nbrow, 27, 32);
+}
+
+// MODE 0: the operator (t from x).  MODE 1: the set-up pass -- right-hand side (t = target) into `part`, Jacobi diagonal
+// (P2 += rows^2) into `part2`, and the count of non-zero slots, all in one sweep over the rows.
 // U rows per trip.  Levels < NG (the fine ones, where a cell holds a handful of rows) fetch the stencil of EVERY row (neighbour
 // row, then 27 x values: the loads of a trip go out together, nothing to decide); levels >= NG keep the stencil of their current
 // cell in registers and refresh it on the rare trip that crosses a cell boundary -- that trip is processed in two parts, before
 // and after the refresh.  Which rows change cell / have a cell at all is known up front as two 32-bit masks per level.
 template <int MODE, int D, int U, int NG>
 __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
-                                                      const int* __restrict__ done) {
+                                                      float* __restrict__ part2, float* __restrict__ cellp, const int* __restrict__ done) {
     if (done && *done) return;
     constexpr int G = NG < D ? NG : D;                               // levels that gather per row
-    const int hw = (blockIdx.x * FZ_BLOCK + threadIdx.x) >> 5;
-    if (hw >= A.hw_total) return;                                    // whole wavefronts: hw_total is even
-    const int set = hw >= A.hw_set0 ? 1 : 0;                         // uniform per wavefront: hw_set0 is even
-    const int item = hw - (set ? A.hw_set0 : 0);
-    const int64_t rs = (int64_t)item * FZ_RC;
-    const int64_t left = A.set_rows[set] - rs;
+    const int item = (blockIdx.x * FZ_BLOCK + threadIdx.x) >> 5;
+    if (item >= A.hw_total) return;                                  // whole wavefronts: hw_total is even
+    const int64_t R0 = (int64_t)item * FZ_RC;
+    const int64_t left = A.rows_total - R0;
     const int nrows = left >= FZ_RC ? FZ_RC : (left > 0 ? (int)left : 0);
-    const int64_t R0 = A.row_off[set] + rs;
     const int s = threadIdx.x & 31;
     const bool act = s < 27, upper = (threadIdx.x & 32) != 0;
     const int sh = upper ? 32 : 0;
@@ -211,12 +172,13 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
         chg[d] = (unsigned)(__ballot(cells[d] != (s ? before : -1)) >> sh);
         pos[d] = (unsigned)(__ballot(cells[d] >= 0) >> sh);
     }
-    const float tg = (MODE == 1 && s < nrows) ? A.targets_all[R0 + s] : 0.f;
-    int fb[D];
-    float P[D], xs[D];
+    const float tg = (MODE == 1 && A.targets_all && s < nrows) ? A.targets_all[R0 + s] : 0.f;
+    int fb[D];                       // block base of the current cell (or the cell itself: direct[d])
+    bool direct[D];
+    float P[D], P2[MODE == 1 ? D : 1], xs[D];
     bool have[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) { fb[d] = 0; P[d] = 0.f; xs[d] = 0.f; have[d] = false; }
+    for (int d = 0; d < D; ++d) { fb[d] = 0; direct[d] = false; P[d] = 0.f; P2[MODE == 1 ? d : 0] = 0.f; xs[d] = 0.f; have[d] = false; }
     // coarse levels: the stencils of the item's first row, all levels in one round trip (then one more for x)
     {
         int c0[D], nb0[D];
@@ -231,14 +193,14 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
 #pragma unroll
         for (int d = G; d < D; ++d) {
             have[d] = c0[d] >= 0;
-            fb[d] = __shfl(nb0[d], 27 + set, 32);
+            fb[d] = fz_block_base<MODE>(nb0[d], c0[d], direct[d]);
             xs[d] = (have[d] && act && nb0[d] >= 0) ? x0[d] : 0.f;
             chg[d] &= ~1u;
         }
     }
     const int nlo = __builtin_amdgcn_readlane(nrows, 0), nhi = __builtin_amdgcn_readlane(nrows, 32);
     const int nmax = nlo > nhi ? nlo : nhi;
-    int nnz = 0;                                                     // MODE 2: stored entries of G and Q (roofline accounting)
+    int nnz = 0;                                                     // MODE 1: this lane's non-zero slots (stored entries of G and Q)
     // the neighbour rows of the fine levels are requested one trip ahead: with them in hand all loads of a trip (kernel rows, x
     // stencils, the next trip's neighbour rows) are independent -- one memory round trip per trip instead of two
     // (all loads of the row loop are UNCONDITIONAL -- clamped addresses, results masked afterwards: a load under a branch makes
@@ -268,7 +230,7 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
 #pragma unroll
             for (int d = 0; d < G; ++d) {
                 nb[u][d] = nbn[u][d];
-                xg[u][d] = MODE == 0 ? x[nb[u][d] >= 0 ? nb[u][d] : 0] : 0.f;
+                xg[u][d] = MODE == 0 ? x[(act && nb[u][d] >= 0) ? nb[u][d] : 0] : 0.f;      // (lanes 27.. of a neighbour row are not x indices)
             }
         {
             const int nr = rr + U < 32 ? rr + U : 0;                  // (the last trip's request is a harmless repeat)
@@ -288,9 +250,9 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
             for (int d = 0; d < D; ++d) w[u][d] = ok ? w[u][d] : 0.f;
 #pragma unroll
             for (int d = 0; d < G; ++d) xg[u][d] = (ok && nb[u][d] >= 0) ? xg[u][d] : 0.f;
-            if (MODE == 2) {
+            if (MODE == 1) {
 #pragma unroll
-                for (int d = 0; d < D; ++d) nnz += __popcll(__ballot(w[u][d] != 0.f));
+                for (int d = 0; d < D; ++d) nnz += w[u][d] != 0.f ? 1 : 0;
             }
         }
         // rows of the trip that cross a cell boundary of a level >= NG: the trip is cut there
@@ -305,13 +267,14 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
 #pragma unroll
                 for (int d = G; d < D; ++d)
                     if ((chg[d] >> (rr + from)) & 1u) {
-                        if (have[d]) part[((int64_t)fb[d] + item) * 32 + s] = P[d];
+                        if (have[d]) { (direct[d] ? cellp + (int64_t)fb[d] * 32 : part + ((int64_t)fb[d] + item) * 32)[s] = P[d]; if (MODE == 1) part2[((int64_t)fb[d] + item) * 32 + s] = P2[d]; }
                         P[d] = 0.f;
+                        if (MODE == 1) P2[d] = 0.f;
                         xs[d] = 0.f;
                         have[d] = (pos[d] >> (rr + from)) & 1u;
                         if (have[d]) {
                             const int nbv = A.nbr32[(int64_t)__shfl(cells[d], (rr + from) & 31, 32) * 32 + s];      // `from` differs between the halves: no scalar lane read here
-                            fb[d] = __shfl(nbv, 27 + set, 32);
+                            fb[d] = fz_block_base<MODE>(nbv, __shfl(cells[d], (rr + from) & 31, 32), direct[d]);
                             if (MODE == 0 && act && nbv >= 0) xs[d] = x[nbv];
                         }
                     }
@@ -347,12 +310,16 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     if (d < G && in && ((chg[d] >> (rr + u)) & 1u)) {      // fine levels: the block leaves with its cell
-                        if (have[d]) part[((int64_t)fb[d] + item) * 32 + s] = P[d];
+                        if (have[d]) { (direct[d] ? cellp + (int64_t)fb[d] * 32 : part + ((int64_t)fb[d] + item) * 32)[s] = P[d]; if (MODE == 1) part2[((int64_t)fb[d] + item) * 32 + s] = P2[d]; }
                         P[d] = 0.f;
+                        if (MODE == 1) P2[d] = 0.f;
                         have[d] = (pos[d] >> (rr + u)) & 1u;
-                        if (have[d]) fb[d] = __shfl(nb[u][d < G ? d : 0], 27 + set, 32);
+                        if (have[d]) fb[d] = fz_block_base<MODE>(nb[u][d < G ? d : 0], half_lane_i(cells[d], (rr + u) & 31, upper), direct[d]);
                     }
-                    if (in && have[d]) P[d] = MODE == 2 ? fmaf(w[u][d], w[u][d], P[d]) : fmaf(w[u][d], t[u], P[d]);
+                    if (in && have[d]) {
+                        P[d] = fmaf(w[u][d], t[u], P[d]);
+                        if (MODE == 1) P2[d] = fmaf(w[u][d], w[u][d], P2[d]);
+                    }
                 }
             }
             if (to >= U) break;
@@ -361,27 +328,37 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
     }
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (have[d]) part[((int64_t)fb[d] + item) * 32 + s] = P[d];
-    if (MODE == 2 && A.nnz_counter && (threadIdx.x & 63) == 0 && nnz) atomicAdd(A.nnz_counter, (unsigned long long)nnz);   // integer: order-free
+        if (have[d]) { (direct[d] ? cellp + (int64_t)fb[d] * 32 : part + ((int64_t)fb[d] + item) * 32)[s] = P[d]; if (MODE == 1) part2[((int64_t)fb[d] + item) * 32 + s] = P2[d]; }
+    if (MODE == 1 && A.nnz_counter) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o);
+        if ((threadIdx.x & 63) == 0 && nnz) atomicAdd(A.nnz_counter, (unsigned long long)nnz);           // integer: order-free
+    }
 }
 
-// C[c][s] = sum of the partial blocks of cell c (a cell has one block per 32-row item its rows touch and per site set: 1.6 on
-// average, hundreds for a coarse cell): one coalesced pass over the blocks, so that the gather below reads exactly one block
-// per neighbour.  A half-wave takes FOUR cells at once (lane = slot): the pass is latency-bound, the first two blocks of the
-// four cells are requested together.  Fixed order.
+// C[c][s] = sum of the partial blocks of cell c (one block per 32-row item the cell's rows touch: mostly one, hundreds for a
+// coarse cell), so that the gather below reads exactly one block per neighbour.  LIST: only the cells with more than one block
+// (A.multi) -- inside the operator the sweep writes single-block cells straight into C.  A half-wave takes FOUR cells at once
+// (lane = slot): the pass is latency-bound, the first two blocks of the four cells are requested together.  Fixed order.
 #define FZ_GI 4
+template <bool LIST>
 __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __restrict__ part, float* __restrict__ cellp,
                                                    const int* __restrict__ done) {
     if (done && *done) return;
-    const int j0 = ((blockIdx.x * 256 + threadIdx.x) >> 5) * FZ_GI;
-    if (j0 >= A.M) return;
+    const int ncell = LIST ? A.n_multi : A.M;
+    const int i0 = ((blockIdx.x * 256 + threadIdx.x) >> 5) * FZ_GI;
+    if (i0 >= ncell) return;
     const int s = threadIdx.x & 31;
-    int b0[FZ_GI], n[FZ_GI];
+    int cell[FZ_GI], b0[FZ_GI], n[FZ_GI];
 #pragma unroll
     for (int k = 0; k < FZ_GI; ++k) {
-        const int j = j0 + k < A.M ? j0 + k : A.M - 1;
-        b0[k] = A.offsets[j];
-        n[k] = j0 + k < A.M ? A.offsets[j + 1] - b0[k] : 0;
+        const int i = i0 + k < ncell ? i0 + k : ncell - 1;
+        cell[k] = LIST ? A.multi[i] : i;
+    }
+#pragma unroll
+    for (int k = 0; k < FZ_GI; ++k) {
+        b0[k] = A.offsets[cell[k]];
+        n[k] = i0 + k < ncell ? A.offsets[cell[k] + 1] - b0[k] : 0;
     }
     float acc[FZ_GI], a1[FZ_GI];
 #pragma unroll
@@ -396,7 +373,7 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
         int b = 2;
         for (; b + 4 <= n[k]; b += 4, p += 128) acc[k] += (p[0] + p[32]) + (p[64] + p[96]);
         for (; b < n[k]; ++b, p += 32) acc[k] += p[0];
-        if (j0 + k < A.M) cellp[(int64_t)(j0 + k) * 32 + s] = acc[k];
+        if (i0 + k < ncell) cellp[(int64_t)cell[k] * 32 + s] = acc[k];
     }
 }
 
@@ -431,33 +408,39 @@ static void fz_gather_dims(int M, dim3& grid, int& per_xcd) {
 
 static size_t fz_align(size_t v) { return (v + 255) / 256 * 256; }
 
-struct FusedWork { float* part; float* cellp; };      // [nblocks][32] partial blocks, [M][32] their per-cell sums
-extern "C" size_t nksr_fused_workspace_bytes(int32_t M, int64_t nblocks) {
-    return fz_align((size_t)(nblocks > 0 ? nblocks : 1) * 32 * sizeof(float)) + fz_align((size_t)(M > 0 ? M : 1) * 32 * sizeof(float));
-}
-static FusedWork fz_carve(void* ws, int64_t nblocks) {
+struct FusedWork { float* part; float* part2; float* cellp; };   // [nblocks][32] partial blocks (x 2: the set-up pass makes two), [M][32] per-cell sums
+static size_t fz_blocks_bytes(int64_t nblocks) { return fz_align((size_t)(nblocks > 0 ? nblocks : 1) * 32 * sizeof(float)); }
+extern "C" size_t nksr_fused_workspace_bytes(int64_t nblocks) { return 2 * fz_blocks_bytes(nblocks); }
+static FusedWork fz_carve(const nksr_fused_op_t* op) {
     FusedWork w;
-    w.part = (float*)ws;
-    w.cellp = (float*)((char*)ws + fz_align((size_t)(nblocks > 0 ? nblocks : 1) * 32 * sizeof(float)));
+    w.part = (float*)op->workspace;
+    w.part2 = (float*)((char*)op->workspace + fz_blocks_bytes(op->nblocks));
+    w.cellp = op->cell_sums;
     return w;
 }
 
-extern "C" int nksr_fused_block_counts(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, int32_t* counts_out, void* stream) {
-    SetupArgs A;
-    if (int rc = fz_setup_args(A, h, sets, nsets)) return rc;
-    hipLaunchKernelGGL(k_fz_block_counts, dim3(nksr_blocks((int64_t)A.M + 1, 256)), dim3(256), 0, (hipStream_t)stream, A, counts_out);
+extern "C" int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_total, const int32_t* row_cells, int32_t* span_out,
+                                       int32_t* counts_out, void* stream) {
+    if (depth < 1 || depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", depth);
+    if (M <= 0) return NKSR_OK;
+    if (rows_total < 0 || rows_total >= ((int64_t)1 << 31) - 64) return nksr_set_error(NKSR_ERR_CAPACITY, "too many kernel rows");
+    if (!span_out || !counts_out || (rows_total > 0 && !row_cells)) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    hipStream_t st = (hipStream_t)stream;
+    NKSR_CHECK_HIP(hipMemsetAsync(span_out, 0xFF, (size_t)2 * M * sizeof(int32_t), st));
+    if (rows_total > 0)
+        hipLaunchKernelGGL(k_fz_spans, dim3(nksr_blocks(rows_total * depth, 256)), dim3(256), 0, st, depth, rows_total, row_cells, span_out, span_out + M);
+    hipLaunchKernelGGL(k_fz_block_counts, dim3(nksr_blocks((int64_t)M + 1, 256)), dim3(256), 0, st, M, (const int32_t*)span_out,
+                       (const int32_t*)(span_out + M), counts_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
 
-extern "C" int nksr_fused_tables(const nksr_hier_t* h, const nksr_fused_set_t* sets, int nsets, const int32_t* offsets, int32_t* nbr32_out,
-                                 int32_t* row_cells_out, void* stream) {
-    SetupArgs A;
-    if (int rc = fz_setup_args(A, h, sets, nsets)) return rc;
-    if (A.M > 0) hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)A.M * 32, 256)), dim3(256), 0, (hipStream_t)stream, A, offsets, nbr32_out);
-    for (int s = 0; s < nsets; ++s)
-        if (A.sets[s].n > 0)
-            hipLaunchKernelGGL(k_fz_row_cells, dim3(nksr_blocks(A.sets[s].n * A.hier.depth, 256)), dim3(256), 0, (hipStream_t)stream, A, s, row_cells_out);
+extern "C" int nksr_fused_tables(const nksr_hier_t* h, const int32_t* offsets, const int32_t* span, int32_t* nbr32_out, void* stream) {
+    if (!h || h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad hierarchy");
+    const int M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
+    if (M <= 0) return NKSR_OK;
+    if (!offsets || !span || !nbr32_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)M * 32, 256)), dim3(256), 0, (hipStream_t)stream, *h, M, offsets, span, nbr32_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -465,31 +448,18 @@ extern "C" int nksr_fused_tables(const nksr_hier_t* h, const nksr_fused_set_t* s
 static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
     if (!op) return nksr_set_error(NKSR_ERR_ARG, "operator is NULL");
     if (op->depth < 1 || op->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", op->depth);
-    if (op->nsets < 1 || op->nsets > FZ_MAX_SETS) return nksr_set_error(NKSR_ERR_ARG, "1..%d site sets", FZ_MAX_SETS);
-    if (op->M > 0 && (!op->rows_all || !op->row_cells || !op->nbr32 || !op->offsets || !op->workspace))
+    if (op->M > 0 && (!op->rows_all || !op->row_cells || !op->nbr32 || !op->offsets || !op->workspace || !op->cell_sums ||
+                      (op->n_multi > 0 && !op->multi)))
         return nksr_set_error(NKSR_ERR_ARG, "operator has NULL arrays");
-    int64_t rows = 0;
-    for (int s = 0; s < op->nsets; ++s) {
-        if (op->set_rows[s] < 0) return nksr_set_error(NKSR_ERR_ARG, "negative row count");
-        rows += op->set_rows[s];
-    }
-    if (rows != op->rows_total) return nksr_set_error(NKSR_ERR_ARG, "set_rows do not add up to rows_total");
-    if (op->rows_total >= ((int64_t)1 << 31) - 64 || op->nblocks >= ((int64_t)1 << 31) - ((int64_t)1 << 26))
+    if (op->rows_total < 0 || op->rows_total >= ((int64_t)1 << 31) - 64 || op->nblocks >= ((int64_t)1 << 31) - ((int64_t)1 << 26))
         return nksr_set_error(NKSR_ERR_CAPACITY, "operator too large");
     memset(&A, 0, sizeof(A));
     A.rows_all = op->rows_all; A.targets_all = op->targets_all; A.row_cells = op->row_cells; A.nbr32 = op->nbr32; A.offsets = op->offsets;
-    A.nsets = op->nsets; A.M = op->M; A.depth = op->depth; A.rows_total = op->rows_total; A.nblocks = op->nblocks;
+    A.multi = op->multi; A.n_multi = op->n_multi;
+    A.M = op->M; A.depth = op->depth; A.rows_total = op->rows_total; A.nblocks = op->nblocks;
     A.nnz_counter = (unsigned long long*)op->nnz_counter;
-    int64_t off = 0, hw = 0;
-    for (int s = 0; s < op->nsets; ++s) {
-        A.set_rows[s] = op->set_rows[s];
-        A.row_off[s] = off;
-        off += op->set_rows[s];
-        const int64_t items = (op->set_rows[s] + FZ_RC - 1) / FZ_RC;
-        hw += (items + 1) / 2 * 2;
-        if (s == 0) A.hw_set0 = (int)hw;
-    }
-    A.hw_total = (int)hw;
+    const int64_t items = (op->rows_total + FZ_RC - 1) / FZ_RC;
+    A.hw_total = (int)((items + 1) / 2 * 2);
     return NKSR_OK;
 }
 
@@ -506,27 +476,27 @@ static int fz_variant() {
 }
 
 template <int MODE, int U, int NG>
-static void fz_sweep_v(const FusedArgs& A, const float* x, float* part, const int* done, hipStream_t st) {
+static void fz_sweep_v(const FusedArgs& A, const float* x, float* part, float* part2, float* cellp, const int* done, hipStream_t st) {
     const dim3 grid(nksr_blocks((int64_t)A.hw_total * 32, FZ_BLOCK)), blk(FZ_BLOCK);
     switch (A.depth) {
-        case 1: hipLaunchKernelGGL((k_fz_sweep<MODE, 1, U, NG>), grid, blk, 0, st, A, x, part, done); break;
-        case 2: hipLaunchKernelGGL((k_fz_sweep<MODE, 2, U, NG>), grid, blk, 0, st, A, x, part, done); break;
-        case 3: hipLaunchKernelGGL((k_fz_sweep<MODE, 3, U, NG>), grid, blk, 0, st, A, x, part, done); break;
-        case 4: hipLaunchKernelGGL((k_fz_sweep<MODE, 4, U, NG>), grid, blk, 0, st, A, x, part, done); break;
-        case 5: hipLaunchKernelGGL((k_fz_sweep<MODE, 5, U, NG>), grid, blk, 0, st, A, x, part, done); break;
-        default: hipLaunchKernelGGL((k_fz_sweep<MODE, 6, U, NG>), grid, blk, 0, st, A, x, part, done); break;
+        case 1: hipLaunchKernelGGL((k_fz_sweep<MODE, 1, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
+        case 2: hipLaunchKernelGGL((k_fz_sweep<MODE, 2, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
+        case 3: hipLaunchKernelGGL((k_fz_sweep<MODE, 3, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
+        case 4: hipLaunchKernelGGL((k_fz_sweep<MODE, 4, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
+        case 5: hipLaunchKernelGGL((k_fz_sweep<MODE, 5, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
+        default: hipLaunchKernelGGL((k_fz_sweep<MODE, 6, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
     }
 }
 
 template <int MODE>
-static void fz_sweep(const FusedArgs& A, const float* x, float* part, const int* done, hipStream_t st) {
+static void fz_sweep(const FusedArgs& A, const float* x, float* part, float* part2, float* cellp, const int* done, hipStream_t st) {
     if (A.hw_total <= 0) return;
-    if (MODE != 0) { fz_sweep_v<MODE, 4, 1>(A, x, part, done, st); return; }
+    if (MODE != 0) { fz_sweep_v<MODE, 4, 1>(A, x, part, part2, cellp, done, st); return; }
     switch (fz_variant()) {
-        case 0: fz_sweep_v<MODE, 4, 1>(A, x, part, done, st); break;
-        case 1: fz_sweep_v<MODE, 2, 1>(A, x, part, done, st); break;
-        case 2: fz_sweep_v<MODE, 4, 2>(A, x, part, done, st); break;
-        default: fz_sweep_v<MODE, 2, 2>(A, x, part, done, st); break;
+        case 0: fz_sweep_v<MODE, 4, 1>(A, x, part, part2, cellp, done, st); break;
+        case 1: fz_sweep_v<MODE, 2, 1>(A, x, part, part2, cellp, done, st); break;
+        case 2: fz_sweep_v<MODE, 4, 2>(A, x, part, part2, cellp, done, st); break;
+        default: fz_sweep_v<MODE, 2, 2>(A, x, part, part2, cellp, done, st); break;
     }
 }
 
@@ -534,8 +504,9 @@ static int fz_apply(const FusedArgs& A, float reg, const FusedWork& w, const flo
     dim3 gg;
     int per_xcd;
     fz_gather_dims(A.M, gg, per_xcd);
-    fz_sweep<0>(A, x, w.part, done, st);
-    hipLaunchKernelGGL(k_fz_cellsum, dim3(nksr_blocks(((int64_t)A.M + FZ_GI - 1) / FZ_GI * 32, 256)), dim3(256), 0, st, A, (const float*)w.part, w.cellp, done);
+    fz_sweep<0>(A, x, w.part, nullptr, w.cellp, done, st);
+    if (A.n_multi > 0)
+        hipLaunchKernelGGL(k_fz_cellsum<true>, dim3(nksr_blocks(((int64_t)A.n_multi + FZ_GI - 1) / FZ_GI * 32, 256)), dim3(256), 0, st, A, (const float*)w.part, w.cellp, done);
     hipLaunchKernelGGL((k_fz_gather<0>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.cellp, x, reg, y, done);
     return NKSR_OK;
 }
@@ -544,7 +515,7 @@ extern "C" int nksr_fused_apply(const nksr_fused_op_t* op, float reg, const floa
     FusedArgs A;
     if (int rc = fz_args(A, op)) return rc;
     if (A.M <= 0) return NKSR_OK;
-    fz_apply(A, reg, fz_carve(op->workspace, A.nblocks), x, y, nullptr, (hipStream_t)stream);
+    fz_apply(A, reg, fz_carve(op), x, y, nullptr, (hipStream_t)stream);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -553,7 +524,7 @@ extern "C" int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* 
     FusedArgs A;
     if (int rc = fz_args(A, op)) return rc;
     if (A.M <= 0) return NKSR_OK;
-    const FusedWork w = fz_carve(op->workspace, A.nblocks);
+    const FusedWork w = fz_carve(op);
     hipStream_t st = (hipStream_t)stream;
     const dim3 gm(nksr_blocks(((int64_t)A.M + FZ_GI - 1) / FZ_GI * 32, 256));
     dim3 gg;
@@ -561,16 +532,17 @@ extern "C" int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* 
     fz_gather_dims(A.M, gg, per_xcd);
     const float* nof = nullptr;
     const int* nod = nullptr;
+    if (b_out && !A.targets_all) return nksr_set_error(NKSR_ERR_ARG, "targets_all is NULL");
+    if (!b_out && !diag_out) return NKSR_OK;
+    // one sweep over the rows makes the blocks of both (and counts the stored entries)
+    if (A.nnz_counter) (void)hipMemsetAsync(A.nnz_counter, 0, sizeof(unsigned long long), st);
+    fz_sweep<1>(A, nof, w.part, w.part2, nullptr, nod, st);
     if (b_out) {
-        if (!A.targets_all) return nksr_set_error(NKSR_ERR_ARG, "targets_all is NULL");
-        fz_sweep<1>(A, nof, w.part, nod, st);
-        hipLaunchKernelGGL(k_fz_cellsum, gm, dim3(256), 0, st, A, (const float*)w.part, w.cellp, nod);
+        hipLaunchKernelGGL(k_fz_cellsum<false>, gm, dim3(256), 0, st, A, (const float*)w.part, w.cellp, nod);
         hipLaunchKernelGGL((k_fz_gather<1>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.cellp, nof, reg, b_out, nod);
     }
     if (diag_out) {
-        if (A.nnz_counter) (void)hipMemsetAsync(A.nnz_counter, 0, sizeof(unsigned long long), st);
-        fz_sweep<2>(A, nof, w.part, nod, st);
-        hipLaunchKernelGGL(k_fz_cellsum, gm, dim3(256), 0, st, A, (const float*)w.part, w.cellp, nod);
+        hipLaunchKernelGGL(k_fz_cellsum<false>, gm, dim3(256), 0, st, A, (const float*)w.part2, w.cellp, nod);
         hipLaunchKernelGGL((k_fz_gather<2>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.cellp, nof, reg, diag_out, nod);
     }
     NKSR_CHECK_LAUNCH();
@@ -600,7 +572,7 @@ extern "C" int nksr_pcg_solve_fused(const nksr_fused_op_t* opd, float reg, const
     if (op.A.M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
     if (!pcg_workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     op.reg = reg;
-    op.w = fz_carve(opd->workspace, op.A.nblocks);
+    op.w = fz_carve(opd);
     return nksr_pcg_run(op, diag, op.A.M, b, x, tol, max_iter, check_every, pcg_workspace, info_out, (hipStream_t)stream);
 }
 

@@ -170,7 +170,8 @@ __device__ __forceinline__ void store_row27(float* __restrict__ p, const float v
 // grid.y = level; one thread per site.
 template <int K, int H, bool GRAD, bool JAC>
 __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float row_scale,
-                              int64_t level_stride, float* __restrict__ val, float* __restrict__ dval) {
+                              int64_t level_stride, const int32_t* __restrict__ row_index, int32_t* __restrict__ row_cells,
+                              float* __restrict__ val, float* __restrict__ dval) {
     const int d = blockIdx.y, L = hier.depth;
     const nksr_level_t& lv = hier.lv[d];
     __shared__ float w[MlpView<K, H>::SIZE];
@@ -181,10 +182,18 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
     float x[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
     SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
     // site-major [n, (3,) L, 27] for the assembly, level-major [L, stride, 27] (row = site * ncomp + component) for the matrix-free solve
-    float* vrow = val + (level_stride ? ((int64_t)d * level_stride + i) * 27 : (i * L + d) * 27);
+    // (level-major rows can be scattered: row_index[i] = first row of site i, so that several site sets share one Morton-ordered row list)
+    const int64_t vr = row_index ? row_index[i] : i, gr = row_index ? row_index[i] : i * 3;
+    float* vrow = val + (level_stride ? ((int64_t)d * level_stride + vr) * 27 : (i * L + d) * 27);
     float* grow[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) grow[a] = dval + (level_stride ? ((int64_t)d * level_stride + i * 3 + a) * 27 : ((i * 3 + a) * L + d) * 27);
+    for (int a = 0; a < 3; ++a) grow[a] = dval + (level_stride ? ((int64_t)d * level_stride + gr + a) * 27 : ((i * 3 + a) * L + d) * 27);
+    if (row_cells && level_stride) {                // the level-d cell of the site's rows (global unknown index, -1 = none)
+        const int cj = sc.cell >= 0 ? lv.offset + sc.cell : -1;
+        int32_t* rc = row_cells + (int64_t)d * level_stride;
+        if (val) rc[vr] = cj;
+        if (GRAD) { rc[gr] = cj; rc[gr + 1] = cj; rc[gr + 2] = cj; }
+    }
     if (sc.cell < 0) {
         if (val)
             for (int s = 0; s < 27; ++s) vrow[s] = 0.f;
@@ -316,15 +325,17 @@ extern "C" int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden
 }
 
 extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, int64_t level_stride,
-                                float* val, float* dval, void* stream) {
+                                const int32_t* row_index, int32_t* row_cells, float* val, float* dval, void* stream) {
     if (n <= 0) return NKSR_OK;
     if (!val && !dval) return nksr_set_error(NKSR_ERR_ARG, "val and dval are both NULL");
+    if ((row_index || row_cells) && (level_stride <= 0 || (val && dval)))
+        return nksr_set_error(NKSR_ERR_ARG, "row_index / row_cells need the level-major layout and ONE kind of rows (val or dval)");
     if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
     dim3 grid(nksr_blocks(n, 128), h->depth), block(128);
     DISPATCH_KH(h->kdim, h->hidden, {
-        if (!dval) hipLaunchKernelGGL((k_kernel_rows<K, H, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, val, dval);
-        else if (approx) hipLaunchKernelGGL((k_kernel_rows<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, val, dval);
-        else hipLaunchKernelGGL((k_kernel_rows<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, val, dval);
+        if (!dval) hipLaunchKernelGGL((k_kernel_rows<K, H, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, row_index, row_cells, val, dval);
+        else if (approx) hipLaunchKernelGGL((k_kernel_rows<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, row_index, row_cells, val, dval);
+        else hipLaunchKernelGGL((k_kernel_rows<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, row_index, row_cells, val, dval);
     })
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;

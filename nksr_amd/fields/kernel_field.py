@@ -17,7 +17,7 @@ import time
 import torch
 
 from .. import _lib, ops
-from .._lib import FusedOpT, FusedSetT, HierT, SiteSetT, call, ptr, stream
+from .._lib import FusedOpT, HierT, SiteSetT, call, ptr, stream
 from .base_field import BaseField, EvaluationResult
 
 
@@ -73,14 +73,15 @@ class KernelField(BaseField):
         n, L = xyz.shape[0], self.svh.depth
         val = torch.empty((n, L, 27), dtype=torch.float32, device=self.device) if values else None
         dval = torch.empty((n, 3, L, 27), dtype=torch.float32, device=self.device) if grad else None
-        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), 0, ptr(val), ptr(dval), stream())
+        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), 0, None, None, ptr(val), ptr(dval), stream())
         return val, dval
 
-    def kernel_rows_level_major(self, xyz, grad, scale, out, level_stride):
-        """Rows of the sites ``xyz`` written LEVEL-MAJOR into ``out`` (a flat view starting at the set's first row of the
-        [L, level_stride, 27] array): position rows (grad=False, one per site) or gradient rows (three per site)."""
+    def kernel_rows_level_major(self, xyz, grad, scale, out, level_stride, row_index=None, row_cells=None):
+        """Rows of the sites ``xyz`` written LEVEL-MAJOR into ``out`` ([L, level_stride, 27]): position rows (grad=False, one per
+        site) or gradient rows (three per site), site i at row ``row_index[i]`` (default i * rows-per-site); ``row_cells``
+        [L, level_stride] receives the level-d cell (global unknown index) of every row written."""
         call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), xyz.shape[0], int(self.approx_kernel_grad), float(scale), int(level_stride),
-             None if grad else ptr(out), ptr(out) if grad else None, stream())
+             ptr(row_index), ptr(row_cells), None if grad else ptr(out), ptr(out) if grad else None, stream())
 
     def _sorted_sites(self, xyz):
         """Permutation that Morton-sorts sites by their level-0 cell + the sorted keys."""
@@ -245,46 +246,57 @@ class KernelField(BaseField):
             specs.append((xs, ks, perm, target, float(weight) ** 0.5, ncomp))
         if not specs:
             raise RuntimeError('no constraint sites')
-        nsets = len(specs)
-        rows_total = sum(sp[0].shape[0] * sp[5] for sp in specs)
-        rows_all = torch.empty(L * rows_total * 27, dtype=torch.float32, device=dev)
+        # ONE Morton-ordered row list for all site sets (stable sort of the sites' level-0 keys; a position site owns one row, a
+        # normal site three): the rows of a cell -- of both sets -- are then one contiguous run at every level
+        counts_s = [sp[0].shape[0] for sp in specs]
+        rows_total = sum(n * sp[5] for n, sp in zip(counts_s, specs))
+        if len(specs) == 1:
+            row_index = [torch.arange(counts_s[0], dtype=torch.int32, device=dev) * specs[0][5]]
+        else:
+            nsite = sum(counts_s)
+            _, order = ops.sort_pairs(torch.cat([sp[1] for sp in specs]), torch.arange(nsite, dtype=torch.int32, device=dev))
+            order = order.long()
+            ncomp_site = torch.cat([torch.full((n,), sp[5], dtype=torch.int32, device=dev) for n, sp in zip(counts_s, specs)])
+            first_row = ops.exclusive_sum_i32(torch.cat([ncomp_site[order], ncomp_site.new_zeros(1)]))[:nsite]
+            row_of_site = torch.empty(nsite, dtype=torch.int32, device=dev)
+            row_of_site[order] = first_row
+            row_index = list(torch.split(row_of_site, counts_s))
+        pad = 64 * 27      # (the operator's loads are unconditional: the last wavefront reads up to 63 rows past the end)
+        rows_all = torch.empty(L * rows_total * 27 + pad, dtype=torch.float32, device=dev)
+        rows_all[L * rows_total * 27:].zero_()
+        row_cells = torch.empty((L, rows_total), dtype=torch.int32, device=dev)
         targets_all = torch.zeros(rows_total, dtype=torch.float32, device=dev)
-        sets = (FusedSetT * 2)()
-        keep = [rows_all, targets_all]
-        off = 0
-        for i, (xs, ks, perm, target, sw, ncomp) in enumerate(specs):
-            self.kernel_rows_level_major(xs, ncomp == 3, sw, rows_all[off * 27:], rows_total)
+        keep = [rows_all, targets_all, row_cells]
+        for (xs, ks, perm, target, sw, ncomp), ri in zip(specs, row_index):
+            ri = ri.contiguous()
+            self.kernel_rows_level_major(xs, ncomp == 3, sw, rows_all, rows_total, ri, row_cells)
             if target is not None:
                 tgt = target.detach().to(dev, torch.float32)
-                tgt = (tgt[perm] if perm is not None else tgt) * sw                       # [n] / [n, 3] == row order (site, component)
-                targets_all[off:off + xs.shape[0] * ncomp] = tgt.reshape(-1)
-            st, en = self._site_ranges(ks)
-            sets[i].n, sets[i].ncomp = xs.shape[0], ncomp
-            for d in range(L):
-                sets[i].start[d], sets[i].end[d] = ptr(st[d]), ptr(en[d])
-            keep += [xs, ks, st, en]
-            off += xs.shape[0] * ncomp
+                tgt = ((tgt[perm] if perm is not None else tgt) * sw).reshape(xs.shape[0], ncomp)      # row order (site, component)
+                targets_all[(ri.long()[:, None] + torch.arange(ncomp, device=dev)[None]).reshape(-1)] = tgt.reshape(-1)
+            keep += [xs, ri]
         # work items = runs of 32 rows; a cell owns one partial block per item its rows touch
+        span = torch.empty((2, M), dtype=torch.int32, device=dev)
         counts = torch.empty(M + 1, dtype=torch.int32, device=dev)
-        call('nksr_fused_block_counts', C.byref(self._hier), sets, nsets, ptr(counts), stream())
+        call('nksr_fused_block_counts', L, M, rows_total, ptr(row_cells), ptr(span), ptr(counts), stream())
         offsets = ops.exclusive_sum_i32(counts)
         nbr32 = torch.empty((M, 32), dtype=torch.int32, device=dev)
-        row_cells = torch.empty((L, rows_total), dtype=torch.int32, device=dev)
-        call('nksr_fused_tables', C.byref(self._hier), sets, nsets, ptr(offsets), ptr(nbr32), ptr(row_cells), stream())
+        call('nksr_fused_tables', C.byref(self._hier), ptr(offsets), ptr(span), ptr(nbr32), stream())
+        multi = torch.nonzero(counts[:M] > 1).reshape(-1).to(torch.int32)
         nblocks = int(offsets[M].item())
-        ws = torch.empty(int(_lib.lib.nksr_fused_workspace_bytes(M, nblocks)), dtype=torch.uint8, device=dev)
+        ws = torch.empty(int(_lib.lib.nksr_fused_workspace_bytes(nblocks)), dtype=torch.uint8, device=dev)
+        cell_sums = torch.zeros((M, 32), dtype=torch.float32, device=dev)
         op = FusedOpT()
-        op.depth, op.nsets, op.M, op.rows_total, op.nblocks = L, nsets, M, rows_total, nblocks
-        for i in range(nsets):
-            op.set_rows[i] = int(sets[i].n) * int(sets[i].ncomp)
+        op.depth, op.M, op.n_multi, op.rows_total, op.nblocks = L, M, int(multi.numel()), rows_total, nblocks
         op.rows_all, op.targets_all, op.row_cells, op.nbr32 = ptr(rows_all), ptr(targets_all), ptr(row_cells), ptr(nbr32)
-        op.offsets, op.workspace = ptr(offsets), ptr(ws)
+        op.offsets, op.multi, op.workspace, op.cell_sums = ptr(offsets), (ptr(multi) if multi.numel() else None), ptr(ws), ptr(cell_sums)
         # SURVEY.md section 8d counts the operator's bytes per STORED entry; the dense-slot rows hold structural zeros (absent
-        # neighbours, B-spline support ends): the diagonal pass counts the non-zero slots on its way (read back on demand)
+        # neighbours, B-spline support ends): the set-up pass counts the non-zero slots on its way (read back on demand)
         nnz_counter = torch.zeros(1, dtype=torch.int64, device=dev)
         op.nnz_counter = ptr(nnz_counter)
-        keep += [nbr32, row_cells, offsets, ws, nnz_counter]
-        return {'op': op, 'nsets': nsets, 'nblocks': nblocks, 'rows_total': rows_total, 'nnz_counter': nnz_counter, 'keep': keep}
+        keep += [nbr32, offsets, multi, ws, cell_sums, nnz_counter]
+        return {'op': op, 'nsets': len(specs), 'nblocks': nblocks, 'rows_total': rows_total, 'n_multi': int(multi.numel()),
+                'nnz_counter': nnz_counter, 'keep': keep}
 
     def fused_rhs_diag(self, op, reg_weight=1.0):
         M = self.svh.num_unknowns

@@ -118,13 +118,11 @@ def test_c_abi_argument_errors_without_a_gpu():
     assert 'channels' in err()
     h = _lib.HierT()
     h.depth = 4
-    assert lib.nksr_kernel_rows(C.byref(h), null, C.c_int64(5), C.c_int(0), C.c_float(1.0), C.c_int64(0), null, null, null) != 0 and 'NULL' in err()
-    fs = (_lib.FusedSetT * 2)()
-    fs[0].n, fs[0].ncomp = 10, 2
-    assert lib.nksr_fused_block_counts(C.byref(h), fs, C.c_int(1), null, null) != 0 and 'ncomp' in err()
-    assert lib.nksr_fused_block_counts(C.byref(h), fs, C.c_int(3), null, null) != 0 and 'site sets' in err()
+    assert lib.nksr_kernel_rows(C.byref(h), null, C.c_int64(5), C.c_int(0), C.c_float(1.0), C.c_int64(0), null, null, null, null, null) != 0 and 'NULL' in err()
+    assert lib.nksr_fused_block_counts(C.c_int32(9), C.c_int32(10), C.c_int64(5), null, null, null, null) != 0 and 'depth' in err()
+    assert lib.nksr_fused_block_counts(C.c_int32(4), C.c_int32(10), C.c_int64(5), null, null, null, null) != 0 and 'NULL' in err()
     op = _lib.FusedOpT()
-    op.depth, op.nsets, op.M = 4, 1, 10
+    op.depth, op.M = 4, 10
     assert lib.nksr_fused_apply(C.byref(op), C.c_float(1.0), null, null, null) != 0 and 'NULL' in err()
     with __import__('pytest').raises(RuntimeError):
         _lib.call('nksr_pack_cols21', null, 100, null, null)
