@@ -212,7 +212,7 @@ int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_out);
  *      recons_waymo_cpu.py:58, gis_app.py:40; KernelField.solve (csrc/fused.hip).  The system matrix is never built:
  *      y = (sum_s R_s^T R_s + reg I) x is applied from the dense-slot kernel rows, cell by cell. ------------------ */
 typedef struct {
-    int32_t depth, M, n_multi, reserved;
+    int32_t depth, M, n_multi, n_big;
     int64_t rows_total;        /* rows of all site sets in ONE Morton-ordered list (level-0 key of the site; position rows 1 per site,
                                 * gradient rows 3 per site); also the level stride of rows_all / row_cells                   */
     const float* rows_all;     /* LEVEL-MAJOR dense-slot rows [depth][rows_total][27], pre-multiplied by sqrt(w) (nksr_kernel_rows, level_stride, row_index) */
@@ -220,7 +220,8 @@ typedef struct {
     const int32_t* row_cells;  /* [depth][rows_total] GLOBAL unknown index of the row's level-d cell, -1 = none (nksr_kernel_rows) */
     const int32_t* nbr32;      /* [M, 32]: [0..26] GLOBAL unknown index of every neighbour voxel or -1; [27] block base, [28] single-block flag (nksr_fused_tables) */
     const int32_t* offsets;    /* [M + 1] partial blocks of a cell = [offsets[j], offsets[j + 1])                             */
-    const int32_t* multi;      /* [n_multi] the cells with more than one block, ascending                                    */
+    const int32_t* multi;      /* [n_multi] the cells with more than one block: first the n_big cells with more than 16 blocks (one
+                                * workgroup each in the per-cell sum), then the others                                        */
     int64_t nblocks;           /* offsets[M]                                                                                 */
     uint64_t* nnz_counter;     /* device counter or NULL: nksr_fused_rhs_diag leaves the non-zero slots of rows_all here = the
                                 * stored entries of G and Q (roofline accounting) */

@@ -24,7 +24,7 @@ class HierT(C.Structure):
 
 
 class FusedOpT(C.Structure):
-    _fields_ = [('depth', _i32), ('M', _i32), ('n_multi', _i32), ('reserved', _i32), ('rows_total', _i64), ('rows_all', _vp),
+    _fields_ = [('depth', _i32), ('M', _i32), ('n_multi', _i32), ('n_big', _i32), ('rows_total', _i64), ('rows_all', _vp),
                 ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('offsets', _vp), ('multi', _vp), ('nblocks', _i64),
                 ('nnz_counter', _vp), ('workspace', _vp), ('cell_sums', _vp)]
 

@@ -81,8 +81,8 @@ struct FusedArgs {               // uniform scalars and base pointers only
     const int32_t* row_cells;    // [depth][rows_total]
     const int32_t* nbr32;        // [M][32]
     const int32_t* offsets;      // [M + 1] blocks of a cell
-    const int32_t* multi;        // cells with more than one block
-    int n_multi, M, depth;
+    const int32_t* multi;        // cells with more than one block: the n_big cells with more than FZ_BIG blocks first
+    int n_multi, n_big, M, depth;
     int hw_total;                // half-waves = items, rounded up to whole wavefronts
     int64_t rows_total, nblocks;
     unsigned long long* nnz_counter;   // the set-up pass (MODE 1) adds the non-zero slots it sees (may be NULL)
@@ -345,14 +345,35 @@ template <bool LIST>
 __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __restrict__ part, float* __restrict__ cellp,
                                                    const int* __restrict__ done) {
     if (done && *done) return;
-    const int ncell = LIST ? A.n_multi : A.M;
-    const int i0 = ((blockIdx.x * 256 + threadIdx.x) >> 5) * FZ_GI;
-    if (i0 >= ncell) return;
     const int s = threadIdx.x & 31;
+    if (LIST && (int)blockIdx.x < A.n_big) {
+        // a coarse cell with many blocks (A.multi[0 .. n_big)): the whole workgroup sums it -- half-wave h takes blocks h, h + 8, ...
+        // (one serial chain over hundreds of blocks was the critical path of the pass), then the eight partial sums in order
+        __shared__ float partial[8][32];
+        const int cell = A.multi[blockIdx.x], h = threadIdx.x >> 5;
+        const int b0 = A.offsets[cell], n = A.offsets[cell + 1] - b0;
+        const float* p = part + (int64_t)(b0 + h) * 32 + s;
+        float acc = 0.f;
+        int b = h;
+        for (; b + 24 < n; b += 32, p += 1024) acc += (p[0] + p[256]) + (p[512] + p[768]);
+        for (; b < n; b += 8, p += 256) acc += p[0];
+        partial[h][s] = acc;
+        __syncthreads();
+        if (h == 0) {
+            float t = partial[0][s];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) t += partial[k][s];
+            cellp[(int64_t)cell * 32 + s] = t;
+        }
+        return;
+    }
+    const int first = LIST ? A.n_big : 0, ncell = (LIST ? A.n_multi : A.M) - first;
+    const int i0 = (((LIST ? (int)blockIdx.x - A.n_big : (int)blockIdx.x) * 256 + (int)threadIdx.x) >> 5) * FZ_GI;
+    if (i0 >= ncell) return;
     int cell[FZ_GI], b0[FZ_GI], n[FZ_GI];
 #pragma unroll
     for (int k = 0; k < FZ_GI; ++k) {
-        const int i = i0 + k < ncell ? i0 + k : ncell - 1;
+        const int i = first + (i0 + k < ncell ? i0 + k : ncell - 1);
         cell[k] = LIST ? A.multi[i] : i;
     }
 #pragma unroll
@@ -449,13 +470,13 @@ static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
     if (!op) return nksr_set_error(NKSR_ERR_ARG, "operator is NULL");
     if (op->depth < 1 || op->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", op->depth);
     if (op->M > 0 && (!op->rows_all || !op->row_cells || !op->nbr32 || !op->offsets || !op->workspace || !op->cell_sums ||
-                      (op->n_multi > 0 && !op->multi)))
+                      (op->n_multi > 0 && !op->multi) || op->n_big < 0 || op->n_big > op->n_multi))
         return nksr_set_error(NKSR_ERR_ARG, "operator has NULL arrays");
     if (op->rows_total < 0 || op->rows_total >= ((int64_t)1 << 31) - 64 || op->nblocks >= ((int64_t)1 << 31) - ((int64_t)1 << 26))
         return nksr_set_error(NKSR_ERR_CAPACITY, "operator too large");
     memset(&A, 0, sizeof(A));
     A.rows_all = op->rows_all; A.targets_all = op->targets_all; A.row_cells = op->row_cells; A.nbr32 = op->nbr32; A.offsets = op->offsets;
-    A.multi = op->multi; A.n_multi = op->n_multi;
+    A.multi = op->multi; A.n_multi = op->n_multi; A.n_big = op->n_big;
     A.M = op->M; A.depth = op->depth; A.rows_total = op->rows_total; A.nblocks = op->nblocks;
     A.nnz_counter = (unsigned long long*)op->nnz_counter;
     const int64_t items = (op->rows_total + FZ_RC - 1) / FZ_RC;
@@ -506,7 +527,8 @@ static int fz_apply(const FusedArgs& A, float reg, const FusedWork& w, const flo
     fz_gather_dims(A.M, gg, per_xcd);
     fz_sweep<0>(A, x, w.part, nullptr, w.cellp, done, st);
     if (A.n_multi > 0)
-        hipLaunchKernelGGL(k_fz_cellsum<true>, dim3(nksr_blocks(((int64_t)A.n_multi + FZ_GI - 1) / FZ_GI * 32, 256)), dim3(256), 0, st, A, (const float*)w.part, w.cellp, done);
+        hipLaunchKernelGGL(k_fz_cellsum<true>, dim3(A.n_big + nksr_blocks(((int64_t)(A.n_multi - A.n_big) + FZ_GI - 1) / FZ_GI * 32, 256)), dim3(256), 0, st, A,
+                           (const float*)w.part, w.cellp, done);
     hipLaunchKernelGGL((k_fz_gather<0>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.cellp, x, reg, y, done);
     return NKSR_OK;
 }

@@ -282,12 +282,13 @@ class KernelField(BaseField):
         offsets = ops.exclusive_sum_i32(counts)
         nbr32 = torch.empty((M, 32), dtype=torch.int32, device=dev)
         call('nksr_fused_tables', C.byref(self._hier), ptr(offsets), ptr(span), ptr(nbr32), stream())
-        multi = torch.nonzero(counts[:M] > 1).reshape(-1).to(torch.int32)
+        big = torch.nonzero(counts[:M] > 16).reshape(-1).to(torch.int32)          # coarse cells: a workgroup each in the per-cell sum
+        multi = torch.cat([big, torch.nonzero((counts[:M] > 1) & (counts[:M] <= 16)).reshape(-1).to(torch.int32)])
         nblocks = int(offsets[M].item())
         ws = torch.empty(int(_lib.lib.nksr_fused_workspace_bytes(nblocks)), dtype=torch.uint8, device=dev)
         cell_sums = torch.zeros((M, 32), dtype=torch.float32, device=dev)
         op = FusedOpT()
-        op.depth, op.M, op.n_multi, op.rows_total, op.nblocks = L, M, int(multi.numel()), rows_total, nblocks
+        op.depth, op.M, op.n_multi, op.n_big, op.rows_total, op.nblocks = L, M, int(multi.numel()), int(big.numel()), rows_total, nblocks
         op.rows_all, op.targets_all, op.row_cells, op.nbr32 = ptr(rows_all), ptr(targets_all), ptr(row_cells), ptr(nbr32)
         op.offsets, op.multi, op.workspace, op.cell_sums = ptr(offsets), (ptr(multi) if multi.numel() else None), ptr(ws), ptr(cell_sums)
         # SURVEY.md section 8d counts the operator's bytes per STORED entry; the dense-slot rows hold structural zeros (absent

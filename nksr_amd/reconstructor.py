@@ -28,9 +28,11 @@ class Reconstructor:
         self.timing = {}
         self.sync_timing = False   # insert stream syncs so that per-stage wall times are exact
         # chunk mode: chunks can be solved concurrently on this many HIP streams (one host thread each; bit-identical results).
-        # Measured on configs[4] (64 chunks of ~260 k points, one MI355X): 1 stream 1.96 s, 2 streams 1.90 s, 3 streams 2.32 s,
-        # 4 streams 6.0 s -- the chunks are GPU-bound, the host threads contend (GIL, allocator pools per stream): default 1
-        self.chunk_streams = 1
+        # Measured on configs[4] (64 chunks of ~260 k points, one MI355X, matrix-free solve): 1 stream 1.56 s, 2 streams 1.46 s; with
+        # the assembled solve 1.96 / 1.90 / 2.32 (3 streams) / 6.0 s (4) -- the chunks are GPU-bound, more host threads contend
+        # (GIL, allocator pools per stream; two assembled solves at once also fight over their 11 GB workspaces: 3.05 s).
+        # None = 2 for the matrix-free solve, 1 for the assembled one
+        self.chunk_streams = None
         self.col_format = 1        # physical layout of the assembled matrix (include/nksr_hip.h); int32 columns when M > 2^21
 
     # ---- scale selection (NKSR-USAGE.md:129-137) ---------------------------------------------------
