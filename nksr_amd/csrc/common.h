@@ -93,3 +93,45 @@ __device__ __forceinline__ void bspline3(float u, float w[3], float dw[3]) {
     dw[1] = -2.0f * uc;
     dw[2] = u;
 }
+
+// ---- reductions over the 32 lanes of a half-wavefront (fixed trees: deterministic) ------------------------------------------------
+__device__ __forceinline__ float half_sum(float p) {      // sum over the 32 lanes of this half-wave, fixed tree
+    p += __shfl_xor(p, 16, 32);
+    p += __shfl_xor(p, 8, 32);
+    p += __shfl_xor(p, 4, 32);
+    p += __shfl_xor(p, 2, 32);
+    p += __shfl_xor(p, 1, 32);
+    return p;
+}
+
+// sums of FOUR rows over the 32 lanes of a half-wave in 6 lane exchanges instead of 4 x 5: a transposing butterfly -- after the
+// xor-16 step a lane keeps two of the four rows (its own + its partner's share), after xor-8 one, then 3 plain steps.
+// Returns, in every lane, the total of row  2 * bit4(lane) + bit3(lane).
+// lane exchanges inside a 16-lane row as DPP modifiers of a VALU move (no LDS crossbar): quad_perm [1,0,3,2] (xor 1),
+// [2,3,0,1] (xor 2), row_half_mirror (l -> 7 - l: the other quad of an 8-lane group once quads are uniform), row_ror:8 (xor 8)
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float half_sum4(float p0, float p1, float p2, float p3, int lane) {
+    const bool hi = (lane >> 4) & 1, b = (lane >> 3) & 1;
+    const float r0 = __shfl_xor(hi ? p0 : p2, 16, 32), r1 = __shfl_xor(hi ? p1 : p3, 16, 32);       // the only two crossbar trips
+    const float q0 = (hi ? p2 : p0) + r0, q1 = (hi ? p3 : p1) + r1;          // rows {2,3} in the upper 16 lanes, {0,1} in the lower
+    float r = (b ? q1 : q0) + dpp_move<0x128>(b ? q0 : q1);                  // row_ror:8
+    r += dpp_move<0xB1>(r);                                                  // xor 1
+    r += dpp_move<0x4E>(r);                                                  // xor 2
+    r += dpp_move<0x141>(r);                                                 // row_half_mirror: the other quad
+    return r;
+}
+
+// two rows: after the xor-16 step the lower 16 lanes hold row 0, the upper 16 row 1.  Returns the total of row bit4(lane).
+__device__ __forceinline__ float half_sum2(float p0, float p1, int lane) {
+    const bool hi = (lane >> 4) & 1;
+    float r = (hi ? p1 : p0) + __shfl_xor(hi ? p0 : p1, 16, 32);
+    r += dpp_move<0x128>(r);
+    r += dpp_move<0xB1>(r);
+    r += dpp_move<0x4E>(r);
+    r += dpp_move<0x141>(r);
+    return r;
+}
+

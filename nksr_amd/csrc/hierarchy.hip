@@ -169,38 +169,49 @@ extern "C" int nksr_sorted_lookup(const int64_t* sorted, int64_t n, const int64_
 // cells (contiguous ranges of the Morton-sorted cloud) and weights them with the hat function
 // prod_a max(0, 1 - |x_a/w - (j_a + 1/2)|).  Used by the point encoder (network.encoder,
 // reference call site models/nksr_net.py:73) for the input-normal skip path.
-__global__ void k_splat_trilinear(const float* __restrict__ xyz, const float* __restrict__ feat, int C,
-                                  const int32_t* __restrict__ start, const int32_t* __restrict__ end,
-                                  const int32_t* __restrict__ nbr, const int32_t* __restrict__ ijk, int n, float inv_w,
-                                  float* __restrict__ out, float* __restrict__ wsum_out) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
+// One 32-lane half-wave per voxel, lane = neighbour cell: the 27 chains cell -> point range -> coordinates -> features run side by
+// side (a thread per voxel walked them one after the other: latency-bound, 0.68 ms at 7.8e5 voxels), then one fixed-tree sum per
+// channel over the lanes.
+__global__ void __launch_bounds__(256) k_splat_trilinear(const float* __restrict__ xyz, const float* __restrict__ feat, int C,
+                                                         const int32_t* __restrict__ start, const int32_t* __restrict__ end,
+                                                         const int32_t* __restrict__ nbr, const int32_t* __restrict__ ijk, int n,
+                                                         float inv_w, float* __restrict__ out, float* __restrict__ wsum_out) {
+    const int j = (blockIdx.x * 256 + threadIdx.x) >> 5, s = threadIdx.x & 31;
     if (j >= n) return;
     float acc[8];
-    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
     float wsum = 0.f;
     const float cx = (float)ijk[j * 3] + 0.5f, cy = (float)ijk[j * 3 + 1] + 0.5f, cz = (float)ijk[j * 3 + 2] + 0.5f;
-    for (int s = 0; s < 27; ++s) {
-        int c = nbr[(int64_t)j * 27 + s];
-        if (c < 0) continue;
-        for (int k = start[c]; k < end[c]; ++k) {
-            float wx = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3], inv_w) - cx);
-            float wy = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 1], inv_w) - cy);
-            float wz = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 2], inv_w) - cz);
+    const int c = s < 27 ? nbr[(int64_t)j * 27 + s] : -1;
+    if (c >= 0) {
+        for (int k = start[c], k1 = end[c]; k < k1; ++k) {
+            const float wx = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3], inv_w) - cx);
+            const float wy = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 1], inv_w) - cy);
+            const float wz = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 2], inv_w) - cz);
             if (wx <= 0.f || wy <= 0.f || wz <= 0.f) continue;
-            float w = wx * wy * wz;
+            const float w = wx * wy * wz;
             wsum += w;
-            for (int c2 = 0; c2 < C; ++c2) acc[c2] = fmaf(w, feat[(int64_t)k * C + c2], acc[c2]);
+#pragma unroll
+            for (int c2 = 0; c2 < 8; ++c2)
+                if (c2 < C) acc[c2] = fmaf(w, feat[(int64_t)k * C + c2], acc[c2]);
         }
     }
-    for (int c = 0; c < C; ++c) out[(int64_t)j * C + c] = acc[c];
-    wsum_out[j] = wsum;
+    wsum = half_sum(wsum);
+#pragma unroll
+    for (int c2 = 0; c2 < 8; ++c2)
+        if (c2 < C) {
+            const float t = half_sum(acc[c2]);
+            if (s == 0) out[(int64_t)j * C + c2] = t;
+        }
+    if (s == 0) wsum_out[j] = wsum;
 }
 
 extern "C" int nksr_splat_trilinear(const float* xyz_sorted, const float* feat_sorted, int C, const int32_t* start,
                                     const int32_t* end, const int32_t* nbr, const int32_t* ijk, int32_t n, float inv_w,
                                     float* out, float* wsum_out, void* stream) {
     if (C < 1 || C > 8) return nksr_set_error(NKSR_ERR_ARG, "splat supports 1..8 channels");
-    LAUNCH1D(k_splat_trilinear, (int64_t)n, stream, xyz_sorted, feat_sorted, C, start, end, nbr, ijk, n, inv_w, out, wsum_out);
+    LAUNCH1D(k_splat_trilinear, (int64_t)n * 32, stream, xyz_sorted, feat_sorted, C, start, end, nbr, ijk, n, inv_w, out, wsum_out);
     return NKSR_OK;
 }
 
