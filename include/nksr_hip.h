@@ -147,6 +147,9 @@ typedef struct {
     const float* target;       /* [n, ncomp] right-hand side values or NULL (zero)     */
     const int32_t* start[NKSR_MAX_DEPTH]; /* per level: [n_d] site range per voxel     */
     const int32_t* end[NKSR_MAX_DEPTH];
+    int64_t level_stride;      /* 0: val is site-major as above.  > 0: val is the LEVEL-MAJOR array of the matrix-free operator
+                                * ([L, level_stride, 27], nksr_fused_op_t.rows_all) and site i owns the rows row_index[i] .. + ncomp */
+    const int32_t* row_index;  /* [n] first row of every site (level-major layout; NULL = i * ncomp) */
 } nksr_siteset_t;
 
 /* Structure pass.  Per row: rowcount = structural upper entries (column voxel exists, B-spline supports
@@ -163,11 +166,14 @@ size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h);
  * exclusive scan of crosscount.  Same-level lower, own upper entries and the diagonal are written straight
  * into cols_out / vals_out (tile-interleaved physical layout, see nksr_spmv_csr); the mirrored copies of the
  * cross-level entries go to mir_keys (src_row << col_bits | dst_row) / mir_vals.  Also writes diag_out and
- * b = sum_s w_s R_s^T t_s. */
+ * b = sum_s w_s R_s^T t_s.
+ * split_scratch (nksr_assemble_split_bytes(h, sum_s n_s ncomp_s) bytes; NULL = off): levels whose cells hold > 1024 site rows
+ * on average are accumulated by several wavefronts per cell and reduced in a fixed order. */
+size_t nksr_assemble_split_bytes(const nksr_hier_t* h, int64_t total_rows);
 int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, int nsets, float reg, int col_bits,
                   void* workspace, const int32_t* rowptr, const int32_t* indeg, const int32_t* samelow,
                   const int32_t* mir_off, int col_format, int32_t* cols_out, float* vals_out, float* diag_out,
-                  uint64_t* mir_keys, float* mir_vals, float* b_out, void* stream);
+                  uint64_t* mir_keys, float* mir_vals, float* b_out, void* split_scratch, size_t split_scratch_bytes, void* stream);
 /* Mirrors stably sorted by destination row (low col_bits of the key) -> their CSR slots;
  * mirptr = exclusive scan of indeg. */
 int nksr_place_mirrors(const uint64_t* keys_sorted, const float* vals_sorted, int64_t n, int col_bits,
@@ -183,6 +189,8 @@ int nksr_place_mirrors(const uint64_t* keys_sorted, const float* vals_sorted, in
  *   1: 192-entry tiles, entry m at 3*(m%64) + m/64, padded to a multiple of 4608 entries; the SpMV reads
  *      the columns as one 64-bit word per three entries (21 bits each, nksr_pack_cols21 converts the
  *      int32 array written by the assembly): 6.67 instead of 8 bytes per entry, requires M <= 2^21.
+ *   2 (nksr_assemble / nksr_place_mirrors only): plain CSR order, nnz entries, no padding -- the small coarse-level block of the
+ *      preconditioner (nksr_coarse_precond_t); the streaming SpMV does not take it.
  * The plan (first row of every chunk) lives in `workspace` (nksr_spmv_workspace_bytes) and must be built
  * once per matrix with nksr_spmv_plan. */
 size_t nksr_spmv_workspace_bytes(int64_t nnz);
@@ -207,6 +215,26 @@ int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out);
 /* Bytes of the launches timed since the last call (then reset): the algorithmic CSR figure 8 nnz + 12 M + 4 per
  * launch and the bytes the physical layout streams (col_format, padding). */
 int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_out);
+
+/* ---- coarse-level block preconditioner of the PCG (csrc/pcg.hip) -----------------------------------------------------
+ * The unknowns of the levels >= c0 (the LAST n of the M: unknowns are level-major) take `steps` Jacobi-preconditioned
+ * Chebyshev steps on their diagonal block A_cc instead of one Jacobi step; all finer unknowns keep Jacobi.  A_cc: plain CSR
+ * (nksr_assemble with col_format 2 on the hierarchy whose fine levels have n = 0, hcap = 0 and whose coarse levels are
+ * re-based to offset 0), local indices.  lambda_max: largest eigenvalue of D^-1 A_cc (nksr_coarse_lambda_max, x ~1.1);
+ * the polynomial targets the interval [lambda_max / ratio, lambda_max]. */
+#define NKSR_PC_MAX_STEPS 16
+typedef struct {
+    int32_t first, n, steps, reserved;
+    float lambda_max, ratio;
+    const int32_t* rowptr;     /* [n + 1] */
+    const int32_t* cols;       /* [nnz_c] local column indices */
+    const float* vals;         /* [nnz_c] */
+    const float* diag;         /* [n] diagonal of A_cc */
+    float* work;               /* [3 n] floats */
+} nksr_coarse_precond_t;
+/* power iteration (iters steps from the all-ones vector, work: 2 n floats): lambda_out (device) = ||v_k|| / ||v_{k-1}|| */
+int nksr_coarse_lambda_max(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n, int iters,
+                           float* work, float* lambda_out, void* stream);
 
 /* ---- matrix-free ("fused") operator and solve: reconstruct(..., fused_mode=True), examples/recons_waymo.py:33,
  *      recons_waymo_cpu.py:58, gis_app.py:40; KernelField.solve (csrc/fused.hip).  The system matrix is never built:
@@ -242,7 +270,8 @@ int nksr_fused_apply(const nksr_fused_op_t* op, float reg, const float* x, float
 /* Jacobi-PCG with that operator; pcg_workspace: nksr_pcg_vector_workspace_bytes(M).  Syncs like nksr_pcg_solve. */
 size_t nksr_pcg_vector_workspace_bytes(int32_t M);
 int nksr_pcg_solve_fused(const nksr_fused_op_t* op, float reg, const float* diag, const float* b, float* x, float tol, int max_iter,
-                         int check_every, void* pcg_workspace, double* info_out, void* stream);
+                         int check_every, void* pcg_workspace, const nksr_coarse_precond_t* coarse_precond /* or NULL: Jacobi */,
+                         double* info_out, void* stream);
 
 /* ---- grid-hash nearest neighbours (csrc/knn.hip) ----------------------------------------------------
  * Points Morton-sorted by a uniform grid of size `cell` (keys from nksr_point_keys with inv_w0 =

@@ -29,9 +29,14 @@ class FusedOpT(C.Structure):
                 ('nnz_counter', _vp), ('workspace', _vp), ('cell_sums', _vp)]
 
 
+class CoarsePrecondT(C.Structure):
+    _fields_ = [('first', _i32), ('n', _i32), ('steps', _i32), ('reserved', _i32), ('lambda_max', _f32), ('ratio', _f32),
+                ('rowptr', _vp), ('cols', _vp), ('vals', _vp), ('diag', _vp), ('work', _vp)]
+
+
 class SiteSetT(C.Structure):
     _fields_ = [('n', _i64), ('ncomp', _i32), ('weight', _f32), ('val', _vp), ('target', _vp),
-                ('start', _vp * MAX_DEPTH), ('end', _vp * MAX_DEPTH)]
+                ('start', _vp * MAX_DEPTH), ('end', _vp * MAX_DEPTH), ('level_stride', _i64), ('row_index', _vp)]
 
 
 def _load():
@@ -54,6 +59,8 @@ lib.nksr_pcg_workspace_bytes.restype = _sz
 lib.nksr_pcg_workspace_bytes.argtypes = [_i32, _i64]
 lib.nksr_assemble_workspace_bytes.restype = _sz
 lib.nksr_assemble_workspace_bytes.argtypes = [C.POINTER(HierT)]
+lib.nksr_assemble_split_bytes.restype = _sz
+lib.nksr_assemble_split_bytes.argtypes = [C.POINTER(HierT), _i64]
 lib.nksr_spmv_workspace_bytes.restype = _sz
 lib.nksr_spmv_workspace_bytes.argtypes = [_i64]
 lib.nksr_fused_workspace_bytes.restype = _sz
@@ -91,7 +98,7 @@ _PROTOS = {
     'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _f32, _i64, _vp, _vp, _vp, _vp, _vp],
     'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, _vp, _vp, _vp],
     'nksr_assemble_count': [_P(HierT), _vp, _vp, _vp, _vp, _vp, _vp],
-    'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'nksr_place_mirrors': [_vp, _vp, _i64, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp],
     'nksr_spmv_set_variant': [C.c_int],
     'nksr_spmv_plan': [_vp, _i32, _i64, C.c_int, _vp, _vp],
@@ -102,7 +109,8 @@ _PROTOS = {
     'nksr_fused_tables': [_P(HierT), _vp, _vp, _vp, _vp],
     'nksr_fused_rhs_diag': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
-    'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
+    'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(C.c_double), _vp],
+    'nksr_coarse_lambda_max': [_vp, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
     'nksr_pcg_profile_bytes': [_P(C.c_double), _P(C.c_double)],
     'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
@@ -127,6 +135,7 @@ for _name, _args in _PROTOS.items():
     _fn.restype = C.c_int
 
 EXPORTED = ['nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
+            'nksr_assemble_split_bytes',
             'nksr_fused_workspace_bytes', 'nksr_pcg_vector_workspace_bytes'] + sorted(_PROTOS)
 
 

@@ -45,8 +45,10 @@ __device__ __forceinline__ int row_level(const nksr_hier_t& h, int row) {
 }
 
 // physical CSR layout (see csrc/pcg.hip): tiles of 64 EPL entries, logical entry m of a tile at
-// EPL (m % 64) + m / 64;  EPL = 4 (col_format 0, 256-entry tiles) or 3 (col_format 1, 192-entry tiles)
+// EPL (m % 64) + m / 64;  EPL = 4 (col_format 0, 256-entry tiles) or 3 (col_format 1, 192-entry tiles); col_format 2 = plain CSR
+// order (the small coarse-level block of the PCG's preconditioner, csrc/pcg.hip)
 __device__ __forceinline__ int64_t csr_phys(int64_t k, int fmt) {
+    if (fmt == 2) return k;
     if (fmt == 0) {
         const int64_t m = k & 255;
         return (k & ~(int64_t)255) + 4 * (m & 63) + (m >> 6);
@@ -64,6 +66,129 @@ __device__ __forceinline__ int64_t csr_phys(int64_t k, int fmt) {
 // (27 m is never a multiple of 32, so a spare column always exists).  The set weight scales the A
 // operand (the host passes rows pre-multiplied by sqrt(w) and weight 1, see below).  Accumulator register r of lane l is D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31].
 typedef float asm_f32x16 __attribute__((ext_vector_type(16)));
+
+// entry `col` (slot col % 27 of level d + col / 27) of site row q: site-major rows [n ncomp, L, 27], or -- level_stride > 0 -- the
+// level-major rows of the matrix-free operator ([L, level_stride, 27], site i at row row_index[i])
+__device__ __forceinline__ float asm_row_value(const nksr_siteset_t& S, int64_t q, int L, int d, int col) {
+    if (!S.level_stride) return S.val[(q * L + d) * 27 + col];
+    const int dd = col / 27, s = col - dd * 27;
+    const int64_t site = S.ncomp == 1 ? q : q / 3;
+    const int64_t row = (S.row_index ? (int64_t)S.row_index[site] : site * S.ncomp) + (q - site * S.ncomp);
+    return S.val[((int64_t)(d + dd) * S.level_stride + row) * 27 + s];
+}
+
+// writes the accumulated tile(s) of cell c: block rows whose voxel exists, the right-hand-side column, the site count
+template <int NT>
+__device__ __forceinline__ void cell_blocks_finalize(const AsmArgs& A, int d, int c, int lane, asm_f32x16 (&acc)[NT], int total) {
+    const nksr_level_t& lv = A.hier.lv[d];
+    const int T = (A.hier.depth - d) * 27;
+    const int j = lane & 31, half = lane >> 5;
+    if (lane == 0) A.nsites[d][c] = total;
+    if (total == 0) return;
+    float* out = A.blocks[d] + (int64_t)c * 27 * T;
+    float* bv = A.bvec[d] + (int64_t)c * 27;
+    // block row s is consumed by exactly one matrix row, the voxel at stencil slot s of this cell: rows whose
+    // voxel does not exist are never read, so they are not written (about a third of the block traffic)
+    const int nb = (lane < 27) ? lv.nbr[(int64_t)c * 27 + lane] : -1;
+    const unsigned long long need = __ballot(nb >= 0);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = 32 * n + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int s = (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (s < 27 && ((need >> s) & 1ull)) {
+                if (col < T) out[s * T + col] = acc[n][r];
+                else if (col == T) bv[s] = acc[n][r];
+            }
+        }
+    }
+}
+
+// A coarse cell holds thousands of site rows (8x more per level): with one wavefront per cell the two coarsest levels of a
+// tree_depth-5 chunk took 2.6 ms on ~8 k wavefronts.  Such levels are cut: wavefront (c, p) accumulates part p of the cell's rows
+// and leaves its raw accumulator tiles in scratch; k_cell_blocks_reduce adds the parts in order (fixed: deterministic) and finishes.
+template <int NT>
+__global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks_part(AsmArgs A, int d, int nsplit, float* __restrict__ scratch) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const nksr_level_t& lv = A.hier.lv[d];
+    const int64_t idx = (int64_t)blockIdx.x * ASM_WAVES + wave;
+    if (idx >= (int64_t)lv.n * nsplit) return;
+    const int c = (int)(idx / nsplit), p = (int)(idx - (int64_t)c * nsplit);
+    const int L = A.hier.depth;
+    const int T = (L - d) * 27;
+    const int j = lane & 31, half = lane >> 5;
+    asm_f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    int R = 0;
+    for (int si = 0; si < A.nsets; ++si) R += (A.sets[si].end[d][c] - A.sets[si].start[d][c]) * A.sets[si].ncomp;
+    const int rpp = ((R + nsplit - 1) / nsplit + 1) & ~1;                // rows per part, even (two rows per MFMA)
+    const int lo = p * rpp, hi = (p + 1) * rpp < R ? (p + 1) * rpp : R;
+    int base = 0;
+    for (int si = 0; si < A.nsets; ++si) {
+        const nksr_siteset_t& S = A.sets[si];
+        const int k0 = S.start[d][c], k1 = S.end[d][c];
+        const int nrows = (k1 - k0) * S.ncomp;
+        const int m_lo = lo > base ? lo - base : 0, m_hi = hi - base < nrows ? hi - base : nrows;      // this set's rows of the part
+        const int64_t q0 = (int64_t)k0 * S.ncomp;
+        const float w = S.weight;
+        // four row pairs per trip: their loads go out together (one pair per trip left the wavefront waiting on every load)
+        for (int m0 = m_lo; m0 < m_hi; m0 += 8) {
+            float b[4][NT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = m0 + 2 * u + half;
+                const bool valid = m < m_hi;
+                const int64_t q = q0 + (valid ? m : m_lo);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int col = 32 * n + j;
+                    float v = 0.f;
+                    if (col < T) v = asm_row_value(S, q, L, d, col);
+                    else if (col == T && S.target) v = S.target[q];
+                    b[u][n] = valid ? v : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a = (j < 27) ? w * b[u][0] : 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][n], acc[n], 0, 0, 0);
+            }
+        }
+        base += nrows;
+    }
+    float* out = scratch + idx * (NT * 16 * 64) + lane;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(n * 16 + r) * 64] = acc[n][r];
+}
+
+template <int NT>
+__global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks_reduce(AsmArgs A, int d, int nsplit, const float* __restrict__ scratch) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * ASM_WAVES + wave;
+    if (c >= A.hier.lv[d].n) return;
+    asm_f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    for (int p = 0; p < nsplit; ++p) {
+        const float* in = scratch + ((int64_t)c * nsplit + p) * (NT * 16 * 64) + lane;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] += in[(n * 16 + r) * 64];
+    }
+    int total = 0;
+    for (int si = 0; si < A.nsets; ++si) total += A.sets[si].end[d][c] - A.sets[si].start[d][c];
+    cell_blocks_finalize<NT>(A, d, c, lane, acc, total);
+}
 
 template <int NT>
 __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d) {
@@ -93,45 +218,32 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
         // (sw r_s)(sw r_t) then commute exactly.  Keep this loop as it is -- variants that dropped the multiply,
         // added a second code path (88 VGPRs) or called sqrtf here all measured 20 % slower.
         const float w = S.weight;
-        for (int m0 = 0; m0 < nrows; m0 += 2) {
-            const bool valid = m0 + half < nrows;
-            const int64_t q = q0 + m0 + half;
-            const float* ra = S.val + (q * L + d) * 27;
-            float b[NT];
+        // two row pairs per trip, their loads issued together (unconditional, clamped: a load under a branch is waited for at once)
+        for (int m0 = 0; m0 < nrows; m0 += 4) {
+            float b[2][NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int col = 32 * n + j;
-                b[n] = 0.f;
-                if (valid) {
-                    if (col < T) b[n] = ra[col];
-                    else if (col == T && S.target) b[n] = S.target[q];
+            for (int u = 0; u < 2; ++u) {
+                const int m = m0 + 2 * u + half;
+                const bool valid = m < nrows;
+                const int64_t q = q0 + (valid ? m : 0);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int col = 32 * n + j;
+                    float v = 0.f;
+                    if (col < T) v = asm_row_value(S, q, L, d, col);
+                    else if (col == T && S.target) v = S.target[q];
+                    b[u][n] = valid ? v : 0.f;
                 }
             }
-            const float a = (j < 27) ? w * b[0] : 0.f;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
-        }
-    }
-    if (lane == 0) A.nsites[d][c] = total;
-    if (total == 0) return;
-    float* out = A.blocks[d] + (int64_t)c * 27 * T;
-    float* bv = A.bvec[d] + (int64_t)c * 27;
-    // block row s is consumed by exactly one matrix row, the voxel at stencil slot s of this cell: rows whose
-    // voxel does not exist are never read, so they are not written (about a third of the block traffic)
-    const int nb = (lane < 27) ? lv.nbr[(int64_t)c * 27 + lane] : -1;
-    const unsigned long long need = __ballot(nb >= 0);
+            for (int u = 0; u < 2; ++u) {
+                const float a = (j < 27) ? w * b[u][0] : 0.f;
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int col = 32 * n + j;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int s = (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (s < 27 && ((need >> s) & 1ull)) {
-                if (col < T) out[s * T + col] = acc[n][r];
-                else if (col == T) bv[s] = acc[n][r];
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][n], acc[n], 0, 0, 0);
             }
         }
     }
+    cell_blocks_finalize<NT>(A, d, c, lane, acc, total);
 }
 
 // ---- phase 2a: structure.  colmap[row slot] = column of every structural slot ---------------------------
@@ -445,6 +557,26 @@ extern "C" size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h) {
     return tot;
 }
 
+// parts a cell's rows are cut into on a level with n cells (uniform per level): enough wavefronts to fill the chip (~16 k), at
+// least 64 rows per part, at most 64 parts
+static int asm_nsplit(int64_t total_rows, int n) {
+    if (n <= 0) return 1;
+    const int64_t avg = total_rows / n, by_rows = avg / 64, by_fill = 16384 / n;
+    int64_t k = by_rows < by_fill ? by_rows : by_fill;
+    if (k > 64) k = 64;
+    return k < 2 ? 1 : (int)k;
+}
+extern "C" size_t nksr_assemble_split_bytes(const nksr_hier_t* h, int64_t total_rows) {
+    size_t best = 0;
+    for (int d = 0; d < h->depth; ++d) {
+        const int n = h->lv[d].n, ns = asm_nsplit(total_rows, n);
+        if (n <= 0 || ns <= 1) continue;
+        const size_t NT = ((size_t)(h->depth - d) * 27 + 32) / 32, b = (size_t)n * ns * NT * 16 * 64 * sizeof(float);
+        if (b > best) best = b;
+    }
+    return best;
+}
+
 extern "C" int nksr_assemble_count(const nksr_hier_t* h, void* workspace, int32_t* rowcount, int32_t* crosscount, int32_t* samelow,
                                    int32_t* indeg, void* stream) {
     AsmArgs A;
@@ -464,28 +596,46 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
                              void* workspace, const int32_t* rowptr, const int32_t* indeg, const int32_t* samelow,
                              const int32_t* mir_off, int col_format,
                              int32_t* cols_out, float* vals_out, float* diag_out, uint64_t* mir_keys, float* mir_vals,
-                             float* b_out, void* stream) {
+                             float* b_out, void* split_scratch, size_t split_scratch_bytes, void* stream) {
     AsmArgs A;
     int rc = fill_args(A, h, sets, nsets, reg, col_bits, workspace);
     if (rc) return rc;
-    if (col_format != 0 && col_format != 1) return nksr_set_error(NKSR_ERR_ARG, "col_format must be 0 or 1");
+    if (col_format < 0 || col_format > 2) return nksr_set_error(NKSR_ERR_ARG, "col_format must be 0, 1 or 2");
     A.col_format = col_format;
     if (A.M <= 0) return NKSR_OK;
     hipStream_t st = (hipStream_t)stream;
     const dim3 blk(ASM_WAVES * 64);
     const size_t lds = (size_t)ASM_WAVES * NKSR_MAX_DEPTH * 125 * sizeof(float);
+    int64_t total_rows = 0;
+    for (int si = 0; si < nsets; ++si) total_rows += sets[si].n * sets[si].ncomp;
     for (int d = 0; d < h->depth; ++d) {
         const int n = h->lv[d].n;
         if (n <= 0) continue;
-        const int T = (h->depth - d) * 27;
+        const int T = (h->depth - d) * 27, NT = (T + 32) / 32;      // column tiles incl. the right-hand-side column
         const dim3 grid(nksr_blocks(n, ASM_WAVES));
-        switch ((T + 32) / 32) {      // column tiles incl. the right-hand-side column
-            case 1: hipLaunchKernelGGL((k_cell_blocks<1>), grid, blk, 0, st, A, d); break;
-            case 2: hipLaunchKernelGGL((k_cell_blocks<2>), grid, blk, 0, st, A, d); break;
-            case 3: hipLaunchKernelGGL((k_cell_blocks<3>), grid, blk, 0, st, A, d); break;
-            case 4: hipLaunchKernelGGL((k_cell_blocks<4>), grid, blk, 0, st, A, d); break;
-            case 5: hipLaunchKernelGGL((k_cell_blocks<5>), grid, blk, 0, st, A, d); break;
-            default: hipLaunchKernelGGL((k_cell_blocks<6>), grid, blk, 0, st, A, d); break;
+        const int nsplit = split_scratch ? asm_nsplit(total_rows, n) : 1;
+        if (nsplit > 1 && (size_t)n * nsplit * NT * 16 * 64 * sizeof(float) <= split_scratch_bytes) {
+            const dim3 gp(nksr_blocks((int64_t)n * nsplit, ASM_WAVES));
+            float* sc = (float*)split_scratch;
+#define CELLSPLIT(N) hipLaunchKernelGGL((k_cell_blocks_part<N>), gp, blk, 0, st, A, d, nsplit, sc); \
+                     hipLaunchKernelGGL((k_cell_blocks_reduce<N>), grid, blk, 0, st, A, d, nsplit, (const float*)sc)
+            switch (NT) {
+                case 1: CELLSPLIT(1); break;
+                case 2: CELLSPLIT(2); break;
+                case 3: CELLSPLIT(3); break;
+                case 4: CELLSPLIT(4); break;
+                case 5: CELLSPLIT(5); break;
+                default: CELLSPLIT(6); break;
+            }
+        } else {
+            switch (NT) {
+                case 1: hipLaunchKernelGGL((k_cell_blocks<1>), grid, blk, 0, st, A, d); break;
+                case 2: hipLaunchKernelGGL((k_cell_blocks<2>), grid, blk, 0, st, A, d); break;
+                case 3: hipLaunchKernelGGL((k_cell_blocks<3>), grid, blk, 0, st, A, d); break;
+                case 4: hipLaunchKernelGGL((k_cell_blocks<4>), grid, blk, 0, st, A, d); break;
+                case 5: hipLaunchKernelGGL((k_cell_blocks<5>), grid, blk, 0, st, A, d); break;
+                default: hipLaunchKernelGGL((k_cell_blocks<6>), grid, blk, 0, st, A, d); break;
+            }
         }
         NKSR_CHECK_LAUNCH();
     }
@@ -507,7 +657,7 @@ extern "C" int nksr_place_mirrors(const uint64_t* keys_sorted, const float* vals
                                   const int32_t* rowptr, const int32_t* mirptr, int col_format, int32_t* cols_out, float* vals_out,
                                   void* stream) {
     if (n <= 0) return NKSR_OK;
-    if (col_format != 0 && col_format != 1) return nksr_set_error(NKSR_ERR_ARG, "col_format must be 0 or 1");
+    if (col_format < 0 || col_format > 2) return nksr_set_error(NKSR_ERR_ARG, "col_format must be 0, 1 or 2");
     hipLaunchKernelGGL(k_place_mirrors, dim3(nksr_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, keys_sorted, vals_sorted, n,
                        col_bits, rowptr, mirptr, cols_out, vals_out, col_format);
     NKSR_CHECK_LAUNCH();

@@ -548,14 +548,14 @@ struct FusedOperator : PcgOperator {
 };
 
 extern "C" int nksr_pcg_solve_fused(const nksr_fused_op_t* opd, float reg, const float* diag, const float* b, float* x, float tol, int max_iter,
-                                    int check_every, void* pcg_workspace, double* info_out, void* stream) {
+                                    int check_every, void* pcg_workspace, const nksr_coarse_precond_t* pc, double* info_out, void* stream) {
     FusedOperator op;
     if (int rc = fz_args(op.A, opd)) return rc;
     if (op.A.M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
     if (!pcg_workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     op.reg = reg;
     op.w = fz_carve(opd);
-    return nksr_pcg_run(op, diag, op.A.M, b, x, tol, max_iter, check_every, pcg_workspace, info_out, (hipStream_t)stream);
+    return nksr_pcg_run(op, diag, op.A.M, b, x, tol, max_iter, check_every, pcg_workspace, info_out, (hipStream_t)stream, pc);
 }
 
 extern "C" size_t nksr_pcg_vector_workspace_bytes(int32_t M) { return nksr_pcg_vector_bytes(M); }

@@ -437,14 +437,150 @@ extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_ou
     return NKSR_OK;
 }
 
+// ---- coarse-level block preconditioner -------------------------------------------------------------------------------------------
+// The multi-level system is badly conditioned through its COARSE basis functions (each overlaps 124 neighbours of its own level and
+// every finer voxel under its support): Jacobi needs 47 iterations per tree_depth-5 chunk where an exact solve of the diagonal
+// block of the levels >= 2 (8 % of the unknowns, 4.5 % of the non-zeros) would need 12.  That block A_cc is assembled once per
+// solve (plain CSR, nksr_assemble on the hierarchy with its fine levels masked) and z_c ~ A_cc^-1 r_c is approximated by a FIXED
+// number of Jacobi-preconditioned Chebyshev steps -- a fixed polynomial in A_cc, hence a constant SPD preconditioner (plain CG
+// stays valid) and deterministic.  One kernel per step, one wavefront per row:
+//   t = (A_cc d)_j;  y_j += d_j;  res_j -= t;  d'_j = a d_j + b res_j / D_j          (d double-buffered: rows read their neighbours' d)
+__global__ void __launch_bounds__(256) k_cheb_init(int n, const float* __restrict__ r, const float* __restrict__ diag, float inv_theta,
+                                                   float* __restrict__ res, float* __restrict__ d0, float* __restrict__ y,
+                                                   const int* __restrict__ done) {
+    if (done && *done) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const float rj = r[j];
+    res[j] = rj;
+    d0[j] = rj / diag[j] * inv_theta;
+    y[j] = 0.f;
+}
+
+__global__ void __launch_bounds__(256) k_cheb_step(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                   const float* __restrict__ vals, const float* __restrict__ diag, float a, float b,
+                                                   float* __restrict__ res, const float* __restrict__ d_old, float* __restrict__ d_new,
+                                                   float* __restrict__ y, const int* __restrict__ done) {
+    if (done && *done) return;
+    const int j = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (j >= n) return;
+    float t = 0.f, t1 = 0.f;
+    int k = rowptr[j] + lane;
+    const int k1 = rowptr[j + 1];
+    for (; k + 64 < k1; k += 128) {          // two independent chains: the block sits in L2, the row loop is latency-bound
+        const float v0 = vals[k], v1 = vals[k + 64];
+        const int c0 = cols[k], c1 = cols[k + 64];
+        t = fmaf(v0, d_old[c0], t);
+        t1 = fmaf(v1, d_old[c1], t1);
+    }
+    if (k < k1) t = fmaf(vals[k], d_old[cols[k]], t);
+    t += t1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) {
+        const float dj = d_old[j], rj = res[j] - t;
+        y[j] += dj;
+        res[j] = rj;
+        d_new[j] = fmaf(a, dj, b * rj / diag[j]);
+    }
+}
+
+// v' = D^-1 A_cc v (power iteration for the largest eigenvalue of the Jacobi-scaled block)
+__global__ void __launch_bounds__(256) k_coarse_power(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                      const float* __restrict__ vals, const float* __restrict__ diag,
+                                                      const float* __restrict__ v, float* __restrict__ out) {
+    const int j = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (j >= n) return;
+    float t = 0.f;
+    for (int k = rowptr[j] + lane, k1 = rowptr[j + 1]; k < k1; k += 64) t = fmaf(vals[k], v[cols[k]], t);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) out[j] = t / diag[j];
+}
+// out = sqrt(sum b^2 / sum a^2), one workgroup, fixed order
+__global__ void __launch_bounds__(PCG_BLOCK) k_norm_ratio(int n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+    __shared__ double sm[PCG_BLOCK / 64];
+    double sa = 0.0, sb = 0.0;
+    for (int i = threadIdx.x; i < n; i += PCG_BLOCK) { sa += (double)a[i] * a[i]; sb += (double)b[i] * b[i]; }
+    const double ta = block_sum(sa, sm), tb = block_sum(sb, sm);
+    if (threadIdx.x == 0) out[0] = ta > 0.0 ? (float)sqrt(tb / ta) : 0.f;
+}
+
+extern "C" int nksr_coarse_lambda_max(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n, int iters,
+                                      float* work, float* lambda_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (!rowptr || !cols || !vals || !diag || !work || !lambda_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    if (iters < 2) iters = 2;
+    hipStream_t st = (hipStream_t)stream;
+    float* v[2] = {work, work + n};
+    const dim3 g1(nksr_blocks(n, 256)), gw(nksr_blocks((int64_t)n * 64, 256));
+    hipLaunchKernelGGL(k_cheb_init, g1, dim3(256), 0, st, n, diag, diag, 1.f, v[1], v[0], v[1], (const int*)nullptr);   // v0 = 1 (diag / diag)
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL(k_coarse_power, gw, dim3(256), 0, st, n, rowptr, cols, vals, diag, (const float*)v[i & 1], v[(i + 1) & 1]);
+    hipLaunchKernelGGL(k_norm_ratio, dim3(1), dim3(PCG_BLOCK), 0, st, n, (const float*)v[(iters - 1) & 1], (const float*)v[iters & 1], lambda_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+struct ChebPlan { int steps; float inv_theta; float a[NKSR_PC_MAX_STEPS], b[NKSR_PC_MAX_STEPS]; };
+static int cheb_plan(ChebPlan& P, const nksr_coarse_precond_t* pc) {
+    if (pc->n <= 0 || pc->steps < 1 || pc->steps > NKSR_PC_MAX_STEPS) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: 1..%d steps", NKSR_PC_MAX_STEPS);
+    if (!(pc->lambda_max > 0.f) || !(pc->ratio > 1.f)) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: lambda_max > 0, ratio > 1");
+    if (!pc->rowptr || !pc->cols || !pc->vals || !pc->diag || !pc->work) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner has NULL arrays");
+    const double lmax = pc->lambda_max, lmin = lmax / pc->ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
+    const double sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    P.steps = pc->steps;
+    P.inv_theta = (float)(1.0 / theta);
+    for (int i = 0; i < pc->steps; ++i) {
+        const double rho_n = 1.0 / (2.0 * sigma - rho);
+        P.a[i] = (float)(rho_n * rho);
+        P.b[i] = (float)(2.0 * rho_n / delta);
+        rho = rho_n;
+    }
+    return NKSR_OK;
+}
+// z_c = p_k(A_cc) r_c  (r, z: the coarse slices of the PCG vectors)
+static void cheb_apply(const nksr_coarse_precond_t* pc, const ChebPlan& P, const float* r, float* z, const int* done, hipStream_t st) {
+    const int n = pc->n;
+    float *res = pc->work, *d[2] = {pc->work + n, pc->work + 2 * (size_t)n};
+    hipLaunchKernelGGL(k_cheb_init, dim3(nksr_blocks(n, 256)), dim3(256), 0, st, n, r, pc->diag, P.inv_theta, res, d[0], z, done);
+    for (int i = 0; i < P.steps; ++i)
+        hipLaunchKernelGGL(k_cheb_step, dim3(nksr_blocks((int64_t)n * 64, 256)), dim3(256), 0, st, n, pc->rowptr, pc->cols, pc->vals, pc->diag,
+                           P.a[i], P.b[i], res, (const float*)d[i & 1], d[(i + 1) & 1], z, done);
+}
+
+// partial r.z again (second column of part2) after the coarse slice of z changed; init: p = z as well
+__global__ void __launch_bounds__(PCG_BLOCK) k_pcg_rz(int M, PcgWork w, int copy_p) {
+    if (!copy_p && w.sc->done) return;
+    __shared__ double sm[PCG_BLOCK / 64];
+    double rz = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        const float zi = w.z[i];
+        if (copy_p) w.p[i] = zi;
+        rz += (double)w.r[i] * zi;
+    }
+    const double t = block_sum(rz, sm);
+    if (threadIdx.x == 0) w.part2[2 * blockIdx.x + 1] = t;
+}
+
 int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, float* x, float tol, int max_iter, int check_every,
-                 void* vector_workspace, double* info_out, hipStream_t st) {
+                 void* vector_workspace, double* info_out, hipStream_t st, const nksr_coarse_precond_t* pc) {
     if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
     if (!vector_workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     if (check_every < 1) check_every = 1;
     PcgWork w = carve(vector_workspace, M);
     const int nbv = nksr_blocks(M, PCG_BLOCK) > PCG_MAX_BLOCKS ? PCG_MAX_BLOCKS : nksr_blocks(M, PCG_BLOCK);
+    ChebPlan plan;
+    if (pc) {
+        if (int rc = cheb_plan(plan, pc)) return rc;
+        if (pc->first < 0 || pc->first + pc->n != M) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: the block must be the last %d unknowns", pc->n);
+    }
     hipLaunchKernelGGL(k_pcg_init, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, b, diag, w, x);
+    if (pc) {
+        cheb_apply(pc, plan, w.r + pc->first, w.z + pc->first, nullptr, st);
+        hipLaunchKernelGGL(k_pcg_rz, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w, 1);
+    }
     hipLaunchKernelGGL(k_pcg_init_finish, dim3(1), dim3(PCG_BLOCK), 0, st, w, nbv);
     NKSR_CHECK_LAUNCH();
     PcgScalars host;
@@ -466,6 +602,10 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
             if (prof) (void)hipEventRecord(g_prof_events[2 * c + 1], st);
             hipLaunchKernelGGL(k_pcg_dot, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w);
             hipLaunchKernelGGL(k_pcg_update, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, diag, w, x, nbv, parity);
+            if (pc) {
+                cheb_apply(pc, plan, w.r + pc->first, w.z + pc->first, &w.sc->done, st);
+                hipLaunchKernelGGL(k_pcg_rz, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w, 0);
+            }
             hipLaunchKernelGGL(k_pcg_pupdate, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w, nbv, parity, tol);
         }
         NKSR_CHECK_LAUNCH();

@@ -12,12 +12,13 @@ normal equations (w_p G^T G + w_n Q^T Q + reg I) alpha = w_n Q^T n solved by Jac
 All numeric work runs in HIP kernels (csrc/kfield.hip, assemble.hip, pcg.hip).
 """
 import ctypes as C
+import os
 import time
 
 import torch
 
 from .. import _lib, ops
-from .._lib import FusedOpT, HierT, SiteSetT, call, ptr, stream
+from .._lib import CoarsePrecondT, FusedOpT, HierT, SiteSetT, call, ptr, stream
 from .base_field import BaseField, EvaluationResult
 
 
@@ -67,14 +68,27 @@ class KernelField(BaseField):
         return h
 
     # ---- kernel rows ---------------------------------------------------------------------------------
-    def kernel_rows(self, xyz, grad, scale=1.0, values=True):
+    def kernel_rows(self, xyz, grad, scale=1.0, values=True, hier=None):
         """Dense-slot rows: val [n, L, 27] (``None`` with values=False) and (grad) dval [n, 3, L, 27]
-        (model units), times ``scale``."""
+        (model units), times ``scale``.  ``hier``: a masked copy of the hierarchy (_coarse_hier): rows of masked levels are 0."""
         n, L = xyz.shape[0], self.svh.depth
         val = torch.empty((n, L, 27), dtype=torch.float32, device=self.device) if values else None
         dval = torch.empty((n, 3, L, 27), dtype=torch.float32, device=self.device) if grad else None
-        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), 0, None, None, ptr(val), ptr(dval), stream())
+        call('nksr_kernel_rows', C.byref(hier if hier is not None else self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), 0, None, None,
+             ptr(val), ptr(dval), stream())
         return val, dval
+
+    def _coarse_hier(self, c0):
+        """The hierarchy restricted to its levels >= c0: the finer levels are EMPTY (no voxels, no hash: every site misses them),
+        the coarse ones keep their level index -- and with it their geometry -- and are re-based to unknown 0."""
+        h = HierT.from_buffer_copy(self._hier)
+        off = self.svh.offsets
+        for d in range(self.svh.depth):
+            if d < c0:
+                h.lv[d].n, h.lv[d].offset, h.lv[d].hcap = 0, 0, 0
+            else:
+                h.lv[d].offset = off[d] - off[c0]
+        return h
 
     def kernel_rows_level_major(self, xyz, grad, scale, out, level_stride, row_index=None, row_cells=None):
         """Rows of the sites ``xyz`` written LEVEL-MAJOR into ``out`` ([L, level_stride, 27]): position rows (grad=False, one per
@@ -105,18 +119,35 @@ class KernelField(BaseField):
 
     # ---- assembly -----------------------------------------------------------------------------------
     def assemble(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0,
-                 pos_sorted_keys=None, normal_sorted_keys=None):
+                 pos_sorted_keys=None, normal_sorted_keys=None, coarse_from=None, fused_op=None):
         """Materialise the CSR normal equations.  Returns (rowptr, cols, vals, diag, b).
-        ``*_sorted_keys``: level-0 Morton keys of site sets that are ALREADY Morton-sorted."""
+        ``*_sorted_keys``: level-0 Morton keys of site sets that are ALREADY Morton-sorted.
+        ``coarse_from`` = c0: only the diagonal block of the levels >= c0 (plain CSR, local indices) -- the preconditioner's;
+        with ``fused_op`` (fused_operator's result) it reads the kernel rows the matrix-free operator already holds."""
         dev = self.device
-        M = self.svh.num_unknowns
+        hier = self._hier if coarse_from is None else self._coarse_hier(int(coarse_from))
+        M = self.svh.num_unknowns if coarse_from is None else self.svh.num_unknowns - self.svh.offsets[int(coarse_from)]
         if M == 0:
             raise RuntimeError('empty hierarchy')
         keep = []  # keep every buffer alive until the launches are enqueued
         sets = (SiteSetT * 2)()
         nsets = 0
-        for xyz, target, weight, ncomp, pre in ((pos_xyz, None, pos_weight, 1, pos_sorted_keys),
-                                                 (normal_xyz, normal_value, normal_weight, 3, normal_sorted_keys)):
+        if fused_op is not None:
+            # the operator's Morton-ordered row list IS a site set with one row per "site": the rows of a cell are the run
+            # span[0][j] .. span[1][j] (fused tables), so neither site ranges nor a row index are needed
+            first, last = fused_op['span'][0], fused_op['span'][1]
+            st_all, en_all = first.clamp(min=0), (last + 1).contiguous()
+            off = self.svh.offsets
+            S = sets[0]
+            S.n, S.ncomp, S.weight = fused_op['rows_total'], 1, 1.0
+            S.val, S.level_stride = ptr(fused_op['rows_all']), fused_op['rows_total']
+            for d in range(self.svh.depth):
+                nd = self.svh.level(d).num_voxels
+                S.start[d], S.end[d] = ptr(st_all[off[d]:off[d] + nd]), ptr(en_all[off[d]:off[d] + nd])
+            keep += [st_all, en_all]
+            nsets = 1
+        for xyz, target, weight, ncomp, pre in (((pos_xyz, None, pos_weight, 1, pos_sorted_keys),
+                                                  (normal_xyz, normal_value, normal_weight, 3, normal_sorted_keys)) if fused_op is None else ()):
             if xyz is None or xyz.shape[0] == 0:
                 continue
             xyz = xyz.to(dev, torch.float32).contiguous()
@@ -130,7 +161,7 @@ class KernelField(BaseField):
             # rows (and targets) are produced pre-multiplied by sqrt(weight): the Gram products of the
             # assembly are then bitwise symmetric and its matrix-core operands need no scaling
             sw = float(weight) ** 0.5
-            val, dval = self.kernel_rows(xs, grad=(ncomp == 3), scale=sw, values=(ncomp == 1))
+            val, dval = self.kernel_rows(xs, grad=(ncomp == 3), scale=sw, values=(ncomp == 1), hier=hier)
             rows = val if ncomp == 1 else dval
             st, en = self._site_ranges(ks)
             S = sets[nsets]
@@ -148,8 +179,8 @@ class KernelField(BaseField):
         # structure pass: own-upper counts + in-degrees -> exclusive scans -> final CSR row pointers
         counts = torch.zeros((4, M + 1), dtype=torch.int32, device=dev)
         rowcount, crosscount, samelow, indeg = counts[0], counts[1], counts[2], counts[3]
-        ws = torch.empty(int(_lib.lib.nksr_assemble_workspace_bytes(C.byref(self._hier))), dtype=torch.uint8, device=dev)
-        call('nksr_assemble_count', C.byref(self._hier), ptr(ws), ptr(rowcount), ptr(crosscount), ptr(samelow), ptr(indeg), stream())
+        ws = torch.empty(int(_lib.lib.nksr_assemble_workspace_bytes(C.byref(hier))), dtype=torch.uint8, device=dev)
+        call('nksr_assemble_count', C.byref(hier), ptr(ws), ptr(rowcount), ptr(crosscount), ptr(samelow), ptr(indeg), stream())
         n_up, n_mir = [int(v) for v in counts[:2].sum(dim=1, dtype=torch.int64).tolist()]
         nnz = 2 * n_up + M
         if nnz >= 2 ** 31 - 4096:
@@ -164,7 +195,9 @@ class KernelField(BaseField):
         # physical (tile-interleaved, zero-padded) CSR arrays for the streaming SpMV: packed 21-bit columns
         # (6.67 bytes per entry) whenever the unknowns fit, int32 columns otherwise (include/nksr_hip.h)
         fmt = 1 if M <= (1 << 21) and int(self.solver_config.get('col_format', 1)) == 1 else 0
-        chunk, tile = (4608, 192) if fmt else (4096, 256)
+        if coarse_from is not None:
+            fmt = 2
+        chunk, tile = (4608, 192) if fmt == 1 else ((4096, 256) if fmt == 0 else (1, 1))
         npad = (nnz + chunk - 1) // chunk * chunk
         cols = torch.empty(npad, dtype=torch.int32, device=dev)
         vals = torch.empty(npad, dtype=torch.float32, device=dev)
@@ -177,19 +210,24 @@ class KernelField(BaseField):
         b = torch.empty(M, dtype=torch.float32, device=dev)
         mir_k = torch.empty(n_mir, dtype=torch.int64, device=dev)
         mir_v = torch.empty(n_mir, dtype=torch.float32, device=dev)
-        call('nksr_assemble', C.byref(self._hier), sets, nsets, float(reg_weight), col_bits, ptr(ws), ptr(rowptr), ptr(indeg),
-             ptr(samelow), ptr(mir_off), fmt, ptr(cols), ptr(vals), ptr(diag), ptr(mir_k), ptr(mir_v), ptr(b), stream())
+        # coarse cells hold thousands of site rows: their Gram blocks are accumulated by several wavefronts each (csrc/assemble.hip)
+        split_bytes = int(_lib.lib.nksr_assemble_split_bytes(C.byref(hier), sum(int(sets[i].n) * int(sets[i].ncomp) for i in range(nsets))))
+        split = torch.empty(split_bytes, dtype=torch.uint8, device=dev) if split_bytes else None
+        call('nksr_assemble', C.byref(hier), sets, nsets, float(reg_weight), col_bits, ptr(ws), ptr(rowptr), ptr(indeg),
+             ptr(samelow), ptr(mir_off), fmt, ptr(cols), ptr(vals), ptr(diag), ptr(mir_k), ptr(mir_v), ptr(b), ptr(split), split_bytes, stream())
+        del split
         del ws
         ks, vs = ops.sort_pairs(mir_k, mir_v.view(torch.int32), end_bit=col_bits)   # stable, destination-row bits only
         del mir_k, mir_v
         call('nksr_place_mirrors', ptr(ks), ptr(vs.view(torch.float32)), n_mir, col_bits, ptr(rowptr), ptr(mirptr), fmt, ptr(cols),
              ptr(vals), stream())
         del ks, vs
-        if fmt:
+        if fmt == 1:
             packed = torch.empty(npad // 3, dtype=torch.int64, device=dev)
             call('nksr_pack_cols21', ptr(cols), npad, ptr(packed), stream())
             cols = packed
-        self.nnz = nnz
+        if coarse_from is None:
+            self.nnz = nnz
         del keep
         return rowptr, cols, vals, diag, b
 
@@ -297,7 +335,7 @@ class KernelField(BaseField):
         op.nnz_counter = ptr(nnz_counter)
         keep += [nbr32, offsets, multi, ws, cell_sums, nnz_counter]
         return {'op': op, 'nsets': len(specs), 'nblocks': nblocks, 'rows_total': rows_total, 'n_multi': int(multi.numel()),
-                'nnz_counter': nnz_counter, 'keep': keep}
+                'nnz_counter': nnz_counter, 'keep': keep, 'span': span, 'rows_all': rows_all}
 
     def fused_rhs_diag(self, op, reg_weight=1.0):
         M = self.svh.num_unknowns
@@ -317,6 +355,36 @@ class KernelField(BaseField):
         call('nksr_fused_apply', C.byref(op['op']), float(reg_weight), ptr(x.contiguous()), ptr(y), stream())
         return y
 
+    def _coarse_precond(self, op, reg_weight):
+        """Block preconditioner of the coarse levels (nksr_coarse_precond_t, csrc/pcg.hip): the diagonal block of the levels >= c0
+        assembled as a small plain CSR + its largest Jacobi-scaled eigenvalue.  solver_config['coarse_precond']: None = automatic
+        (hierarchies of 5+ levels: Jacobi alone needs ~47 iterations per tree_depth-5 chunk, ~11 at depth 4 where the set-up would
+        not pay), False = off, or a dict {'first_level', 'steps', 'ratio'}."""
+        cfg = self.solver_config.get('coarse_precond')
+        L = self.svh.depth
+        if cfg is False or (cfg is None and L < 5):
+            return None
+        cfg = dict(cfg) if isinstance(cfg, dict) else {}
+        for k, e in (('first_level', 'NKSR_PC_LEVEL'), ('steps', 'NKSR_PC_STEPS'), ('ratio', 'NKSR_PC_RATIO')):      # tuning knobs
+            if e in os.environ and k not in cfg:
+                cfg[k] = float(os.environ[e])
+        c0 = int(cfg.get('first_level', 2))
+        off = self.svh.offsets
+        M = self.svh.num_unknowns
+        if not 0 < c0 < L or M - off[c0] < 1:
+            return None
+        n = M - off[c0]
+        rowptr, cols, vals, diag, _ = self.assemble(None, None, None, 1.0, 1.0, reg_weight, coarse_from=c0, fused_op=op)
+        work = torch.empty(3 * n, dtype=torch.float32, device=self.device)
+        lam = torch.empty(1, dtype=torch.float32, device=self.device)
+        call('nksr_coarse_lambda_max', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), n, 8, ptr(work), ptr(lam), stream())
+        lmax = 1.1 * float(lam.item())          # eight power-iteration steps from the all-ones vector land within ~1 % (measured): 10 % margin
+        pc = CoarsePrecondT()
+        pc.first, pc.n, pc.steps, pc.lambda_max, pc.ratio = off[c0], n, int(cfg.get('steps', 6)), lmax, float(cfg.get('ratio', 100.0))
+        pc.rowptr, pc.cols, pc.vals, pc.diag, pc.work = ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), ptr(work)
+        return {'pc': pc, 'first_level': c0, 'unknowns': n, 'nnz': int(cols.numel()), 'steps': int(pc.steps), 'lambda_max': lmax,
+                'keep': (rowptr, cols, vals, diag, work)}
+
     def solve_fused(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0,
                     pos_sorted_keys=None, normal_sorted_keys=None):
         """Matrix-free Jacobi-PCG on the normal equations: no assembly, ~8 bytes per dense kernel-row slot per
@@ -327,6 +395,7 @@ class KernelField(BaseField):
         dev = self.device
         M = self.svh.num_unknowns
         b, diag = self.fused_rhs_diag(op, reg_weight)
+        pc = self._coarse_precond(op, reg_weight)
         if self.solver_config.get('verbose') or self.solver_config.get('sync_timing'):
             torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
@@ -334,7 +403,7 @@ class KernelField(BaseField):
         pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=dev)
         info = (C.c_double * 2)()
         call('nksr_pcg_solve_fused', C.byref(op['op']), float(reg_weight), ptr(diag), ptr(b), ptr(x), float(self.solver_config['tol']),
-             int(self.solver_config['max_iter']), int(self.solver_config['check_every']), ptr(pws), info, stream())
+             int(self.solver_config['max_iter']), int(self.solver_config['check_every']), ptr(pws), C.byref(pc['pc']) if pc else None, info, stream())
         t2 = time.perf_counter()
         self.alpha = x
         self.matrix = None
@@ -344,6 +413,7 @@ class KernelField(BaseField):
         self.nnz = 0
         self.solve_info = {'iters': int(info[0]), 'rel_residual': float(info[1]), 'M': int(M), 'nnz': 0, 'fused': True,
                            'kernel_row_slots': 27 * self.svh.depth * op['rows_total'], 'partial_blocks': op['nblocks'],
+                           'coarse_precond': ({k: pc[k] for k in ('first_level', 'unknowns', 'nnz', 'steps', 'lambda_max')} if pc else None),
                            't_assemble': t1 - t0, 't_pcg': t2 - t1}
         if self.solver_config.get('verbose'):
             print('[KernelField] fused: M=%d rows=%d iters=%d rel=%.3e rows+rhs=%.3fs pcg=%.3fs' % (
@@ -368,7 +438,7 @@ class KernelField(BaseField):
         pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=self.device)
         info = (C.c_double * 2)()
         call('nksr_pcg_solve_fused', C.byref(self._fused_op['op']), self._fused_reg, ptr(self.diag), ptr(rhs.contiguous()), ptr(x), float(cfg['tol']),
-             int(cfg['max_iter']), int(cfg['check_every']), ptr(pws), info, stream())
+             int(cfg['max_iter']), int(cfg['check_every']), ptr(pws), None, info, stream())
         return x
 
     def _attach_autograd(self, normal_xyz, normal_value, normal_weight, reg_weight):
