@@ -33,6 +33,8 @@ class Reconstructor:
         # (GIL, allocator pools per stream; two assembled solves at once also fight over their 11 GB workspaces: 3.05 s).
         # None = 2 for the matrix-free solve, 1 for the assembled one
         self.chunk_streams = None
+        self.coarse_precond = None  # matrix-free solve: None = automatic (coarse-level block preconditioner for 5+ levels), False = Jacobi only,
+        #                             or {'first_level', 'steps', 'ratio'} (fields/kernel_field.py _coarse_precond)
         self.col_format = 1        # physical layout of the assembled matrix (include/nksr_hip.h); int32 columns when M > 2^21
 
     # ---- scale selection (NKSR-USAGE.md:129-137) ---------------------------------------------------
@@ -63,7 +65,7 @@ class Reconstructor:
         field = KernelField(svh=dec_svh, interpolator=self.network.interpolators, features=feat.basis_features,
                             approx_kernel_grad=approx_kernel_grad)
         field.solver_config.update({'max_iter': int(solver_max_iter), 'tol': float(solver_tol), 'sync_timing': self.sync_timing,
-                                    'col_format': self.col_format})
+                                    'col_format': self.col_format, 'coarse_precond': self.coarse_precond})
         normal_xyz = torch.cat([dec_svh.get_voxel_centers(d) for d in range(hp.adaptive_depth)])
         normal_value = torch.cat([feat.normal_features[d] for d in range(hp.adaptive_depth)])
         if self.sync_timing:
