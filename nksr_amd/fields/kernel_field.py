@@ -358,11 +358,10 @@ class KernelField(BaseField):
     def _coarse_precond(self, op, reg_weight):
         """Block preconditioner of the coarse levels (nksr_coarse_precond_t, csrc/pcg.hip): the diagonal block of the levels >= c0
         assembled as a small plain CSR + its largest Jacobi-scaled eigenvalue.  solver_config['coarse_precond']: None = automatic
-        (hierarchies of 5+ levels: Jacobi alone needs ~47 iterations per tree_depth-5 chunk, ~11 at depth 4 where the set-up would
-        not pay), False = off, or a dict {'first_level', 'steps', 'ratio'}."""
+        (see solve_fused), False = off, or a dict {'first_level', 'steps', 'ratio'}."""
         cfg = self.solver_config.get('coarse_precond')
         L = self.svh.depth
-        if cfg is False or (cfg is None and L < 5):
+        if cfg is False:
             return None
         cfg = dict(cfg) if isinstance(cfg, dict) else {}
         for k, e in (('first_level', 'NKSR_PC_LEVEL'), ('steps', 'NKSR_PC_STEPS'), ('ratio', 'NKSR_PC_RATIO')):      # tuning knobs
@@ -395,15 +394,40 @@ class KernelField(BaseField):
         dev = self.device
         M = self.svh.num_unknowns
         b, diag = self.fused_rhs_diag(op, reg_weight)
-        pc = self._coarse_precond(op, reg_weight)
-        if self.solver_config.get('verbose') or self.solver_config.get('sync_timing'):
+        cfg, tol = self.solver_config, float(self.solver_config['tol'])
+        max_iter, check_every = int(cfg['max_iter']), int(cfg['check_every'])
+        # Preconditioner policy (coarse_precond = None): hierarchies of 5+ levels get the coarse-level block at once (Jacobi alone
+        # needs ~47 iterations per tree_depth-5 chunk); shallower ones start with Jacobi -- the 1M-point headline converges in 11
+        # iterations, a set-up would not pay -- and switch after one unconverged round of check_every iterations (sparse /
+        # sensor-only inputs and adaptive_depth 2 take 100+ Jacobi iterations at depth 4 too).
+        auto = cfg.get('coarse_precond') is None
+        pc = self._coarse_precond(op, reg_weight) if (not auto or self.svh.depth >= 5) else None
+        if cfg.get('verbose') or cfg.get('sync_timing'):
             torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
-        x = torch.empty(M, dtype=torch.float32, device=dev)
         pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=dev)
-        info = (C.c_double * 2)()
-        call('nksr_pcg_solve_fused', C.byref(op['op']), float(reg_weight), ptr(diag), ptr(b), ptr(x), float(self.solver_config['tol']),
-             int(self.solver_config['max_iter']), int(self.solver_config['check_every']), ptr(pws), C.byref(pc['pc']) if pc else None, info, stream())
+
+        def pcg(rhs, rtol, iters, precond):
+            sol = torch.empty(M, dtype=torch.float32, device=dev)
+            inf = (C.c_double * 2)()
+            call('nksr_pcg_solve_fused', C.byref(op['op']), float(reg_weight), ptr(diag), ptr(rhs), ptr(sol), float(rtol), int(iters),
+                 check_every, ptr(pws), C.byref(precond['pc']) if precond else None, inf, stream())
+            return sol, int(inf[0]), float(inf[1])
+        if pc is not None or not auto or max_iter <= check_every:
+            x, iters, rel = pcg(b, tol, max_iter, pc)
+        else:
+            x, iters, rel = pcg(b, tol, check_every, None)
+            if rel > tol:
+                # restart on the residual with the block preconditioner: A e = b - A x to the remaining accuracy
+                pc = self._coarse_precond(op, reg_weight)
+                r = b - self.fused_apply(op, x, reg_weight)
+                bn, rn = float(torch.linalg.vector_norm(b.double())), float(torch.linalg.vector_norm(r.double()))
+                if rn > tol * bn:
+                    e, it2, rel2 = pcg(r, tol * bn / rn, max_iter - iters, pc)
+                    x, iters, rel = x + e, iters + it2, rel2 * rn / bn
+                else:
+                    rel = rn / bn
+        info = (float(iters), rel)
         t2 = time.perf_counter()
         self.alpha = x
         self.matrix = None

@@ -170,7 +170,7 @@ def test_fused_operator_matches_the_assembled_matrix(approx):
         pu.check('fused:apply_vs_oracle[%d]' % trial, (np.abs(yf - A64 @ x.astype(np.float64)) / bound).max(), 1e-5)
         pu.check('fused:apply_vs_csr[%d]' % trial, (np.abs(yf - yc) / bound).max(), 1e-5)
     # same PCG, two operators: iterates after a fixed number of iterations
-    fld.solver_config.update({'tol': 0.0, 'max_iter': 6, 'check_every': 2})
+    fld.solver_config.update({'tol': 0.0, 'max_iter': 6, 'check_every': 2, 'coarse_precond': False})      # Jacobi only: the CSR solve's preconditioner
     x_csr = solver.pcg_solve(rowptr, cols, vals, diag, gb, tol=0.0, max_iter=6, check_every=2)[0]
     fld.solve_fused(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
     assert fld.solve_info['iters'] == 6 and fld.solve_info['fused']
@@ -459,6 +459,34 @@ def test_coarse_block_preconditioner_same_solution_fewer_iterations():
     D = abs(Ac - ref)
     pu.check('coarse_precond:block_vs_assembled_rel', float(D.max() / abs(ref).max()), 1e-5)
     assert abs(Ac - Ac.T).max() <= 1e-6 * abs(ref).max()
+
+
+def test_shallow_hierarchies_switch_to_the_coarse_block_when_jacobi_stalls():
+    """Depth-4 hierarchies start with Jacobi (the dense 1M-point cloud converges in 11 iterations) and restart on the residual with
+    the coarse-level block after one unconverged round of check_every iterations: sparse input with normal sites on two levels
+    (adaptive_depth 2, the carla preset's) takes 100+ Jacobi iterations.  Same solution, fewer iterations, deterministic."""
+    import nksr_amd
+    from nksr_amd import configs
+    n = 2500
+    k = np.arange(n) + 0.5
+    phi, z = np.pi * (1 + 5 ** 0.5) * k, 1 - 2 * k / n
+    nrm = np.stack([np.cos(phi) * np.sqrt(1 - z * z), np.sin(phi) * np.sqrt(1 - z * z), z], 1).astype(np.float32)
+    xyz = (nrm * np.float32(0.45)).astype(np.float32)
+    hp = configs.get_hparams('ks', adaptive_depth=2)
+    t = lambda a: torch.from_numpy(a).to(_dev())
+    res = {}
+    for name, pc in (('jacobi', False), ('auto', None), ('auto2', None)):
+        rec = nksr_amd.Reconstructor(_dev(), hparams=hp)
+        rec.coarse_precond = pc
+        fld = rec.reconstruct(t(xyz), t(nrm), voxel_size=0.02, solver_tol=1e-6)
+        assert fld.svh.depth == 4 and fld.solve_info['rel_residual'] <= 1e-6
+        res[name] = (fld.alpha.clone(), fld.solve_info['iters'], fld.solve_info['coarse_precond'])
+    pu.report('coarse_precond:adaptive_iters', auto=res['auto'][1], jacobi_only=res['jacobi'][1])
+    assert res['jacobi'][1] > 48 and res['jacobi'][2] is None, res['jacobi'][1]          # otherwise this input does not exercise the switch
+    assert res['auto'][2] is not None and res['auto'][1] < res['jacobi'][1]
+    assert torch.equal(res['auto'][0], res['auto2'][0]) and res['auto'][1] == res['auto2'][1]
+    pu.check('coarse_precond:adaptive_alpha_vs_jacobi_rel', float((res['auto'][0] - res['jacobi'][0]).abs().max() / res['jacobi'][0].abs().max()),
+             pu.ALPHA_TOL)
 
 
 def test_adaptive_depth_meshing_covers_what_the_finest_level_leaves_open():
