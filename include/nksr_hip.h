@@ -282,6 +282,20 @@ int nksr_pcg_solve_fused(const nksr_fused_op_t* op, float reg, const float* diag
 int nksr_knn_pca_normals(const float* xyz_sorted, int64_t n, const int32_t* start, const int32_t* end,
                          const int64_t* hkeys, const int32_t* hvals, int32_t hcap, float cell, float inv_cell, int k,
                          int max_ring, float* normal_out, float* radius2_out, int32_t* valid_out, void* stream);
+/* Signed distance of arbitrary queries to an oriented cloud from their k = nb_points nearest reference points: the training
+ * ground truth ext.sdfgen.sdf_from_points(queries, ref_xyz, ref_normal, nb_points, stdv, compute_grad, imls, adaptive_knn)
+ * (ext/sdfgen/sdf_from_points.cu:32-235; models/loss.py:85, dataset/av_gt_geometry.py:72).  imls = 0: nearest-neighbour magnitude
+ * (|n.(x-p)| inside stdv * ref_std[p], |x-p| outside) with the sign voted by the k neighbours; imls != 0: IMLS weights
+ * exp(-|x-p_k|^2 / stdv^2).  ref_std_sorted may be NULL (= 1); grad_out may be NULL.  valid_out[i] = 0: fewer than k points within
+ * max_ring cells (retry on a coarser grid).  nksr_knn_mean_dist: mean distance of every reference point to its k nearest
+ * (itself included) = ref_std for adaptive_knn = k. */
+int nksr_sdf_from_points(const float* xyz_sorted, const float* normal_sorted, const float* ref_std_sorted, const int32_t* start,
+                         const int32_t* end, const int64_t* hkeys, const int32_t* hvals, int32_t hcap, float cell, float inv_cell,
+                         const float* query, int64_t nq, int k, int max_ring, float stdv, int imls, float* sdf_out, float* grad_out,
+                         int32_t* valid_out, void* stream);
+int nksr_knn_mean_dist(const float* xyz_sorted, int64_t n, const int32_t* start, const int32_t* end, const int64_t* hkeys,
+                       const int32_t* hvals, int32_t hcap, float cell, float inv_cell, int k, int max_ring, float* out,
+                       int32_t* valid_out, void* stream);
 /* index (into the sorted cloud) of the nearest point of every query: fields.PCNNField,
  * examples/recons_colored_mesh.py:28 */
 int nksr_nearest_index(const float* xyz_sorted, const int32_t* start, const int32_t* end, const int64_t* hkeys,

@@ -115,6 +115,8 @@ _PROTOS = {
     'nksr_pcg_profile_bytes': [_P(C.c_double), _P(C.c_double)],
     'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
     'nksr_nearest_index': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, _vp, _vp],
+    'nksr_sdf_from_points': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp],
+    'nksr_knn_mean_dist': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp],
     'nksr_base_cell_flags': [_vp, _i32, _vp, _vp],
     'nksr_base_cell_keys': [_vp, _vp, _i64, C.c_int, _vp, _vp],
     'nksr_level_cell_keys': [_vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp],

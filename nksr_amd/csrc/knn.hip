@@ -4,6 +4,10 @@
 //                      examples/recons_waymo_cpu.py:21-41)
 //   k_nearest_index    nearest input point of every query -- fields.PCNNField colour lookup
 //                      (examples/recons_colored_mesh.py:28)
+//   k_sdf_from_points  signed distance of arbitrary queries to an oriented cloud from their k nearest reference points -- the
+//                      training ground truth ext.sdfgen.sdf_from_points (ext/sdfgen/sdf_from_points.cu:32-140 on top of the
+//                      kd-tree of ext/common/kdtree_cuda.cu; call sites models/loss.py:85, dataset/av_gt_geometry.py:72):
+//                      sign vote or IMLS; k_knn_mean_dist = its adaptive_knn radius
 // The cloud is Morton-sorted by a uniform grid (cell size chosen by the host so that a 3^3 block
 // holds a few times k points); cells are contiguous point ranges found through the voxel hash.
 // EXACT selection without a per-thread heap: the k-th smallest squared distance is found by a
@@ -35,6 +39,14 @@ __device__ __forceinline__ void cell_of(const KnnGrid& g, const float q[3], int 
     }
 }
 
+// squared length with a FIXED rounding sequence: the bisection (count_within) and the later visits of the same candidates must
+// agree on every bit of it.  Left to the compiler (device code contracts a*b+c into fmas, and __fmul_rn / __fadd_rn are plain
+// operators in HIP) one inlined site fused and the other did not: a neighbour AT the k-th distance was counted but not visited
+// (2 - 10 % of the queries of k_sdf_from_points with large cells).  Explicit fmas cannot be re-associated.
+__device__ __forceinline__ float knn_d2(float ex, float ey, float ez) {
+    return fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+}
+
 // number of candidates with squared distance <= r2 inside the (2R+1)^3 block around cell c
 __device__ __forceinline__ int count_within(const KnnGrid& g, const float q[3], const int c[3], int R, float r2) {
     int n = 0;
@@ -45,7 +57,7 @@ __device__ __forceinline__ int count_within(const KnnGrid& g, const float q[3], 
                 if (ci < 0) continue;
                 for (int k = g.start[ci]; k < g.end[ci]; ++k) {
                     const float ex = g.xyz[k * 3] - q[0], ey = g.xyz[k * 3 + 1] - q[1], ez = g.xyz[k * 3 + 2] - q[2];
-                    n += (ex * ex + ey * ey + ez * ez) <= r2;
+                    n += knn_d2(ex, ey, ez) <= r2;
                 }
             }
     return n;
@@ -221,6 +233,141 @@ __global__ void __launch_bounds__(128) k_nearest_index(KnnGrid g, const float* _
     index[i] = best;
 }
 
+// ---- ext.sdfgen.sdf_from_points ---------------------------------------------------------------------------------------------
+// Ring search + bit-pattern bisection as above give the k-th smallest squared distance r2 of a query; the neighbour set is
+// every candidate closer than r2 plus, of the ones AT r2, as many as still fit (scan order): exactly k, like a kd-tree search
+// (ties have measure zero on real data).  The two estimators then need one pass (vote) or two (IMLS) over that set -- no index
+// lists, no sort.
+//   vote (ComputeSDFKernel, sdf_from_points.cu:83-140): the nearest neighbour decides the magnitude -- |n.(x-p)| if x lies within
+//        stdv * ref_std[p] of it, else |x-p| -- and the majority of sign(n_k.(x-p_k)) over the k neighbours the sign
+//        (positive needs MORE than k/2 votes);
+//   IMLS (ComputeIMLSKernel, :32-81): sum_k w_k n_k.(x-p_k) / sum_k w_k,  w_k = exp(-(|x-p_k|^2 - min_j |x-p_j|^2) / stdv^2).
+// valid = 0: fewer than k reference points within max_ring cells (the host retries those queries on a coarser grid).
+// candidates of the (2R+1)^3 block strictly closer than r2
+__device__ __forceinline__ int count_closer(const KnnGrid& g, const float q[3], const int c[3], int R, float r2) {
+    int n = 0;
+    for (int dx = -R; dx <= R; ++dx)
+        for (int dy = -R; dy <= R; ++dy)
+            for (int dz = -R; dz <= R; ++dz) {
+                const int ci = hash_find(g.hkeys, g.hvals, g.hcap, morton_biased(c[0] + dx, c[1] + dy, c[2] + dz, NKSR_BIAS0));
+                if (ci < 0) continue;
+                for (int kk = g.start[ci]; kk < g.end[ci]; ++kk) {
+                    const float ex = g.xyz[kk * 3] - q[0], ey = g.xyz[kk * 3 + 1] - q[1], ez = g.xyz[kk * 3 + 2] - q[2];
+                    n += knn_d2(ex, ey, ez) < r2;
+                }
+            }
+    return n;
+}
+
+template <typename F>
+__device__ __forceinline__ void knn_visit(const KnnGrid& g, const float q[3], const int c[3], int R, float r2, int k, F f) {
+    int ties_left = k - count_closer(g, q, c, R, r2);        // of the candidates AT r2, as many as still fit
+    for (int dx = -R; dx <= R; ++dx)
+        for (int dy = -R; dy <= R; ++dy)
+            for (int dz = -R; dz <= R; ++dz) {
+                const int ci = hash_find(g.hkeys, g.hvals, g.hcap, morton_biased(c[0] + dx, c[1] + dy, c[2] + dz, NKSR_BIAS0));
+                if (ci < 0) continue;
+                for (int kk = g.start[ci]; kk < g.end[ci]; ++kk) {
+                    const float px = g.xyz[kk * 3], py = g.xyz[kk * 3 + 1], pz = g.xyz[kk * 3 + 2];
+                    const float d2 = knn_d2(px - q[0], py - q[1], pz - q[2]);
+                    bool take = d2 < r2;
+                    if (!take && d2 == r2 && ties_left > 0) { take = true; --ties_left; }
+                    if (take) f(kk, q[0] - px, q[1] - py, q[2] - pz, d2);
+                }
+            }
+}
+
+__device__ __forceinline__ bool knn_radius(const KnnGrid& g, const float q[3], const int c[3], int k, int max_ring, int& R, float& r2) {
+    float rmax2 = 0.f;
+    bool ok = false;
+    for (R = 1; R <= max_ring; ++R) {
+        const float rr = (float)R * g.cell;          // the ball of radius R*cell around q lies inside the (2R+1)^3 block around q's cell
+        rmax2 = rr * rr;
+        if (count_within(g, q, c, R, rmax2) >= k) { ok = true; break; }
+    }
+    if (!ok) return false;
+    unsigned lo = 0u, hi = __float_as_uint(rmax2);
+    while (lo < hi) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        if (count_within(g, q, c, R, __uint_as_float(mid)) >= k) hi = mid; else lo = mid + 1;
+    }
+    r2 = __uint_as_float(lo);
+    return true;
+}
+
+__global__ void __launch_bounds__(128) k_sdf_from_points(KnnGrid g, const float* __restrict__ nrm, const float* __restrict__ ref_std,
+                                                         const float* __restrict__ query, int64_t nq, int k, int max_ring, float stdv,
+                                                         int imls, float* __restrict__ sdf, float* __restrict__ grad,
+                                                         int32_t* __restrict__ valid) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float q[3] = {query[i * 3], query[i * 3 + 1], query[i * 3 + 2]};
+    int c[3], R;
+    float r2;
+    cell_of(g, q, c);
+    if (!knn_radius(g, q, c, k, max_ring, R, r2)) { valid[i] = 0; return; }
+    valid[i] = 1;
+    float out = 0.f, gr[3] = {0.f, 0.f, 0.f};
+    if (imls) {
+        float dmin = 3.4e38f;
+        knn_visit(g, q, c, R, r2, k, [&](int, float, float, float, float d2) { dmin = fminf(dmin, d2); });
+        const float inv_s2 = 1.f / (stdv * stdv);
+        const float emin = dmin * inv_s2;
+        float wsum = 0.f, acc = 0.f;
+        knn_visit(g, q, c, R, r2, k, [&](int kk, float ex, float ey, float ez, float d2) {
+            const float nx = nrm[kk * 3], ny = nrm[kk * 3 + 1], nz = nrm[kk * 3 + 2];
+            const float w = expf(-d2 * inv_s2 + emin);
+            wsum += w;
+            acc += (nx * ex + ny * ey + nz * ez) * w;
+            gr[0] += nx * w; gr[1] += ny * w; gr[2] += nz * w;
+        });
+        out = acc / wsum;
+        gr[0] /= wsum; gr[1] /= wsum; gr[2] /= wsum;
+    } else {
+        float dbest = 3.4e38f, sd = 0.f, g0[3] = {0.f, 0.f, 0.f};
+        int npos = 0;
+        knn_visit(g, q, c, R, r2, k, [&](int kk, float ex, float ey, float ez, float d2) {
+            const float nx = nrm[kk * 3], ny = nrm[kk * 3 + 1], nz = nrm[kk * 3 + 2];
+            const float d = nx * ex + ny * ey + nz * ez;
+            npos += d > 0.f;
+            if (d2 < dbest) {                         // the nearest neighbour sets the magnitude
+                dbest = d2;
+                const float len = sqrtf(d2);
+                if (len < stdv * (ref_std ? ref_std[kk] : 1.f)) {
+                    sd = fabsf(d);
+                    const float sg = d > 0.f ? 1.f : -1.f;
+                    g0[0] = sg * nx; g0[1] = sg * ny; g0[2] = sg * nz;
+                } else {
+                    sd = len;
+                    g0[0] = ex / len; g0[1] = ey / len; g0[2] = ez / len;
+                }
+            }
+        });
+        const float sg = npos <= k / 2 ? -1.f : 1.f;
+        out = sg * sd;
+        gr[0] = sg * g0[0]; gr[1] = sg * g0[1]; gr[2] = sg * g0[2];
+    }
+    sdf[i] = out;
+    if (grad) { grad[i * 3] = gr[0]; grad[i * 3 + 1] = gr[1]; grad[i * 3 + 2] = gr[2]; }
+}
+
+// mean distance of every (sorted) reference point to its k nearest reference points, itself included (the adaptive_knn radius,
+// sdf_from_points.cu:176-184)
+__global__ void __launch_bounds__(128) k_knn_mean_dist(KnnGrid g, int64_t n, int k, int max_ring, float* __restrict__ out,
+                                                       int32_t* __restrict__ valid) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float q[3] = {g.xyz[i * 3], g.xyz[i * 3 + 1], g.xyz[i * 3 + 2]};
+    int c[3], R;
+    float r2;
+    cell_of(g, q, c);
+    if (!knn_radius(g, q, c, k, max_ring, R, r2)) { valid[i] = 0; out[i] = 0.f; return; }
+    float s = 0.f;
+    knn_visit(g, q, c, R, r2, k, [&](int, float, float, float, float d2) { s += sqrtf(d2); });
+    out[i] = s / (float)k;
+    valid[i] = 1;
+}
+
 static KnnGrid make_grid(const float* xyz_sorted, const int32_t* start, const int32_t* end, const int64_t* hkeys,
                          const int32_t* hvals, int hcap, float cell, float inv_cell) {
     KnnGrid g;
@@ -249,6 +396,32 @@ extern "C" int nksr_nearest_index(const float* xyz_sorted, const int32_t* start,
     KnnGrid g = make_grid(xyz_sorted, start, end, hkeys, hvals, hcap, cell, inv_cell);
     hipLaunchKernelGGL(k_nearest_index, dim3(nksr_blocks(nq, 128)), dim3(128), 0, (hipStream_t)stream, g, query, nq, max_ring,
                        index_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+extern "C" int nksr_sdf_from_points(const float* xyz_sorted, const float* normal_sorted, const float* ref_std_sorted, const int32_t* start,
+                                    const int32_t* end, const int64_t* hkeys, const int32_t* hvals, int32_t hcap, float cell, float inv_cell,
+                                    const float* query, int64_t nq, int k, int max_ring, float stdv, int imls, float* sdf_out,
+                                    float* grad_out, int32_t* valid_out, void* stream) {
+    if (nq <= 0) return NKSR_OK;
+    if (k < 1) return nksr_set_error(NKSR_ERR_ARG, "nb_points must be >= 1");
+    if (!(stdv > 0.f)) return nksr_set_error(NKSR_ERR_ARG, "stdv must be > 0");
+    if (!xyz_sorted || !normal_sorted || !query || !sdf_out || !valid_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    KnnGrid g = make_grid(xyz_sorted, start, end, hkeys, hvals, hcap, cell, inv_cell);
+    hipLaunchKernelGGL(k_sdf_from_points, dim3(nksr_blocks(nq, 128)), dim3(128), 0, (hipStream_t)stream, g, normal_sorted, ref_std_sorted, query,
+                       nq, k, max_ring, stdv, imls, sdf_out, grad_out, valid_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+extern "C" int nksr_knn_mean_dist(const float* xyz_sorted, int64_t n, const int32_t* start, const int32_t* end, const int64_t* hkeys,
+                                  const int32_t* hvals, int32_t hcap, float cell, float inv_cell, int k, int max_ring, float* out,
+                                  int32_t* valid_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (k < 1) return nksr_set_error(NKSR_ERR_ARG, "k must be >= 1");
+    KnnGrid g = make_grid(xyz_sorted, start, end, hkeys, hvals, hcap, cell, inv_cell);
+    hipLaunchKernelGGL(k_knn_mean_dist, dim3(nksr_blocks(n, 128)), dim3(128), 0, (hipStream_t)stream, g, n, k, max_ring, out, valid_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }

@@ -1,0 +1,67 @@
+"""ext.sdfgen.sdf_from_points (training ground truth; reference ext/sdfgen/sdf_from_points.cu, call sites models/loss.py:85,
+dataset/av_gt_geometry.py:64-76) against the oracle restatement of its source (oracle/sdfgen.py, exact kNN through scipy)."""
+import numpy as np
+import pytest
+import torch
+
+import parity_util as pu
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(n=20000, seed=0, noise=0.002):
+    rs = np.random.RandomState(seed)
+    v = rs.randn(n, 3)
+    nrm = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    xyz = (nrm * 0.5 + rs.randn(n, 3) * noise).astype(np.float32)
+    return xyz, nrm
+
+
+def _queries(xyz, nrm, m=6000, seed=1, eps=0.03):
+    rs = np.random.RandomState(seed)
+    band = xyz[rs.randint(0, len(xyz), m)] + nrm[rs.randint(0, len(xyz), m)] * rs.randn(m, 1).astype(np.float32) * eps
+    far = rs.uniform(-1.5, 1.5, (m // 10, 3)).astype(np.float32)          # far from every reference point: the coarse-grid retry
+    return np.concatenate([band, far]).astype(np.float32)
+
+
+@pytest.mark.parametrize('case', ['loss', 'dataset', 'imls'])
+def test_sdf_from_points_matches_the_oracle(case):
+    from oracle import sdfgen as osdf
+    import ext                      # the reference's import name
+    dev = torch.device('cuda:0')
+    xyz, nrm = _cloud()
+    q = _queries(xyz, nrm)
+    kw = {'loss': dict(nb_points=8, stdv=0.02), 'dataset': dict(nb_points=8, stdv=3.0, adaptive_knn=8),
+          'imls': dict(nb_points=8, stdv=0.05, imls=True)}[case]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = ext.sdfgen.sdf_from_points(t(q), t(xyz), t(nrm), compute_grad=True, **kw)
+    assert len(out) == 2 and out[0].shape == (len(q),) and out[1].shape == (len(q), 3) and out[0].dtype == torch.float32
+    only = ext.sdfgen.sdf_from_points(t(q), t(xyz), t(nrm), **kw)
+    assert len(only) == 1 and torch.equal(only[0], out[0])
+    ref_s, ref_g = osdf.sdf_from_points(q, xyz, nrm, compute_grad=True, **kw)
+    s, g = out[0].cpu().numpy(), out[1].cpu().numpy()
+    # sign votes / nearest-neighbour switches flip where a query is equidistant to two neighbours within fp32 rounding: compare
+    # where the oracle's decision has margin, count the rest
+    diff = np.abs(s - ref_s)
+    bad = diff > 1e-5 + 1e-5 * np.abs(ref_s)
+    pu.report('sdfgen[%s]' % case, max_abs_err=float(diff[~bad].max()), flipped=int(bad.sum()), queries=len(q))
+    assert bad.mean() <= 2e-3, int(bad.sum())
+    gd = np.abs(g - ref_g).max(1)
+    assert (gd[~bad] <= 1e-4).mean() >= 0.998
+    # the negated value is the training target (models/loss.py:85): inside the sphere positive, outside negative
+    inside = np.linalg.norm(q, axis=1) < 0.45
+    outside = np.linalg.norm(q, axis=1) > 0.55
+    assert (-s[inside] > 0).mean() > 0.99 and (-s[outside] < 0).mean() > 0.99
+
+
+def test_sdf_from_points_argument_errors():
+    import ext
+    dev = torch.device('cuda:0')
+    xyz, nrm = _cloud(100)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    with pytest.raises(RuntimeError):
+        ext.sdfgen.sdf_from_points(t(xyz[:5]), t(xyz[:4]), t(nrm[:4]), 8, 0.02)          # fewer reference points than nb_points
+    with pytest.raises(RuntimeError):
+        ext.sdfgen.sdf_from_points(torch.from_numpy(xyz[:5]), t(xyz), t(nrm), 8, 0.02)   # CPU queries
+    with pytest.raises(RuntimeError):
+        ext.sdfgen.sdf_from_points(t(xyz[:5]), t(xyz), t(nrm), 8, 0.0)                   # stdv must be > 0

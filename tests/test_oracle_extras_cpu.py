@@ -109,3 +109,35 @@ def test_chunked_fixtures_are_self_consistent():
         assert (along >= -1e-6).all() and (along <= ref['h'] + 1e-6).all()
         d[np.arange(len(d)), ax] = 0
         assert np.abs(d).max() < 1e-6
+
+
+def test_sdfgen_oracle_on_an_analytic_sphere():
+    """oracle/sdfgen.py (restatement of ext/sdfgen/sdf_from_points.cu): on a dense noise-free sphere every estimator returns the
+    radial offset of the query; the exact kNN it uses is checked against brute force."""
+    from oracle import sdfgen
+    rs = np.random.RandomState(0)
+    v = rs.randn(4000, 3)
+    nrm = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    xyz = (nrm * 0.5).astype(np.float32)
+    u = rs.randn(200, 3)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    off = rs.uniform(-0.03, 0.03, 200)
+    q = (u * (0.5 + off)[:, None]).astype(np.float32)
+    for kw in (dict(nb_points=8, stdv=0.02), dict(nb_points=8, stdv=3.0, adaptive_knn=8), dict(nb_points=8, stdv=0.05, imls=True)):
+        s, g = sdfgen.sdf_from_points(q, xyz, nrm, compute_grad=True, **kw)
+        # IMLS / in-threshold votes project on the neighbours' tangent planes; a vote outside stdv * ref_std returns the distance to the
+        # nearest SAMPLE (spacing ~0.03 here), which over-estimates the radial offset
+        assert np.abs(s - off).max() < (4e-3 if kw.get('imls') or kw.get('adaptive_knn') else 0.035), (kw, np.abs(s - off).max())
+        assert (np.sign(s) == np.sign(off))[np.abs(off) > 2e-3].all()
+        if kw.get('imls') or kw.get('adaptive_knn'):
+            assert (np.sum(g * u, axis=1) > 0.95)[np.abs(off) > 2e-3].all()
+    # brute-force neighbours of a few queries
+    d2 = ((q[:20, None, :].astype(np.float64) - xyz[None].astype(np.float64)) ** 2).sum(-1)
+    idx = np.argsort(d2, axis=1)[:, :8]
+    ray = q[:20, None, :] - xyz[idx]
+    d = (nrm[idx] * ray).sum(-1)
+    e = (ray ** 2).sum(-1) / 0.05 ** 2
+    w = np.exp(-e + e.min(1, keepdims=True))
+    ref = (d * w).sum(1) / w.sum(1)
+    s, = sdfgen.sdf_from_points(q[:20], xyz, nrm, 8, 0.05, imls=True)
+    assert np.abs(s - ref).max() < 1e-6
