@@ -190,7 +190,8 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks_reduce(AsmArgs A
     cell_blocks_finalize<NT>(A, d, c, lane, acc, total);
 }
 
-template <int NT>
+// LM: the site sets hold LEVEL-MAJOR rows (nksr_siteset_t.level_stride > 0)
+template <int NT, bool LM>
 __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const nksr_level_t& lv = A.hier.lv[d];
@@ -218,7 +219,30 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
         // (sw r_s)(sw r_t) then commute exactly.  Keep this loop as it is -- variants that dropped the multiply,
         // added a second code path (88 VGPRs) or called sqrtf here all measured 20 % slower.
         const float w = S.weight;
-        // two row pairs per trip, their loads issued together (unconditional, clamped: a load under a branch is waited for at once)
+        if (!LM) {
+            // site-major rows (the assembled solve): one row pair per trip.  Fine cells hold ~3 rows; batching the loads of two
+            // pairs (as below) measured 25 % slower here
+            for (int m0 = 0; m0 < nrows; m0 += 2) {
+                const bool valid = m0 + half < nrows;
+                const int64_t q = q0 + m0 + half;
+                const float* ra = S.val + (q * L + d) * 27;
+                float b[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const int col = 32 * n + j;
+                    b[n] = 0.f;
+                    if (valid) {
+                        if (col < T) b[n] = ra[col];
+                        else if (col == T && S.target) b[n] = S.target[q];
+                    }
+                }
+                const float a = (j < 27) ? w * b[0] : 0.f;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[n], acc[n], 0, 0, 0);
+            }
+            continue;
+        }
+        // level-major rows (coarse block of the preconditioner: cells of 60+ rows): two row pairs per trip, loads issued together
         for (int m0 = 0; m0 < nrows; m0 += 4) {
             float b[2][NT];
 #pragma unroll
@@ -607,7 +631,12 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
     const dim3 blk(ASM_WAVES * 64);
     const size_t lds = (size_t)ASM_WAVES * NKSR_MAX_DEPTH * 125 * sizeof(float);
     int64_t total_rows = 0;
-    for (int si = 0; si < nsets; ++si) total_rows += sets[si].n * sets[si].ncomp;
+    bool lm = false;
+    for (int si = 0; si < nsets; ++si) {
+        total_rows += sets[si].n * sets[si].ncomp;
+        if (si > 0 && (sets[si].level_stride != 0) != lm) return nksr_set_error(NKSR_ERR_ARG, "site sets mix site-major and level-major rows");
+        lm = sets[si].level_stride != 0;
+    }
     for (int d = 0; d < h->depth; ++d) {
         const int n = h->lv[d].n;
         if (n <= 0) continue;
@@ -629,12 +658,12 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
             }
         } else {
             switch (NT) {
-                case 1: hipLaunchKernelGGL((k_cell_blocks<1>), grid, blk, 0, st, A, d); break;
-                case 2: hipLaunchKernelGGL((k_cell_blocks<2>), grid, blk, 0, st, A, d); break;
-                case 3: hipLaunchKernelGGL((k_cell_blocks<3>), grid, blk, 0, st, A, d); break;
-                case 4: hipLaunchKernelGGL((k_cell_blocks<4>), grid, blk, 0, st, A, d); break;
-                case 5: hipLaunchKernelGGL((k_cell_blocks<5>), grid, blk, 0, st, A, d); break;
-                default: hipLaunchKernelGGL((k_cell_blocks<6>), grid, blk, 0, st, A, d); break;
+                case 1: if (lm) hipLaunchKernelGGL((k_cell_blocks<1, true>), grid, blk, 0, st, A, d); else hipLaunchKernelGGL((k_cell_blocks<1, false>), grid, blk, 0, st, A, d); break;
+                case 2: if (lm) hipLaunchKernelGGL((k_cell_blocks<2, true>), grid, blk, 0, st, A, d); else hipLaunchKernelGGL((k_cell_blocks<2, false>), grid, blk, 0, st, A, d); break;
+                case 3: if (lm) hipLaunchKernelGGL((k_cell_blocks<3, true>), grid, blk, 0, st, A, d); else hipLaunchKernelGGL((k_cell_blocks<3, false>), grid, blk, 0, st, A, d); break;
+                case 4: if (lm) hipLaunchKernelGGL((k_cell_blocks<4, true>), grid, blk, 0, st, A, d); else hipLaunchKernelGGL((k_cell_blocks<4, false>), grid, blk, 0, st, A, d); break;
+                case 5: if (lm) hipLaunchKernelGGL((k_cell_blocks<5, true>), grid, blk, 0, st, A, d); else hipLaunchKernelGGL((k_cell_blocks<5, false>), grid, blk, 0, st, A, d); break;
+                default: if (lm) hipLaunchKernelGGL((k_cell_blocks<6, true>), grid, blk, 0, st, A, d); else hipLaunchKernelGGL((k_cell_blocks<6, false>), grid, blk, 0, st, A, d); break;
             }
         }
         NKSR_CHECK_LAUNCH();
