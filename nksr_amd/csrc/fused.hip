@@ -22,7 +22,6 @@
 // twice, t through memory: 1.05 ms per application at the bench workload.)
 #include "common.h"
 #include "pcg_core.h"
-#include <stdlib.h>
 
 #define FZ_RC 32
 #define FZ_BLOCK 256
@@ -444,17 +443,10 @@ static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
     return NKSR_OK;
 }
 
-// (rows per trip, per-row-gather levels): probe variants, NKSR_FZ_VARIANT = 0..3; the default is the fastest one measured
-#define FZ_DEFAULT_VARIANT 0
-static int g_fz_variant = -1;
-static int fz_variant() {
-    if (g_fz_variant < 0) {
-        const char* e = getenv("NKSR_FZ_VARIANT");
-        g_fz_variant = e ? atoi(e) : FZ_DEFAULT_VARIANT;
-        if (g_fz_variant < 0 || g_fz_variant > 3) g_fz_variant = FZ_DEFAULT_VARIANT;
-    }
-    return g_fz_variant;
-}
+// rows per trip / per-row-gather levels.  Measured on the bench workload: (4, 1) 587 us per application,
+// (2, 1) 600, (4, 2) 649, (2, 2) 647; the tree_depth-5 chunks of configs[4] rank the same way.
+#define FZ_ROWS_PER_TRIP 4
+#define FZ_GATHER_LEVELS 1
 
 template <int MODE, int U, int NG>
 static void fz_sweep_v(const FusedArgs& A, const float* x, float* part, float* part2, float* cellp, const int* done, hipStream_t st) {
@@ -472,13 +464,7 @@ static void fz_sweep_v(const FusedArgs& A, const float* x, float* part, float* p
 template <int MODE>
 static void fz_sweep(const FusedArgs& A, const float* x, float* part, float* part2, float* cellp, const int* done, hipStream_t st) {
     if (A.hw_total <= 0) return;
-    if (MODE != 0) { fz_sweep_v<MODE, 4, 1>(A, x, part, part2, cellp, done, st); return; }
-    switch (fz_variant()) {
-        case 0: fz_sweep_v<MODE, 4, 1>(A, x, part, part2, cellp, done, st); break;
-        case 1: fz_sweep_v<MODE, 2, 1>(A, x, part, part2, cellp, done, st); break;
-        case 2: fz_sweep_v<MODE, 4, 2>(A, x, part, part2, cellp, done, st); break;
-        default: fz_sweep_v<MODE, 2, 2>(A, x, part, part2, cellp, done, st); break;
-    }
+    fz_sweep_v<MODE, FZ_ROWS_PER_TRIP, FZ_GATHER_LEVELS>(A, x, part, part2, cellp, done, st);
 }
 
 static int fz_apply(const FusedArgs& A, float reg, const FusedWork& w, const float* x, float* y, const int* done, hipStream_t st) {
