@@ -133,7 +133,8 @@ int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int appr
  * r_i = row_index ? row_index[i] : i * ncomp (ncomp = 1 for val, 3 for dval; ONE of val / dval when row_index is given) -- the layout
  * of the matrix-free solve (nksr_fused_op_t.rows_all): row_index lets several site sets share one Morton-ordered row list;
  * row_cells [L, level_stride] (may be NULL) receives the global unknown index of the level-d cell of every row written (-1 = none). */
-/* f(x) (and gradient if grad_out != NULL): field.evaluate_f, models/loss.py:189-198. */
+/* f(x) (and gradient if grad_out != NULL): field.evaluate_f, models/loss.py:189-198.  alpha == NULL: the hierarchy's psi arrays
+ * already hold alpha_j psi_j (one gather per neighbour instead of two). */
 int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx,
                     float* f_out, float* grad_out, void* stream);
 

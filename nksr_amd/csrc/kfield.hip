@@ -83,6 +83,20 @@ struct SiteCell {
     float u[3];    // local coordinate in [0,1)
 };
 
+// the 27 neighbour indices of an active cell as seven 16-byte loads (4-byte aligned: rows are 108 bytes) instead of 27 scalar ones:
+// every load instruction of these per-site kernels touches 64 different lines (one per lane), their count is what they cost
+struct i32x4_u { int x, y, z, w; } __attribute__((packed, aligned(4)));
+struct i32x3_u { int x, y, z; } __attribute__((packed, aligned(4)));
+__device__ __forceinline__ void load_nbr_row(const int32_t* __restrict__ row, int nb[27]) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const i32x4_u v = reinterpret_cast<const i32x4_u*>(row)[q];
+        nb[4 * q] = v.x; nb[4 * q + 1] = v.y; nb[4 * q + 2] = v.z; nb[4 * q + 3] = v.w;
+    }
+    const i32x3_u v = *reinterpret_cast<const i32x3_u*>(row + 24);
+    nb[24] = v.x; nb[25] = v.y; nb[26] = v.z;
+}
+
 // neighbour slot s of the site's cell: through the 27-neighbour table when the cell is active,
 // through the hash otherwise (FALLBACK: query points in inactive cells still see every existing
 // voxel whose support covers them -- field.evaluate_f on arbitrary positions, models/loss.py:99)
@@ -210,7 +224,8 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
     float bw[3][3], bd[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
-    const int32_t* nb = lv.nbr + (int64_t)sc.cell * 27;
+    int nb[27];
+    load_nbr_row(lv.nbr + (int64_t)sc.cell * 27, nb);
     // All 27 (x 4 with gradients) results stay in registers and every output row leaves as one burst of
     // 16-byte stores: written word by word across the slot loop, the 108-byte rows kept ~10^6 partially
     // filled cache lines in flight and the kernel ran at 0.5 TB/s of useful stores.
@@ -276,8 +291,15 @@ __global__ void __launch_bounds__(128) k_evaluate_f(nksr_hier_t hier, const floa
 #pragma unroll
         for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
         float fl = 0.f, gl[3] = {0.f, 0.f, 0.f};
+        int nbv[27];
+        if (sc.cell >= 0) load_nbr_row(lv.nbr + (int64_t)sc.cell * 27, nbv);
+        else {
+#pragma unroll
+            for (int s = 0; s < 27; ++s) nbv[s] = nbr_of<true>(lv, d, sc, s);
+        }
+#pragma unroll
         for (int s = 0; s < 27; ++s) {
-            int j = nbr_of<true>(lv, d, sc, s);
+            const int j = nbv[s];
             if (j < 0) continue;
             const int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
             const float* ps = lv.psi + (int64_t)j * K;
@@ -288,7 +310,7 @@ __global__ void __launch_bounds__(128) k_evaluate_f(nksr_hier_t hier, const floa
                 dot = fmaf(phi[k], pk, dot);
                 if (JAC) { jd[0] = fmaf(J[k][0], pk, jd[0]); jd[1] = fmaf(J[k][1], pk, jd[1]); jd[2] = fmaf(J[k][2], pk, jd[2]); }
             }
-            float a = alpha[lv.offset + j];
+            const float a = alpha ? alpha[lv.offset + j] : 1.f;      // alpha == NULL: psi arrives pre-multiplied by it
             float bx = sel3(bw[0], ox), by = sel3(bw[1], oy), bz = sel3(bw[2], oz);
             float B = bx * by * bz;
             fl = fmaf(a, dot * B, fl);

@@ -491,10 +491,27 @@ class KernelField(BaseField):
             return EvaluationResult(f, g if grad else None)
         return self._evaluate_raw(self.alpha, xyz, grad, max_points)
 
+    def _alpha_hier(self, alpha):
+        """A copy of the hierarchy whose psi arrays hold alpha_j psi_j: evaluation then gathers ONE 16-byte value per neighbour
+        (these per-point kernels are bound by the number of gather instructions).  Rebuilt when alpha changes."""
+        key = (alpha.data_ptr(), alpha._version, self.device)
+        if getattr(self, '_apsi_key', None) != key:
+            off = self.svh.offsets
+            self._apsi = [(self._psi[d] * alpha[off[d]:off[d] + self._psi[d].shape[0], None]).contiguous() for d in range(self.svh.depth)]
+            h = HierT.from_buffer_copy(self._hier)
+            for d in range(self.svh.depth):
+                h.lv[d].psi = ptr(self._apsi[d])
+            self._apsi_hier, self._apsi_key = h, key
+        return self._apsi_hier
+
     def _evaluate_raw(self, alpha, xyz, grad, max_points=1 << 22):
         n = xyz.shape[0]
         xyz = xyz.to(self.device)
         alpha = alpha.detach().contiguous()
+        if alpha is self.alpha or alpha.data_ptr() == self.alpha.data_ptr():
+            hier, alpha_arg = self._alpha_hier(alpha), None
+        else:
+            hier, alpha_arg = self._hier, alpha
         f = torch.empty(n, dtype=torch.float32, device=self.device)
         g = torch.empty((n, 3), dtype=torch.float32, device=self.device) if grad else None
         for s in range(0, n, max_points):
@@ -502,7 +519,7 @@ class KernelField(BaseField):
             xs = xyz[s:e].contiguous()
             fs = f[s:e]
             gs = g[s:e] if grad else None
-            call('nksr_evaluate_f', C.byref(self._hier), ptr(alpha), ptr(xs), e - s, int(self.approx_kernel_grad),
+            call('nksr_evaluate_f', C.byref(hier), ptr(alpha_arg), ptr(xs), e - s, int(self.approx_kernel_grad),
                  ptr(fs), ptr(gs), stream())
         return EvaluationResult(f, g)
 
