@@ -327,18 +327,20 @@ int nksr_cell_active_flags(const int32_t* config, int64_t ncell, int32_t* flags,
 int nksr_compact_block_counts(const int32_t* flags, int64_t n, int32_t* block_counts, void* stream);
 int nksr_compact_scatter(const int32_t* flags, int64_t n, const int32_t* block_offsets, int32_t* sel, void* stream);
 /* MISE hanging-vertex constraint: a refined vertex on a coarse edge / face gets the mean of the coarse
- * end points / face corners unless every coarse cell sharing that edge / face was refined (sorted key
- * lists; f_fine is updated in place) -- closes T-junction cracks between refined and unrefined cells */
-int nksr_mise_constrain(const int64_t* vkeys_fine, int64_t nv, float* f_fine, const int64_t* vkeys_coarse, int64_t nvc,
-                        const float* f_coarse, const int64_t* active_cells, int64_t na, void* stream);
+ * end points / face corners unless every coarse cell sharing that edge / face was refined (f_fine is updated in
+ * place) -- closes T-junction cracks between refined and unrefined cells.  The coarse lattice vertices (key -> index into
+ * f_coarse) and the refined coarse cells are given as nksr_hash_build tables. */
+int nksr_mise_constrain(const int64_t* vkeys_fine, int64_t nv, float* f_fine, const int64_t* chash_keys, const int32_t* chash_vals,
+                        int32_t chash_cap, const float* f_coarse, const int64_t* ahash_keys, const int32_t* ahash_vals,
+                        int32_t ahash_cap, void* stream);
 /* children of the flagged cells: out has 8 keys per selected cell */
 int nksr_cell_children(const int64_t* cell_keys, const int32_t* sel, int64_t nsel, int64_t* child_keys, void* stream);
 /* triangle emission: edge keys (lower vertex index*3+axis) [ntri_total,3] */
 int nksr_mc_emit(const int32_t* corner_idx, const int32_t* config, const int32_t* tri_offset, int64_t ncell,
                  int64_t* edge_keys, void* stream);
-/* mesh vertices from unique edge keys */
-int nksr_mc_vertices(const int64_t* edge_keys, int64_t nedge, const int64_t* vkeys, int64_t nv, const float* vpos,
-                     const float* f, float h, float* verts_out, void* stream);
+/* mesh vertices from unique edge keys (vhash: nksr_hash_build table of vkeys) */
+int nksr_mc_vertices(const int64_t* edge_keys, int64_t nedge, const int64_t* vkeys, const int64_t* vhash_keys, const int32_t* vhash_vals,
+                     int32_t vhash_cap, const float* vpos, const float* f, float h, float* verts_out, void* stream);
 
 #ifdef __cplusplus
 }

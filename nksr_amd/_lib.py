@@ -126,10 +126,10 @@ _PROTOS = {
     'nksr_cell_active_flags': [_vp, _i64, _vp, _vp],
     'nksr_compact_block_counts': [_vp, _i64, _vp, _vp],
     'nksr_compact_scatter': [_vp, _i64, _vp, _vp, _vp],
-    'nksr_mise_constrain': [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _vp],
+    'nksr_mise_constrain': [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp],
     'nksr_cell_children': [_vp, _vp, _i64, _vp, _vp],
     'nksr_mc_emit': [_vp, _vp, _vp, _i64, _vp, _vp],
-    'nksr_mc_vertices': [_vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _vp],
+    'nksr_mc_vertices': [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp],
 }
 for _name, _args in _PROTOS.items():
     _fn = getattr(lib, _name)

@@ -156,8 +156,11 @@ __global__ void k_mc_emit(const int32_t* __restrict__ corner_idx, const int32_t*
     }
 }
 
+// (lattice vertices are looked up through an open-addressing hash of their keys: one or two probes instead of the ~21 dependent
+// loads of a binary search over millions of sorted keys -- every such load costs a full gather instruction per wavefront)
 __global__ void k_mc_vertices(const int64_t* __restrict__ edge_keys, int64_t nedge, const int64_t* __restrict__ vkeys,
-                              int64_t nv, const float* __restrict__ vpos, const float* __restrict__ f, float h,
+                              const int64_t* __restrict__ hkeys, const int32_t* __restrict__ hvals, int hcap,
+                              const float* __restrict__ vpos, const float* __restrict__ f, float h,
                               float* __restrict__ verts) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nedge) return;
@@ -167,13 +170,9 @@ __global__ void k_mc_vertices(const int64_t* __restrict__ edge_keys, int64_t ned
     int g[3];
     morton_decode_biased(vkeys[v0], NKSR_BIAS0, g[0], g[1], g[2]);
     g[axis] += 1;
-    int64_t k1 = morton_biased(g[0], g[1], g[2], NKSR_BIAS0);
-    int64_t lo = 0, hi = nv;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (vkeys[mid] < k1) lo = mid + 1; else hi = mid;
-    }
-    float f0 = f[v0], f1 = f[lo];
+    const int64_t k1 = morton_biased(g[0], g[1], g[2], NKSR_BIAS0);
+    const int v1 = hash_find(hkeys, hvals, hcap, k1);          // the far end of an emitted edge is a lattice vertex
+    float f0 = f[v0], f1 = f[v1 >= 0 ? v1 : v0];
     float t = __fdiv_rn(f0, __fsub_rn(f0, f1));
     float p[3] = {vpos[v0 * 3], vpos[v0 * 3 + 1], vpos[v0 * 3 + 2]};
     p[axis] = __fadd_rn(p[axis], __fmul_rn(t, h));
@@ -231,9 +230,10 @@ extern "C" int nksr_mc_emit(const int32_t* corner_idx, const int32_t* config, co
     LAUNCH1D(k_mc_emit, ncell, stream, corner_idx, config, tri_offset, ncell, edge_keys);
     return NKSR_OK;
 }
-extern "C" int nksr_mc_vertices(const int64_t* edge_keys, int64_t nedge, const int64_t* vkeys, int64_t nv, const float* vpos,
-                                const float* f, float h, float* verts_out, void* stream) {
-    LAUNCH1D(k_mc_vertices, nedge, stream, edge_keys, nedge, vkeys, nv, vpos, f, h, verts_out);
+extern "C" int nksr_mc_vertices(const int64_t* edge_keys, int64_t nedge, const int64_t* vkeys, const int64_t* vhash_keys,
+                                const int32_t* vhash_vals, int32_t vhash_cap, const float* vpos, const float* f, float h, float* verts_out,
+                                void* stream) {
+    LAUNCH1D(k_mc_vertices, nedge, stream, edge_keys, nedge, vkeys, vhash_keys, vhash_vals, vhash_cap, vpos, f, h, verts_out);
     return NKSR_OK;
 }
 
@@ -243,18 +243,10 @@ extern "C" int nksr_mc_vertices(const int64_t* edge_keys, int64_t nedge, const i
 // value is then replaced by the mean of the coarse end points / face corners: an unrefined neighbour
 // has equal-sign corners, so no sign change can appear on the shared face and the refined mesh closes
 // against it (no T-junction cracks).
-__device__ __forceinline__ int64_t find_key(const int64_t* __restrict__ a, int64_t n, int64_t v) {
-    int64_t lo = 0, hi = n;
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (a[mid] < v) lo = mid + 1; else hi = mid;
-    }
-    return (lo < n && a[lo] == v) ? lo : -1;
-}
-
 __global__ void k_mise_constrain(const int64_t* __restrict__ vkeys_fine, int64_t nv, float* __restrict__ f_fine,
-                                 const int64_t* __restrict__ vkeys_coarse, int64_t nvc, const float* __restrict__ f_coarse,
-                                 const int64_t* __restrict__ active_cells, int64_t na) {
+                                 const int64_t* __restrict__ ch_keys, const int32_t* __restrict__ ch_vals, int ch_cap,
+                                 const float* __restrict__ f_coarse, const int64_t* __restrict__ ah_keys,
+                                 const int32_t* __restrict__ ah_vals, int ah_cap) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv) return;
     int g[3];
@@ -263,7 +255,7 @@ __global__ void k_mise_constrain(const int64_t* __restrict__ vkeys_fine, int64_t
     const int k = odd[0] + odd[1] + odd[2];
     if (k == 3) return;
     if (k == 0) {   // coincides with a coarse vertex: inherit its (possibly constrained) value
-        const int64_t j = find_key(vkeys_coarse, nvc, morton_biased(g[0] >> 1, g[1] >> 1, g[2] >> 1, NKSR_BIAS0));
+        const int j = hash_find(ch_keys, ch_vals, ch_cap, morton_biased(g[0] >> 1, g[1] >> 1, g[2] >> 1, NKSR_BIAS0));
         if (j >= 0) f_fine[i] = f_coarse[j];
         return;
     }
@@ -279,7 +271,7 @@ __global__ void k_mise_constrain(const int64_t* __restrict__ vkeys_fine, int64_t
     for (int x = 0; x < cnt[0]; ++x)
         for (int y = 0; y < cnt[1]; ++y)
             for (int z = 0; z < cnt[2]; ++z)
-                all_active = all_active && find_key(active_cells, na, morton_biased(lo[0] + x, lo[1] + y, lo[2] + z, NKSR_BIAS0)) >= 0;
+                all_active = all_active && hash_find(ah_keys, ah_vals, ah_cap, morton_biased(lo[0] + x, lo[1] + y, lo[2] + z, NKSR_BIAS0)) >= 0;
     if (all_active) return;
     // mean over the coarse vertices spanning the edge / face: odd axes take both (g-1)/2 and (g+1)/2
     float s = 0.f;
@@ -289,14 +281,15 @@ __global__ void k_mise_constrain(const int64_t* __restrict__ vkeys_fine, int64_t
             for (int z = 0; z <= odd[2]; ++z) {
                 const int cx = odd[0] ? ((g[0] - 1) >> 1) + x : g[0] >> 1, cy = odd[1] ? ((g[1] - 1) >> 1) + y : g[1] >> 1,
                           cz = odd[2] ? ((g[2] - 1) >> 1) + z : g[2] >> 1;
-                const int64_t j = find_key(vkeys_coarse, nvc, morton_biased(cx, cy, cz, NKSR_BIAS0));
+                const int j = hash_find(ch_keys, ch_vals, ch_cap, morton_biased(cx, cy, cz, NKSR_BIAS0));
                 if (j >= 0) { s += f_coarse[j]; ++n; }
             }
     if (n == (1 << k)) f_fine[i] = s * (k == 1 ? 0.5f : 0.25f);
 }
 
-extern "C" int nksr_mise_constrain(const int64_t* vkeys_fine, int64_t nv, float* f_fine, const int64_t* vkeys_coarse, int64_t nvc,
-                                   const float* f_coarse, const int64_t* active_cells, int64_t na, void* stream) {
-    LAUNCH1D(k_mise_constrain, nv, stream, vkeys_fine, nv, f_fine, vkeys_coarse, nvc, f_coarse, active_cells, na);
+extern "C" int nksr_mise_constrain(const int64_t* vkeys_fine, int64_t nv, float* f_fine, const int64_t* chash_keys, const int32_t* chash_vals,
+                                   int32_t chash_cap, const float* f_coarse, const int64_t* ahash_keys, const int32_t* ahash_vals,
+                                   int32_t ahash_cap, void* stream) {
+    LAUNCH1D(k_mise_constrain, nv, stream, vkeys_fine, nv, f_fine, chash_keys, chash_vals, chash_cap, f_coarse, ahash_keys, ahash_vals, ahash_cap);
     return NKSR_OK;
 }

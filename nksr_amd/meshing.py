@@ -23,8 +23,9 @@ def _cell_vertices(cell_keys_raw):
     ck = torch.empty(nc * 8, dtype=torch.int64, device=dev)
     call('nksr_cell_corner_keys', ptr(cells), nc, ptr(ck), stream())
     vkeys = ops.sort_unique(ck)
-    cidx = ops.sorted_lookup(vkeys, ck).view(nc, 8)
-    return cells, vkeys, cidx
+    vhash = ops.HashTable(vkeys)      # key -> index into vkeys: one or two probes instead of a 21-step binary search per lookup
+    cidx = vhash.query(ck).view(nc, 8)
+    return cells, vkeys, cidx, vhash
 
 
 def extract_dual_mesh(field, mise_iter=0, grid_upsample=1, max_points=-1):
@@ -86,14 +87,15 @@ def _extract(field, mise_iter, grid_upsample, max_points):
     h = w0 / U
     prev = None          # (vertex keys, values, active cell keys) of the coarser MISE level
     for m in range(mise_iter + 1):
-        cells, vkeys, cidx = _cell_vertices(raw)
+        cells, vkeys, cidx, vhash = _cell_vertices(raw)
         nv, nc = vkeys.numel(), cells.numel()
         pos = torch.empty((nv, 3), dtype=torch.float32, device=dev)
         call('nksr_lattice_positions', ptr(vkeys), nv, float(h), float(0.5 * w0), ptr(pos), stream())
         f = field._evaluate_f_model(pos, False, max_points=batch).value
         if prev is not None:   # hanging vertices take the coarse interpolant: no T-junction cracks
-            call('nksr_mise_constrain', ptr(vkeys), nv, ptr(f), ptr(prev[0]), prev[0].numel(), ptr(prev[1]), ptr(prev[2]),
-                 prev[2].numel(), stream())
+            ch, ah = prev[0], prev[2]
+            call('nksr_mise_constrain', ptr(vkeys), nv, ptr(f), ptr(ch.hkeys), ptr(ch.hvals), ch.cap, ptr(prev[1]), ptr(ah.hkeys), ptr(ah.hvals),
+                 ah.cap, stream())
         config = torch.empty(nc, dtype=torch.int32, device=dev)
         ntri = torch.empty(nc + 1, dtype=torch.int32, device=dev)
         ntri[nc] = 0
@@ -106,7 +108,7 @@ def _extract(field, mise_iter, grid_upsample, max_points):
                 return empty
             raw = torch.empty(asel.numel() * 8, dtype=torch.int64, device=dev)
             call('nksr_cell_children', ptr(cells), ptr(asel), asel.numel(), ptr(raw), stream())
-            prev = (vkeys, f, cells[asel.long()].contiguous())      # cells is sorted => so is the subset
+            prev = (vhash, f, ops.HashTable(cells[asel.long()].contiguous()))      # coarse vertices / refined coarse cells (sorted subset)
             h = h / 2
 
     if owned_only:      # halo cells emit nothing: ownership follows the base voxel that contains the cell
@@ -123,10 +125,10 @@ def _extract(field, mise_iter, grid_upsample, max_points):
     ekeys = torch.empty(T * 3, dtype=torch.int64, device=dev)
     call('nksr_mc_emit', ptr(cidx), ptr(config), ptr(tri_off), nc, ptr(ekeys), stream())
     uek = ops.sort_unique(ekeys)
-    faces = ops.sorted_lookup(uek, ekeys).view(T, 3)
+    faces = ops.HashTable(uek).query(ekeys).view(T, 3)
     ne = uek.numel()
     verts = torch.empty((ne, 3), dtype=torch.float32, device=dev)
-    call('nksr_mc_vertices', ptr(uek), ne, ptr(vkeys), nv, ptr(pos), ptr(f), float(h), ptr(verts), stream())
+    call('nksr_mc_vertices', ptr(uek), ne, ptr(vkeys), ptr(vhash.hkeys), ptr(vhash.hvals), vhash.cap, ptr(pos), ptr(f), float(h), ptr(verts), stream())
 
     # canonical identity of every mesh vertex: (lattice key of the lower end point, axis)
     ev = torch.div(uek, 3, rounding_mode='floor')
