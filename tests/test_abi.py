@@ -126,5 +126,17 @@ def test_c_abi_argument_errors_without_a_gpu():
     op = _lib.FusedOpT()
     op.depth, op.M = 4, 10
     assert lib.nksr_fused_apply(C.byref(op), C.c_float(1.0), null, null, null) != 0 and 'NULL' in err()
+    # round-2 entry points: argument errors are reported before anything is launched
+    hh = _lib.HierT()
+    hh.depth = 4
+    hh.lv[3].n = 5
+    assert lib.nksr_fused_tables(C.byref(hh), null, null, null, null) != 0 and 'NULL' in err()
+    assert lib.nksr_coarse_lambda_max(null, null, null, null, C.c_int32(5), C.c_int(8), null, null, null) != 0 and 'NULL' in err()
+    one = (C.c_float * 8)()
+    assert lib.nksr_sdf_from_points(one, one, null, null, null, null, null, C.c_int32(0), C.c_float(1.0), C.c_float(1.0), one, C.c_int64(1), C.c_int(0),
+                                    C.c_int(4), C.c_float(0.02), C.c_int(0), one, null, one, null) != 0 and 'nb_points' in err()
+    assert lib.nksr_sdf_from_points(one, one, null, null, null, null, null, C.c_int32(0), C.c_float(1.0), C.c_float(1.0), one, C.c_int64(1), C.c_int(8),
+                                    C.c_int(4), C.c_float(0.0), C.c_int(0), one, null, one, null) != 0 and 'stdv' in err()
+    assert lib.nksr_assemble_split_bytes(C.byref(h), C.c_int64(10 ** 6)) == 0           # no voxels: nothing to split
     with __import__('pytest').raises(RuntimeError):
         _lib.call('nksr_pack_cols21', null, 100, null, null)
