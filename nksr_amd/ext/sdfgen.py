@@ -15,6 +15,9 @@ from ..normals import PointGrid, choose_cell_size
 from .._lib import call, ptr, stream
 
 
+_MAX_ROUNDS = 16        # the cell size grows 4x per round: 4^16 cells of the first size span any finite cloud
+
+
 def _grid_args(pg):
     h = pg.grid.hash
     return ptr(pg.start), ptr(pg.end), ptr(h.hkeys), ptr(h.hvals), h.cap, pg.cell, pg.inv_cell
@@ -25,7 +28,9 @@ def _mean_knn_distance(ref_xyz, k, cell):
     n = ref_xyz.shape[0]
     out = torch.zeros(n, dtype=torch.float32, device=ref_xyz.device)
     todo = torch.arange(n, device=ref_xyz.device)
-    while todo.numel():
+    for _ in range(_MAX_ROUNDS):
+        if not todo.numel():
+            break
         pg = PointGrid(ref_xyz, cell)
         std = torch.empty(n, dtype=torch.float32, device=ref_xyz.device)
         valid = torch.empty(n, dtype=torch.int32, device=ref_xyz.device)
@@ -38,6 +43,8 @@ def _mean_knn_distance(ref_xyz, k, cell):
         out[sel] = back[sel]
         todo = todo[~ok[todo]]
         cell *= 4.0
+    if todo.numel():
+        raise RuntimeError('sdf_from_points: %d reference points found no %d neighbours' % (todo.numel(), k))
     return out
 
 
@@ -50,6 +57,8 @@ def sdf_from_points(queries, ref_xyz, ref_normal, nb_points, stdv, compute_grad=
     if n < max(k, int(adaptive_knn), 1):
         raise RuntimeError('sdf_from_points: %d reference points for nb_points=%d' % (n, k))
     dev = queries.device
+    if not (bool(torch.isfinite(queries).all()) and bool(torch.isfinite(ref_xyz).all()) and bool(torch.isfinite(ref_normal).all())):
+        raise RuntimeError('sdf_from_points: non-finite input')
     q = queries.to(torch.float32).contiguous()
     ref = ref_xyz.to(torch.float32).contiguous()
     nrm = ref_normal.to(torch.float32).contiguous()
@@ -59,7 +68,9 @@ def sdf_from_points(queries, ref_xyz, ref_normal, nb_points, stdv, compute_grad=
     sdf = torch.zeros(nq, dtype=torch.float32, device=dev)
     grad = torch.zeros((nq, 3), dtype=torch.float32, device=dev) if compute_grad else None
     todo = torch.arange(nq, device=dev)
-    while todo.numel():
+    for _ in range(_MAX_ROUNDS):
+        if not todo.numel():
+            break
         pg = PointGrid(ref, cell)
         ns = nrm[pg.perm].contiguous()
         stds = ref_std[pg.perm].contiguous() if ref_std is not None else None
@@ -76,4 +87,6 @@ def sdf_from_points(queries, ref_xyz, ref_normal, nb_points, stdv, compute_grad=
             grad[todo[ok]] = g[ok]
         todo = todo[~ok]
         cell *= 4.0
+    if todo.numel():
+        raise RuntimeError('sdf_from_points: %d queries found no %d neighbours' % (todo.numel(), k))
     return [sdf, grad] if compute_grad else [sdf]

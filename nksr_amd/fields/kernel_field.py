@@ -378,6 +378,8 @@ class KernelField(BaseField):
         lam = torch.empty(1, dtype=torch.float32, device=self.device)
         call('nksr_coarse_lambda_max', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), n, 8, ptr(work), ptr(lam), stream())
         lmax = 1.1 * float(lam.item())          # eight power-iteration steps from the all-ones vector land within ~1 % (measured): 10 % margin
+        if not (lmax > 0.0 and lmax < float('inf')):        # degenerate block (no constraint rows on these levels): Jacobi only
+            return None
         pc = CoarsePrecondT()
         pc.first, pc.n, pc.steps, pc.lambda_max, pc.ratio = off[c0], n, int(cfg.get('steps', 6)), lmax, float(cfg.get('ratio', 100.0))
         pc.rowptr, pc.cols, pc.vals, pc.diag, pc.work = ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), ptr(work)
