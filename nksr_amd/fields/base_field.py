@@ -71,6 +71,7 @@ class BaseField:
             return None
         return self.mask_field.evaluate_mask(xyz_model)
 
+    @torch.no_grad()       # a mesh is not differentiated: plain evaluation of the lattice values
     def extract_dual_mesh(self, mise_iter=0, grid_upsample=1, max_points=-1):
         from .. import meshing
         return meshing.extract_dual_mesh(self, mise_iter=mise_iter, grid_upsample=grid_upsample, max_points=max_points)

@@ -37,6 +37,7 @@ class KernelField(BaseField):
         self.hidden = int(interpolator[0].hidden_dim)
         dev = svh.device
         self._mlp = [pack_interpolator(interpolator[d]).detach().to(dev, torch.float32).contiguous() for d in range(svh.depth)]
+        self._interps_in, self._feat_in = list(interpolator), list(features)      # the caller's tensors / modules (autograd, training path)
         self._feat, self._psi = [], []
         for d in range(svh.depth):
             n = svh.num_voxels(d)
@@ -251,7 +252,7 @@ class KernelField(BaseField):
         self.rhs, self.diag = b, diag
         self.solve_info = {'iters': iters, 'rel_residual': rel, 'M': int(b.numel()), 'nnz': int(self.nnz),
                            't_assemble': t1 - t0, 't_pcg': t2 - t1}
-        self._attach_autograd(normal_xyz, normal_value, normal_weight, reg_weight)
+        self._attach_autograd(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight)
         if self.solver_config.get('verbose'):
             print('[KernelField] M=%d nnz=%d iters=%d rel=%.3e assemble=%.3fs pcg=%.3fs' % (
                 b.numel(), self.nnz, iters, rel, t1 - t0, t2 - t1))
@@ -444,9 +445,9 @@ class KernelField(BaseField):
         if self.solver_config.get('verbose'):
             print('[KernelField] fused: M=%d rows=%d iters=%d rel=%.3e rows+rhs=%.3fs pcg=%.3fs' % (
                 M, op['rows_total'], int(info[0]), float(info[1]), t1 - t0, t2 - t1))
-        if not (torch.is_grad_enabled() and torch.is_tensor(normal_value) and normal_value.requires_grad):
+        if not self._wants_grad(normal_value):
             self._fused_op = None          # only the backward pass needs the operator again: do not pin ~2 GB of rows
-        self._attach_autograd(normal_xyz, normal_value, normal_weight, reg_weight)
+        self._attach_autograd(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight)
         return self
 
     # ---- differentiable solve (training path, models/nksr_net.py:105-112) ---------------------------------------
@@ -467,13 +468,63 @@ class KernelField(BaseField):
              int(cfg['max_iter']), int(cfg['check_every']), ptr(pws), None, info, stream())
         return x
 
-    def _attach_autograd(self, normal_xyz, normal_value, normal_weight, reg_weight):
-        """Under autograd, alpha becomes a differentiable function of the normal targets (implicit differentiation: one more
-        PCG solve with the same system in backward).  Gradients w.r.t. the basis features / interpolator weights (the
-        dA/dtheta terms) are NOT implemented: DESIGN.md section 6."""
-        if not (torch.is_grad_enabled() and torch.is_tensor(normal_value) and normal_value.requires_grad):
+    def _theta(self):
+        """The caller's basis-feature tensors and interpolator parameters that take part in an autograd graph.  The switch is the
+        FEATURES: a field whose basis features carry no graph (inference: they come out of the HIP U-Net; tests: constants) stays
+        out of autograd in theta even though an nn.Module's parameters require grad by default."""
+        th = [f for f in self._feat_in if torch.is_tensor(f) and f.requires_grad]
+        if not th:
+            return []
+        for m in self._interps_in:
+            if isinstance(m, torch.nn.Module):
+                th += [q for q in m.parameters() if q.requires_grad]
+        return th
+
+    def _wants_grad(self, normal_value):
+        return torch.is_grad_enabled() and ((torch.is_tensor(normal_value) and normal_value.requires_grad) or len(self._theta()) > 0)
+
+    def _attach_autograd(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight):
+        """Under autograd, alpha becomes a differentiable function of the normal targets, the basis features and the interpolator
+        weights by implicit differentiation: one more PCG solve with the same system in backward, then (for the features /
+        weights) the vector-Jacobian product through the torch statement of the kernel rows (fields/kernel_rows_torch.py)."""
+        if not self._wants_grad(normal_value):
             return
-        self.alpha = _SolveFunction.apply(self, self.alpha, normal_xyz.detach(), normal_value, float(normal_weight))
+        nv = normal_value if torch.is_tensor(normal_value) else torch.zeros((0, 3), device=self.device)
+        self.alpha = _SolveFunction.apply(self, self.alpha, None if pos_xyz is None else pos_xyz.detach(),
+                                          None if normal_xyz is None else normal_xyz.detach(), nv, float(pos_weight), float(normal_weight),
+                                          *self._theta())
+
+    def _theta_vjp(self, sets, alpha, lam=None):
+        """sum_r g_r . dR'_r / dtheta for the site sets ``sets`` = [(xyz, gradient rows?, sqrt weight, per-row coefficient fn)]:
+        the coefficient function maps (u = R' alpha [, v = R' lambda]) of a set to the row factors (a, b) of
+        g_r = a_r lambda + b_r alpha  (solve)  or  g_r = a_r alpha  (evaluation)."""
+        from . import kernel_rows_torch as krt
+        theta = self._theta()
+        if not theta:
+            return []
+        with torch.enable_grad():
+            S = torch.zeros((), dtype=torch.float32, device=self.device)
+            for xyz, grad_rows, sw, coeff in sets:
+                if xyz is None or xyz.shape[0] == 0:
+                    continue
+                R, idx = krt.rows(self.svh, self._interps_in, [f if torch.is_tensor(f) else torch.zeros((0, self.kdim), device=self.device)
+                                                              for f in self._feat_in], xyz.to(self.device, torch.float32), grad_rows,
+                                  self.approx_kernel_grad, scale=sw)
+                with torch.no_grad():
+                    Rd = R.detach()
+                    u = krt.apply_rows(Rd, idx, alpha, grad_rows)
+                    v = krt.apply_rows(Rd, idx, lam, grad_rows) if lam is not None else None
+                    a, b = coeff(u, v)
+                    m = (idx >= 0).to(torch.float32)
+                    ag = alpha[idx.clamp(min=0)] * m                                   # [n, L, 27]
+                    lg = lam[idx.clamp(min=0)] * m if lam is not None else None
+                    if grad_rows:                                                      # rows [n, 3, L, 27], factors [n, 3]
+                        g = (a[..., None, None] * lg[:, None] if lg is not None else 0.0) + b[..., None, None] * ag[:, None]
+                    else:
+                        g = (a[:, None, None] * lg if lg is not None else 0.0) + b[:, None, None] * ag
+                S = S + (R * g).sum()
+            grads = torch.autograd.grad(S, theta, allow_unused=True)
+        return [gr if gr is not None else torch.zeros_like(t) for gr, t in zip(grads, theta)]
 
     def solve(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0, fused_mode=True,
               pos_sorted_keys=None, normal_sorted_keys=None):
@@ -488,8 +539,8 @@ class KernelField(BaseField):
 
     # ---- evaluation -------------------------------------------------------------------------------------
     def _evaluate_f_model(self, xyz, grad, max_points=1 << 22):
-        if torch.is_grad_enabled() and self.alpha.requires_grad:
-            f, g = _EvaluateFunction.apply(self, self.alpha, xyz.detach(), bool(grad), max_points)
+        if torch.is_grad_enabled() and (self.alpha.requires_grad or self._theta()):
+            f, g = _EvaluateFunction.apply(self, self.alpha, xyz.detach(), bool(grad), max_points, *self._theta())
             return EvaluationResult(f, g if grad else None)
         return self._evaluate_raw(self.alpha, xyz, grad, max_points)
 
@@ -541,13 +592,17 @@ class KernelField(BaseField):
 
 
 class _SolveFunction(torch.autograd.Function):
-    """alpha(normal targets) for the system of the field's last solve.  (w_p G^T G + w_n Q^T Q + reg I) alpha = w_n Q^T n  =>
-    dL/dn = w_n Q lambda with A lambda = dL/dalpha, and (Q lambda)[k, a] is d/dx_a of the kernel field with coefficients lambda
-    at normal site k -- one PCG solve and one gradient evaluation."""
+    """alpha(normal targets, theta) for the system of the field's last solve:  A(theta) alpha = b(theta, n),
+    A = sum_r R'_r^T R'_r + reg I,  b = sum_r R'_r t'_r  (R' = sqrt(w) R, t' = sqrt(w) n on the gradient rows, 0 on the position rows).
+    With A lambda = dL/dalpha:  dL/dn = w_n Q lambda  ((Q lambda)[k, a] is d/dx_a of the kernel field with coefficients lambda at
+    normal site k -- one PCG solve and one gradient evaluation) and
+    dL/dtheta = sum_r dR'_r . [(t'_r - u_r) lambda - v_r alpha],  u = R' alpha, v = R' lambda  (KernelField._theta_vjp)."""
 
     @staticmethod
-    def forward(ctx, field, alpha, normal_xyz, normal_value, normal_weight):
-        ctx.field, ctx.normal_xyz, ctx.normal_weight = field, normal_xyz, normal_weight
+    def forward(ctx, field, alpha, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, *theta):
+        ctx.field, ctx.pos_xyz, ctx.normal_xyz = field, pos_xyz, normal_xyz
+        ctx.pos_weight, ctx.normal_weight, ctx.n_theta = pos_weight, normal_weight, len(theta)
+        ctx.normal_value = normal_value.detach()
         return alpha.clone()
 
     @staticmethod
@@ -555,18 +610,30 @@ class _SolveFunction(torch.autograd.Function):
     def backward(ctx, g_alpha):
         fld = ctx.field
         lam = fld._solve_system(g_alpha.to(torch.float32))
-        q_lam = fld._evaluate_raw(lam, ctx.normal_xyz, True).gradient
-        return None, None, None, ctx.normal_weight * q_lam, None
+        g_n = None
+        if ctx.normal_xyz is not None and ctx.normal_value.numel():
+            g_n = ctx.normal_weight * fld._evaluate_raw(lam, ctx.normal_xyz, True).gradient
+        g_theta = []
+        if ctx.n_theta:
+            alpha = fld.alpha.detach()
+            swp, swn = ctx.pos_weight ** 0.5, ctx.normal_weight ** 0.5
+            tn = ctx.normal_value.to(fld.device, torch.float32) * swn if ctx.normal_value.numel() else None
+            sets = [(ctx.pos_xyz, False, swp, lambda u, v: (-u, -v)),
+                    (ctx.normal_xyz, True, swn, lambda u, v: ((tn - u) if tn is not None else -u, -v))]
+            g_theta = fld._theta_vjp(sets, alpha, lam)
+        return (None, None, None, None, g_n, None, None) + tuple(g_theta)
 
 
 class _EvaluateFunction(torch.autograd.Function):
-    """f(x) and grad f(x) as functions of alpha (linear): dL/dalpha = G_x^T g_f + Q_x^T g_grad, the transposed pass of the
-    matrix-free operator over the kernel rows of the query points.  Query points are not differentiated; points outside every
-    active cell of a level contribute nothing at that level here (evaluate_f itself looks their neighbours up in the hash)."""
+    """f(x) and grad f(x) as functions of alpha (linear) and theta: dL/dalpha = G_x^T g_f + Q_x^T g_grad, the set-up pass of the
+    matrix-free operator over the kernel rows of the query points; dL/dtheta = sum_x dR_x . (g alpha) (KernelField._theta_vjp).
+    Query points are not differentiated; points outside every active cell of a level contribute nothing at that level here
+    (evaluate_f itself looks their neighbours up in the hash)."""
 
     @staticmethod
-    def forward(ctx, field, alpha, xyz, want_grad, max_points):
-        ctx.field, ctx.xyz, ctx.want_grad = field, xyz, want_grad
+    def forward(ctx, field, alpha, xyz, want_grad, max_points, *theta):
+        ctx.field, ctx.xyz, ctx.want_grad, ctx.n_theta = field, xyz, want_grad, len(theta)
+        ctx.alpha = alpha.detach()
         res = field._evaluate_raw(alpha, xyz, want_grad, max_points)
         g = res.gradient if want_grad else torch.zeros((0, 3), dtype=torch.float32, device=res.value.device)
         return res.value, g
@@ -576,10 +643,16 @@ class _EvaluateFunction(torch.autograd.Function):
     def backward(ctx, g_f, g_grad):
         fld = ctx.field
         use_g = ctx.want_grad and g_grad is not None and g_grad.numel() > 0
-        op = fld.fused_operator(ctx.xyz, ctx.xyz if use_g else None, g_grad if use_g else None, 1.0, 1.0,
-                                pos_value=g_f if g_f is not None else torch.zeros(ctx.xyz.shape[0], device=fld.device))
+        g_f = g_f if g_f is not None else torch.zeros(ctx.xyz.shape[0], device=fld.device)
+        op = fld.fused_operator(ctx.xyz, ctx.xyz if use_g else None, g_grad if use_g else None, 1.0, 1.0, pos_value=g_f)
         b, _ = fld.fused_rhs_diag(op, 0.0)
-        return None, b, None, None, None
+        g_theta = []
+        if ctx.n_theta:
+            sets = [(ctx.xyz, False, 1.0, lambda u, v: (None, g_f.to(torch.float32)))]
+            if use_g:
+                sets.append((ctx.xyz, True, 1.0, lambda u, v: (None, g_grad.to(torch.float32))))
+            g_theta = fld._theta_vjp(sets, ctx.alpha, None)
+        return (None, b, None, None, None) + tuple(g_theta)
 
 
 class _PackedInterpolator:

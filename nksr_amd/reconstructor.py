@@ -88,6 +88,7 @@ class Reconstructor:
         field.timing = t           # chunk mode solves several chunks at once: the per-field copy is the race-free one
         return field
 
+    @torch.no_grad()       # the inference API: nothing here builds an autograd graph (training drives KernelField directly)
     def reconstruct(self, xyz, normal=None, sensor=None, detail_level=0.0, voxel_size=None, chunk_size=-1.0,
                     overlap_ratio=0.05, approx_kernel_grad=False, solver_max_iter=2000, solver_tol=1e-5,
                     fused_mode=True, preprocess_fn=None, sharded_input=False, chunk_owner=None, chunk_bounds=None):

@@ -234,8 +234,141 @@ def test_solve_is_differentiable_wrt_the_normal_targets(fused):
         fd = 0.5 * (oracle_loss(nval + v) - oracle_loss(nval - v))
         pu.check('autograd[fused=%s]:directional_derivative[%d]' % (fused, trial), abs((g * v).sum() - fd) / max(abs(fd), 1e-12), 2e-3)
     # no autograd, no graph: the plain solve keeps returning a leaf
-    fld.solve_non_fused(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
+    with torch.no_grad():
+        fld.solve_non_fused(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
     assert not fld.alpha.requires_grad
+
+
+@pytest.mark.parametrize('approx', [False, True])
+def test_torch_rows_match_the_hip_rows(approx):
+    """fields/kernel_rows_torch.py (the differentiable statement of the kernel rows the training-path backward goes through)
+    against nksr_kernel_rows: value rows and gradient rows, exact and approx_kernel_grad, incl. sites outside the finest level."""
+    from nksr_amd.fields import KernelField, kernel_rows_torch as krt
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=2500, init_scale=0.4)
+    net.to(_dev())
+    tf = [torch.from_numpy(f).to(_dev()) for f in feats]
+    fld = KernelField(svh, net.interpolators, tf, approx_kernel_grad=approx)
+    q = np.concatenate([xyz[:900], oh.levels[0].centers()[:300], oh.levels[2].centers()[:50] + np.float32(0.3)]).astype(np.float32)
+    qt = torch.from_numpy(q).to(_dev())
+    hv, hd = fld.kernel_rows(qt, grad=True)
+    with torch.no_grad():
+        tv, idx = krt.rows(svh, net.interpolators, tf, qt, False, approx)
+        td, _ = krt.rows(svh, net.interpolators, tf, qt, True, approx, scale=0.7)
+    pu.check('torch_rows[approx=%s]:val' % approx, float((tv - hv).abs().max() / hv.abs().max()), 1e-5)
+    pu.check('torch_rows[approx=%s]:dval' % approx, float((td / 0.7 - hd).abs().max() / hd.abs().max()), 1e-5)
+    # the index table: global unknown index of every slot
+    off = svh.offsets
+    for d in range(svh.depth):
+        cell = svh.level(d).hash.query(_level_keys(svh, qt, d))
+        nb = svh.level(d).nbr[cell.clamp(min=0).long()].long()
+        want = torch.where((cell >= 0)[:, None] & (nb >= 0), nb + off[d], torch.full_like(nb, -1))
+        assert torch.equal(idx[:, d], want)
+
+
+def _level_keys(svh, xyz, d):
+    from nksr_amd._lib import call, ptr, stream
+    p = xyz * torch.tensor(svh.inv_w0, dtype=torch.float32, device=xyz.device)
+    ijk = ((torch.floor(p * 2.0).long() >> d) >> 1).to(torch.int32).contiguous()
+    keys = torch.empty(xyz.shape[0], dtype=torch.int64, device=xyz.device)
+    call('nksr_encode_keys', ptr(ijk), xyz.shape[0], d, ptr(keys), stream())
+    return keys
+
+
+@pytest.mark.parametrize('approx,fused', [(False, False), (True, False), (True, True)])
+def test_solve_is_differentiable_wrt_features_and_interpolators(approx, fused):
+    """models/nksr_net.py:105-112 back-propagates through solve_non_fused into the basis features and the
+    interpolator weights.  alpha(theta) by implicit differentiation (one more PCG solve), the theta terms as the vector-Jacobian
+    product through the torch statement of the rows; checked against central differences of the ORACLE's loss (assembly, direct
+    solve and evaluation redone for theta +- eps v) along random directions in feature space and in weight space."""
+    import scipy.sparse.linalg as sla
+    from nksr_amd.fields import KernelField
+    from oracle import field as ofield, kernel, solve
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=1200, init_scale=0.3)
+    net.to(_dev())
+    t = lambda a: torch.from_numpy(a).to(_dev())
+    tf = [t(f).requires_grad_(True) for f in feats]
+    fld = KernelField(svh, net.interpolators, tf, approx_kernel_grad=approx)
+    fld.solver_config.update({'tol': 1e-7, 'max_iter': 4000})
+    nxyz = oh.levels[0].centers()
+    rs = np.random.RandomState(7)
+    nval = rs.randn(len(nxyz), 3).astype(np.float32)
+    wp, wn = 1e4 / len(xyz), 1e4 / len(nxyz) * 0.01
+    q = (xyz[:300] + rs.randn(300, 3).astype(np.float32) * np.float32(0.02)).astype(np.float32)
+    c1, c3 = rs.randn(300), rs.randn(300, 3)
+
+    def oracle_loss(fs, its):
+        A, b, G, Q, psis = solve.assemble(oh, fs, its, xyz, nxyz, nval, wp, wn, 1.0, approx)
+        alpha = sla.splu(A.astype(np.float64).tocsc()).solve(b.astype(np.float64)).astype(np.float32)
+        f, g = ofield.evaluate_f(oh, fs, its, psis, alpha, q, True, approx)
+        return float((c1 * f).sum() + (c3 * g).sum() + 0.5 * (f.astype(np.float64) ** 2).sum())
+
+    (fld.solve if fused else fld.solve_non_fused)(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
+    assert fld.alpha.requires_grad and bool(fld.solve_info.get('fused', False)) == fused
+    res = fld.evaluate_f(t(q), grad=True)
+    loss = (t(c1.astype(np.float32)) * res.value).sum() + (t(c3.astype(np.float32)) * res.gradient).sum() + 0.5 * (res.value ** 2).sum()
+    base = oracle_loss(feats, ointerps)
+    pu.check('autograd_theta[approx=%s]:loss_rel' % approx, abs(float(loss) - base) / abs(base), 1e-4)
+    params = [p for it in net.interpolators for p in (it.W1, it.b1, it.W2, it.b2, it.W3, it.b3)]
+    grads = torch.autograd.grad(loss, tf + params)
+    gf = [g.cpu().numpy().astype(np.float64) for g in grads[:len(tf)]]
+    gp = [g.cpu().numpy().astype(np.float64) for g in grads[len(tf):]]
+    assert all(np.isfinite(g).all() for g in gf + gp) and max(np.abs(g).max() for g in gf) > 0 and max(np.abs(g).max() for g in gp) > 0
+    # (1) the implicit-function algebra, independent of finite differences: the same loss through a DENSE float64 solve of the
+    #     system built from the torch rows, differentiated end to end by autograd (exact-gradient rows are discontinuous in theta
+    #     across ReLU kinks -- d(phi)/dx is piecewise constant -- so central differences are only meaningful in approx mode)
+    from nksr_amd.fields import kernel_rows_torch as krt
+    M = svh.num_unknowns
+
+    def dense(R, idx, rows_per_site):
+        n = R.shape[0]
+        Rf = R.reshape(n * rows_per_site, -1) if rows_per_site == 1 else R.reshape(n, 3, -1).reshape(n * 3, -1)
+        ix = idx.reshape(n, -1)
+        ix = ix if rows_per_site == 1 else ix[:, None, :].expand(n, 3, ix.shape[1]).reshape(n * 3, -1)
+        D = torch.zeros((Rf.shape[0], M + 1), dtype=torch.float64, device=R.device)
+        D = D.scatter_add(1, torch.where(ix >= 0, ix, torch.full_like(ix, M)), Rf.double())
+        return D[:, :M]
+    RG, iG = krt.rows(svh, net.interpolators, tf, t(xyz), False, approx, scale=wp ** 0.5)
+    RQ, iQ = krt.rows(svh, net.interpolators, tf, t(nxyz), True, approx, scale=wn ** 0.5)
+    Gd, Qd = dense(RG, iG, 1), dense(RQ, iQ, 3)
+    Ad = Gd.T @ Gd + Qd.T @ Qd + torch.eye(M, dtype=torch.float64, device=_dev())
+    bd = Qd.T @ (t(nval).double().reshape(-1) * wn ** 0.5)
+    ad = torch.linalg.solve(Ad, bd)
+    Rf_, if_ = krt.rows(svh, net.interpolators, tf, t(q), False, approx)
+    Rg_, ig_ = krt.rows(svh, net.interpolators, tf, t(q), True, approx)
+    fd_ = dense(Rf_, if_, 1) @ ad
+    gd_ = (dense(Rg_, ig_, 3) @ ad).reshape(-1, 3)
+    loss_d = (t(c1).double() * fd_).sum() + (t(c3).double() * gd_).sum() + 0.5 * (fd_ ** 2).sum()
+    pu.check('autograd_theta[approx=%s]:dense_loss_rel' % approx, abs(float(loss_d) - float(loss)) / abs(float(loss)), 1e-4)
+    gd_all = torch.autograd.grad(loss_d, tf + params)
+    num = sum(float(((a_.double() - b_.double()) ** 2).sum()) for a_, b_ in zip(grads, gd_all)) ** 0.5
+    den = sum(float((b_.double() ** 2).sum()) for b_ in gd_all) ** 0.5
+    pu.check('autograd_theta[approx=%s]:gradient_vs_dense_autograd_rel_l2' % approx, num / den, 1e-4)
+    for name, lo, hi in (('features', 0, len(tf)), ('weights', len(tf), len(tf) + len(params))):
+        num = sum(float(((a_.double() - b_.double()) ** 2).sum()) for a_, b_ in zip(grads[lo:hi], gd_all[lo:hi])) ** 0.5
+        den = sum(float((b_.double() ** 2).sum()) for b_ in gd_all[lo:hi]) ** 0.5
+        pu.check('autograd_theta[approx=%s]:%s_vs_dense_autograd_rel_l2' % (approx, name), num / den, 1e-4)
+    if not approx or fused:
+        return
+    # (2) approx mode (rows continuous in theta): central differences of the ORACLE's loss along random directions
+    eps = 2e-3
+    for trial in range(2):            # directions in feature space
+        v = [rs.randn(*f.shape).astype(np.float32) for f in feats]
+        fd = (oracle_loss([f + np.float32(eps) * d for f, d in zip(feats, v)], ointerps) -
+              oracle_loss([f - np.float32(eps) * d for f, d in zip(feats, v)], ointerps)) / (2 * eps)
+        an = sum((g * d).sum() for g, d in zip(gf, v))
+        pu.report('autograd_theta[approx=%s]:d_features[%d]:values' % (approx, trial), analytic=float(an), finite_difference=float(fd), loss=float(base))
+        pu.check('autograd_theta[approx=%s]:d_features[%d]' % (approx, trial), abs(an - fd) / max(abs(fd), 1e-12), 6e-2)
+    P0 = [p.detach().cpu().numpy() for p in params]
+    for trial in range(2):            # directions in weight space
+        v = [rs.randn(*p.shape).astype(np.float32) for p in P0]
+
+        def interps(sign):
+            P = [p + np.float32(sign * eps) * d for p, d in zip(P0, v)]
+            return [kernel.Interpolator(*P[6 * i:6 * i + 6]) for i in range(len(net.interpolators))]
+        fd = (oracle_loss(feats, interps(1.0)) - oracle_loss(feats, interps(-1.0))) / (2 * eps)
+        an = sum((g * d).sum() for g, d in zip(gp, v))
+        pu.report('autograd_theta[approx=%s]:d_weights[%d]:values' % (approx, trial), analytic=float(an), finite_difference=float(fd), loss=float(base))
+        pu.check('autograd_theta[approx=%s]:d_weights[%d]' % (approx, trial), abs(an - fd) / max(abs(fd), 1e-12), 6e-2)
 
 
 def test_pcg_matches_oracle_and_scipy():
