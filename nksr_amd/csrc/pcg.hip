@@ -464,24 +464,33 @@ __global__ void __launch_bounds__(256) k_cheb_step(int n, const int32_t* __restr
     if (done && *done) return;
     const int j = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (j >= n) return;
-    float t = 0.f, t1 = 0.f;
-    int k = rowptr[j] + lane;
-    const int k1 = rowptr[j + 1];
-    for (; k + 64 < k1; k += 128) {          // two independent chains: the block sits in L2, the row loop is latency-bound
-        const float v0 = vals[k], v1 = vals[k + 64];
-        const int c0 = cols[k], c1 = cols[k + 64];
-        t = fmaf(v0, d_old[c0], t);
-        t1 = fmaf(v1, d_old[c1], t1);
-    }
-    if (k < k1) t = fmaf(vals[k], d_old[cols[k]], t);
-    t += t1;
+    // a wavefront's time is a chain of dependent load latencies (the block streams from L2 / HBM): everything that does not depend on
+    // the row's entries is requested up front, and four 64-entry groups (rows hold ~190 entries) are in flight at once -- clamped
+    // addresses instead of predicated loads, so that the compiler does not serialise them
+    const int k0 = rowptr[j], k1 = rowptr[j + 1];
+    const float dj = d_old[j], rs = res[j], dg = diag[j], yj = y[j];
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int base = k0 + lane; base - lane < k1; base += 256) {
+        float v[4];
+        int c[4];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        for (int q = 0; q < 4; ++q) {
+            const int k = base + 64 * q, kc = k < k1 ? k : k1 - 1;
+            v[q] = vals[kc];
+            c[q] = cols[kc];
+            if (k >= k1) v[q] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = fmaf(v[q], d_old[c[q]], t[q]);
+    }
+    float tt = (t[0] + t[1]) + (t[2] + t[3]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tt += __shfl_xor(tt, o);
     if (lane == 0) {
-        const float dj = d_old[j], rj = res[j] - t;
-        y[j] += dj;
+        const float rj = rs - tt;
+        y[j] = yj + dj;
         res[j] = rj;
-        d_new[j] = fmaf(a, dj, b * rj / diag[j]);
+        d_new[j] = fmaf(a, dj, b * rj / dg);
     }
 }
 
