@@ -69,6 +69,12 @@ int nksr_splat_keys(const float* xyz, int64_t n, float inv_w0, int level, int mo
  * point: mode 0 -> 8 keys per cell at level+1 (the level-(l+1) half index of a point is its level-l cell
  * index), mode 1 -> 27 keys per cell at the same level. */
 int nksr_cell_footprint_keys(const int64_t* cell_keys, int64_t nc, int level, int mode, int64_t* keys_out, void* stream);
+/* The same key streams (xyz != NULL: nksr_splat_keys; cell_keys != NULL: nksr_cell_footprint_keys; exactly one of them) with the
+ * duplicates inside each workgroup's run of Morton-ordered elements removed (LDS hash set): the multiset differs, the SET of keys
+ * is the same, so sort + unique behind it give the identical level.  keys_out: room for n * (8 | 27) keys; *count_out (device)
+ * = number of keys written, in no particular order.  mode 2 (cell_keys, level 0): the corner keys of nksr_cell_corner_keys. */
+int nksr_footprint_keys_dedup(const float* xyz, const int64_t* cell_keys, int64_t n, float inv_w0, int level, int mode,
+                              int64_t* keys_out, int64_t* count_out, void* stream);
 /* Morton key of the level-0 cell containing each point. */
 int nksr_point_keys(const float* xyz, int64_t n, float inv_w0, int64_t* keys_out, void* stream);
 int nksr_decode_keys(const int64_t* keys, int64_t n, int level, int32_t* ijk_out, void* stream);

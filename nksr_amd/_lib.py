@@ -77,6 +77,7 @@ _PROTOS = {
     'nksr_exclusive_sum_i64': [_vp, _P(_sz), _vp, _vp, _i64, _vp],
     'nksr_splat_keys': [_vp, _i64, _f32, C.c_int, C.c_int, _vp, _vp],
     'nksr_cell_footprint_keys': [_vp, _i64, C.c_int, C.c_int, _vp, _vp],
+    'nksr_footprint_keys_dedup': [_vp, _vp, _i64, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp],
     'nksr_point_keys': [_vp, _i64, _f32, _vp, _vp],
     'nksr_decode_keys': [_vp, _i64, C.c_int, _vp, _vp],
     'nksr_encode_keys': [_vp, _i64, C.c_int, _vp, _vp],

@@ -236,6 +236,90 @@ __global__ void k_cell_footprint_keys(const int64_t* __restrict__ cell_keys, int
     }
 }
 
+// ---- the same footprints with the duplicates of a workgroup's neighbourhood removed before they reach HBM -------------------
+// Points and cells arrive in Morton order, so the 8 / 27 keys of consecutive elements repeat each other several times over: a
+// workgroup inserts the keys of its elements into an LDS hash set and emits the distinct ones (order within the stream is free:
+// the caller sorts it).  The level-0 streams shrink 4-7x, and so do the radix sort and the unique pass behind them.
+#define DD_SLOTS 4096
+template <int SRC>   // 0: points (k_splat_keys)   1: cells (k_cell_footprint_keys)
+__global__ void __launch_bounds__(256) k_footprint_dedup(const float* __restrict__ xyz, const int64_t* __restrict__ cell_keys, int64_t n, float inv_w0,
+                                                         int level, int mode, int epb, int64_t* __restrict__ out,
+                                                         unsigned long long* __restrict__ counter) {
+    __shared__ unsigned long long tab[DD_SLOTS];
+    __shared__ int wsum[4];
+    __shared__ unsigned long long gbase;
+    const unsigned long long EMPTY = ~0ull;
+    for (int t = threadIdx.x; t < DD_SLOTS; t += 256) tab[t] = EMPTY;
+    __syncthreads();
+    const int per = mode == 1 ? 27 : 8;
+    const int64_t e0 = (int64_t)blockIdx.x * epb;
+    const int ne = (int)(n - e0 < epb ? n - e0 : epb);
+    for (int t = threadIdx.x; t < ne * per; t += 256) {
+        const int e = t / per, sl = t - e * per;
+        const int64_t i = e0 + e;
+        int x, y, z, bias;
+        if (SRC == 0) {
+            float p;
+            const int hx = half_index(xyz[i * 3 + 0], inv_w0, p) >> level, hy = half_index(xyz[i * 3 + 1], inv_w0, p) >> level,
+                      hz = half_index(xyz[i * 3 + 2], inv_w0, p) >> level;
+            bias = NKSR_BIAS0 >> level;
+            if (mode == 0) { x = ((hx - 1) >> 1) + (sl >> 2); y = ((hy - 1) >> 1) + ((sl >> 1) & 1); z = ((hz - 1) >> 1) + (sl & 1); }
+            else { x = (hx >> 1) + sl / 9 - 1; y = (hy >> 1) + (sl / 3) % 3 - 1; z = (hz >> 1) + sl % 3 - 1; }
+        } else {
+            morton_decode_biased(cell_keys[i], NKSR_BIAS0 >> level, x, y, z);
+            if (mode == 2) { bias = NKSR_BIAS0; x += sl >> 2; y += (sl >> 1) & 1; z += sl & 1; }       // lattice corners of a dual cell
+            else if (mode == 0) { bias = NKSR_BIAS0 >> (level + 1); x = ((x - 1) >> 1) + (sl >> 2); y = ((y - 1) >> 1) + ((sl >> 1) & 1); z = ((z - 1) >> 1) + (sl & 1); }
+            else { bias = NKSR_BIAS0 >> level; x += sl / 9 - 1; y += (sl / 3) % 3 - 1; z += sl % 3 - 1; }
+        }
+        const unsigned long long key = (unsigned long long)morton_biased(x, y, z, bias);
+        unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 52);
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&tab[h], EMPTY, key);
+            if (prev == EMPTY || prev == key) break;
+            h = (h + 1) & (DD_SLOTS - 1);
+        }
+    }
+    __syncthreads();
+    // ordered emission: thread t owns slots [16 t, 16 t + 16)
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < DD_SLOTS / 256; ++q) cnt += tab[threadIdx.x * (DD_SLOTS / 256) + q] != EMPTY;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) gbase = atomicAdd(counter, (unsigned long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]));
+    __syncthreads();
+    int64_t pos = (int64_t)gbase + incl - cnt;
+    for (int w = 0; w < wave; ++w) pos += wsum[w];
+#pragma unroll
+    for (int q = 0; q < DD_SLOTS / 256; ++q) {
+        const unsigned long long k = tab[threadIdx.x * (DD_SLOTS / 256) + q];
+        if (k != EMPTY) out[pos++] = (int64_t)k;
+    }
+}
+
+// Distinct-per-workgroup footprint keys of points (xyz != NULL: nksr_splat_keys) or of cells (cell_keys != NULL:
+// nksr_cell_footprint_keys; mode 2: the 8 lattice corners of dual-grid cells, nksr_cell_corner_keys).  keys_out needs room for every key (n * 8 or n * 27); *count_out = number written.
+extern "C" int nksr_footprint_keys_dedup(const float* xyz, const int64_t* cell_keys, int64_t n, float inv_w0, int level, int mode,
+                                         int64_t* keys_out, int64_t* count_out, void* stream) {
+    if ((xyz != nullptr) == (cell_keys != nullptr)) return nksr_set_error(NKSR_ERR_ARG, "exactly one of xyz / cell_keys");
+    if (level < 0 || level + (cell_keys && mode == 0) >= NKSR_MAX_DEPTH || mode < 0 || mode > 2 || (mode == 2 && (!cell_keys || level != 0)))
+        return nksr_set_error(NKSR_ERR_ARG, "bad level/mode");
+    if (!keys_out || !count_out) return nksr_set_error(NKSR_ERR_ARG, "NULL output");
+    hipStream_t st = (hipStream_t)stream;
+    NKSR_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int64_t), st));
+    if (n <= 0) return NKSR_OK;
+    const int epb = mode == 1 ? 64 : 256;       // <= 2048 / 1728 keys per 4096-slot set
+    const dim3 grid((unsigned)((n + epb - 1) / epb));
+    if (xyz) hipLaunchKernelGGL(k_footprint_dedup<0>, grid, dim3(256), 0, st, xyz, cell_keys, n, inv_w0, level, mode, epb, keys_out, (unsigned long long*)count_out);
+    else hipLaunchKernelGGL(k_footprint_dedup<1>, grid, dim3(256), 0, st, xyz, cell_keys, n, inv_w0, level, mode, epb, keys_out, (unsigned long long*)count_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
 extern "C" int nksr_cell_footprint_keys(const int64_t* cell_keys, int64_t nc, int level, int mode, int64_t* keys_out,
                                         void* stream) {
     if (level < 0 || level + (mode == 0) >= NKSR_MAX_DEPTH || (mode != 0 && mode != 1)) return nksr_set_error(NKSR_ERR_ARG, "bad level/mode");

@@ -18,11 +18,11 @@ from .fields.base_field import MeshingResult
 def _cell_vertices(cell_keys_raw):
     """sorted-unique cells, their sorted-unique lattice vertices, and the [ncell,8] corner table"""
     dev = cell_keys_raw.device
-    cells = ops.sort_unique(cell_keys_raw)
+    cells = ops.sort_unique(cell_keys_raw, maybe_sorted=True)      # base cells of Morton-ordered voxels / children of sorted cells
     nc = cells.numel()
     ck = torch.empty(nc * 8, dtype=torch.int64, device=dev)
     call('nksr_cell_corner_keys', ptr(cells), nc, ptr(ck), stream())
-    vkeys = ops.sort_unique(ck)
+    vkeys = ops.sort_unique(ops.dedup_corner_keys(cells) if nc >= (1 << 16) else ck)
     vhash = ops.HashTable(vkeys)      # key -> index into vkeys: one or two probes instead of a 21-step binary search per lookup
     cidx = vhash.query(ck).view(nc, 8)
     return cells, vkeys, cidx, vhash

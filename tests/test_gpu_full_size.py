@@ -36,6 +36,28 @@ def test_hierarchy_is_sorted_and_nested(big):
             assert bool((nb[j[ok], 26 - s].long() == idx[ok]).all())
 
 
+def test_hierarchies_do_not_depend_on_the_lds_dedup_of_the_key_streams(big, monkeypatch):
+    """nksr_footprint_keys_dedup drops duplicates before the sort: same SET of keys, hence bit-identical levels
+    (both hierarchies of the hot path: point splatting and cell neighbourhoods)."""
+    from nksr_amd import svh as svh_mod
+    from nksr_amd.nn.network import sort_cloud
+    from nksr_amd.svh import SparseFeatureHierarchy, inv_w0_f32
+    rec, _, xyz, _ = big
+    hp = rec.hparams
+    ks, xs, _ = sort_cloud(xyz.contiguous(), xyz.contiguous(), inv_w0_f32(hp.voxel_size))
+    built = {}
+    for name, limit in (('dedup', 1), ('plain', 1 << 62)):
+        monkeypatch.setattr(svh_mod, '_DEDUP_MIN', limit)
+        a = SparseFeatureHierarchy(hp.voxel_size, hp.tree_depth, xyz.device).build_point_splatting_sorted(xs, ks)
+        b = SparseFeatureHierarchy(hp.voxel_size, hp.tree_depth, xyz.device).build_point_neighborhood_sorted(ks)
+        built[name] = [h.level(d).keys for h in (a, b) for d in range(hp.tree_depth)]
+    for u, v in zip(built['dedup'], built['plain']):
+        assert u.numel() > 0 and torch.equal(u, v)
+    ref = SparseFeatureHierarchy(hp.voxel_size, hp.tree_depth, xyz.device).build_point_splatting(xs)     # per-point keys, no shortcuts
+    for d in range(hp.tree_depth):
+        assert torch.equal(built['dedup'][d], ref.level(d).keys)
+
+
 def test_matrix_is_exactly_symmetric_and_positive(big):
     from nksr_amd import solver
     _, fld, _, _ = big
