@@ -69,10 +69,15 @@ int nksr_splat_keys(const float* xyz, int64_t n, float inv_w0, int level, int mo
  * point: mode 0 -> 8 keys per cell at level+1 (the level-(l+1) half index of a point is its level-l cell
  * index), mode 1 -> 27 keys per cell at the same level. */
 int nksr_cell_footprint_keys(const int64_t* cell_keys, int64_t nc, int level, int mode, int64_t* keys_out, void* stream);
+/* Axis-aligned bounding box of a cloud (the host side of detail_level / chunk_size needs it: NKSR-USAGE.md:129-137):
+ * out6 = (min x, y, z, max x, y, z), exact; work: nksr_bbox_work_floats() floats of scratch. */
+int nksr_bbox(const float* xyz, int64_t n, float* work, float* out6, void* stream);
+int64_t nksr_bbox_work_floats(void);
 /* The same key streams (xyz != NULL: nksr_splat_keys; cell_keys != NULL: nksr_cell_footprint_keys; exactly one of them) with the
  * duplicates inside each workgroup's run of Morton-ordered elements removed (LDS hash set): the multiset differs, the SET of keys
  * is the same, so sort + unique behind it give the identical level.  keys_out: room for n * (8 | 27) keys; *count_out (device)
- * = number of keys written, in no particular order.  mode 2 (cell_keys, level 0): the corner keys of nksr_cell_corner_keys. */
+ * = number of keys written, in no particular order.  mode 2 (cell_keys, level 0): the corner keys of nksr_cell_corner_keys;
+ * mode 3 (cell_keys, level 0): cell_keys IS the stream (n non-negative keys, e.g. the edge keys of nksr_mc_emit). */
 int nksr_footprint_keys_dedup(const float* xyz, const int64_t* cell_keys, int64_t n, float inv_w0, int level, int mode,
                               int64_t* keys_out, int64_t* count_out, void* stream);
 /* Morton key of the level-0 cell containing each point. */

@@ -56,6 +56,8 @@ def _load():
 lib = _load()
 lib.nksr_last_error.restype = C.c_char_p
 lib.nksr_pcg_workspace_bytes.restype = _sz
+lib.nksr_bbox_work_floats.restype = _i64
+lib.nksr_bbox_work_floats.argtypes = []
 lib.nksr_pcg_workspace_bytes.argtypes = [_i32, _i64]
 lib.nksr_assemble_workspace_bytes.restype = _sz
 lib.nksr_assemble_workspace_bytes.argtypes = [C.POINTER(HierT)]
@@ -77,6 +79,7 @@ _PROTOS = {
     'nksr_exclusive_sum_i64': [_vp, _P(_sz), _vp, _vp, _i64, _vp],
     'nksr_splat_keys': [_vp, _i64, _f32, C.c_int, C.c_int, _vp, _vp],
     'nksr_cell_footprint_keys': [_vp, _i64, C.c_int, C.c_int, _vp, _vp],
+    'nksr_bbox': [_vp, _i64, _vp, _vp, _vp],
     'nksr_footprint_keys_dedup': [_vp, _vp, _i64, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp],
     'nksr_point_keys': [_vp, _i64, _f32, _vp, _vp],
     'nksr_decode_keys': [_vp, _i64, C.c_int, _vp, _vp],
@@ -139,7 +142,7 @@ for _name, _args in _PROTOS.items():
 
 EXPORTED = ['nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
             'nksr_assemble_split_bytes',
-            'nksr_fused_workspace_bytes', 'nksr_pcg_vector_workspace_bytes'] + sorted(_PROTOS)
+            'nksr_fused_workspace_bytes', 'nksr_pcg_vector_workspace_bytes', 'nksr_bbox_work_floats'] + sorted(_PROTOS)
 
 
 def check(rc):

@@ -236,6 +236,49 @@ __global__ void k_cell_footprint_keys(const int64_t* __restrict__ cell_keys, int
     }
 }
 
+// ---- bounding box of a cloud: exact min / max per axis (two fixed-order stages; NaNs are skipped, callers validate) ----------
+#define BB_BLOCKS 1024
+__device__ __forceinline__ void bb_wave(float (&lo)[3], float (&hi)[3]) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o)); }
+}
+__global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ xyz, int64_t n, const float* __restrict__ part_in, float* __restrict__ out) {
+    __shared__ float sm[4][6];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (part_in) {       // second stage: BB_BLOCKS partial boxes
+        for (int i = threadIdx.x; i < BB_BLOCKS; i += 256)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], part_in[i * 6 + a]); hi[a] = fmaxf(hi[a], part_in[i * 6 + 3 + a]); }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)BB_BLOCKS * 256)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { const float v = xyz[i * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+    }
+    bb_wave(lo, hi);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { sm[threadIdx.x >> 6][a] = lo[a]; sm[threadIdx.x >> 6][3 + a] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int a = threadIdx.x;
+        float v = sm[0][a];
+        for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, sm[w][a]) : fmaxf(v, sm[w][a]);
+        out[(part_in ? 0 : (int64_t)blockIdx.x * 6) + a] = v;
+    }
+}
+// out6 = (min x, y, z, max x, y, z);  work: BB_BLOCKS * 6 floats
+extern "C" int nksr_bbox(const float* xyz, int64_t n, float* work, float* out6, void* stream) {
+    if (n <= 0 || !xyz || !work || !out6) return nksr_set_error(NKSR_ERR_ARG, "nksr_bbox: empty cloud or NULL arrays");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bbox, dim3(BB_BLOCKS), dim3(256), 0, st, xyz, n, (const float*)nullptr, work);
+    hipLaunchKernelGGL(k_bbox, dim3(1), dim3(256), 0, st, xyz, n, (const float*)work, out6);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+extern "C" int64_t nksr_bbox_work_floats(void) { return (int64_t)BB_BLOCKS * 6; }
+
 // ---- the same footprints with the duplicates of a workgroup's neighbourhood removed before they reach HBM -------------------
 // Points and cells arrive in Morton order, so the 8 / 27 keys of consecutive elements repeat each other several times over: a
 // workgroup inserts the keys of its elements into an LDS hash set and emits the distinct ones (order within the stream is free:
@@ -251,7 +294,7 @@ __global__ void __launch_bounds__(256) k_footprint_dedup(const float* __restrict
     const unsigned long long EMPTY = ~0ull;
     for (int t = threadIdx.x; t < DD_SLOTS; t += 256) tab[t] = EMPTY;
     __syncthreads();
-    const int per = mode == 1 ? 27 : 8;
+    const int per = mode == 1 ? 27 : mode == 3 ? 1 : 8;
     const int64_t e0 = (int64_t)blockIdx.x * epb;
     const int ne = (int)(n - e0 < epb ? n - e0 : epb);
     for (int t = threadIdx.x; t < ne * per; t += 256) {
@@ -266,12 +309,14 @@ __global__ void __launch_bounds__(256) k_footprint_dedup(const float* __restrict
             if (mode == 0) { x = ((hx - 1) >> 1) + (sl >> 2); y = ((hy - 1) >> 1) + ((sl >> 1) & 1); z = ((hz - 1) >> 1) + (sl & 1); }
             else { x = (hx >> 1) + sl / 9 - 1; y = (hy >> 1) + (sl / 3) % 3 - 1; z = (hz >> 1) + sl % 3 - 1; }
         } else {
-            morton_decode_biased(cell_keys[i], NKSR_BIAS0 >> level, x, y, z);
-            if (mode == 2) { bias = NKSR_BIAS0; x += sl >> 2; y += (sl >> 1) & 1; z += sl & 1; }       // lattice corners of a dual cell
+            if (mode == 3) { x = y = z = bias = 0; }                                                    // the keys themselves
+            else morton_decode_biased(cell_keys[i], NKSR_BIAS0 >> level, x, y, z);
+            if (mode == 3) {}
+            else if (mode == 2) { bias = NKSR_BIAS0; x += sl >> 2; y += (sl >> 1) & 1; z += sl & 1; }       // lattice corners of a dual cell
             else if (mode == 0) { bias = NKSR_BIAS0 >> (level + 1); x = ((x - 1) >> 1) + (sl >> 2); y = ((y - 1) >> 1) + ((sl >> 1) & 1); z = ((z - 1) >> 1) + (sl & 1); }
             else { bias = NKSR_BIAS0 >> level; x += sl / 9 - 1; y += (sl / 3) % 3 - 1; z += sl % 3 - 1; }
         }
-        const unsigned long long key = (unsigned long long)morton_biased(x, y, z, bias);
+        const unsigned long long key = (SRC == 1 && mode == 3) ? (unsigned long long)cell_keys[e0 + t] : (unsigned long long)morton_biased(x, y, z, bias);
         unsigned h = (unsigned)((key * 0x9E3779B97F4A7C15ull) >> 52);
         for (;;) {
             const unsigned long long prev = atomicCAS(&tab[h], EMPTY, key);
@@ -302,17 +347,18 @@ __global__ void __launch_bounds__(256) k_footprint_dedup(const float* __restrict
 }
 
 // Distinct-per-workgroup footprint keys of points (xyz != NULL: nksr_splat_keys) or of cells (cell_keys != NULL:
-// nksr_cell_footprint_keys; mode 2: the 8 lattice corners of dual-grid cells, nksr_cell_corner_keys).  keys_out needs room for every key (n * 8 or n * 27); *count_out = number written.
+// nksr_cell_footprint_keys; mode 2: the 8 lattice corners of dual-grid cells, nksr_cell_corner_keys; mode 3: cell_keys is the
+// stream itself, any non-negative keys).  keys_out needs room for every key (n * 8 or n * 27); *count_out = number written.
 extern "C" int nksr_footprint_keys_dedup(const float* xyz, const int64_t* cell_keys, int64_t n, float inv_w0, int level, int mode,
                                          int64_t* keys_out, int64_t* count_out, void* stream) {
     if ((xyz != nullptr) == (cell_keys != nullptr)) return nksr_set_error(NKSR_ERR_ARG, "exactly one of xyz / cell_keys");
-    if (level < 0 || level + (cell_keys && mode == 0) >= NKSR_MAX_DEPTH || mode < 0 || mode > 2 || (mode == 2 && (!cell_keys || level != 0)))
+    if (level < 0 || level + (cell_keys && mode == 0) >= NKSR_MAX_DEPTH || mode < 0 || mode > 3 || (mode >= 2 && (!cell_keys || level != 0)))
         return nksr_set_error(NKSR_ERR_ARG, "bad level/mode");
     if (!keys_out || !count_out) return nksr_set_error(NKSR_ERR_ARG, "NULL output");
     hipStream_t st = (hipStream_t)stream;
     NKSR_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(int64_t), st));
     if (n <= 0) return NKSR_OK;
-    const int epb = mode == 1 ? 64 : 256;       // <= 2048 / 1728 keys per 4096-slot set
+    const int epb = mode == 1 ? 64 : mode == 3 ? 2048 : 256;       // <= 2048 / 1728 keys per 4096-slot set
     const dim3 grid((unsigned)((n + epb - 1) / epb));
     if (xyz) hipLaunchKernelGGL(k_footprint_dedup<0>, grid, dim3(256), 0, st, xyz, cell_keys, n, inv_w0, level, mode, epb, keys_out, (unsigned long long*)count_out);
     else hipLaunchKernelGGL(k_footprint_dedup<1>, grid, dim3(256), 0, st, xyz, cell_keys, n, inv_w0, level, mode, epb, keys_out, (unsigned long long*)count_out);

@@ -124,7 +124,7 @@ def _extract(field, mise_iter, grid_upsample, max_points):
         return empty
     ekeys = torch.empty(T * 3, dtype=torch.int64, device=dev)
     call('nksr_mc_emit', ptr(cidx), ptr(config), ptr(tri_off), nc, ptr(ekeys), stream())
-    uek = ops.sort_unique(ekeys)
+    uek = ops.sort_unique(ops.dedup_keys(ekeys) if ekeys.numel() >= (1 << 19) else ekeys)      # every edge vertex is named by ~6 triangle corners
     faces = ops.HashTable(uek).query(ekeys).view(T, 3)
     ne = uek.numel()
     verts = torch.empty((ne, 3), dtype=torch.float32, device=dev)

@@ -64,6 +64,15 @@ def sort_unique(keys, maybe_sorted=False):
     return unique_sorted(sort_keys(keys))
 
 
+def dedup_keys(keys):
+    """A shorter stream with the same key set: repeats within runs of 2048 consecutive keys dropped (mode 3)."""
+    n = keys.numel()
+    raw = torch.empty(n, dtype=torch.int64, device=keys.device)
+    cnt = torch.empty(1, dtype=torch.int64, device=keys.device)
+    call('nksr_footprint_keys_dedup', None, ptr(keys), n, 0.0, 0, 3, ptr(raw), ptr(cnt), stream())
+    return raw[:int(cnt.item())]
+
+
 def dedup_corner_keys(cells):
     """The lattice corner keys of sorted dual cells with the repeats of neighbouring cells dropped (LDS hash set per
     workgroup, nksr_footprint_keys_dedup mode 2): same key SET as nksr_cell_corner_keys, 3-4x shorter stream."""
