@@ -234,7 +234,7 @@ def main():
         cfg = {'workload': 'configs[4]: synthetic %d-point km-scale terrain + boxes (8x8 tiles of 125 m), tree_depth=5, chunk_size=125 m '
                            '(64 chunks), reconstruct(chunk_size=)+extract_dual_mesh(mise_iter=%d), STRONG scaling' % (n_scene, args.mise_iter),
                'scene_points': n_scene, 'fused_mode': fused, 'tree_depth': 5, 'kernel_dim': rec.hparams.kernel_dim, 'global_scale': scale,
-               'chunks': TILES * TILES, 'chunk_streams': rec.chunk_streams if rec.chunk_streams is not None else (2 if fused else 1), 'chunks_this_rank': sum(1 for c in owner if c == rank), 'tiles_loaded_this_rank': ntiles,
+               'chunks': TILES * TILES, 'chunk_streams': rec.chunk_streams if rec.chunk_streams is not None else (3 if fused else 1), 'chunks_this_rank': sum(1 for c in owner if c == rank), 'tiles_loaded_this_rank': ntiles,
                'points_resident_this_rank': int(xyz.shape[0]),
                'unknowns_M_per_chunk': int(np.mean([i['M'] for i in infos])) if infos else 0,
                'nnz_A_per_chunk': int(np.mean([i['nnz'] for i in infos])) if infos else 0,

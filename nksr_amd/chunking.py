@@ -402,7 +402,7 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
 
     jobs = [c for c in range(nchunk) if owner[c] == rank and counts[c] > 0]
     cs = getattr(rec, 'chunk_streams', None)
-    nstreams = max(1, min(int(cs if cs is not None else (2 if fused_mode else 1)), len(jobs)))
+    nstreams = max(1, min(int(cs if cs is not None else (3 if fused_mode else 1)), len(jobs)))
     if nstreams > 1:
         # Chunks are independent: solve them on several HIP streams, one host thread each.  A chunk of a few 100 k points is a chain
         # of ~100 short kernels with host round trips for sizes in between (unique counts, nnz, PCG convergence checks); with

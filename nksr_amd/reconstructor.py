@@ -28,10 +28,12 @@ class Reconstructor:
         self.timing = {}
         self.sync_timing = False   # insert stream syncs so that per-stage wall times are exact
         # chunk mode: chunks can be solved concurrently on this many HIP streams (one host thread each; bit-identical results).
-        # Measured on configs[4] (64 chunks of ~260 k points, one MI355X, matrix-free solve): 1 stream 1.56 s, 2 streams 1.46 s; with
-        # the assembled solve 1.96 / 1.90 / 2.32 (3 streams) / 6.0 s (4) -- the chunks are GPU-bound, more host threads contend
-        # (GIL, allocator pools per stream; two assembled solves at once also fight over their 11 GB workspaces: 3.05 s).
-        # None = 2 for the matrix-free solve, 1 for the assembled one
+        # Measured on configs[4] (64 chunks of ~260 k points, one MI355X, matrix-free solve, end of round 2; pairs taken on the same
+        # box): 1 stream 1.08 s, 2 streams 1.08 / 1.26 / 1.20 s, 3 streams 1.00 / 0.94 / 0.91 s, 4 streams 1.02 s -- the kernels
+        # of one chunk fill the GPU less than half the time (chains of short launches with host round trips in between), a third
+        # stream keeps it busy, a fourth adds host-thread contention (GIL, per-stream allocator pools).  Assembled solve:
+        # 1.96 / 1.90 / 2.32 (3 streams) / 6.0 s (4): two of its solves at once already fight over their 11 GB workspaces.
+        # None = 3 for the matrix-free solve, 1 for the assembled one
         self.chunk_streams = None
         self.coarse_precond = None  # matrix-free solve: None = automatic (coarse-level block preconditioner for 5+ levels), False = Jacobi only,
         #                             or {'first_level', 'steps', 'ratio'} (fields/kernel_field.py _coarse_precond)
