@@ -500,11 +500,26 @@ __global__ void __launch_bounds__(256) k_coarse_power(int n, const int32_t* __re
                                                       const float* __restrict__ v, float* __restrict__ out) {
     const int j = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (j >= n) return;
-    float t = 0.f;
-    for (int k = rowptr[j] + lane, k1 = rowptr[j + 1]; k < k1; k += 64) t = fmaf(vals[k], v[cols[k]], t);
+    const int k0 = rowptr[j], k1 = rowptr[j + 1];
+    const float dg = diag[j];
+    float t4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int base = k0 + lane; base - lane < k1; base += 256) {          // as k_cheb_step: four entry groups in flight, clamped addresses
+        float a[4];
+        int c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = base + 64 * q, kc = k < k1 ? k : k1 - 1;
+            a[q] = vals[kc];
+            c[q] = cols[kc];
+            if (k >= k1) a[q] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t4[q] = fmaf(a[q], v[c[q]], t4[q]);
+    }
+    float t = (t4[0] + t4[1]) + (t4[2] + t4[3]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-    if (lane == 0) out[j] = t / diag[j];
+    if (lane == 0) out[j] = t / dg;
 }
 // out = sqrt(sum b^2 / sum a^2), one workgroup, fixed order
 __global__ void __launch_bounds__(PCG_BLOCK) k_norm_ratio(int n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
