@@ -109,6 +109,21 @@ class Hierarchy:
                 L.parent = np.full(L.n, -1, np.int32)
 
     # -- queries ----------------------------------------------------------------------
+    def evaluate_voxel_status(self, query_ijk, depth):
+        """Class of every voxel of a level-``depth`` query grid w.r.t. this hierarchy (models/loss.py:155: ground truth of the
+        structure cross-entropy): 0 = not a voxel here, 1 = voxel without children one level finer, 2 = voxel with children."""
+        lv = self.levels[depth]
+        status = np.zeros(query_ijk.shape[0], np.int64)
+        if lv is None or lv.n == 0 or query_ijk.shape[0] == 0:
+            return status
+        exist = lv.lookup(query_ijk) >= 0
+        status[exist] = 1
+        if depth > 0 and self.levels[depth - 1] is not None and self.levels[depth - 1].n:
+            parents = set(map(tuple, (self.levels[depth - 1].ijk >> 1)))      # floor(ijk / 2): the level-depth voxel a finer voxel sits in
+            has_child = np.fromiter((tuple(q) in parents for q in query_ijk), bool, query_ijk.shape[0])
+            status[exist & has_child] = 2
+        return status
+
     def get_voxel_centers(self, d):
         return self.levels[d].centers()
 

@@ -62,6 +62,35 @@ def test_hierarchy_exact():
             np.testing.assert_array_equal(svh.get_voxel_centers(d).cpu().numpy(), oh.levels[d].centers())
 
 
+def test_voxel_status_and_visualization_match_the_oracle():
+    """SparseFeatureHierarchy.evaluate_voxel_status (models/loss.py:155: structure ground truth) on a query grid that is larger
+    than the hierarchy's own (the decoder's candidate grid), and get_visualization (models/nksr_net.py:71)."""
+    import nksr_amd
+    from oracle import hierarchy
+    xyz, nrm = make_cloud('torus', 4000, 0.005, 5)
+    xyz = xyz * np.float32(2.0)
+    dev = _dev()
+    tx, tn = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
+    gt = nksr_amd.SparseFeatureHierarchy(0.1, 4, dev).build_adaptive_normal_variation(tx, tn, tau=0.05, adaptive_depth=2)
+    ogt = hierarchy.Hierarchy(0.1, 4).build_adaptive_normal_variation(xyz, nrm, tau=0.05, adaptive_depth=2)
+    cand = nksr_amd.SparseFeatureHierarchy(0.1, 4, dev).build_point_neighborhood(tx)
+    seen = set()
+    for d in range(4):
+        assert np.array_equal(gt.level(d).keys.cpu().numpy(), ogt.levels[d].keys)
+        g = cand.grids[d]
+        got = gt.evaluate_voxel_status(g, d).cpu().numpy()
+        want = ogt.evaluate_voxel_status(g.ijk.cpu().numpy(), d)
+        assert np.array_equal(got, want)
+        seen |= set(np.unique(got).tolist())
+        assert (got > 0).sum() == gt.num_voxels(d)          # the candidate grid covers every ground-truth voxel
+    assert seen == {0, 1, 2}                                 # adaptive structure: stopped voxels exist next to refined ones
+    vis = gt.get_visualization()
+    assert len(vis) == 4
+    for d, (centres, size) in enumerate(vis):
+        assert size == pytest.approx(0.1 * (1 << d))
+        np.testing.assert_array_equal(centres, ogt.levels[d].centers())
+
+
 def test_empty_and_tiny_inputs():
     import nksr_amd
     svh = nksr_amd.SparseFeatureHierarchy(0.1, 3, _dev()).build_point_splatting(torch.zeros((0, 3), device=_dev()))
