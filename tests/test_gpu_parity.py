@@ -91,6 +91,35 @@ def test_voxel_status_and_visualization_match_the_oracle():
         np.testing.assert_array_equal(centres, ogt.levels[d].centers())
 
 
+def test_grid_accessors_of_the_reference_surface():
+    """``grids[d].active_grid_coords()`` / ``grid_to_world`` / ``voxel_size`` (models/loss.py:36,45-46), ``world_to_grid``,
+    ``ijk_to_index``, ``build_from_grid_coords`` and ``build_from_keys`` against the oracle's levels."""
+    import nksr_amd
+    from oracle import hierarchy
+    xyz, _ = make_cloud('sphere', 3000, 0.005, 11)
+    dev = _dev()
+    oh = hierarchy.Hierarchy(0.1, 3).build_point_splatting(xyz)
+    svh = nksr_amd.SparseFeatureHierarchy(0.1, 3, dev).build_point_splatting(torch.from_numpy(xyz).to(dev))
+    rebuilt = nksr_amd.SparseFeatureHierarchy(0.1, 3, dev)
+    for d in range(3):
+        g, lv = svh.grids[d], oh.levels[d]
+        ijk = g.active_grid_coords()
+        assert np.array_equal(ijk.cpu().numpy(), lv.ijk) and g.voxel_size == pytest.approx(lv.voxel_size)
+        world = g.grid_to_world(ijk.float())
+        np.testing.assert_array_equal(world.cpu().numpy(), lv.centers())
+        np.testing.assert_allclose(g.world_to_grid(world).cpu().numpy(), lv.ijk.astype(np.float32), atol=2e-4)
+        # canonical index of coordinates: identity on the active voxels, -1 one lattice step outside the bounding box
+        perm = torch.randperm(g.num_voxels, device=dev)
+        assert torch.equal(g.ijk_to_index(ijk[perm]).long(), perm)
+        outside = ijk.max(0).values[None] + torch.tensor([[1, 0, 0], [0, 2, 0]], dtype=ijk.dtype, device=dev)
+        assert g.ijk_to_index(outside).tolist() == [-1, -1]
+        rebuilt.build_from_grid_coords(d, ijk[perm])          # any order, duplicates allowed
+    for d in range(3):
+        assert torch.equal(rebuilt.level(d).keys, svh.level(d).keys) and torch.equal(rebuilt.level(d).nbr, svh.level(d).nbr)
+    again = nksr_amd.SparseFeatureHierarchy(0.1, 3, dev).build_from_keys([svh.level(d).keys.flip(0) for d in range(3)])
+    assert all(torch.equal(again.level(d).keys, svh.level(d).keys) for d in range(3))
+
+
 def test_empty_and_tiny_inputs():
     import nksr_amd
     svh = nksr_amd.SparseFeatureHierarchy(0.1, 3, _dev()).build_point_splatting(torch.zeros((0, 3), device=_dev()))
