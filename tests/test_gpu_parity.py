@@ -480,6 +480,8 @@ def test_evaluate_f(approx):
     mag = abs(fo).max()
     np.testing.assert_allclose(res.value.cpu().numpy(), fo, rtol=0, atol=1e-4 * mag)
     np.testing.assert_allclose(res.gradient.cpu().numpy(), go, rtol=0, atol=1e-4 * abs(go).max())
+    # occupancy convention of models/loss.py:99: evaluate_f_bar(x) > 0 <=> inside; same numbers as evaluate_f
+    assert torch.equal(fld.evaluate_f_bar(torch.from_numpy(q).to(_dev())), fld.evaluate_f(torch.from_numpy(q).to(_dev())).value)
 
 
 @pytest.mark.parametrize('kind,vs', [('sphere', 0.05), ('torus', 0.04)])
