@@ -382,7 +382,7 @@ class KernelField(BaseField):
         if not (lmax > 0.0 and lmax < float('inf')):        # degenerate block (no constraint rows on these levels): Jacobi only
             return None
         pc = CoarsePrecondT()
-        pc.first, pc.n, pc.steps, pc.lambda_max, pc.ratio = off[c0], n, int(cfg.get('steps', 6)), lmax, float(cfg.get('ratio', 100.0))
+        pc.first, pc.n, pc.steps, pc.lambda_max, pc.ratio = off[c0], n, int(cfg.get('steps', 8)), lmax, float(cfg.get('ratio', 100.0))
         pc.rowptr, pc.cols, pc.vals, pc.diag, pc.work = ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), ptr(work)
         return {'pc': pc, 'first_level': c0, 'unknowns': n, 'nnz': int(cols.numel()), 'steps': int(pc.steps), 'lambda_max': lmax,
                 'keep': (rowptr, cols, vals, diag, work)}
