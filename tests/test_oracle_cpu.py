@@ -49,6 +49,33 @@ def test_hierarchy_parent_property_and_nbr_symmetry():
             assert np.array_equal(L.nbr[j[ok], 26 - s], np.nonzero(ok)[0])
 
 
+def test_voxel_status_classes_of_an_adaptive_hierarchy():
+    """oracle.hierarchy.evaluate_voxel_status (models/loss.py:155): 0 outside, 1 voxel without children, 2 voxel with children --
+    checked through the parent links the hierarchy already holds, on a ground-truth structure that stops early in flat regions."""
+    from oracle import hierarchy
+    xyz, nrm = make_cloud('torus', 4000, 0.005, 5)
+    xyz = xyz * np.float32(2.0)
+    gt = hierarchy.Hierarchy(0.1, 4).build_adaptive_normal_variation(xyz, nrm, tau=0.05, adaptive_depth=2)
+    cand = hierarchy.Hierarchy(0.1, 4).build_point_neighborhood(xyz)
+    classes = set()
+    for d in range(4):
+        q = cand.levels[d].ijk
+        st = gt.evaluate_voxel_status(q, d)
+        inside = gt.levels[d].lookup(q) >= 0
+        assert np.array_equal(st > 0, inside) and inside.sum() == gt.levels[d].n
+        if d == 0:
+            assert not (st == 2).any()                    # the finest level has no children
+        else:
+            kids = np.zeros(gt.levels[d].n, bool)
+            kids[gt.levels[d - 1].parent] = True          # parent index of every finer voxel
+            assert np.array_equal(st[inside] == 2, kids[gt.levels[d].lookup(q[inside])])
+        classes |= set(np.unique(st).tolist())
+    assert classes == {0, 1, 2}
+    # own grid: never class 0; a foreign level far away: all 0
+    assert (gt.evaluate_voxel_status(gt.levels[2].ijk, 2) > 0).all()
+    assert not gt.evaluate_voxel_status(gt.levels[2].ijk + 1000, 2).any()
+
+
 def test_mc_table_matches_product_header_and_is_watertight():
     import re
     from oracle import mc_tables as m
