@@ -72,32 +72,36 @@ def load_traffic_fused(bytes_per_launch):
     return best
 
 
-def roofline_record(ms, launches, alg, phys, fused=False):
-    """The CG operator application ("SpMV") measured live with HIP events on the solve stream.
-    achieved / frac   = ALGORITHMIC bytes of SURVEY.md section 8d / time:  assembled CSR 8 nnz + 12 M + 4;  matrix-free operator
-                        G and Q once in each direction at 8 bytes per stored entry (2 x 8 x non-zero slots) + 12 M + 4.
-    achieved_physical = the bytes the implementation really moves: packed 21-bit columns (6.67 B per entry) for the CSR; for the
-                        matrix-free operator 4 B per dense slot ONCE (no column indices, one pass serves both products) + the
-                        partial blocks + tables.  It moves ~2.3x fewer bytes than the algorithmic figure, so ``frac`` can
-                        exceed what the HBM could stream: read frac_physical for how busy the memory system is."""
+def roofline_record(ms, launches, alg, phys, survey, fused=False):
+    """The CG operator application ("SpMV") measured live with HIP events on the solve stream inside the timed region.
+    achieved / frac   = ALGORITHMIC bytes / time, a fraction of the 8 TB/s HBM peak (always <= 1):
+                        assembled CSR: SURVEY.md section 8d, 8 nnz + 12 M + 4;
+                        matrix-free operator: its algorithmic minimum -- 4 B per STORED entry of G and Q read
+                        once + 4 B per row and level (row -> cell) + 108 B per unknown (one 27-entry stencil per cell) + x, y.
+    achieved_physical = the bytes the implementation's layout really moves (packed 21-bit columns for the CSR; dense 27-slot rows
+                        incl. structural zeros + partial blocks + tables for the operator) / time.
+    survey_formula_*  = the same launches priced by SURVEY.md section 8d's matrix-free formula (2 x 8 B per stored entry + 12 M + 4):
+                        the operator holds no column indices and reads every row once, so this exceeds what it moves -- kept for
+                        comparison with round 2's line, NOT a utilisation figure.
+    traffic           = HBM bytes per application from the committed rocprofv3 --pmc pass of the same system (static: not measured in
+                        this run; ``traffic_source`` names the file)."""
     avg_s = (ms / max(launches, 1)) * 1e-3
     a = alg / max(launches, 1)
     p = phys / max(launches, 1)
+    sv = survey / max(launches, 1)
     rate = lambda b: (b / avg_s if avg_s > 0 else 0.0)
+    traffic, src = ((load_traffic_fused(p) if fused else load_traffic(a)) if launches else (None, None))
+    rec = {'bound': 'hbm',
+           'kernel': ('k_fz_sweep + k_fz_cellsum + k_fz_gather (matrix-free normal-equation operator inside the PCG loop, fused_mode=True)' if fused else
+                      'k_spmv<3,0> + k_spmv_fixup (packed-column CSR SpMV inside the PCG loop, fused_mode=False)'),
+           'achieved': rate(a) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(a) / HBM_PEAK,
+           'achieved_physical': rate(p) / 1e9, 'frac_physical': rate(p) / HBM_PEAK,
+           'traffic': traffic, 'traffic_source': ('static: ' + src) if traffic is not None else None,
+           'bytes_per_launch': a, 'physical_bytes_per_launch': p, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
     if fused:
-        traffic, src = load_traffic_fused(p) if launches else (None, None)
-        return {'bound': 'hbm', 'kernel': 'k_fz_sweep + k_fz_cellsum + k_fz_gather (matrix-free normal-equation operator inside the PCG loop, '
-                                          'fused_mode=True)',
-                'achieved': rate(a) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(a) / HBM_PEAK,
-                'achieved_physical': rate(p) / 1e9, 'frac_physical': rate(p) / HBM_PEAK,
-                'traffic': traffic, 'traffic_source': src if traffic is not None else None,
-                'bytes_per_launch': a, 'physical_bytes_per_launch': p, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
-    traffic, src = load_traffic(a) if launches else (None, None)
-    return {'bound': 'hbm', 'kernel': 'k_spmv<3,0> + k_spmv_fixup (packed-column CSR SpMV inside the PCG loop, fused_mode=False)',
-            'achieved': rate(a) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(a) / HBM_PEAK,
-            'achieved_physical': rate(p) / 1e9, 'frac_physical': rate(p) / HBM_PEAK,
-            'traffic': traffic, 'traffic_source': src if traffic is not None else None,
-            'bytes_per_launch': a, 'physical_bytes_per_launch': p, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
+        rec['survey_formula_bytes_per_launch'] = sv
+        rec['survey_formula_frac'] = rate(sv) / HBM_PEAK
+    return rec
 
 
 # ---- configs[4]: the scaling scene ------------------------------------------------------------------------------------
@@ -145,11 +149,10 @@ def main():
     ap.add_argument('--cpu-cores', type=int, default=0, help='CPU baseline worker processes (0 = all host cores, at most 64)')
     ap.add_argument('--cpu-repeats', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--chunk-streams', type=int, default=0, help='concurrent chunk streams in chunk mode (0 = the Reconstructor default)')
+    ap.add_argument('--chunk-batch-points', type=int, default=0, help='chunk mode: points per batched solve (0 = the Reconstructor default, all chunks of a rank in one batch up to 2^25 points)')
     ap.add_argument('--no-scale-scene', action='store_true')
     ap.add_argument('--no-other-mode', action='store_true')
     ap.add_argument('--non-fused', action='store_true', help='configs[2] headline through the assembled CSR solve (fused_mode=False)')
-    ap.add_argument('--assembled-scene', action='store_true', help='configs[4] through the assembled CSR solve (default: matrix-free, fused_mode=True)')
     ap.add_argument('--scene', choices=['auto', 'cloud', 'terrain'], default='auto',
                     help="'terrain' runs configs[4] as the headline at N=1 too")
     args = ap.parse_args()
@@ -198,12 +201,12 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         ms, launches = solver.profile_spmv(False)
-        alg, phys = solver.profile_spmv_bytes()
+        alg, phys, survey = solver.profile_spmv_bytes()
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, out, (ms, launches, alg, phys)
+        return dt, out, (ms, launches, alg, phys, survey)
 
     def acc_stages(acc, rec, tm):
         if acc is not None:
@@ -214,8 +217,8 @@ def main():
     def run_terrain(steps, warmup, fused):
         rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', tree_depth=5))
         rec.sync_timing = True
-        if args.chunk_streams > 0:
-            rec.chunk_streams = args.chunk_streams
+        if args.chunk_batch_points > 0:
+            rec.chunk_batch_points = args.chunk_batch_points
         xyz, nrm, scale, owner, bounds, n_scene, ntiles = terrain_setup(rec, dev, args.scene_points, rank, world)
         chunk_size = TILE * scale
 
@@ -230,15 +233,16 @@ def main():
 
         acc = {}
         dt, (field, mesh), prof = timed_loop(step, steps, warmup, acc)
-        infos = [f.solve_info for f in field.fields.values() if f.solve_info]
+        infos = field.chunk_infos()
         cfg = {'workload': 'configs[4]: synthetic %d-point km-scale terrain + boxes (8x8 tiles of 125 m), tree_depth=5, chunk_size=125 m '
                            '(64 chunks), reconstruct(chunk_size=)+extract_dual_mesh(mise_iter=%d), STRONG scaling' % (n_scene, args.mise_iter),
                'scene_points': n_scene, 'fused_mode': fused, 'tree_depth': 5, 'kernel_dim': rec.hparams.kernel_dim, 'global_scale': scale,
-               'chunks': TILES * TILES, 'chunk_streams': rec.chunk_streams if rec.chunk_streams is not None else (3 if fused else 1), 'chunks_this_rank': sum(1 for c in owner if c == rank), 'tiles_loaded_this_rank': ntiles,
+               'chunks': TILES * TILES, 'batched_solves_this_rank': len([p for p in field.parts if p.solved]), 'chunks_this_rank': sum(1 for c in owner if c == rank), 'tiles_loaded_this_rank': ntiles,
                'points_resident_this_rank': int(xyz.shape[0]),
                'unknowns_M_per_chunk': int(np.mean([i['M'] for i in infos])) if infos else 0,
-               'nnz_A_per_chunk': int(np.mean([i['nnz'] for i in infos])) if infos else 0,
                'pcg_iters_per_chunk': float(np.mean([i['iters'] for i in infos])) if infos else 0,
+               'pcg_iters_max_chunk': int(max([i['iters'] for i in infos])) if infos else 0,
+               'pcg_iters_min_chunk': int(min([i['iters'] for i in infos])) if infos else 0,
                'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]),
                'parallelism': 'none' if world == 1 else 'chunks sharded over %d ranks (Morton-contiguous), sharded input, no collective in the solve, '
                                                         'one halo exchange, mesh gather + stitch on rank 0' % world}
@@ -276,7 +280,7 @@ def main():
     # Both workloads run through the API default, fused_mode=True (what the reference's examples pass): the matrix-free solve
     # skips the assembly and its operator (one pass over the index-free kernel rows) is about as fast per application as the CSR
     # SpMV; the other mode is measured and reported next to each (DESIGN.md section 3.5 has the cost model).
-    fused = (not args.non_fused) if not terrain_headline else (not args.assembled_scene)
+    fused = (not args.non_fused) if not terrain_headline else True      # chunk mode = the batched matrix-free solve
     if terrain_headline:
         dt, npts, cfg, prof, stages = run_terrain(args.steps, args.warmup, fused)
     else:
@@ -293,19 +297,14 @@ def main():
         out['other_solve_mode'] = {'fused_mode': not fused, 'value': npts * 2 / odt, 'unit': 'points/s', 'ms_per_step': odt / 2 * 1e3, 'steps': 2,
                                    'warmup': 1, 'unknowns_M': ocfg['unknowns_M'], 'nnz_A': ocfg['nnz_A'], 'pcg_iters': ocfg['pcg_iters'],
                                    'roofline': roofline_record(*oprof, fused=not fused), 'stages_s_per_step': ostages}
+        # north_star's KPI, in every line: the CSR SpMV roofline (target 0.70 of 8 TB/s), whichever solve the headline ran
+        out['spmv_csr_roofline'] = out['other_solve_mode']['roofline'] if fused else out['roofline']
     if not terrain_headline and not args.no_scale_scene:
         # the same scene the N > 1 runs solve, on this one GPU (1 warm-up + 2 timed steps): the N=1 point of the curve
         torch.cuda.empty_cache()
-        sf = (not args.assembled_scene)
-        sdt, sn, scfg, sprof, sstages = run_terrain(2, 1, sf)
+        sdt, sn, scfg, sprof, sstages = run_terrain(2, 1, True)
         out['scale_scene'] = {'value': sn * 2 / sdt, 'unit': 'points/s', 'ms_per_step': sdt / 2 * 1e3, 'steps': 2, 'warmup': 1,
-                              'config': scfg, 'roofline': roofline_record(*sprof, fused=sf), 'stages_s_per_step': sstages}
-        if not args.no_other_mode:
-            torch.cuda.empty_cache()
-            odt, _, ocfg, oprof, ostages = run_terrain(1, 1, not sf)
-            out['scale_scene']['other_solve_mode'] = {'fused_mode': not sf, 'value': sn / odt, 'unit': 'points/s', 'ms_per_step': odt * 1e3,
-                                                      'steps': 1, 'warmup': 1, 'pcg_iters_per_chunk': ocfg['pcg_iters_per_chunk'],
-                                                      'roofline': roofline_record(*oprof, fused=not sf), 'stages_s_per_step': ostages}
+                              'config': scfg, 'roofline': roofline_record(*sprof, fused=True), 'stages_s_per_step': sstages}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and extra is not None:
         from oracle import waymo_cpu
         rec, xyz_np, nrm_np, scale = extra

@@ -137,9 +137,10 @@ int nksr_udf_decode(const nksr_level_t* level, int level_index, const float* fea
 int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden, const float* mlp, float* psi_out, void* stream);
 /* Dense-slot kernel rows at arbitrary sites.  val [n, L, 27] (may be NULL when only the gradient rows are
  * wanted); dval [n, 3, L, 27] (may be NULL).  approx!=0 drops the d(phi)/dx term (approx_kernel_grad, recons_waymo.py:33).  Every output is
- * multiplied by row_scale (the assembly takes rows pre-multiplied by sqrt(set weight), see nksr_assemble). */
-int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, int64_t level_stride,
-                     const int32_t* row_index, int32_t* row_cells, float* val, float* dval, void* stream);
+ * multiplied by row_scale (the assembly takes rows pre-multiplied by sqrt(set weight), see nksr_assemble) -- or, when site_scale
+ * (device, [n]) is given, by site_scale[i] instead: the sites of a batched chunk solve carry their own chunk's weight. */
+int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, const float* site_scale,
+                     int64_t level_stride, const int32_t* row_index, int32_t* row_cells, float* val, float* dval, void* stream);
 /* level_stride > 0: LEVEL-MAJOR output, row (site i, component a) of level d at val / dval + ((d * level_stride + r_i + a) * 27) with
  * r_i = row_index ? row_index[i] : i * ncomp (ncomp = 1 for val, 3 for dval; ONE of val / dval when row_index is given) -- the layout
  * of the matrix-free solve (nksr_fused_op_t.rows_all): row_index lets several site sets share one Morton-ordered row list;
@@ -224,9 +225,13 @@ int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, c
 /* Live profiling of the SpMV launches inside nksr_pcg_solve (HIP events on the solve's stream).
  * Returns and resets the accumulated milliseconds / launch count, then sets the enable flag. */
 int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out);
-/* Bytes of the launches timed since the last call (then reset): the algorithmic CSR figure 8 nnz + 12 M + 4 per
- * launch and the bytes the physical layout streams (col_format, padding). */
+/* Bytes of the launches timed since the last call (then reset): the algorithmic figure -- CSR: 8 nnz + 12 M + 4 per launch
+ * (SURVEY.md section 8d); matrix-free operator: its algorithmic minimum, 4 bytes per stored entry + 4 per row and level (row ->
+ * cell) + 116 per unknown (stencil, x, y) -- and the bytes the physical layout streams (col_format, padding, partial blocks). */
 int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_out);
+/* The launches of the last nksr_pcg_profile_bytes call priced by SURVEY.md section 8d's formula (equal to the algorithmic figure for
+ * the CSR SpMV; 2 x 8 bytes per stored entry + 12 M + 4 for the matrix-free operator, more than it moves). */
+double nksr_pcg_profile_survey_bytes(void);
 
 /* ---- coarse-level block preconditioner of the PCG (csrc/pcg.hip) -----------------------------------------------------
  * The unknowns of the levels >= c0 (the LAST n of the M: unknowns are level-major) take `steps` Jacobi-preconditioned
@@ -235,18 +240,35 @@ int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_out);
  * re-based to offset 0), local indices.  lambda_max: largest eigenvalue of D^-1 A_cc (nksr_coarse_lambda_max, x ~1.1);
  * the polynomial targets the interval [lambda_max / ratio, lambda_max]. */
 #define NKSR_PC_MAX_STEPS 16
+/* Independent diagonal blocks of one system ("segments": the chunks of a batched chunk solve -- the reference solves its
+ * chunks one after the other, examples/recons_by_chunk.py:26-29; here all chunks of a rank share every launch).  The unknowns
+ * of segment c are the nranges index ranges [lo[c * nranges + k], hi[c * nranges + k]) (one per hierarchy level, possibly
+ * empty).  The PCG gives every segment its own dot products (fixed, segment-relative reduction order), alpha / beta, stopping
+ * test and iteration count: the iterates of a segment do not depend on which other segments share the launch.
+ * NULL wherever a segments pointer is taken = one segment [0, M). */
+typedef struct {
+    int32_t nseg, nranges;
+    const int32_t* lo;         /* [nseg * nranges] device */
+    const int32_t* hi;         /* [nseg * nranges] device */
+    double* info;              /* device [nseg * 2] or NULL: iterations, relative residual (negated when the segment stopped on
+                                * r.z <= 0) of every segment, refreshed at every convergence check */
+} nksr_segments_t;
 typedef struct {
     int32_t first, n, steps, reserved;
-    float lambda_max, ratio;
+    float lambda_scale, ratio; /* the eigenvalue bound of segment c is lambda_scale * lambda[c] (safety margin, ~1.1)          */
+    const float* lambda;       /* device [nseg]: nksr_coarse_lambda_max; <= 0 / non-finite: that segment keeps plain Jacobi     */
+    const int32_t* row_seg;    /* device [n]: segment of every coarse row; NULL with one segment                                */
     const int32_t* rowptr;     /* [n + 1] */
     const int32_t* cols;       /* [nnz_c] local column indices */
     const float* vals;         /* [nnz_c] */
     const float* diag;         /* [n] diagonal of A_cc */
     float* work;               /* [3 n] floats */
+    float* coef;               /* [nseg * (1 + 2 * NKSR_PC_MAX_STEPS)] floats: the solve writes the Chebyshev coefficients here */
 } nksr_coarse_precond_t;
-/* power iteration (iters steps from the all-ones vector, work: 2 n floats): lambda_out (device) = ||v_k|| / ||v_{k-1}|| */
+/* power iteration (iters steps from the all-ones vector, work: 2 n floats): lambda_out (device, [nseg]) = ||v_k|| / ||v_{k-1}||
+ * over the coarse rows of every segment (`first` = unknown index of coarse row 0; the ranges below it are skipped). */
 int nksr_coarse_lambda_max(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n, int iters,
-                           float* work, float* lambda_out, void* stream);
+                           float* work, float* lambda_out, const nksr_segments_t* segments, int32_t first, void* stream);
 
 /* ---- matrix-free ("fused") operator and solve: reconstruct(..., fused_mode=True), examples/recons_waymo.py:33,
  *      recons_waymo_cpu.py:58, gis_app.py:40; KernelField.solve (csrc/fused.hip).  The system matrix is never built:
@@ -267,6 +289,9 @@ typedef struct {
                                 * stored entries of G and Q (roofline accounting) */
     void* workspace;           /* nksr_fused_workspace_bytes(nblocks)                                                        */
     float* cell_sums;          /* [M, 32] per-cell block sums, ZERO-INITIALISED by the caller                                */
+    const int32_t* item_seg;   /* batched chunks (nksr_segments_t), both or neither: [ceil(rows_total / 32) + 1] segment of every 32-row work
+                                * item (a segment's rows are padded to whole items) and                                      */
+    const int32_t* unknown_seg;/* [M] segment of every unknown: the solve skips the rows / unknowns of segments that have converged */
 } nksr_fused_op_t;
 /* Work items are runs of 32 consecutive rows; a cell whose rows touch k items owns k partial blocks.
  * nksr_fused_block_counts: span_out [2, M] (first / last row of every cell, -1 = none), counts_out [M + 1] (last entry 0) ->
@@ -279,11 +304,14 @@ size_t nksr_fused_workspace_bytes(int64_t nblocks);
 int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* b_out, float* diag_out, void* stream);
 /* y = (sum_s R_s^T R_s + reg I) x */
 int nksr_fused_apply(const nksr_fused_op_t* op, float reg, const float* x, float* y, void* stream);
-/* Jacobi-PCG with that operator; pcg_workspace: nksr_pcg_vector_workspace_bytes(M).  Syncs like nksr_pcg_solve. */
+/* Jacobi-PCG with that operator; pcg_workspace: nksr_pcg_vector_workspace_bytes(M), or ..._seg(M, nseg, nranges) with segments.
+ * Syncs like nksr_pcg_solve.  info_out: [0] = iterations (max over the segments), [1] = relative residual (max; negated if a
+ * segment stopped on r.z <= 0). */
 size_t nksr_pcg_vector_workspace_bytes(int32_t M);
+size_t nksr_pcg_vector_workspace_bytes_seg(int32_t M, int32_t nseg, int32_t nranges);
 int nksr_pcg_solve_fused(const nksr_fused_op_t* op, float reg, const float* diag, const float* b, float* x, float tol, int max_iter,
                          int check_every, void* pcg_workspace, const nksr_coarse_precond_t* coarse_precond /* or NULL: Jacobi */,
-                         double* info_out, void* stream);
+                         const nksr_segments_t* segments /* or NULL */, double* info_out, void* stream);
 
 /* ---- grid-hash nearest neighbours (csrc/knn.hip) ----------------------------------------------------
  * Points Morton-sorted by a uniform grid of size `cell` (keys from nksr_point_keys with inv_w0 =

@@ -26,12 +26,19 @@ class HierT(C.Structure):
 class FusedOpT(C.Structure):
     _fields_ = [('depth', _i32), ('M', _i32), ('n_multi', _i32), ('n_big', _i32), ('rows_total', _i64), ('rows_all', _vp),
                 ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('offsets', _vp), ('multi', _vp), ('nblocks', _i64),
-                ('nnz_counter', _vp), ('workspace', _vp), ('cell_sums', _vp)]
+                ('nnz_counter', _vp), ('workspace', _vp), ('cell_sums', _vp), ('item_seg', _vp), ('unknown_seg', _vp)]
+
+
+class SegmentsT(C.Structure):
+    _fields_ = [('nseg', _i32), ('nranges', _i32), ('lo', _vp), ('hi', _vp), ('info', _vp)]
 
 
 class CoarsePrecondT(C.Structure):
-    _fields_ = [('first', _i32), ('n', _i32), ('steps', _i32), ('reserved', _i32), ('lambda_max', _f32), ('ratio', _f32),
-                ('rowptr', _vp), ('cols', _vp), ('vals', _vp), ('diag', _vp), ('work', _vp)]
+    _fields_ = [('first', _i32), ('n', _i32), ('steps', _i32), ('reserved', _i32), ('lambda_scale', _f32), ('ratio', _f32),
+                ('lambda_', _vp), ('row_seg', _vp), ('rowptr', _vp), ('cols', _vp), ('vals', _vp), ('diag', _vp), ('work', _vp), ('coef', _vp)]
+
+
+PC_MAX_STEPS = 16
 
 
 class SiteSetT(C.Structure):
@@ -69,6 +76,10 @@ lib.nksr_fused_workspace_bytes.restype = _sz
 lib.nksr_fused_workspace_bytes.argtypes = [_i64]
 lib.nksr_pcg_vector_workspace_bytes.restype = _sz
 lib.nksr_pcg_vector_workspace_bytes.argtypes = [_i32]
+lib.nksr_pcg_profile_survey_bytes.restype = C.c_double
+lib.nksr_pcg_profile_survey_bytes.argtypes = []
+lib.nksr_pcg_vector_workspace_bytes_seg.restype = _sz
+lib.nksr_pcg_vector_workspace_bytes_seg.argtypes = [_i32, _i32, _i32]
 
 _P = C.POINTER
 _PROTOS = {
@@ -99,7 +110,7 @@ _PROTOS = {
     'nksr_splat_plane': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp],
     'nksr_udf_decode': [_P(LevelT), C.c_int, _vp, _vp, _i64, _f32, _f32, C.c_int, _vp, _vp],
     'nksr_voxel_psi': [_vp, _i32, C.c_int, C.c_int, _vp, _vp, _vp],
-    'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _f32, _i64, _vp, _vp, _vp, _vp, _vp],
+    'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, _vp, _vp, _vp],
     'nksr_assemble_count': [_P(HierT), _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
@@ -113,8 +124,8 @@ _PROTOS = {
     'nksr_fused_tables': [_P(HierT), _vp, _vp, _vp, _vp],
     'nksr_fused_rhs_diag': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
-    'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(C.c_double), _vp],
-    'nksr_coarse_lambda_max': [_vp, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _vp],
+    'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(SegmentsT), _P(C.c_double), _vp],
+    'nksr_coarse_lambda_max': [_vp, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _P(SegmentsT), _i32, _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
     'nksr_pcg_profile_bytes': [_P(C.c_double), _P(C.c_double)],
     'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
@@ -142,7 +153,7 @@ for _name, _args in _PROTOS.items():
 
 EXPORTED = ['nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
             'nksr_assemble_split_bytes',
-            'nksr_fused_workspace_bytes', 'nksr_pcg_vector_workspace_bytes', 'nksr_bbox_work_floats'] + sorted(_PROTOS)
+            'nksr_fused_workspace_bytes', 'nksr_pcg_vector_workspace_bytes', 'nksr_pcg_vector_workspace_bytes_seg', 'nksr_pcg_profile_survey_bytes', 'nksr_bbox_work_floats'] + sorted(_PROTOS)
 
 
 def check(rc):

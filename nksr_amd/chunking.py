@@ -1,4 +1,4 @@
-"""Spatial chunking (``chunk_size=``) and its multi-GPU sharding.
+"""Spatial chunking (``chunk_size=``), batched over all chunks of a rank, and its multi-GPU sharding.
 
 Reference behaviour (call sites; the implementation is in the absent wheel): ``reconstruct(xyz,
 normal, detail_level=None, chunk_size=50.0)`` examples/recons_by_chunk.py:29; solved chunks are
@@ -10,9 +10,18 @@ chunk_size is provided" NKSR-USAGE.md:137.  Spec (DESIGN.md s
     w_c(x) = prod_axis ramp((x - (lo-ov)) / 2ov) * ramp(((hi+ov) - x) / 2ov)  (linear ramps of
     neighbouring chunks add up to 1 inside the 2*ov band; a chunk's weight vanishes ov inside
     its data boundary, so it never contributes where its hierarchy is truncated)
-  * all chunks share ONE global voxel lattice (cells are floor(x / w) in global coordinates), so
-    the union of the chunks' finest levels is a consistent dual grid; every dual cell is meshed by
-    the rank that owns the chunk whose core contains the cell's base voxel centre.
+  * every dual cell is meshed by the rank that owns the chunk whose core contains the cell's base voxel centre.
+
+The reference runs its chunks one after the other (examples/recons_by_chunk.py:26-29).  Here ALL chunks of a rank are
+ONE launch sequence: chunk c is moved into its own aligned cube ("slot") of an EXPLODED FRAME -- x' = x + T_c, T_c a
+whole number of coarsest voxels, slots far enough apart that no kernel support reaches from one into another -- and the
+union of the translated clouds is reconstructed like a single cloud.  Its system is block diagonal by construction (one
+block per chunk); the PCG keeps per-chunk scalars and stopping tests (nksr_segments_t), every summation order of the
+operator is chunk-relative, so a chunk's solution does not depend on its batch mates, and the slot of a chunk depends on
+its grid position only: the same chunk gives the same bits on 1, 2 or 8 ranks.  A slot is an aligned cube of the Morton
+lattice, hence one contiguous key range per level: the chunks are the segments of the batch.  The blend evaluates the
+batch field at x + T_c for every chunk c that weighs at x.
+
 Multi-GPU (one process per GPU): chunks are sharded over ranks (nksr_amd.dist) along a Morton curve; every rank is
 given either the same full cloud or -- ``sharded_input=True`` -- only the points of its own chunks (+ band).  No
 collective on the solve path, one all_gather of the chunk HALOS before meshing, one point-to-point gather of the
@@ -20,12 +29,16 @@ mesh pieces to rank 0 after it.
 """
 import math
 
+import numpy as np
 import torch
 
 from . import dist as D
+from . import ops
+from ._lib import call, ptr, stream
 from .fields.base_field import BaseField, EvaluationResult
-from .fields.kernel_field import KernelField
+from .fields.kernel_field import KernelField, Segments
 from .fields.mask_fields import LayerField, NeuralField
+from .normals import TooFewPoints as ChunkTooSmall      # a normal-estimating preprocess_fn on a chunk with fewer points than k: chunk skipped
 from .svh import SparseFeatureHierarchy
 
 
@@ -34,6 +47,76 @@ def chunk_grid(lo, hi, chunk_size):
     return n
 
 
+OV_FLOOR = 1.0        # blend half-width floor, in coarsest voxels
+BAND_EXTRA = 1.5      # data margin beyond core +- ov, in coarsest voxels (= the support radius of the coarsest kernel); None = ov
+MIN_CHUNK_POINTS = 8
+SLOT_GAP = 6          # empty coarsest voxels between the data of two slots (kernel support 1.5 + structure dilation 1, both sides, + slack)
+
+
+def chunk_geometry(hp, chunk_size, overlap_ratio):
+    wc = hp.voxel_size * 2 ** (hp.tree_depth - 1)
+    ov = max(overlap_ratio * chunk_size, OV_FLOOR * wc)
+    band = 2 * ov if BAND_EXTRA is None else ov + BAND_EXTRA * wc
+    return ov, band
+
+
+class ChunkFrame:
+    """Geometry of the exploded frame.  Chunk (cx, cy, cz) of the grid owns the cube [s * 2^S, (s + 1) * 2^S)^3 of the finest
+    lattice, s = (cx, cy, cz) - grid // 2 (centred: small coordinates keep fp32 resolution); its data is translated by
+    T_c = slot origin + low - a_c, a_c = the chunk's data corner rounded down to a multiple of 2^depth finest voxels, low = 4
+    coarsest voxels -- a whole number of voxels at EVERY level, so the chunk's own lattice is kept.
+    2^S >= low + data extent + alignment slack + SLOT_GAP / 2 coarsest voxels."""
+
+    def __init__(self, voxel_size, depth, lo, grid, chunk_size, band):
+        self.w0, self.depth = float(voxel_size), int(depth)
+        self.lo, self.grid, self.chunk_size, self.band = [float(v) for v in lo], [int(g) for g in grid], float(chunk_size), float(band)
+        self.align = 1 << self.depth
+        # a chunk's voxels reach up to one coarsest voxel beyond its points (structure dilation) and its kernels 1.5 more: the data
+        # sits `low` finest voxels (4 coarsest, a multiple of the alignment) inside its slot and ends >= SLOT_GAP / 2 coarsest
+        # voxels before the slot's end, so that ALL voxels of a chunk lie inside its slot (= its Morton key range)
+        self.low = 2 * self.align
+        ext = int(math.ceil((self.chunk_size + 2 * self.band) / self.w0)) + 2
+        need = self.low + ext + self.align + ((SLOT_GAP // 2) << (self.depth - 1))
+        S = self.depth
+        while (1 << S) < need:
+            S += 1
+        self.S = S
+        self.half = [g // 2 for g in self.grid]
+        reach = max(max(self.grid[a] - self.half[a], self.half[a]) for a in range(3)) << S
+        if reach >= (1 << 20) - (1 << S):
+            raise RuntimeError('chunk grid %s with %d-voxel slots does not fit the 2^20 lattice: use a larger chunk_size' % (self.grid, 1 << S))
+        # data must stay inside [usable_lo, usable_hi) of its slot (model units)
+        self.usable_lo = (self.low - 1) * self.w0
+        self.usable_hi = ((1 << S) - ((SLOT_GAP // 2) << (self.depth - 1))) * self.w0
+
+    def chunk3(self, c):
+        g = self.grid
+        return (c // (g[1] * g[2]), (c // g[2]) % g[1], c % g[2])
+
+    def slot_origin(self, c):
+        c3 = self.chunk3(c)
+        return [(c3[a] - self.half[a]) << self.S for a in range(3)]
+
+    def shift_cells(self, c):
+        c3 = self.chunk3(c)
+        out = []
+        for a in range(3):
+            data_lo = self.lo[a] + c3[a] * self.chunk_size - self.band if self.grid[a] > 1 else self.lo[a]
+            corner = int(math.floor(math.floor(data_lo / self.w0) / self.align)) * self.align
+            out.append(((c3[a] - self.half[a]) << self.S) + self.low - corner)
+        return out
+
+    def shift(self, c):
+        """T_c in model units, fp32 (the product of the integer voxel count and the voxel size, rounded once)."""
+        return np.asarray([np.float32(t * self.w0) for t in self.shift_cells(c)], np.float32)
+
+    def key_range(self, c):
+        o = self.slot_origin(c)
+        k = D._morton3(o[0] + (1 << 20), o[1] + (1 << 20), o[2] + (1 << 20))
+        return k, k + (1 << (3 * self.S))
+
+
+# ---- per-chunk payloads (rank exchange, save_field) ---------------------------------------------------------------------
 def _udf_levels(f):
     m = f.mask_field
     if not isinstance(m, NeuralField):
@@ -60,64 +143,178 @@ def exchange_band(core, cidx3, grid, ov, w0):
     return out
 
 
-def pack_field(f, band=None):
-    """KernelField (+ its UDF mask features, when the mask is a NeuralField) -> (int64 tensor, float32 tensor).
-    ``band`` (exchange_band): keep only the voxels that can contribute to an evaluation inside the band -- at
-    level d those whose centre lies within 2.5 w_d of it (B-spline support 1.5 w_d, trilinear feature
-    stencil 1 w_d).  This is the "halo" payload of the rank exchange: evaluations
-    inside the band are bit-identical to those of the full field."""
-    svh = f.svh
-    nu = _udf_levels(f)
-    keep = [None] * svh.depth
-    if band is not None:
-        for d in range(svh.depth):
-            g = svh.level(d)
-            w = g.voxel_size
-            m = torch.zeros(g.num_voxels, dtype=torch.bool, device=svh.device)
-            for a, lo, hi in band:
-                ca = (g.ijk[:, a].to(torch.float32) + 0.5) * w
-                m |= (ca >= lo - 2.5 * w) & (ca <= hi + 2.5 * w)
-            keep[d] = m
-    sel = lambda t, d: t if keep[d] is None else t[keep[d]]
+def _pack(svh, kdim, approx, feat, alpha, udf_feats, level_set, ranges, band, shift):
+    """Payload of the voxels ``ranges[d] = (lo, hi)`` of a hierarchy (one chunk of a batch, or a whole field)."""
+    depth = svh.depth
+    nu = len(udf_feats)
     off = svh.offsets
-    ns = [int(svh.num_voxels(d) if keep[d] is None else keep[d].sum()) for d in range(svh.depth)]
-    head = [svh.depth, f.kdim, int(f.approx_kernel_grad), nu] + ns
-    ints = torch.cat([torch.tensor(head, dtype=torch.int64, device=svh.device)] + [sel(svh.level(d).keys, d) for d in range(svh.depth)])
-    parts = [sel(f._feat[d], d).reshape(-1) for d in range(svh.depth)]
-    parts += [sel(f.alpha[off[d]:off[d] + svh.num_voxels(d)], d) for d in range(svh.depth)]
+    sels, ns = [], []
+    for d in range(depth):
+        g = svh.level(d)
+        lo, hi = ranges[d]
+        if band is None:
+            sels.append(slice(lo, hi))
+            ns.append(hi - lo)
+            continue
+        w = g.voxel_size
+        m = torch.zeros(hi - lo, dtype=torch.bool, device=svh.device)
+        for a, blo, bhi in band:
+            ca = (g.ijk[lo:hi, a].to(torch.float32) + 0.5) * w - float(shift[a])
+            m |= (ca >= blo - 2.5 * w) & (ca <= bhi + 2.5 * w)
+        idx = torch.nonzero(m).reshape(-1) + lo
+        sels.append(idx)
+        ns.append(int(idx.numel()))
+    head = [depth, kdim, int(approx), nu] + ns
+    ints = torch.cat([torch.tensor(head, dtype=torch.int64, device=svh.device)] + [svh.level(d).keys[sels[d]] for d in range(depth)])
+    parts = [feat[d][sels[d]].reshape(-1) for d in range(depth)]
+    for d in range(depth):
+        s = sels[d]
+        parts.append(alpha[off[d] + s.start:off[d] + s.stop] if isinstance(s, slice) else alpha[s + off[d]])
     if nu:
-        parts += [sel(f.mask_field.features[d], d).reshape(-1) for d in range(nu)]
-        parts.append(torch.tensor([f.mask_field.level_set], dtype=torch.float32, device=svh.device))
+        parts += [udf_feats[d][sels[d]].reshape(-1) for d in range(nu)]
+        parts.append(torch.tensor([level_set], dtype=torch.float32, device=svh.device))
     return ints, torch.cat(parts)
 
 
-def unpack_field(ints, flts, voxel_size, interpolators, device):
-    ints, flts = ints.to(device), flts.to(device)
+def pack_field(f, band=None, shift=None):
+    """KernelField (+ its UDF mask features, when the mask is a NeuralField) -> (int64 tensor, float32 tensor).
+    ``band`` (exchange_band, GLOBAL coordinates; ``shift`` = the translation of the field's frame, default the field's
+    ``chunk_shift`` or 0): keep only the voxels that can contribute to an evaluation inside the band -- at level d those whose
+    centre lies within 2.5 w_d of it (B-spline support 1.5 w_d, trilinear feature stencil 1 w_d).  This is the "halo" payload of
+    the rank exchange: evaluations inside the band are bit-identical to those of the full field."""
+    svh = f.svh
+    nu = _udf_levels(f)
+    if shift is None:
+        shift = getattr(f, 'chunk_shift', (0.0, 0.0, 0.0))
+    return _pack(svh, f.kdim, f.approx_kernel_grad, f._feat, f.alpha, [f.mask_field.features[d] for d in range(nu)],
+                 f.mask_field.level_set if nu else 0.0, [(0, svh.num_voxels(d)) for d in range(svh.depth)], band, shift)
+
+
+def _parse_payload(ints, flts):
     depth, kdim, approx, nu = int(ints[0]), int(ints[1]), bool(int(ints[2])), int(ints[3])
     ns = [int(v) for v in ints[4:4 + depth]]
     off = 4 + depth
     keys = []
     for n in ns:
-        keys.append(ints[off:off + n].contiguous())
+        keys.append(ints[off:off + n])
         off += n
-    svh = SparseFeatureHierarchy(voxel_size, depth, device).build_from_keys(keys, sorted_unique=True)
     feats, fo = [], 0
     for n in ns:
-        feats.append(flts[fo:fo + n * kdim].view(n, kdim).contiguous())
+        feats.append(flts[fo:fo + n * kdim].view(n, kdim))
         fo += n * kdim
+    alphas = []
+    for n in ns:
+        alphas.append(flts[fo:fo + n])
+        fo += n
+    uf, level_set = [], 0.0
+    if nu:
+        for d in range(nu):
+            uf.append(flts[fo:fo + ns[d] * 8].view(ns[d], 8))
+            fo += ns[d] * 8
+        level_set = float(flts[fo])
+    return dict(depth=depth, kdim=kdim, approx=approx, nu=nu, ns=ns, keys=keys, feats=feats, alphas=alphas, udf=uf, level_set=level_set)
+
+
+def fields_from_payloads(payloads, voxel_size, interpolators, device):
+    """ONE KernelField from the payloads of several chunks -- [(key_lo of the chunk's slot, ints, flts), ...]; the slots are
+    disjoint key ranges, so concatenating the chunks in slot order gives every level in canonical (ascending key) order."""
+    ps = [_parse_payload(i.to(device), f.to(device)) for _, i, f in sorted(payloads, key=lambda p: p[0])]
+    depth, kdim, approx, nu = ps[0]['depth'], ps[0]['kdim'], ps[0]['approx'], max(p['nu'] for p in ps)
+    keys = [torch.cat([p['keys'][d] for p in ps]).contiguous() for d in range(depth)]
+    svh = SparseFeatureHierarchy(voxel_size, depth, device).build_from_keys(keys, sorted_unique=True)
+    feats = [torch.cat([p['feats'][d] for p in ps]).contiguous() for d in range(depth)]
     fld = KernelField(svh, interpolators, feats, approx_kernel_grad=approx)
-    fld.alpha = flts[fo:fo + sum(ns)].contiguous()
-    fo += sum(ns)
+    fld.alpha = torch.cat([p['alphas'][d] for d in range(depth) for p in ps]).contiguous()
     if nu:
         from .nn.network import UDFDecoder
         uf = [None] * depth
         for d in range(nu):
-            uf[d] = flts[fo:fo + ns[d] * 8].view(ns[d], 8).contiguous()
-            fo += ns[d] * 8
+            uf[d] = torch.cat([p['udf'][d] if d < p['nu'] else torch.zeros((p['ns'][d], 8), device=device) for p in ps]).contiguous()
         mask = NeuralField(svh, UDFDecoder(), uf)
-        mask.set_level_set(float(flts[fo]))
+        mask.set_level_set(next(p['level_set'] for p in ps if p['nu']))
         fld.set_mask_field(mask)
     return fld
+
+
+def unpack_field(ints, flts, voxel_size, interpolators, device):
+    return fields_from_payloads([(0, ints, flts)], voxel_size, interpolators, device)
+
+
+class ChunkPart:
+    """A KernelField in the exploded frame holding the chunks ``ids`` (ascending slot key), whole or as halos."""
+
+    def __init__(self, field, ids, frame, solved=True):
+        self.field, self.ids, self.frame, self.solved = field, list(ids), frame, solved
+        self._ranges = None
+
+    def ranges(self):
+        """{chunk: [(lo, hi) per level]} voxel index ranges (one host read)."""
+        if self._ranges is None:
+            svh = self.field.svh
+            kr = [self.frame.key_range(c) for c in self.ids]
+            klo = torch.tensor([k[0] for k in kr], dtype=torch.int64, device=svh.device)
+            khi = torch.tensor([k[1] for k in kr], dtype=torch.int64, device=svh.device)
+            lo = torch.stack([torch.searchsorted(svh.level(d).keys, klo >> (3 * d)) for d in range(svh.depth)], 1).tolist()
+            hi = torch.stack([torch.searchsorted(svh.level(d).keys, khi >> (3 * d)) for d in range(svh.depth)], 1).tolist()
+            self._ranges = {c: [(lo[i][d], hi[i][d]) for d in range(svh.depth)] for i, c in enumerate(self.ids)}
+        return self._ranges
+
+    def pack_chunk(self, c, band=None):
+        f = self.field
+        nu = _udf_levels(f)
+        return _pack(f.svh, f.kdim, f.approx_kernel_grad, f._feat, f.alpha, [f.mask_field.features[d] for d in range(nu)],
+                     f.mask_field.level_set if nu else 0.0, self.ranges()[c], band, self.frame.shift(c))
+
+    def chunk_view(self, c, interpolators):
+        """Chunk c as a KernelField of its own (exploded frame): tests, save_field, simulated ranks."""
+        ints, flts = self.pack_chunk(c)
+        g = unpack_field(ints, flts, self.field.svh.voxel_size, interpolators, self.field.device)
+        g.chunk_shift = tuple(float(v) for v in self.frame.shift(c))
+        if g.mask_field is None:
+            g.set_mask_field(LayerField(g.svh, getattr(self.field.mask_field, 'adaptive_depth', 1)))
+        g.meshing_depth = getattr(self.field, 'meshing_depth', 1)
+        info = self.field.solve_info
+        g.solve_info = {}
+        if self.solved and info:
+            si = info.get('segment_info')
+            i = self.ids.index(c)
+            g.solve_info = {'M': int(g.svh.num_unknowns), 'nnz': 0, 'fused': True,
+                            'iters': int(si[i, 0]) if si is not None else info.get('iters'),
+                            'rel_residual': float(si[i, 1]) if si is not None else info.get('rel_residual')}
+        return g
+
+
+class _ChunkViews:
+    """``multi.fields``: per-chunk KernelFields, built on demand from the batch (the batch is what evaluates)."""
+
+    def __init__(self, multi):
+        self._m, self._cache = multi, {}
+
+    def _ids(self):
+        return sorted(self._m.part_of)
+
+    def __iter__(self):
+        return iter(self._ids())
+
+    def __len__(self):
+        return len(self._m.part_of)
+
+    def __contains__(self, c):
+        return c in self._m.part_of
+
+    def keys(self):
+        return self._ids()
+
+    def __getitem__(self, c):
+        if c not in self._cache:
+            self._cache[c] = self._m.parts[self._m.part_of[c]].chunk_view(c, self._m.interpolators)
+        return self._cache[c]
+
+    def values(self):
+        return [self[c] for c in self._ids()]
+
+    def items(self):
+        return [(c, self[c]) for c in self._ids()]
 
 
 class ChunkUnionMask(BaseField):
@@ -129,14 +326,16 @@ class ChunkUnionMask(BaseField):
         self.multi = multi
 
     def evaluate_mask(self, xyz_model):
+        m = self.multi
         keep = torch.zeros(xyz_model.shape[0], dtype=torch.bool, device=xyz_model.device)
-        for c in sorted(self.multi.fields):
-            f = self.multi.fields[c]
-            if f.mask_field is None:
-                continue
-            sel = torch.nonzero(self.multi._weight(c, xyz_model) > 0).reshape(-1)
-            if sel.numel():
-                keep[sel] |= f.mask_field.evaluate_mask(xyz_model[sel].contiguous())
+        for q, cid, w, xq in m._pairs(xyz_model):
+            for pi, part in enumerate(m.parts):
+                if part.field.mask_field is None or not isinstance(part.field.mask_field, NeuralField):
+                    continue
+                s = torch.nonzero(m._part_lut[cid] == pi).reshape(-1) if len(m.parts) > 1 else None
+                qq, xx = (q, xq) if s is None else (q[s], xq[s].contiguous())
+                if qq.numel():
+                    keep[qq] |= part.field.mask_field.evaluate_mask(xx)
         return keep
 
     def to_(self, device):
@@ -149,72 +348,155 @@ class MultiChunkField(BaseField):
     (chunking.exchange_band): ``evaluate_f`` is then exact inside the rank's own cores (+ the one-voxel ring it
     meshes) and must not be used elsewhere -- ``extract_dual_mesh`` respects that and gathers the pieces."""
 
-    def __init__(self, fields, cores, ov, origin, chunk_size, grid, owner, rank, world_size, voxel_size, device):
-        self.fields = fields              # {chunk id: KernelField}
+    def __init__(self, parts, cores, ov, origin, chunk_size, grid, owner, rank, world_size, frame, interpolators, device, distributed=False,
+                 adaptive_depth=1):
+        self.parts = [p for p in parts if p.ids]
         self.cores = cores                # {chunk id: (lo[3], hi[3])} model units
         self.ov = float(ov)
         self.origin, self.chunk_size, self.grid = origin, float(chunk_size), grid
         self.owner, self.rank, self.world_size = owner, rank, world_size
-        keys = [f.svh.level(0).keys for f in fields.values() if f.svh.num_voxels(0) > 0]
-        union = SparseFeatureHierarchy(voxel_size, 1, device)
-        union.build_from_keys([torch.cat(keys) if keys else None])
+        self.frame, self.interpolators, self.distributed = frame, interpolators, bool(distributed)
+        self.part_of = {c: i for i, p in enumerate(self.parts) for c in p.ids}
+        nchunk = grid[0] * grid[1] * grid[2]
+        lut = torch.full((nchunk,), -1, dtype=torch.long)
+        shifts = np.zeros((nchunk, 3), np.float32)
+        cells = np.zeros((nchunk, 3), np.int32)
+        for c, i in self.part_of.items():
+            lut[c] = i
+            shifts[c] = frame.shift(c)
+            cells[c] = frame.shift_cells(c)
+        self._part_lut = lut.to(device)
+        self._shift = torch.from_numpy(shifts).to(device)
+        # union of the chunks' voxels on the GLOBAL lattice (integer translation back; T_c is a whole number of voxels at every
+        # level): the dual grid that is meshed -- the finest level and, below adaptive_depth, the coarser ones (LayerField(dec_svh,
+        # adaptive_depth), models/nksr_net.py:132; 2 in the carla preset, configs/carla/train.yaml:6)
+        nlev = max(1, min(int(adaptive_depth), frame.depth))
+        keys = [[] for _ in range(nlev)]
+        for p in self.parts:
+            kr = torch.tensor([frame.key_range(c)[0] for c in p.ids], dtype=torch.int64, device=device)
+            sc_all = torch.from_numpy(cells[p.ids]).to(device)
+            for d in range(min(nlev, p.field.svh.depth)):
+                g = p.field.svh.level(d)
+                if g.num_voxels == 0:
+                    continue
+                seg = torch.bucketize(g.keys, kr >> (3 * d), right=True) - 1
+                ijk = (g.ijk - (sc_all[seg] >> d)).contiguous()
+                k = torch.empty(ijk.shape[0], dtype=torch.int64, device=device)
+                call('nksr_encode_keys', ptr(ijk), ijk.shape[0], d, ptr(k), stream())
+                keys[d].append(k)
+        union = SparseFeatureHierarchy(frame.w0, nlev, device)
+        union.build_from_keys([torch.cat(k) if k else None for k in keys])
         super().__init__(union)
-        self.mask_field = LayerField(union, 1)
-        if any(isinstance(f.mask_field, NeuralField) for f in fields.values()):
+        self.meshing_depth = nlev
+        self.mask_field = LayerField(union, nlev)
+        if any(isinstance(p.field.mask_field, NeuralField) for p in self.parts):
             self.mask_field = ChunkUnionMask(self)
         self.solve_info = {}
+        self.fields = _ChunkViews(self)
+
+    def chunk_infos(self):
+        """[{'chunk', 'M', 'iters', 'rel_residual'}] of the chunks solved here (one host read per part)."""
+        out = []
+        for p in self.parts:
+            info = p.field.solve_info
+            if not p.solved or not info:
+                continue
+            si = info.get('segment_info')
+            si = si.tolist() if si is not None else [[info['iters'], info['rel_residual']]]
+            rg = p.ranges()
+            for i, c in enumerate(p.ids):
+                out.append({'chunk': c, 'M': sum(h - l for l, h in rg[c]), 'iters': int(si[i][0]), 'rel_residual': float(si[i][1])})
+        return out
 
     # ---- blend weights ------------------------------------------------------------------------
     def _weight(self, c, xyz):
         lo, hi = self.cores[c]
         w = torch.ones(xyz.shape[0], dtype=torch.float32, device=xyz.device)
+        inv = float(np.float32(1.0) / np.float32(2 * self.ov))
         for a in range(3):
             x = xyz[:, a]
             if self.grid[a] > 1:          # no ramp along an axis that is not split
-                w = w * ((x - (lo[a] - self.ov)) / (2 * self.ov)).clamp(0, 1) * (((hi[a] + self.ov) - x) / (2 * self.ov)).clamp(0, 1)
+                w = (w * ((x - float(np.float32(lo[a] - self.ov))) * inv).clamp(0, 1)) * ((float(np.float32(hi[a] + self.ov)) - x) * inv).clamp(0, 1)
         return w
+
+    def _pairs(self, xyz):
+        """(query index, chunk, weight, translated position) of every (query, chunk) with a positive blend weight, as a list of
+        groups in ASCENDING chunk order per query (a query appears at most once per group): adding the groups in order is the
+        fixed summation order of the blend.  A chunk's weight is supported on core +- ov, so only the chunks around a query's
+        home chunk are candidates."""
+        n = xyz.shape[0]
+        dev = xyz.device
+        if n == 0:
+            return []
+        g = self.grid
+        inv = float(np.float32(1.0) / np.float32(2 * self.ov))
+        reach = max(1, int(math.ceil(self.ov / self.chunk_size)))
+        home, wax = [], []
+        for a in range(3):
+            x = xyz[:, a]
+            if g[a] > 1:
+                i = torch.floor((x - self.origin[a]) / self.chunk_size).long().clamp_(0, g[a] - 1)
+                lo_t = torch.tensor([np.float32(self.origin[a] + j * self.chunk_size - self.ov) for j in range(g[a])], dtype=torch.float32, device=dev)
+                hi_t = torch.tensor([np.float32(self.origin[a] + j * self.chunk_size + self.chunk_size + self.ov) for j in range(g[a])], dtype=torch.float32, device=dev)
+                ws = {}
+                for o in range(-reach, reach + 1):
+                    j = i + o
+                    ok = (j >= 0) & (j < g[a])
+                    jc = j.clamp(0, g[a] - 1)
+                    up = torch.where(ok, ((x - lo_t[jc]) * inv).clamp(0, 1), torch.zeros_like(x))
+                    ws[o] = (up, ((hi_t[jc] - x) * inv).clamp(0, 1))
+                home.append(i)
+                wax.append(ws)
+            else:
+                home.append(torch.zeros(n, dtype=torch.long, device=dev))
+                wax.append({0: None})
+        out = []
+        for ox in sorted(wax[0]):
+            for oy in sorted(wax[1]):
+                for oz in sorted(wax[2]):
+                    w = torch.ones(n, dtype=torch.float32, device=dev)
+                    for a, o in ((0, ox), (1, oy), (2, oz)):
+                        if wax[a][o] is not None:
+                            w = (w * wax[a][o][0]) * wax[a][o][1]          # the order of _weight(): ((w up_x) dn_x) up_y ...
+                    cid = ((home[0] + ox).clamp(0, g[0] - 1) * g[1] + (home[1] + oy).clamp(0, g[1] - 1)) * g[2] + (home[2] + oz).clamp(0, g[2] - 1)
+                    sel = torch.nonzero((w > 0) & (self._part_lut[cid] >= 0)).reshape(-1)
+                    if sel.numel():
+                        cs = cid[sel]
+                        out.append((sel, cs, w[sel], (xyz[sel] + self._shift[cs]).contiguous()))
+        return out
 
     def _evaluate_f_model(self, xyz, grad, max_points=1 << 22):
         n = xyz.shape[0]
         num = torch.zeros(n, dtype=torch.float32, device=xyz.device)
         den = torch.zeros(n, dtype=torch.float32, device=xyz.device)
         gnum = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if grad else None
-        # a chunk's weight is supported on core +- ov: only queries whose home chunk lies within `reach`
-        # chunks of it can see it.  Queries are binned by home chunk once (one sort), so every chunk
-        # weighs its neighbourhood instead of the whole query set (O(27 n) instead of O(chunks * n)).
-        nchunk = self.grid[0] * self.grid[1] * self.grid[2]
-        binned = n > 0 and nchunk > 8
-        if binned:
-            home = self.chunk_of(xyz)
-            order = torch.sort(home, stable=True).indices
-            off = [0] + torch.cumsum(torch.bincount(home, minlength=nchunk), 0).tolist()
-            reach = max(1, int(math.ceil(self.ov / self.chunk_size)))
-        for c in sorted(self.fields):     # fixed order => identical arithmetic on every rank
-            if binned:
-                cz, cy, cx = c % self.grid[2], (c // self.grid[2]) % self.grid[1], c // (self.grid[1] * self.grid[2])
-                segs = []
-                for ax in range(max(cx - reach, 0), min(cx + reach, self.grid[0] - 1) + 1):
-                    for ay in range(max(cy - reach, 0), min(cy + reach, self.grid[1] - 1) + 1):
-                        z0, z1 = max(cz - reach, 0), min(cz + reach, self.grid[2] - 1)
-                        h0 = (ax * self.grid[1] + ay) * self.grid[2] + z0      # z-neighbours are consecutive ids
-                        if off[h0 + z1 - z0 + 1] > off[h0]:
-                            segs.append(order[off[h0]:off[h0 + z1 - z0 + 1]])
-                if not segs:
-                    continue
-                cand = torch.cat(segs) if len(segs) > 1 else segs[0]
-                pts = xyz[cand]
+        groups = self._pairs(xyz)
+        if groups:
+            # one evaluation call per part for ALL groups; the blend then adds the groups in their fixed order
+            sizes = [gq[0].numel() for gq in groups]
+            xq = torch.cat([gq[3] for gq in groups])
+            cid = torch.cat([gq[1] for gq in groups])
+            f = torch.empty(xq.shape[0], dtype=torch.float32, device=xyz.device)
+            gr = torch.empty((xq.shape[0], 3), dtype=torch.float32, device=xyz.device) if grad else None
+            if len(self.parts) == 1:
+                res = self.parts[0].field._evaluate_f_model(xq, grad, max_points)
+                f, gr = res.value, res.gradient
             else:
-                cand, pts = None, xyz
-            w = self._weight(c, pts)
-            sel = torch.nonzero(w > 0).reshape(-1)
-            if sel.numel() == 0:
-                continue
-            res = self.fields[c]._evaluate_f_model(pts[sel].contiguous(), grad, max_points)
-            tgt = sel if cand is None else cand[sel]
-            num.index_add_(0, tgt, res.value * w[sel])
-            den.index_add_(0, tgt, w[sel])
-            if grad:   # the gradient of the weights is ignored (they are flat outside the seams)
-                gnum.index_add_(0, tgt, res.gradient * w[sel, None])
+                pl = self._part_lut[cid]
+                for pi, part in enumerate(self.parts):
+                    s = torch.nonzero(pl == pi).reshape(-1)
+                    if s.numel():
+                        res = part.field._evaluate_f_model(xq[s].contiguous(), grad, max_points)
+                        f[s] = res.value
+                        if grad:
+                            gr[s] = res.gradient
+            o = 0
+            for (q, _, w, _), m in zip(groups, sizes):
+                num[q] = num[q] + f[o:o + m] * w
+                den[q] = den[q] + w
+                if grad:   # the gradient of the weights is ignored (they are flat outside the seams)
+                    gnum[q] = gnum[q] + gr[o:o + m] * w[:, None]
+                o += m
         den = den.clamp_min(1e-20)
         return EvaluationResult(num / den, gnum / den[:, None] if grad else None)
 
@@ -273,7 +555,7 @@ class MultiChunkField(BaseField):
         return m
 
     def finalize_mesh(self, res):
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.distributed:
             return res
         v, f = D.gather_meshes(res.v, res.f, res.edge_vkey, res.edge_axis)
         res.v, res.f = v, f
@@ -281,27 +563,69 @@ class MultiChunkField(BaseField):
         return res
 
     def for_rank(self, rank, world_size, fields):
-        """Same scene seen from another (simulated) rank holding ``fields`` -- test helper."""
-        return MultiChunkField(fields, self.cores, self.ov, self.origin, self.chunk_size, self.grid, self.owner, rank,
-                               world_size, self.svh.voxel_size, self.svh.device)
+        """Same scene seen from another (simulated) rank holding the per-chunk ``fields`` -- test helper."""
+        parts = [ChunkPart(f, [c], self.frame, solved=bool(f.solve_info)) for c, f in sorted(fields.items())]
+        return MultiChunkField(parts, self.cores, self.ov, self.origin, self.chunk_size, self.grid, self.owner, rank,
+                               world_size, self.frame, self.interpolators, self.svh.device, adaptive_depth=self.meshing_depth)
 
     def to_(self, device):
-        for f in self.fields.values():
-            f.to_(device)
+        for p in self.parts:
+            p.field.to_(device)
         self.svh.to_(device)
         return self
 
 
-OV_FLOOR = 1.0        # blend half-width floor, in coarsest voxels
-BAND_EXTRA = 1.5      # data margin beyond core +- ov, in coarsest voxels (= the support radius of the coarsest kernel); None = ov
-MIN_CHUNK_POINTS = 8
-
-
-def chunk_geometry(hp, chunk_size, overlap_ratio):
-    wc = hp.voxel_size * 2 ** (hp.tree_depth - 1)
-    ov = max(overlap_ratio * chunk_size, OV_FLOOR * wc)
-    band = 2 * ov if BAND_EXTRA is None else ov + BAND_EXTRA * wc
-    return ov, band
+# ---- the batched solve ------------------------------------------------------------------------------------------------------
+def select_chunk_points(xyz, lo, grid, chunk_size, band, wanted):
+    """(point index, chunk id) of every point inside core +- band of a chunk in ``wanted`` (bool per chunk), sorted by
+    (chunk, point index), + the points per chunk.  Same comparisons as a per-chunk boolean mask: x >= lo_c - band and
+    x < hi_c + band along the split axes, the bounds rounded to fp32."""
+    dev = xyz.device
+    n = xyz.shape[0]
+    nchunk = grid[0] * grid[1] * grid[2]
+    reach = max(1, int(math.ceil(band / chunk_size)))
+    home, inside = [], []
+    for a in range(3):
+        if grid[a] > 1:
+            x = xyz[:, a]
+            i = torch.floor((x - lo[a]) / chunk_size).long().clamp_(0, grid[a] - 1)
+            lo_t = torch.tensor([np.float32(lo[a] + j * chunk_size - band) for j in range(grid[a])], dtype=torch.float32, device=dev)
+            hi_t = torch.tensor([np.float32(lo[a] + j * chunk_size + chunk_size + band) for j in range(grid[a])], dtype=torch.float32, device=dev)
+            ms = {}
+            for o in range(-reach, reach + 1):
+                j = i + o
+                jc = j.clamp(0, grid[a] - 1)
+                ms[o] = (j >= 0) & (j < grid[a]) & (x >= lo_t[jc]) & (x < hi_t[jc])
+            home.append(i)
+            inside.append(ms)
+        else:
+            home.append(torch.zeros(n, dtype=torch.long, device=dev))
+            inside.append({0: None})
+    want = torch.as_tensor(wanted, dtype=torch.bool, device=dev)
+    idxs, cids = [], []
+    for ox in sorted(inside[0]):
+        for oy in sorted(inside[1]):
+            for oz in sorted(inside[2]):
+                m = None
+                for a, o in ((0, ox), (1, oy), (2, oz)):
+                    if inside[a][o] is not None:
+                        m = inside[a][o] if m is None else (m & inside[a][o])
+                cid = ((home[0] + ox).clamp(0, grid[0] - 1) * grid[1] + (home[1] + oy).clamp(0, grid[1] - 1)) * grid[2] + (home[2] + oz).clamp(0, grid[2] - 1)
+                m = want[cid] if m is None else (m & want[cid])
+                sel = torch.nonzero(m).reshape(-1)
+                if sel.numel():
+                    idxs.append(sel)
+                    cids.append(cid[sel])
+    if not idxs:
+        z = torch.zeros(0, dtype=torch.long, device=dev)
+        return z, z, [0] * nchunk
+    idx, cid = torch.cat(idxs), torch.cat(cids)
+    if nchunk > 1:
+        ks, order = ops.sort_pairs(cid * max(n, 1) + idx, torch.arange(idx.numel(), dtype=torch.int32, device=dev))
+        order = order.long()
+        idx, cid = idx[order], cid[order]
+    counts = torch.bincount(cid, minlength=nchunk).tolist()
+    return idx, cid, counts
 
 
 def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, approx_kernel_grad, solver_max_iter,
@@ -315,7 +639,8 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     hp = rec.hparams
     dev = rec.device
     rank, ws = sim if sim is not None else D.world()
-    collective = sharded_input and ws > 1 and sim is None
+    active = D.active() and sim is None            # a process group takes part (world > 1, or forced at world 1: NKSR_DIST_FORCE)
+    collective = sharded_input and active
     from .density import bbox_center
     if xyz.shape[0] and (not bool(torch.isfinite(xyz).all())):
         raise RuntimeError('non-finite coordinates in the input')
@@ -336,6 +661,7 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
         lo, hi = [float(v) for v in lo_t.tolist()], [float(v) for v in hi_t.tolist()]
     grid = chunk_grid(lo, hi, chunk_size)
     ov, band = chunk_geometry(hp, chunk_size, overlap_ratio)
+    frame = ChunkFrame(hp.voxel_size, hp.tree_depth, lo, grid, chunk_size, band)
     nchunk = grid[0] * grid[1] * grid[2]
     cores = {}
     for c in range(nchunk):
@@ -366,89 +692,121 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
         owner = [int(o) for o in chunk_owner]
     else:
         owner = D.partition_chunks(nchunk, ws, counts, grid)
-    def solve_chunk(c):
-        """select -> (preprocess) -> solve one chunk on the CURRENT stream; returns (c, field or None)"""
+    jobs = [c for c in range(nchunk) if owner[c] == rank and counts[c] > 0]
+    for c in jobs:
         if sharded_input and local_counts[c] != counts[c]:
             raise RuntimeError('sharded input: rank %d owns chunk %d but holds %d of its %d core points' % (rank, c, local_counts[c], counts[c]))
-        clo, chi = cores[c]
-        m = None                                  # points inside core +- band (only along the split axes)
-        for a in range(3):
-            if grid[a] > 1:
-                ma = (xyz[:, a] >= clo[a] - band) & (xyz[:, a] < chi[a] + band)
-                m = ma if m is None else (m & ma)
-        idx = torch.nonzero(m).reshape(-1) if m is not None else torch.arange(xyz.shape[0], device=dev)
-        cx_, cn_, cs_ = xyz[idx].contiguous(), (normal[idx].contiguous() if normal is not None else None), \
-            (sensor[idx].contiguous() if sensor is not None else None)
-        if preprocess_fn is not None:
+    wanted = [False] * nchunk
+    for c in jobs:
+        wanted[c] = True
+    pidx, pcid, npts = select_chunk_points(xyz, lo, grid, chunk_size, band, wanted)
+    bx, bn, bc = xyz[pidx], (normal[pidx] if normal is not None else None), pcid
+    if preprocess_fn is not None:
+        # the reference's contract: preprocess_fn sees the points of ONE chunk, in the caller's coordinates, on the calling thread
+        xs_, ns_, cs_ = [], [], []
+        bs = sensor[pidx] if sensor is not None else None
+        o = 0
+        for c in range(nchunk):
+            m = npts[c]
+            if m == 0:
+                continue
+            sl = slice(o, o + m)
+            o += m
             try:
-                cx_, cn_, cs_ = preprocess_fn(cx_, cn_, cs_)
-            except RuntimeError as e:
-                if 'need at least' in str(e):     # too few points for the normal estimator: treat the chunk as empty
-                    return c, None
-                raise
-        if cn_ is None:
-            raise RuntimeError('oriented input required (normal= or sensor= with a normal-estimating preprocess_fn)')
-        if cx_.shape[0] < MIN_CHUNK_POINTS:       # a handful of stray points: nothing to solve, neighbours cover the band
-            return c, None
-        if not bool(torch.isfinite(cn_).all()):
-            raise RuntimeError('non-finite normals in the input')
-        fld = rec._reconstruct_single(cx_.contiguous(), cn_.to(torch.float32).contiguous(), approx_kernel_grad,
-                                      solver_max_iter, solver_tol, fused_mode)
-        fld.matrix = None                 # the CSR is not needed after the solve
+                cx_, cn_, _ = preprocess_fn(bx[sl].contiguous(), bn[sl].contiguous() if bn is not None else None,
+                                            bs[sl].contiguous() if bs is not None else None)
+            except ChunkTooSmall:
+                npts[c] = 0
+                continue
+            if cn_ is None:
+                raise RuntimeError('oriented input required (normal= or sensor= with a normal-estimating preprocess_fn)')
+            npts[c] = int(cx_.shape[0])
+            xs_.append(cx_)
+            ns_.append(cn_.to(torch.float32))
+            cs_.append(torch.full((cx_.shape[0],), c, dtype=torch.long, device=dev))
+        bx = torch.cat(xs_) if xs_ else xyz[:0]
+        bn = torch.cat(ns_) if ns_ else xyz[:0]
+        bc = torch.cat(cs_) if cs_ else pcid[:0]
+    if bn is None:
+        raise RuntimeError('oriented input required (normal= or sensor= with a normal-estimating preprocess_fn)')
+    small = [c for c in jobs if npts[c] < MIN_CHUNK_POINTS]          # a handful of stray points: nothing to solve, neighbours cover the band
+    if small:
+        keep = torch.ones(nchunk, dtype=torch.bool, device=dev)
+        keep[small] = False
+        s = torch.nonzero(keep[bc]).reshape(-1)
+        bx, bn, bc = bx[s], bn[s], bc[s]
+        for c in small:
+            npts[c] = 0
+    jobs = [c for c in jobs if npts[c] >= MIN_CHUNK_POINTS]
+    if bx.shape[0] and not bool(torch.isfinite(bn).all()):
+        raise RuntimeError('non-finite normals in the input')
+    # sub-batches of whole chunks (memory: ~2 KB per point at tree_depth 5), chunks of a batch in slot order
+    jobs.sort(key=lambda c: frame.key_range(c)[0])
+    budget = int(getattr(rec, 'chunk_batch_points', 0) or (1 << 25))
+    if not fused_mode:
+        budget = 0        # the assembled solve (fused_mode=False) has no segmented form: one chunk per solve, as the reference runs them
+    batches, cur, acc = [], [], 0
+    for c in jobs:
+        if cur and acc + npts[c] > budget:
+            batches.append(cur)
+            cur, acc = [], 0
+        cur.append(c)
+        acc += npts[c]
+    if cur:
+        batches.append(cur)
+    shift_all = torch.from_numpy(np.stack([frame.shift(c) for c in range(nchunk)])).to(dev)
+    slot_org = torch.from_numpy(np.stack([np.asarray(frame.slot_origin(c), np.float64) * frame.w0 for c in range(nchunk)]).astype(np.float32)).to(dev)
+    parts, timing = [], {}
+    for ids in batches:
+        if len(batches) > 1:
+            inb = torch.zeros(nchunk, dtype=torch.bool, device=dev)
+            inb[ids] = True
+            s = torch.nonzero(inb[bc]).reshape(-1)
+            x_b, n_b, c_b = bx[s], bn[s], bc[s]
+        else:
+            x_b, n_b, c_b = bx, bn, bc
+        xs = (x_b + shift_all[c_b]).contiguous()                      # the exploded frame: x' = x + T_c (one fp32 rounding)
+        rlo, rhi, _ = bbox_center((xs - slot_org[c_b]).contiguous())
+        rlo, rhi = rlo.tolist(), rhi.tolist()
+        if min(rlo) < frame.usable_lo or max(rhi) >= frame.usable_hi:
+            raise RuntimeError('chunk data leaves its slot of the exploded frame (extent %s .. %s, usable %.3f .. %.3f): points outside '
+                               'chunk_bounds along an axis that is not split?' % (rlo, rhi, frame.usable_lo, frame.usable_hi))
+        kr = [frame.key_range(c) for c in ids]
+        fld = rec._reconstruct_single(xs, n_b.to(torch.float32).contiguous(), approx_kernel_grad, solver_max_iter, solver_tol, fused_mode,
+                                      chunks=(ids, [k[0] for k in kr], [k[1] for k in kr], frame) if fused_mode else None)
+        fld.matrix = None
         fld._fused_op = None
-        if rec.chunk_tmp_device != dev and ws == 1 and sim is None:
-            fld.to_(rec.chunk_tmp_device)  # reference semantics: park solved chunks elsewhere
-        return c, fld
-
-    jobs = [c for c in range(nchunk) if owner[c] == rank and counts[c] > 0]
-    cs = getattr(rec, 'chunk_streams', None)
-    nstreams = max(1, min(int(cs if cs is not None else (3 if fused_mode else 1)), len(jobs)))
-    if nstreams > 1:
-        # Chunks are independent: solve them on several HIP streams, one host thread each.  A chunk of a few 100 k points is a chain
-        # of ~100 short kernels with host round trips for sizes in between (unique counts, nnz, PCG convergence checks); with
-        # one stream the GPU idles through those, with several the gaps of one chunk are filled by another.  Results do not depend
-        # on the interleaving (no float atomics, every chunk has its own buffers): bit-identical to the sequential run.
-        from concurrent.futures import ThreadPoolExecutor
-        torch.cuda.synchronize(dev)               # inputs (and anything still using memory the workers may be handed) are settled
-        streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-
-        def worker(i):
-            out = []
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(streams[i]):
-                for c in jobs[i::nstreams]:
-                    out.append(solve_chunk(c))
-                streams[i].synchronize()
-            return out
-        with ThreadPoolExecutor(max_workers=nstreams) as ex:
-            results = [r for part in ex.map(worker, range(nstreams)) for r in part]
-    else:
-        results = [solve_chunk(c) for c in jobs]
-    local = {c: f for c, f in sorted(results, key=lambda r: r[0]) if f is not None}
-    timing = {}
-    for f in local.values():              # per-stage host time summed over chunks (they overlap when chunk_streams > 1)
-        for k, v in getattr(f, 'timing', {}).items():
+        for k, v in getattr(fld, 'timing', {}).items():
             timing[k] = timing.get(k, 0.0) + v
+        if rec.chunk_tmp_device != dev and not active and sim is None and len(batches) > 1:
+            fld.to_(rec.chunk_tmp_device)  # reference semantics: park solved chunks elsewhere (only useful when there are several batches)
+        parts.append(ChunkPart(fld, ids, frame))
     rec.timing = timing
-    if ws > 1 and sim is None:
+    interps = rec.network.interpolators
+    if active:
         # the exchange carries the halo of every chunk (the voxels other ranks can touch), not the whole field; which
         # chunks were actually solved travels with it (a sparse chunk may have been skipped by its owner)
         def band_of(c):
-            c3 = (c // (grid[1] * grid[2]), (c // grid[2]) % grid[1], c % grid[2])
-            return exchange_band(cores[c], c3, grid, ov, hp.voxel_size)
-        payload = D.exchange_payloads({c: pack_field(f, band_of(c)) for c, f in local.items()})
+            return exchange_band(cores[c], frame.chunk3(c), grid, ov, hp.voxel_size)
+        local = {c: p.pack_chunk(c, band_of(c)) for p in parts for c in p.ids}
+        payload = D.exchange_payloads(local)
         solved = sorted(payload)
         # a rank only evaluates the blend inside its own cores (+ the halo ring it evaluates): it needs exactly the
         # chunks whose weight support (core +- ov) reaches there -- its spatial neighbours, not all N
-        need = needed_chunks(cores, ov + 2.5 * hp.voxel_size, grid, [c for c in solved if owner[c] == rank], solved)
-        fields = {c: (local[c] if c in local else unpack_field(payload[c][0], payload[c][1], hp.voxel_size,
-                                                              rec.network.interpolators, dev)) for c in need}
+        mine = set(local)
+        need = [c for c in needed_chunks(cores, ov + 2.5 * hp.voxel_size, grid, [c for c in solved if owner[c] == rank], solved) if c not in mine]
+        if need:
+            remote = fields_from_payloads([(frame.key_range(c)[0], payload[c][0], payload[c][1]) for c in need], hp.voxel_size, interps, dev)
+            remote.meshing_depth = int(hp.adaptive_depth)
+            if remote.mask_field is None:
+                remote.set_mask_field(LayerField(remote.svh, hp.adaptive_depth))
+            parts.append(ChunkPart(remote, sorted(need, key=lambda c: frame.key_range(c)[0]), frame, solved=False))
     else:
-        fields = local
-        if rec.chunk_tmp_device != dev and sim is None:
-            for f in fields.values():
-                f.to_(dev)                # meshing runs on the GPU: bring the parked chunks back
-    return MultiChunkField(fields, cores, ov, lo, chunk_size, grid, owner, rank, ws, hp.voxel_size, dev)
+        for p in parts:
+            if p.field.device != dev:
+                p.field.to_(dev)          # meshing runs on the GPU: bring the parked batches back
+    return MultiChunkField(parts, cores, ov, lo, chunk_size, grid, owner, rank, ws, frame, interps, dev, distributed=active,
+                           adaptive_depth=int(hp.adaptive_depth))
 
 
 def needed_chunks(cores, margin, grid, owned, candidates):

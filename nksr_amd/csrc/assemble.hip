@@ -106,27 +106,40 @@ __device__ __forceinline__ void cell_blocks_finalize(const AsmArgs& A, int d, in
 }
 
 // A coarse cell holds thousands of site rows (8x more per level): with one wavefront per cell the two coarsest levels of a
-// tree_depth-5 chunk took 2.6 ms on ~8 k wavefronts.  Such levels are cut: wavefront (c, p) accumulates part p of the cell's rows
-// and leaves its raw accumulator tiles in scratch; k_cell_blocks_reduce adds the parts in order (fixed: deterministic) and finishes.
+// tree_depth-5 chunk took 2.6 ms on ~8 k wavefronts.  The rows of such a cell are cut into PARTS -- a decision that depends on the
+// cell alone: on a level that splits (asm_level_parts(d) > 1) a cell of R rows has min(level parts, R / ASM_PART_ROWS) parts of
+// equal (even) length -- and its block is  sum over the parts, in order, of the part's own accumulator.  Two schedules give
+// that same sum bit for bit: k_cell_blocks_part + k_cell_blocks_reduce (one wavefront per (cell, part), raw accumulator tiles
+// through scratch; used when the level has few cells) and k_cell_blocks_seq (one wavefront per cell walks its parts; used when
+// the level has enough cells to fill the chip, e.g. all chunks of a rank batched into one system).  The result therefore does
+// not depend on how many other cells share the launch.
+#define ASM_PART_ROWS 128
+__host__ __device__ __forceinline__ int asm_level_parts(int d) {          // d = 0..2: 1, 3: 4, 4: 16, 5: 64
+    const int k = d >= 2 ? (1 << (2 * (d - 2))) : 1;
+    return k > 64 ? 64 : k;
+}
+__device__ __forceinline__ int asm_cell_rows(const AsmArgs& A, int d, int c) {
+    int R = 0;
+    for (int si = 0; si < A.nsets; ++si) R += (A.sets[si].end[d][c] - A.sets[si].start[d][c]) * A.sets[si].ncomp;
+    return R;
+}
+// rows [lo, hi) of part p of a cell with R rows
+__device__ __forceinline__ void asm_part_range(int R, int level_parts, int p, int& lo, int& hi) {
+    int np = R / ASM_PART_ROWS;
+    np = np < 1 ? 1 : (np > level_parts ? level_parts : np);
+    const int rpp = ((R + np - 1) / np + 1) & ~1;                        // rows per part, even (two rows per MFMA)
+    lo = p * rpp;
+    hi = (p + 1) * rpp < R ? (p + 1) * rpp : R;
+    if (lo > R) lo = R;
+    if (hi < lo) hi = lo;
+}
+
+// acc += the Gram products of rows [lo, hi) of cell c (row numbering: set 0's rows, then set 1's)
 template <int NT>
-__global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks_part(AsmArgs A, int d, int nsplit, float* __restrict__ scratch) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const nksr_level_t& lv = A.hier.lv[d];
-    const int64_t idx = (int64_t)blockIdx.x * ASM_WAVES + wave;
-    if (idx >= (int64_t)lv.n * nsplit) return;
-    const int c = (int)(idx / nsplit), p = (int)(idx - (int64_t)c * nsplit);
+__device__ __forceinline__ void asm_accumulate_rows(const AsmArgs& A, int d, int c, int lo, int hi, int lane, asm_f32x16 (&acc)[NT]) {
     const int L = A.hier.depth;
     const int T = (L - d) * 27;
     const int j = lane & 31, half = lane >> 5;
-    asm_f32x16 acc[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    int R = 0;
-    for (int si = 0; si < A.nsets; ++si) R += (A.sets[si].end[d][c] - A.sets[si].start[d][c]) * A.sets[si].ncomp;
-    const int rpp = ((R + nsplit - 1) / nsplit + 1) & ~1;                // rows per part, even (two rows per MFMA)
-    const int lo = p * rpp, hi = (p + 1) * rpp < R ? (p + 1) * rpp : R;
     int base = 0;
     for (int si = 0; si < A.nsets; ++si) {
         const nksr_siteset_t& S = A.sets[si];
@@ -161,6 +174,23 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks_part(AsmArgs A, 
         }
         base += nrows;
     }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks_part(AsmArgs A, int d, int nsplit, float* __restrict__ scratch) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const nksr_level_t& lv = A.hier.lv[d];
+    const int64_t idx = (int64_t)blockIdx.x * ASM_WAVES + wave;
+    if (idx >= (int64_t)lv.n * nsplit) return;
+    const int c = (int)(idx / nsplit), p = (int)(idx - (int64_t)c * nsplit);
+    asm_f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    int lo, hi;
+    asm_part_range(asm_cell_rows(A, d, c), nsplit, p, lo, hi);
+    asm_accumulate_rows<NT>(A, d, c, lo, hi, lane, acc);
     float* out = scratch + idx * (NT * 16 * 64) + lane;
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -188,6 +218,37 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks_reduce(AsmArgs A
     int total = 0;
     for (int si = 0; si < A.nsets; ++si) total += A.sets[si].end[d][c] - A.sets[si].start[d][c];
     cell_blocks_finalize<NT>(A, d, c, lane, acc, total);
+}
+
+// the same sum, one wavefront per cell: part after part into a fresh accumulator, added to the total in order
+template <int NT>
+__global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks_seq(AsmArgs A, int d, int nsplit) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int c = blockIdx.x * ASM_WAVES + wave;
+    if (c >= A.hier.lv[d].n) return;
+    asm_f32x16 tot[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot[n][r] = 0.f;
+    const int R = asm_cell_rows(A, d, c);
+    for (int p = 0; p < nsplit; ++p) {
+        int lo, hi;
+        asm_part_range(R, nsplit, p, lo, hi);
+        asm_f32x16 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        if (hi > lo) asm_accumulate_rows<NT>(A, d, c, lo, hi, lane, acc);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tot[n][r] += acc[n][r];
+    }
+    int total = 0;
+    for (int si = 0; si < A.nsets; ++si) total += A.sets[si].end[d][c] - A.sets[si].start[d][c];
+    cell_blocks_finalize<NT>(A, d, c, lane, tot, total);
 }
 
 // LM: the site sets hold LEVEL-MAJOR rows (nksr_siteset_t.level_stride > 0)
@@ -581,20 +642,17 @@ extern "C" size_t nksr_assemble_workspace_bytes(const nksr_hier_t* h) {
     return tot;
 }
 
-// parts a cell's rows are cut into on a level with n cells (uniform per level): enough wavefronts to fill the chip (~16 k), at
-// least 64 rows per part, at most 64 parts
-static int asm_nsplit(int64_t total_rows, int n) {
-    if (n <= 0) return 1;
-    const int64_t avg = total_rows / n, by_rows = avg / 64, by_fill = 16384 / n;
-    int64_t k = by_rows < by_fill ? by_rows : by_fill;
-    if (k > 64) k = 64;
-    return k < 2 ? 1 : (int)k;
+// Levels that split (asm_level_parts) run the parallel schedule -- one wavefront per (cell, part), tiles through scratch -- while
+// that gives at most ~64 k wavefronts and the scratch fits; the sequential schedule (same bits) otherwise.
+static bool asm_parallel_parts(int n, int parts, size_t NT, size_t scratch_bytes) {
+    return parts > 1 && (int64_t)n * parts <= 65536 && (size_t)n * parts * NT * 16 * 64 * sizeof(float) <= scratch_bytes;
 }
 extern "C" size_t nksr_assemble_split_bytes(const nksr_hier_t* h, int64_t total_rows) {
+    (void)total_rows;
     size_t best = 0;
     for (int d = 0; d < h->depth; ++d) {
-        const int n = h->lv[d].n, ns = asm_nsplit(total_rows, n);
-        if (n <= 0 || ns <= 1) continue;
+        const int n = h->lv[d].n, ns = asm_level_parts(d);
+        if (n <= 0 || ns <= 1 || (int64_t)n * ns > 65536) continue;
         const size_t NT = ((size_t)(h->depth - d) * 27 + 32) / 32, b = (size_t)n * ns * NT * 16 * 64 * sizeof(float);
         if (b > best) best = b;
     }
@@ -642,12 +700,15 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
         if (n <= 0) continue;
         const int T = (h->depth - d) * 27, NT = (T + 32) / 32;      // column tiles incl. the right-hand-side column
         const dim3 grid(nksr_blocks(n, ASM_WAVES));
-        const int nsplit = split_scratch ? asm_nsplit(total_rows, n) : 1;
-        if (nsplit > 1 && (size_t)n * nsplit * NT * 16 * 64 * sizeof(float) <= split_scratch_bytes) {
+        // the part structure is a property of the level (and the cell); the schedule is picked by size -- same bits either way
+        const int nsplit = asm_level_parts(d);
+        if (nsplit > 1) {
+            const bool par = split_scratch && asm_parallel_parts(n, nsplit, (size_t)NT, split_scratch_bytes);
             const dim3 gp(nksr_blocks((int64_t)n * nsplit, ASM_WAVES));
             float* sc = (float*)split_scratch;
-#define CELLSPLIT(N) hipLaunchKernelGGL((k_cell_blocks_part<N>), gp, blk, 0, st, A, d, nsplit, sc); \
-                     hipLaunchKernelGGL((k_cell_blocks_reduce<N>), grid, blk, 0, st, A, d, nsplit, (const float*)sc)
+#define CELLSPLIT(N) if (par) { hipLaunchKernelGGL((k_cell_blocks_part<N>), gp, blk, 0, st, A, d, nsplit, sc); \
+                                hipLaunchKernelGGL((k_cell_blocks_reduce<N>), grid, blk, 0, st, A, d, nsplit, (const float*)sc); } \
+                     else hipLaunchKernelGGL((k_cell_blocks_seq<N>), grid, blk, 0, st, A, d, nsplit)
             switch (NT) {
                 case 1: CELLSPLIT(1); break;
                 case 2: CELLSPLIT(2); break;

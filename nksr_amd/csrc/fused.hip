@@ -85,7 +85,14 @@ struct FusedArgs {               // uniform scalars and base pointers only
     int hw_total;                // half-waves = items, rounded up to whole wavefronts
     int64_t rows_total, nblocks;
     unsigned long long* nnz_counter;   // the set-up pass (MODE 1) adds the non-zero slots it sees (may be NULL)
+    const int32_t* item_seg;     // [hw_total] segment of every 32-row item, [M] segment of every unknown (batched chunks; may be NULL)
+    const int32_t* unknown_seg;
+    const int* seg_done;         // device flags of the PCG: segment c finished <=> seg_done[c * seg_stride] != 0 (may be NULL)
+    int seg_stride;
 };
+__device__ __forceinline__ bool fz_seg_done(const FusedArgs& A, const int32_t* seg_of, int64_t i) {
+    return A.seg_done && seg_of && A.seg_done[(int64_t)seg_of[i] * A.seg_stride] != 0;
+}
 
 // lane `l` of the caller's own half-wave, l uniform: two scalar lane reads + a select (no crossbar)
 __device__ __forceinline__ int half_lane_i(int v, int l, bool upper) {
@@ -117,7 +124,9 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
     if (item >= A.hw_total) return;                                  // whole wavefronts: hw_total is even
     const int64_t R0 = (int64_t)item * FZ_RC;
     const int64_t left = A.rows_total - R0;
-    const int nrows = left >= FZ_RC ? FZ_RC : (left > 0 ? (int)left : 0);
+    // (the rows of a segment whose conjugate gradients have finished are skipped: an item lies inside ONE segment -- segments
+    // are padded to whole items -- and a half-wave without rows just idles next to its partner)
+    const int nrows = (MODE == 0 && left > 0 && fz_seg_done(A, A.item_seg, item)) ? 0 : (left >= FZ_RC ? FZ_RC : (left > 0 ? (int)left : 0));
     const int s = threadIdx.x & 31;
     const bool act = s < 27, upper = (threadIdx.x & 32) != 0;
     const int sh = upper ? 32 : 0;
@@ -310,6 +319,7 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
         // (one serial chain over hundreds of blocks was the critical path of the pass), then the eight partial sums in order
         __shared__ float partial[8][32];
         const int cell = A.multi[blockIdx.x], h = threadIdx.x >> 5;
+        if (LIST && fz_seg_done(A, A.unknown_seg, cell)) return;
         const int b0 = A.offsets[cell], n = A.offsets[cell + 1] - b0;
         const float* p = part + (int64_t)(b0 + h) * 32 + s;
         float acc = 0.f;
@@ -338,7 +348,7 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
 #pragma unroll
     for (int k = 0; k < FZ_GI; ++k) {
         b0[k] = A.offsets[cell[k]];
-        n[k] = i0 + k < ncell ? A.offsets[cell[k] + 1] - b0[k] : 0;
+        n[k] = (i0 + k < ncell && !(LIST && fz_seg_done(A, A.unknown_seg, cell[k]))) ? A.offsets[cell[k] + 1] - b0[k] : 0;
     }
     float acc[FZ_GI], a1[FZ_GI];
 #pragma unroll
@@ -353,7 +363,7 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
         int b = 2;
         for (; b + 4 <= n[k]; b += 4, p += 128) acc[k] += (p[0] + p[32]) + (p[64] + p[96]);
         for (; b < n[k]; ++b, p += 32) acc[k] += p[0];
-        if (i0 + k < ncell) cellp[(int64_t)cell[k] * 32 + s] = acc[k];
+        if (i0 + k < ncell && (!LIST || n[k] > 0)) cellp[(int64_t)cell[k] * 32 + s] = acc[k];
     }
 }
 
@@ -372,14 +382,17 @@ __global__ void __launch_bounds__(256) k_fz_gather(FusedArgs A, int per_xcd, con
     if (j0 >= A.M) return;
     const int sp = threadIdx.x & 31;
     int c[FZ_GI];
+    bool live[FZ_GI];
 #pragma unroll
-    for (int k = 0; k < FZ_GI; ++k) c[k] = (sp < 27 && j0 + k < A.M) ? A.nbr32[(int64_t)(j0 + k) * 32 + sp] : -1;
+    for (int k = 0; k < FZ_GI; ++k) live[k] = j0 + k < A.M && !(MODE == 0 && fz_seg_done(A, A.unknown_seg, j0 + k));
+#pragma unroll
+    for (int k = 0; k < FZ_GI; ++k) c[k] = (sp < 27 && live[k]) ? A.nbr32[(int64_t)(j0 + k) * 32 + sp] : -1;
     float v[FZ_GI];
 #pragma unroll
     for (int k = 0; k < FZ_GI; ++k) v[k] = c[k] >= 0 ? cellp[(int64_t)c[k] * 32 + (26 - sp)] : 0.f;
     const float r = half_sum4(v[0], v[1], v[2], v[3], sp);           // lanes 8 k .. 8 k + 7 hold the total of unknown k
     const int k = sp >> 3;
-    if ((sp & 7) == 0 && j0 + k < A.M) y[j0 + k] = r + (MODE == 0 ? reg * x[j0 + k] : (MODE == 2 ? reg : 0.f));
+    if ((sp & 7) == 0 && j0 + k < A.M && !(MODE == 0 && fz_seg_done(A, A.unknown_seg, j0 + k))) y[j0 + k] = r + (MODE == 0 ? reg * x[j0 + k] : (MODE == 2 ? reg : 0.f));
 }
 static void fz_gather_dims(int M, dim3& grid, int& per_xcd) {
     per_xcd = ((M + 7) / 8 + 8 * FZ_GI - 1) / (8 * FZ_GI) * (8 * FZ_GI);        // whole workgroups (8 half-waves x FZ_GI unknowns)
@@ -438,6 +451,7 @@ static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
     A.multi = op->multi; A.n_multi = op->n_multi; A.n_big = op->n_big;
     A.M = op->M; A.depth = op->depth; A.rows_total = op->rows_total; A.nblocks = op->nblocks;
     A.nnz_counter = (unsigned long long*)op->nnz_counter;
+    A.item_seg = op->item_seg; A.unknown_seg = op->unknown_seg;
     const int64_t items = (op->rows_total + FZ_RC - 1) / FZ_RC;
     A.hw_total = (int)((items + 1) / 2 * 2);
     return NKSR_OK;
@@ -519,29 +533,39 @@ extern "C" int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* 
 
 struct FusedOperator : PcgOperator {
     FusedArgs A; float reg; FusedWork w;
-    int apply(const float* p, float* y, const int* done, hipStream_t st) override { return fz_apply(A, reg, w, p, y, done, st); }
-    void bytes(double* alg, double* phys) override {
-        // SURVEY.md section 8d, matrix-free operator: G and Q once in each direction at 8 bytes per stored entry (value + index)
-        // + the vectors; stored entries = the non-zero slots (counted by the diagonal pass; all dense slots without a counter).
-        // Physical: every dense slot once (4 bytes, no indices), the row -> cell table, partial blocks written + read, one
-        // neighbour row per block (sweep), the per-cell sums written + read and one neighbour row per unknown (gather), x and y.
+    int apply(const float* p, float* y, const int* done, const int* seg_done, int seg_stride, hipStream_t st) override {
+        FusedArgs B = A;
+        B.seg_done = (A.item_seg && A.unknown_seg) ? seg_done : nullptr;
+        B.seg_stride = seg_stride;
+        return fz_apply(B, reg, w, p, y, done, st);
+    }
+    void bytes(double* alg, double* phys, double* survey) override {
+        // Algorithmic minimum of the matrix-free operator: every STORED entry of G and Q once (4 bytes:
+        // the value; stored = the non-zero slots, counted by the set-up pass), the row -> cell map (4 bytes per row and level: the
+        // only per-row index), one 27-entry stencil per cell (the column information, 108 bytes) and x, y once.
+        // Physical: every dense slot once (zeros included), the row -> cell map, partial blocks written + read, one neighbour
+        // row per block (sweep), the per-cell sums written + read and one neighbour row per unknown (gather), x and y.
+        // SURVEY.md section 8d's formula prices an index per entry and both products: 2 x 8 bytes per stored entry + 12 M + 4.
         const double slots = 27.0 * A.depth * (double)A.rows_total;
         unsigned long long nnz = 0;                                  // (only reached with nksr_pcg_profile on, after a stream sync)
         if (A.nnz_counter) (void)hipMemcpy(&nnz, A.nnz_counter, sizeof(nnz), hipMemcpyDeviceToHost);
-        *alg = 2.0 * 8.0 * (nnz > 0 ? (double)nnz : slots) + 12.0 * A.M + 4.0;
+        const double stored = nnz > 0 ? (double)nnz : slots;
+        *alg = 4.0 * stored + 4.0 * A.depth * (double)A.rows_total + (108.0 + 8.0) * A.M + 4.0;
         *phys = 4.0 * slots + 4.0 * A.depth * (double)A.rows_total + 3.0 * 128.0 * (double)A.nblocks + (3.0 * 128.0 + 8.0 + 12.0) * A.M;
+        *survey = 2.0 * 8.0 * stored + 12.0 * A.M + 4.0;
     }
 };
 
 extern "C" int nksr_pcg_solve_fused(const nksr_fused_op_t* opd, float reg, const float* diag, const float* b, float* x, float tol, int max_iter,
-                                    int check_every, void* pcg_workspace, const nksr_coarse_precond_t* pc, double* info_out, void* stream) {
+                                    int check_every, void* pcg_workspace, const nksr_coarse_precond_t* pc, const nksr_segments_t* seg,
+                                    double* info_out, void* stream) {
     FusedOperator op;
     if (int rc = fz_args(op.A, opd)) return rc;
     if (op.A.M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
     if (!pcg_workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     op.reg = reg;
     op.w = fz_carve(opd);
-    return nksr_pcg_run(op, diag, op.A.M, b, x, tol, max_iter, check_every, pcg_workspace, info_out, (hipStream_t)stream, pc);
+    return nksr_pcg_run(op, diag, op.A.M, b, x, tol, max_iter, check_every, pcg_workspace, info_out, (hipStream_t)stream, pc, seg);
 }
 
 extern "C" size_t nksr_pcg_vector_workspace_bytes(int32_t M) { return nksr_pcg_vector_bytes(M); }

@@ -3,6 +3,10 @@
 // models/nksr_net.py:57-62, models/loss.py:33-46).  All kernels are HBM-bound integer work:
 // one thread per element, coalesced key streams, hash probes served from L2.
 #include "common.h"
+// The oracle rounds every fp32 product before it is used (numpy).  Device code contracts a * b + c into one fma by default --
+// x * inv_w - centre then keeps the unrounded product, the trilinear weights move by an ulp of p and a splat whose normals nearly
+// cancel amplifies that to 1e-4 in the unit target (measured in round 3) -- so contraction is off in this file; explicit fmaf stays.
+#pragma clang fp contract(off)
 
 __global__ void k_splat_keys(const float* __restrict__ xyz, int64_t n, float inv_w0, int level, int mode,
                              int64_t* __restrict__ out) {
@@ -172,16 +176,27 @@ extern "C" int nksr_sorted_lookup(const int64_t* sorted, int64_t n, const int64_
 // One 32-lane half-wave per voxel, lane = neighbour cell: the 27 chains cell -> point range -> coordinates -> features run side by
 // side (a thread per voxel walked them one after the other: latency-bound, 0.68 ms at 7.8e5 voxels), then one fixed-tree sum per
 // channel over the lanes.
+__device__ __forceinline__ double half_sum_d(double p) {      // sum over the 32 lanes of this half-wave, fixed tree
+    p += __shfl_xor(p, 16, 32);
+    p += __shfl_xor(p, 8, 32);
+    p += __shfl_xor(p, 4, 32);
+    p += __shfl_xor(p, 2, 32);
+    p += __shfl_xor(p, 1, 32);
+    return p;
+}
 __global__ void __launch_bounds__(256) k_splat_trilinear(const float* __restrict__ xyz, const float* __restrict__ feat, int C,
                                                          const int32_t* __restrict__ start, const int32_t* __restrict__ end,
                                                          const int32_t* __restrict__ nbr, const int32_t* __restrict__ ijk, int n,
                                                          float inv_w, float* __restrict__ out, float* __restrict__ wsum_out) {
     const int j = (blockIdx.x * 256 + threadIdx.x) >> 5, s = threadIdx.x & 31;
     if (j >= n) return;
-    float acc[8];
+    // fp64 accumulators: the splat of the input normals is normalised afterwards, and where the normals of a voxel's points nearly
+    // cancel (both sides of a thin sheet) fp32 sums left 1e-4 of noise in the unit target (round 3: sites with |sum w n| ~ 0.1 sum w
+    // differed by 7e-5 from the fp64 oracle); the products w * f are exact in fp64, so only the order of the additions is left
+    double acc[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-    float wsum = 0.f;
+    for (int c = 0; c < 8; ++c) acc[c] = 0.0;
+    double wsum = 0.0;
     const float cx = (float)ijk[j * 3] + 0.5f, cy = (float)ijk[j * 3 + 1] + 0.5f, cz = (float)ijk[j * 3 + 2] + 0.5f;
     const int c = s < 27 ? nbr[(int64_t)j * 27 + s] : -1;
     if (c >= 0) {
@@ -191,20 +206,20 @@ __global__ void __launch_bounds__(256) k_splat_trilinear(const float* __restrict
             const float wz = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 2], inv_w) - cz);
             if (wx <= 0.f || wy <= 0.f || wz <= 0.f) continue;
             const float w = wx * wy * wz;
-            wsum += w;
+            wsum += (double)w;
 #pragma unroll
             for (int c2 = 0; c2 < 8; ++c2)
-                if (c2 < C) acc[c2] = fmaf(w, feat[(int64_t)k * C + c2], acc[c2]);
+                if (c2 < C) acc[c2] = fma((double)w, (double)feat[(int64_t)k * C + c2], acc[c2]);
         }
     }
-    wsum = half_sum(wsum);
+    wsum = half_sum_d(wsum);
 #pragma unroll
     for (int c2 = 0; c2 < 8; ++c2)
         if (c2 < C) {
-            const float t = half_sum(acc[c2]);
-            if (s == 0) out[(int64_t)j * C + c2] = t;
+            const double t = half_sum_d(acc[c2]);
+            if (s == 0) out[(int64_t)j * C + c2] = (float)t;
         }
-    if (s == 0) wsum_out[j] = wsum;
+    if (s == 0) wsum_out[j] = (float)wsum;
 }
 
 extern "C" int nksr_splat_trilinear(const float* xyz_sorted, const float* feat_sorted, int C, const int32_t* start,

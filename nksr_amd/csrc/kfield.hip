@@ -183,8 +183,8 @@ __device__ __forceinline__ void store_row27(float* __restrict__ p, const float v
 // ---- dense-slot kernel rows -------------------------------------------------------------------
 // grid.y = level; one thread per site.
 template <int K, int H, bool GRAD, bool JAC>
-__global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float row_scale,
-                              int64_t level_stride, const int32_t* __restrict__ row_index, int32_t* __restrict__ row_cells,
+__global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float row_scale_,
+                              const float* __restrict__ site_scale, int64_t level_stride, const int32_t* __restrict__ row_index, int32_t* __restrict__ row_cells,
                               float* __restrict__ val, float* __restrict__ dval) {
     const int d = blockIdx.y, L = hier.depth;
     const nksr_level_t& lv = hier.lv[d];
@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float x[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    const float row_scale = site_scale ? site_scale[i] : row_scale_;      // per-site factors (batched chunks: sqrt of the chunk's weight)
     SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
     // site-major [n, (3,) L, 27] for the assembly, level-major [L, stride, 27] (row = site * ncomp + component) for the matrix-free solve
     // (level-major rows can be scattered: row_index[i] = first row of site i, so that several site sets share one Morton-ordered row list)
@@ -346,8 +347,8 @@ extern "C" int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden
     return NKSR_OK;
 }
 
-extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, int64_t level_stride,
-                                const int32_t* row_index, int32_t* row_cells, float* val, float* dval, void* stream) {
+extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int approx, float row_scale, const float* site_scale,
+                                int64_t level_stride, const int32_t* row_index, int32_t* row_cells, float* val, float* dval, void* stream) {
     if (n <= 0) return NKSR_OK;
     if (!val && !dval) return nksr_set_error(NKSR_ERR_ARG, "val and dval are both NULL");
     if ((row_index || row_cells) && (level_stride <= 0 || (val && dval)))
@@ -355,9 +356,9 @@ extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t 
     if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
     dim3 grid(nksr_blocks(n, 128), h->depth), block(128);
     DISPATCH_KH(h->kdim, h->hidden, {
-        if (!dval) hipLaunchKernelGGL((k_kernel_rows<K, H, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, row_index, row_cells, val, dval);
-        else if (approx) hipLaunchKernelGGL((k_kernel_rows<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, row_index, row_cells, val, dval);
-        else hipLaunchKernelGGL((k_kernel_rows<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, level_stride, row_index, row_cells, val, dval);
+        if (!dval) hipLaunchKernelGGL((k_kernel_rows<K, H, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, site_scale, level_stride, row_index, row_cells, val, dval);
+        else if (approx) hipLaunchKernelGGL((k_kernel_rows<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, site_scale, level_stride, row_index, row_cells, val, dval);
+        else hipLaunchKernelGGL((k_kernel_rows<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, site_scale, level_stride, row_index, row_cells, val, dval);
     })
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;

@@ -10,6 +10,10 @@
 // bitwise an fmaf chain) on a 32x32 gathered input tile staged in LDS; the 4 KiB tap weights are
 // read straight from L2/L1 (every wavefront reads the same tile).
 #include "common.h"
+// The oracle rounds every fp32 product before it is used (numpy).  Device code contracts a * b + c into one fma by default --
+// x * inv_w - centre then keeps the unrounded product, the trilinear weights move by an ulp of p and a splat whose normals nearly
+// cancel amplifies that to 1e-4 in the unit target (measured in round 3) -- so contraction is off in this file; explicit fmaf stays.
+#pragma clang fp contract(off)
 
 #define NN_C 32
 

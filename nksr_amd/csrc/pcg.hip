@@ -11,45 +11,82 @@
 
 #define PCG_BLOCK 256
 #define PCG_MAX_BLOCKS 2048
+#define SPCG_BS 1024            // unknowns per reduction block of the segmented PCG (256 threads x 4)
 
-struct PcgScalars {
+// Independent diagonal blocks ("segments": the chunks of a batched chunk solve, nksr_segments_t) run their OWN conjugate gradients
+// inside shared launches: scalars per segment, dot products reduced per segment in a fixed, SEGMENT-RELATIVE order (blocks of
+// SPCG_BS unknowns counted from the start of each of the segment's index ranges, partial sums added in block order), so the
+// iterates of a segment do not depend on which other segments share the launch; a converged segment freezes (its blocks return
+// early) while the others go on.  One segment [0, M) is the ordinary solve.
+struct SegScalars {
     double rz[2];
     double bb;
     double rel;
     int iter;
     int done;
 };
+struct PcgGlobal {          // what the host reads back every check_every iterations
+    double max_rel;
+    int max_iter;
+    int done_all;
+    int done_count;
+    int nblocks;            // reduction blocks in use (k_seg_fill)
+};
 
 struct PcgWork {
     float *r, *z, *p, *y;
-    double* part1;  // [PCG_MAX_BLOCKS]
-    double* part2;  // [2*PCG_MAX_BLOCKS]
-    PcgScalars* sc;
+    double* part1;          // [nb_max]
+    double* part2;          // [2 * nb_max]
+    int32_t *blk_lo, *blk_hi, *blk_seg;   // [nb_max] reduction blocks: unknown range + segment
+    int32_t* seg_blk;       // [nseg + 1] first block of every segment
+    SegScalars* sc;         // [nseg]
+    PcgGlobal* g;
+    int nseg, nranges, nb_max;
+    const int32_t *lo, *hi; // [nseg * nranges] (device) or NULL: one segment [0, M)
+    int M;
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-static size_t pcg_vector_bytes(int32_t M) {
-    size_t vec = align_up((size_t)M * sizeof(float), 256);
-    return 4 * vec + 3 * PCG_MAX_BLOCKS * sizeof(double) + 256;
+static int spcg_nb_max(int32_t M, int nseg, int nranges) { return (M + SPCG_BS - 1) / SPCG_BS + nseg * nranges; }
+
+static size_t pcg_vector_bytes_seg(int32_t M, int nseg, int nranges) {
+    const size_t vec = align_up((size_t)M * sizeof(float), 256), nb = (size_t)spcg_nb_max(M, nseg, nranges);
+    return 4 * vec + align_up(3 * nb * sizeof(double), 256) + align_up(3 * nb * sizeof(int32_t), 256) + align_up(((size_t)nseg + 1) * sizeof(int32_t), 256) +
+           align_up((size_t)nseg * sizeof(SegScalars), 256) + 256;
 }
+static size_t pcg_vector_bytes(int32_t M) { return pcg_vector_bytes_seg(M, 1, 1); }
 size_t nksr_pcg_vector_bytes(int32_t M) { return pcg_vector_bytes(M); }
+extern "C" size_t nksr_pcg_vector_workspace_bytes_seg(int32_t M, int32_t nseg, int32_t nranges) {
+    return pcg_vector_bytes_seg(M, nseg < 1 ? 1 : nseg, nranges < 1 ? 1 : nranges);
+}
 extern "C" size_t nksr_spmv_workspace_bytes(int64_t nnz);
 extern "C" size_t nksr_pcg_workspace_bytes(int32_t M, int64_t nnz) {
     return pcg_vector_bytes(M) + nksr_spmv_workspace_bytes(nnz);
 }
 
-static PcgWork carve(void* ws, int M) {
+static PcgWork carve(void* ws, int M, const nksr_segments_t* seg) {
     PcgWork w;
+    w.nseg = seg ? seg->nseg : 1;
+    w.nranges = seg ? seg->nranges : 1;
+    w.lo = seg ? seg->lo : nullptr;
+    w.hi = seg ? seg->hi : nullptr;
+    w.M = M;
+    w.nb_max = spcg_nb_max(M, w.nseg, w.nranges);
     char* p = (char*)ws;
-    size_t vec = align_up((size_t)M * sizeof(float), 256);
+    const size_t vec = align_up((size_t)M * sizeof(float), 256), nb = (size_t)w.nb_max;
     w.r = (float*)p; p += vec;
     w.z = (float*)p; p += vec;
     w.p = (float*)p; p += vec;
     w.y = (float*)p; p += vec;
-    w.part1 = (double*)p; p += PCG_MAX_BLOCKS * sizeof(double);
-    w.part2 = (double*)p; p += 2 * PCG_MAX_BLOCKS * sizeof(double);
-    w.sc = (PcgScalars*)p;
+    w.part1 = (double*)p;
+    w.part2 = w.part1 + nb; p += align_up(3 * nb * sizeof(double), 256);
+    w.blk_lo = (int32_t*)p;
+    w.blk_hi = w.blk_lo + nb;
+    w.blk_seg = w.blk_hi + nb; p += align_up(3 * nb * sizeof(int32_t), 256);
+    w.seg_blk = (int32_t*)p; p += align_up(((size_t)w.nseg + 1) * sizeof(int32_t), 256);
+    w.sc = (SegScalars*)p; p += align_up((size_t)w.nseg * sizeof(SegScalars), 256);
+    w.g = (PcgGlobal*)p;
     return w;
 }
 
@@ -222,13 +259,70 @@ __global__ void k_spmv_fixup(int nchunks, const float* __restrict__ carry, const
     y[r] += s;
 }
 
-__global__ void __launch_bounds__(PCG_BLOCK) k_pcg_init(int M, const float* __restrict__ b, const float* __restrict__ diag,
-                                                        PcgWork w, float* __restrict__ x) {
+// ---- reduction-block plan of the segmented PCG ------------------------------------------------------------------------------
+__device__ __forceinline__ void seg_range(const PcgWork& w, int c, int k, int& lo, int& hi) {
+    if (w.lo) { lo = w.lo[c * w.nranges + k]; hi = w.hi[c * w.nranges + k]; } else { lo = 0; hi = w.M; }
+    if (hi < lo) hi = lo;
+}
+__device__ __forceinline__ int seg_range_blocks(const PcgWork& w, int c, int k) {
+    int lo, hi;
+    seg_range(w, c, k, lo, hi);
+    return (hi - lo + SPCG_BS - 1) / SPCG_BS;
+}
+__global__ void k_seg_count(PcgWork w) {          // one thread per segment
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= w.nseg) return;
+    int n = 0;
+    for (int k = 0; k < w.nranges; ++k) n += seg_range_blocks(w, c, k);
+    w.seg_blk[c + 1] = n;
+}
+__global__ void k_seg_scan(PcgWork w) {           // a few thousand segments at most: one thread
+    int acc = 0;
+    w.seg_blk[0] = 0;
+    for (int c = 0; c < w.nseg; ++c) { acc += w.seg_blk[c + 1]; w.seg_blk[c + 1] = acc; }
+    w.g->nblocks = acc;
+    w.g->done_all = 0;
+    w.g->done_count = 0;
+    w.g->max_iter = 0;
+    w.g->max_rel = 1.0;
+}
+__global__ void k_seg_fill(PcgWork w) {           // one wavefront per (segment, range)
+    const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (idx >= w.nseg * w.nranges) return;
+    const int c = idx / w.nranges, k = idx - c * w.nranges;
+    int base = w.seg_blk[c];
+    for (int q = 0; q < k; ++q) base += seg_range_blocks(w, c, q);
+    int lo, hi;
+    seg_range(w, c, k, lo, hi);
+    const int nb = (hi - lo + SPCG_BS - 1) / SPCG_BS;
+    for (int j = lane; j < nb; j += 64) {
+        const int s = lo + j * SPCG_BS;
+        w.blk_lo[base + j] = s;
+        w.blk_hi[base + j] = s + SPCG_BS < hi ? s + SPCG_BS : hi;
+        w.blk_seg[base + j] = c;
+    }
+}
+
+// a segment finished (converged / empty / broke down): the launch-wide flag goes up when all have
+__device__ __forceinline__ void seg_retire(PcgWork& w) {
+    if (atomicAdd(&w.g->done_count, 1) + 1 == w.nseg) w.g->done_all = 1;
+}
+
+#define SPCG_BLOCK_PROLOGUE(check_done)                                \
+    const int blk = blockIdx.x;                                        \
+    if (blk >= w.g->nblocks) return;                                   \
+    const int seg = w.blk_seg[blk];                                    \
+    if ((check_done) && w.sc[seg].done) return;                        \
+    const int lo = w.blk_lo[blk], hi = w.blk_hi[blk];                  \
     __shared__ double sm[PCG_BLOCK / 64];
+
+__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_init(PcgWork w, const float* __restrict__ b, const float* __restrict__ diag,
+                                                         float* __restrict__ x) {
+    SPCG_BLOCK_PROLOGUE(false)
     double bb = 0.0, rz = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
-        float bi = b[i];
-        float zi = bi / diag[i];
+    for (int i = lo + threadIdx.x; i < hi; i += PCG_BLOCK) {
+        const float bi = b[i];
+        const float zi = bi / diag[i];
         x[i] = 0.f;
         w.r[i] = bi;
         w.z[i] = zi;
@@ -236,84 +330,120 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_pcg_init(int M, const float* __re
         bb += (double)bi * bi;
         rz += (double)bi * zi;
     }
-    double t0 = block_sum(bb, sm);
-    double t1 = block_sum(rz, sm);
+    const double t0 = block_sum(bb, sm);
+    const double t1 = block_sum(rz, sm);
     if (threadIdx.x == 0) {
-        w.part2[2 * blockIdx.x] = t0;
-        w.part2[2 * blockIdx.x + 1] = t1;
+        w.part2[2 * blk] = t0;
+        w.part2[2 * blk + 1] = t1;
     }
 }
 
-__global__ void k_pcg_init_finish(PcgWork w, int nb) {
+__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_init_finish(PcgWork w) {      // one workgroup per segment
     __shared__ double sm[PCG_BLOCK / 64];
-    double bb = reduce_partials(w.part2, nb, 2, sm);
-    double rz = reduce_partials(w.part2 + 1, nb, 2, sm);
+    const int c = blockIdx.x, b0 = w.seg_blk[c], nb = w.seg_blk[c + 1] - b0;
+    const double bb = reduce_partials(w.part2 + 2 * (int64_t)b0, nb, 2, sm);
+    const double rz = reduce_partials(w.part2 + 2 * (int64_t)b0 + 1, nb, 2, sm);
     if (threadIdx.x == 0) {
-        w.sc->bb = bb;
-        w.sc->rz[0] = rz;
-        w.sc->rz[1] = 0.0;
-        w.sc->rel = 1.0;
-        w.sc->iter = 0;
-        w.sc->done = (bb == 0.0) ? 1 : 0;
+        SegScalars& s = w.sc[c];
+        s.bb = bb;
+        s.rz[0] = rz;
+        s.rz[1] = 0.0;
+        s.rel = bb == 0.0 ? 0.0 : 1.0;
+        s.iter = 0;
+        s.done = 0;
+        if (bb == 0.0 || !(rz > 0.0)) { s.done = bb == 0.0 ? 1 : 2; seg_retire(w); }      // empty / zero right-hand side; 2 = breakdown
     }
 }
 
-// partial sums of p.Ap (fp64, fixed order).  Kept out of the SpMV on purpose: fused there, lane 0 of every
+// partial sums of p.Ap (fp64, fixed order).  Kept out of the operator on purpose: fused into the SpMV, lane 0 of every
 // wavefront waited for a dependent x[r] load once per row, which cost the SpMV ~10 % (761 vs 680 us).
-__global__ void __launch_bounds__(PCG_BLOCK) k_pcg_dot(int M, PcgWork w) {
-    if (w.sc->done) return;
-    __shared__ double sm[PCG_BLOCK / 64];
+__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_dot(PcgWork w) {
+    SPCG_BLOCK_PROLOGUE(true)
     double acc = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
-        acc += (double)w.p[i] * (double)w.y[i];
+    for (int i = lo + threadIdx.x; i < hi; i += PCG_BLOCK) acc += (double)w.p[i] * (double)w.y[i];
     const double t = block_sum(acc, sm);
-    if (threadIdx.x == 0) w.part1[blockIdx.x] = t;
+    if (threadIdx.x == 0) w.part1[blk] = t;
 }
 
-// x += alpha p ; r -= alpha y ; z = r / diag ; partial r.r and r.z
-__global__ void __launch_bounds__(PCG_BLOCK) k_pcg_update(int M, const float* __restrict__ diag, PcgWork w,
-                                                          float* __restrict__ x, int nb1, int parity) {
-    if (w.sc->done) return;
-    __shared__ double sm[PCG_BLOCK / 64];
-    const double pAp = reduce_partials(w.part1, nb1, 1, sm);
-    const float alpha = (float)(w.sc->rz[parity] / pAp);
+// x += alpha p ; r -= alpha y ; z = r / diag ; partial r.r and r.z   (alpha of the block's segment)
+__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_update(PcgWork w, const float* __restrict__ diag, float* __restrict__ x, int parity) {
+    SPCG_BLOCK_PROLOGUE(true)
+    const int b0 = w.seg_blk[seg];
+    const double pAp = reduce_partials(w.part1 + b0, w.seg_blk[seg + 1] - b0, 1, sm);
+    const float alpha = pAp > 0.0 ? (float)(w.sc[seg].rz[parity] / pAp) : 0.f;
     double rr = 0.0, rz = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
-        float pi = w.p[i], yi = w.y[i];
+    for (int i = lo + threadIdx.x; i < hi; i += PCG_BLOCK) {
+        const float pi = w.p[i], yi = w.y[i];
         x[i] = fmaf(alpha, pi, x[i]);
-        float ri = fmaf(-alpha, yi, w.r[i]);
-        float zi = ri / diag[i];
+        const float ri = fmaf(-alpha, yi, w.r[i]);
+        const float zi = ri / diag[i];
         w.r[i] = ri;
         w.z[i] = zi;
         rr += (double)ri * ri;
         rz += (double)ri * zi;
     }
-    double t0 = block_sum(rr, sm);
-    double t1 = block_sum(rz, sm);
+    const double t0 = block_sum(rr, sm);
+    const double t1 = block_sum(rz, sm);
     if (threadIdx.x == 0) {
-        w.part2[2 * blockIdx.x] = t0;
-        w.part2[2 * blockIdx.x + 1] = t1;
+        w.part2[2 * blk] = t0;
+        w.part2[2 * blk + 1] = t1;
     }
 }
 
-// p = z + beta p ; block 0 publishes the scalars of the finished iteration
-__global__ void __launch_bounds__(PCG_BLOCK) k_pcg_pupdate(int M, PcgWork w, int nb2, int parity, float tol) {
-    if (w.sc->done) return;
-    __shared__ double sm[PCG_BLOCK / 64];
-    const double rr = reduce_partials(w.part2, nb2, 2, sm);
-    const double rz_new = reduce_partials(w.part2 + 1, nb2, 2, sm);
-    const double rz_old = w.sc->rz[parity];
-    const double bb = w.sc->bb;
+// partial r.z again (second column of part2) after the coarse slice of z changed; init: p = z as well
+__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_rz(PcgWork w, int copy_p) {
+    SPCG_BLOCK_PROLOGUE(!copy_p)
+    double rz = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += PCG_BLOCK) {
+        const float zi = w.z[i];
+        if (copy_p) w.p[i] = zi;
+        rz += (double)w.r[i] * zi;
+    }
+    const double t = block_sum(rz, sm);
+    if (threadIdx.x == 0) w.part2[2 * blk + 1] = t;
+}
+
+// p = z + beta p ; the first block of a segment publishes the scalars of its finished iteration
+__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_pupdate(PcgWork w, int parity, float tol) {
+    SPCG_BLOCK_PROLOGUE(true)
+    const int b0 = w.seg_blk[seg], nb = w.seg_blk[seg + 1] - b0;
+    const double rr = reduce_partials(w.part2 + 2 * (int64_t)b0, nb, 2, sm);
+    const double rz_new = reduce_partials(w.part2 + 2 * (int64_t)b0 + 1, nb, 2, sm);
+    const double rz_old = w.sc[seg].rz[parity];
+    const double bb = w.sc[seg].bb;
     const float beta = (float)(rz_new / rz_old);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x)
-        w.p[i] = fmaf(beta, w.p[i], w.z[i]);
+    for (int i = lo + threadIdx.x; i < hi; i += PCG_BLOCK) w.p[i] = fmaf(beta, w.p[i], w.z[i]);
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blk == b0 && threadIdx.x == 0) {
+        SegScalars& s = w.sc[seg];
         const double rel = sqrt(rr / bb);
-        w.sc->rz[parity ^ 1] = rz_new;
-        w.sc->rel = rel;
-        w.sc->iter += 1;
-        if (rel <= (double)tol) w.sc->done = 1;
+        s.rz[parity ^ 1] = rz_new;
+        s.rel = rel;
+        s.iter += 1;
+        if (rel <= (double)tol) { s.done = 1; seg_retire(w); }
+        else if (!(rz_new > 0.0) || !(rel < 1e30)) { s.done = 2; seg_retire(w); }      // r.z <= 0: the preconditioner lost definiteness (or NaN)
+    }
+}
+
+// what the host reads every check_every iterations (+ the per-segment results, when asked for)
+__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_summary(PcgWork w, double* __restrict__ seg_info) {
+    __shared__ double smr[PCG_BLOCK];
+    __shared__ int smi[PCG_BLOCK], smb[PCG_BLOCK];
+    double mr = 0.0;
+    int mi = 0, nbk = 0;
+    for (int c = threadIdx.x; c < w.nseg; c += PCG_BLOCK) {
+        const SegScalars& s = w.sc[c];
+        mr = s.rel > mr ? s.rel : mr;
+        mi = s.iter > mi ? s.iter : mi;
+        nbk += s.done == 2;
+        if (seg_info) { seg_info[2 * c] = (double)s.iter; seg_info[2 * c + 1] = s.done == 2 ? -s.rel : s.rel; }
+    }
+    smr[threadIdx.x] = mr; smi[threadIdx.x] = mi; smb[threadIdx.x] = nbk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int t = 1; t < PCG_BLOCK; ++t) { mr = smr[t] > mr ? smr[t] : mr; mi = smi[t] > mi ? smi[t] : mi; nbk += smb[t]; }
+        w.g->max_rel = nbk ? -mr : mr;         // negative: some segment broke down (r.z <= 0)
+        w.g->max_iter = mi;
     }
 }
 
@@ -404,7 +534,7 @@ extern "C" int nksr_spmv_csr(const int32_t* rowptr, const void* cols, const floa
 static int g_prof_enable = 0;
 static double g_prof_ms = 0.0;
 static long long g_prof_launches = 0;
-static double g_prof_alg_bytes = 0.0, g_prof_phys_bytes = 0.0;
+static double g_prof_alg_bytes = 0.0, g_prof_phys_bytes = 0.0, g_prof_survey_bytes = 0.0, g_prof_last_survey = 0.0;
 // several host threads may run solves at once (chunks on separate streams): every thread times with its own event pool and
 // adds to the shared accumulators under a lock
 static thread_local std::vector<hipEvent_t> g_prof_events;
@@ -423,8 +553,15 @@ extern "C" int nksr_pcg_profile_bytes(double* algorithmic_out, double* physical_
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     if (algorithmic_out) *algorithmic_out = g_prof_alg_bytes;
     if (physical_out) *physical_out = g_prof_phys_bytes;
-    g_prof_alg_bytes = g_prof_phys_bytes = 0.0;
+    g_prof_last_survey = g_prof_survey_bytes;
+    g_prof_alg_bytes = g_prof_phys_bytes = g_prof_survey_bytes = 0.0;
     return NKSR_OK;
+}
+// the same launches priced by SURVEY.md section 8d's formula (the CSR SpMV: identical to the algorithmic figure; the matrix-free
+// operator: 16 bytes per stored entry, which it does not move) -- the value of the last nksr_pcg_profile_bytes call
+extern "C" double nksr_pcg_profile_survey_bytes(void) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    return g_prof_last_survey;
 }
 
 extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out) {
@@ -445,30 +582,62 @@ extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_ou
 // number of Jacobi-preconditioned Chebyshev steps -- a fixed polynomial in A_cc, hence a constant SPD preconditioner (plain CG
 // stays valid) and deterministic.  One kernel per step, one wavefront per row:
 //   t = (A_cc d)_j;  y_j += d_j;  res_j -= t;  d'_j = a d_j + b res_j / D_j          (d double-buffered: rows read their neighbours' d)
-__global__ void __launch_bounds__(256) k_cheb_init(int n, const float* __restrict__ r, const float* __restrict__ diag, float inv_theta,
+// Batched chunk solves: A_cc is block diagonal, every segment has its own eigenvalue bound and therefore its own polynomial
+// (coefficient table coef[segment][1 + 2 i], row_seg = segment of every coarse row).
+#define CHEB_STRIDE (1 + 2 * NKSR_PC_MAX_STEPS)
+
+// coef[c] = { 1 / theta, a_0, b_0, a_1, b_1, ... } for the interval [lmax / ratio, lmax], lmax = scale * lambda[c]; a segment without
+// a usable bound (no constraint rows on its coarse levels) gets { 1, 0, 0, ... }: one Jacobi step
+__global__ void k_cheb_coeffs(int nseg, const float* __restrict__ lambda, float scale, float ratio, int steps, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nseg) return;
+    float* o = coef + (int64_t)c * CHEB_STRIDE;
+    const double lmax = (double)scale * (double)lambda[c];
+    if (!(lmax > 0.0) || !(lmax < 1e30)) {
+        o[0] = 1.f;
+        for (int i = 0; i < steps; ++i) { o[1 + 2 * i] = 0.f; o[2 + 2 * i] = 0.f; }
+        return;
+    }
+    const double lmin = lmax / (double)ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin), sigma = theta / delta;
+    double rho = 1.0 / sigma;
+    o[0] = (float)(1.0 / theta);
+    for (int i = 0; i < steps; ++i) {
+        const double rho_n = 1.0 / (2.0 * sigma - rho);
+        o[1 + 2 * i] = (float)(rho_n * rho);
+        o[2 + 2 * i] = (float)(2.0 * rho_n / delta);
+        rho = rho_n;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cheb_init(int n, const float* __restrict__ r, const float* __restrict__ diag,
+                                                   const float* __restrict__ coef, const int32_t* __restrict__ row_seg,
                                                    float* __restrict__ res, float* __restrict__ d0, float* __restrict__ y,
-                                                   const int* __restrict__ done) {
-    if (done && *done) return;
+                                                   const SegScalars* __restrict__ sc) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
+    const int seg = row_seg ? row_seg[j] : 0;
+    if (sc && sc[seg].done) return;
     const float rj = r[j];
     res[j] = rj;
-    d0[j] = rj / diag[j] * inv_theta;
+    d0[j] = rj / diag[j] * (coef ? coef[(int64_t)seg * CHEB_STRIDE] : 1.f);
     y[j] = 0.f;
 }
 
 __global__ void __launch_bounds__(256) k_cheb_step(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
-                                                   const float* __restrict__ vals, const float* __restrict__ diag, float a, float b,
+                                                   const float* __restrict__ vals, const float* __restrict__ diag,
+                                                   const float* __restrict__ coef, int step, const int32_t* __restrict__ row_seg,
                                                    float* __restrict__ res, const float* __restrict__ d_old, float* __restrict__ d_new,
-                                                   float* __restrict__ y, const int* __restrict__ done) {
-    if (done && *done) return;
+                                                   float* __restrict__ y, const SegScalars* __restrict__ sc) {
     const int j = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (j >= n) return;
+    const int seg = row_seg ? row_seg[j] : 0;
+    if (sc && sc[seg].done) return;
     // a wavefront's time is a chain of dependent load latencies (the block streams from L2 / HBM): everything that does not depend on
     // the row's entries is requested up front, and four 64-entry groups (rows hold ~190 entries) are in flight at once -- clamped
     // addresses instead of predicated loads, so that the compiler does not serialise them
     const int k0 = rowptr[j], k1 = rowptr[j + 1];
     const float dj = d_old[j], rs = res[j], dg = diag[j], yj = y[j];
+    const float a = coef[(int64_t)seg * CHEB_STRIDE + 1 + 2 * step], b = coef[(int64_t)seg * CHEB_STRIDE + 2 + 2 * step];
     float t[4] = {0.f, 0.f, 0.f, 0.f};
     for (int base = k0 + lane; base - lane < k1; base += 256) {
         float v[4];
@@ -521,93 +690,85 @@ __global__ void __launch_bounds__(256) k_coarse_power(int n, const int32_t* __re
     for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
     if (lane == 0) out[j] = t / dg;
 }
-// out = sqrt(sum b^2 / sum a^2), one workgroup, fixed order
-__global__ void __launch_bounds__(PCG_BLOCK) k_norm_ratio(int n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out) {
+// out[c] = sqrt(sum b^2 / sum a^2) over the coarse rows of segment c: one workgroup per segment, ranges in order, fixed strides
+// (segment-relative order).  Without segments: the whole block.
+__global__ void __launch_bounds__(PCG_BLOCK) k_norm_ratio(int n, int first, int nranges, const int32_t* __restrict__ lo,
+                                                          const int32_t* __restrict__ hi, const float* __restrict__ a,
+                                                          const float* __restrict__ b, float* __restrict__ out) {
     __shared__ double sm[PCG_BLOCK / 64];
+    const int c = blockIdx.x;
     double sa = 0.0, sb = 0.0;
-    for (int i = threadIdx.x; i < n; i += PCG_BLOCK) { sa += (double)a[i] * a[i]; sb += (double)b[i] * b[i]; }
+    for (int k = 0; k < nranges; ++k) {
+        int l = lo ? lo[c * nranges + k] - first : 0, h = lo ? hi[c * nranges + k] - first : n;
+        if (h > n) h = n;
+        if (l < 0) { if (h <= 0) continue; l = 0; }       // ranges of the fine levels lie below `first`
+        for (int i = l + threadIdx.x; i < h; i += PCG_BLOCK) { sa += (double)a[i] * a[i]; sb += (double)b[i] * b[i]; }
+    }
     const double ta = block_sum(sa, sm), tb = block_sum(sb, sm);
-    if (threadIdx.x == 0) out[0] = ta > 0.0 ? (float)sqrt(tb / ta) : 0.f;
+    if (threadIdx.x == 0) out[c] = ta > 0.0 ? (float)sqrt(tb / ta) : 0.f;
 }
 
 extern "C" int nksr_coarse_lambda_max(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n, int iters,
-                                      float* work, float* lambda_out, void* stream) {
+                                      float* work, float* lambda_out, const nksr_segments_t* seg, int32_t first, void* stream) {
     if (n <= 0) return NKSR_OK;
     if (!rowptr || !cols || !vals || !diag || !work || !lambda_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    if (seg && (seg->nseg < 1 || seg->nranges < 1 || !seg->lo || !seg->hi)) return nksr_set_error(NKSR_ERR_ARG, "bad segments");
     if (iters < 2) iters = 2;
     hipStream_t st = (hipStream_t)stream;
     float* v[2] = {work, work + n};
     const dim3 g1(nksr_blocks(n, 256)), gw(nksr_blocks((int64_t)n * 64, 256));
-    hipLaunchKernelGGL(k_cheb_init, g1, dim3(256), 0, st, n, diag, diag, 1.f, v[1], v[0], v[1], (const int*)nullptr);   // v0 = 1 (diag / diag)
+    hipLaunchKernelGGL(k_cheb_init, g1, dim3(256), 0, st, n, diag, diag, (const float*)nullptr, (const int32_t*)nullptr, v[1], v[0], v[1],
+                       (const SegScalars*)nullptr);   // v0 = 1 (diag / diag)
     for (int i = 0; i < iters; ++i)
         hipLaunchKernelGGL(k_coarse_power, gw, dim3(256), 0, st, n, rowptr, cols, vals, diag, (const float*)v[i & 1], v[(i + 1) & 1]);
-    hipLaunchKernelGGL(k_norm_ratio, dim3(1), dim3(PCG_BLOCK), 0, st, n, (const float*)v[(iters - 1) & 1], (const float*)v[iters & 1], lambda_out);
+    hipLaunchKernelGGL(k_norm_ratio, dim3(seg ? seg->nseg : 1), dim3(PCG_BLOCK), 0, st, n, seg ? first : 0, seg ? seg->nranges : 1,
+                       seg ? seg->lo : (const int32_t*)nullptr, seg ? seg->hi : (const int32_t*)nullptr, (const float*)v[(iters - 1) & 1],
+                       (const float*)v[iters & 1], lambda_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
 
-struct ChebPlan { int steps; float inv_theta; float a[NKSR_PC_MAX_STEPS], b[NKSR_PC_MAX_STEPS]; };
-static int cheb_plan(ChebPlan& P, const nksr_coarse_precond_t* pc) {
+static int cheb_check(const nksr_coarse_precond_t* pc, int nseg) {
     if (pc->n <= 0 || pc->steps < 1 || pc->steps > NKSR_PC_MAX_STEPS) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: 1..%d steps", NKSR_PC_MAX_STEPS);
-    if (!(pc->lambda_max > 0.f) || !(pc->ratio > 1.f)) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: lambda_max > 0, ratio > 1");
-    if (!pc->rowptr || !pc->cols || !pc->vals || !pc->diag || !pc->work) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner has NULL arrays");
-    const double lmax = pc->lambda_max, lmin = lmax / pc->ratio, theta = 0.5 * (lmax + lmin), delta = 0.5 * (lmax - lmin);
-    const double sigma = theta / delta;
-    double rho = 1.0 / sigma;
-    P.steps = pc->steps;
-    P.inv_theta = (float)(1.0 / theta);
-    for (int i = 0; i < pc->steps; ++i) {
-        const double rho_n = 1.0 / (2.0 * sigma - rho);
-        P.a[i] = (float)(rho_n * rho);
-        P.b[i] = (float)(2.0 * rho_n / delta);
-        rho = rho_n;
-    }
+    if (!(pc->lambda_scale > 0.f) || !(pc->ratio > 1.f)) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: lambda_scale > 0, ratio > 1");
+    if (!pc->rowptr || !pc->cols || !pc->vals || !pc->diag || !pc->work || !pc->lambda || !pc->coef) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner has NULL arrays");
+    if (nseg > 1 && !pc->row_seg) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: row_seg is required with more than one segment");
     return NKSR_OK;
 }
 // z_c = p_k(A_cc) r_c  (r, z: the coarse slices of the PCG vectors)
-static void cheb_apply(const nksr_coarse_precond_t* pc, const ChebPlan& P, const float* r, float* z, const int* done, hipStream_t st) {
+static void cheb_apply(const nksr_coarse_precond_t* pc, const float* r, float* z, const SegScalars* sc, hipStream_t st) {
     const int n = pc->n;
     float *res = pc->work, *d[2] = {pc->work + n, pc->work + 2 * (size_t)n};
-    hipLaunchKernelGGL(k_cheb_init, dim3(nksr_blocks(n, 256)), dim3(256), 0, st, n, r, pc->diag, P.inv_theta, res, d[0], z, done);
-    for (int i = 0; i < P.steps; ++i)
+    hipLaunchKernelGGL(k_cheb_init, dim3(nksr_blocks(n, 256)), dim3(256), 0, st, n, r, pc->diag, (const float*)pc->coef, pc->row_seg, res, d[0], z, sc);
+    for (int i = 0; i < pc->steps; ++i)
         hipLaunchKernelGGL(k_cheb_step, dim3(nksr_blocks((int64_t)n * 64, 256)), dim3(256), 0, st, n, pc->rowptr, pc->cols, pc->vals, pc->diag,
-                           P.a[i], P.b[i], res, (const float*)d[i & 1], d[(i + 1) & 1], z, done);
-}
-
-// partial r.z again (second column of part2) after the coarse slice of z changed; init: p = z as well
-__global__ void __launch_bounds__(PCG_BLOCK) k_pcg_rz(int M, PcgWork w, int copy_p) {
-    if (!copy_p && w.sc->done) return;
-    __shared__ double sm[PCG_BLOCK / 64];
-    double rz = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
-        const float zi = w.z[i];
-        if (copy_p) w.p[i] = zi;
-        rz += (double)w.r[i] * zi;
-    }
-    const double t = block_sum(rz, sm);
-    if (threadIdx.x == 0) w.part2[2 * blockIdx.x + 1] = t;
+                           (const float*)pc->coef, i, pc->row_seg, res, (const float*)d[i & 1], d[(i + 1) & 1], z, sc);
 }
 
 int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, float* x, float tol, int max_iter, int check_every,
-                 void* vector_workspace, double* info_out, hipStream_t st, const nksr_coarse_precond_t* pc) {
+                 void* vector_workspace, double* info_out, hipStream_t st, const nksr_coarse_precond_t* pc, const nksr_segments_t* seg) {
     if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
     if (!vector_workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
+    if (seg && (seg->nseg < 1 || seg->nranges < 1 || !seg->lo || !seg->hi)) return nksr_set_error(NKSR_ERR_ARG, "bad segments");
     if (check_every < 1) check_every = 1;
-    PcgWork w = carve(vector_workspace, M);
-    const int nbv = nksr_blocks(M, PCG_BLOCK) > PCG_MAX_BLOCKS ? PCG_MAX_BLOCKS : nksr_blocks(M, PCG_BLOCK);
-    ChebPlan plan;
+    PcgWork w = carve(vector_workspace, M, seg);
+    const dim3 gb(w.nb_max), blkd(PCG_BLOCK);
     if (pc) {
-        if (int rc = cheb_plan(plan, pc)) return rc;
+        if (int rc = cheb_check(pc, w.nseg)) return rc;
         if (pc->first < 0 || pc->first + pc->n != M) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: the block must be the last %d unknowns", pc->n);
+        hipLaunchKernelGGL(k_cheb_coeffs, dim3(nksr_blocks(w.nseg, 64)), dim3(64), 0, st, w.nseg, pc->lambda, pc->lambda_scale, pc->ratio, pc->steps, pc->coef);
     }
-    hipLaunchKernelGGL(k_pcg_init, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, b, diag, w, x);
+    hipLaunchKernelGGL(k_seg_count, dim3(nksr_blocks(w.nseg, 64)), dim3(64), 0, st, w);
+    hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1), 0, st, w);
+    hipLaunchKernelGGL(k_seg_fill, dim3(nksr_blocks((int64_t)w.nseg * w.nranges * 64, 256)), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(k_spcg_init, gb, blkd, 0, st, w, b, diag, x);
     if (pc) {
-        cheb_apply(pc, plan, w.r + pc->first, w.z + pc->first, nullptr, st);
-        hipLaunchKernelGGL(k_pcg_rz, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w, 1);
+        cheb_apply(pc, w.r + pc->first, w.z + pc->first, nullptr, st);
+        hipLaunchKernelGGL(k_spcg_rz, gb, blkd, 0, st, w, 1);
     }
-    hipLaunchKernelGGL(k_pcg_init_finish, dim3(1), dim3(PCG_BLOCK), 0, st, w, nbv);
+    hipLaunchKernelGGL(k_spcg_init_finish, dim3(w.nseg), blkd, 0, st, w);
     NKSR_CHECK_LAUNCH();
-    PcgScalars host;
+    PcgGlobal host;
     memset(&host, 0, sizeof(host));
     int launched = 0;
     const bool prof = g_prof_enable != 0;
@@ -622,51 +783,53 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
         for (int c = 0; c < chunk; ++c) {
             const int parity = (launched + c) & 1;
             if (prof) (void)hipEventRecord(g_prof_events[2 * c], st);
-            if (int rc = A.apply(w.p, w.y, &w.sc->done, st)) return rc;
+            if (int rc = A.apply(w.p, w.y, &w.g->done_all, w.nseg > 1 ? &w.sc[0].done : nullptr, (int)(sizeof(SegScalars) / sizeof(int)), st)) return rc;
             if (prof) (void)hipEventRecord(g_prof_events[2 * c + 1], st);
-            hipLaunchKernelGGL(k_pcg_dot, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w);
-            hipLaunchKernelGGL(k_pcg_update, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, diag, w, x, nbv, parity);
+            hipLaunchKernelGGL(k_spcg_dot, gb, blkd, 0, st, w);
+            hipLaunchKernelGGL(k_spcg_update, gb, blkd, 0, st, w, diag, x, parity);
             if (pc) {
-                cheb_apply(pc, plan, w.r + pc->first, w.z + pc->first, &w.sc->done, st);
-                hipLaunchKernelGGL(k_pcg_rz, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w, 0);
+                cheb_apply(pc, w.r + pc->first, w.z + pc->first, w.sc, st);
+                hipLaunchKernelGGL(k_spcg_rz, gb, blkd, 0, st, w, 0);
             }
-            hipLaunchKernelGGL(k_pcg_pupdate, dim3(nbv), dim3(PCG_BLOCK), 0, st, M, w, nbv, parity, tol);
+            hipLaunchKernelGGL(k_spcg_pupdate, gb, blkd, 0, st, w, parity, tol);
         }
+        hipLaunchKernelGGL(k_spcg_summary, dim3(1), blkd, 0, st, w, seg ? seg->info : (double*)nullptr);
         NKSR_CHECK_LAUNCH();
-        NKSR_CHECK_HIP(hipMemcpyAsync(&host, w.sc, sizeof(host), hipMemcpyDeviceToHost, st));
+        NKSR_CHECK_HIP(hipMemcpyAsync(&host, w.g, sizeof(host), hipMemcpyDeviceToHost, st));
         NKSR_CHECK_HIP(hipStreamSynchronize(st));
         if (prof) {
             // only applications that did real work (the done flag turns later ones into no-ops)
-            double ba, bp;
-            A.bytes(&ba, &bp);
+            double ba, bp, bs;
+            A.bytes(&ba, &bp, &bs);
             std::lock_guard<std::mutex> lock(g_prof_mutex);
-            for (int c = 0; c < chunk && launched + c < host.iter; ++c) {
+            for (int c = 0; c < chunk && launched + c < host.max_iter; ++c) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, g_prof_events[2 * c], g_prof_events[2 * c + 1]) == hipSuccess) {
                     g_prof_ms += ms;
                     g_prof_launches += 1;
                     g_prof_alg_bytes += ba;
                     g_prof_phys_bytes += bp;
+                    g_prof_survey_bytes += bs;
                 }
             }
         }
         launched += chunk;
-        if (host.done) break;
+        if (host.done_all) break;
     }
     if (info_out) {
-        info_out[0] = (double)host.iter;
-        info_out[1] = host.rel;
+        info_out[0] = (double)host.max_iter;
+        info_out[1] = host.max_rel;          // negative: a segment stopped on r.z <= 0 (preconditioner lost definiteness)
     }
     return NKSR_OK;
 }
 
 struct CsrOperator : PcgOperator {
     const int32_t* rowptr; const void* cols; const float* vals; int M; int64_t nnz; int fmt; SpmvPlan plan;
-    int apply(const float* p, float* y, const int* done, hipStream_t st) override {
+    int apply(const float* p, float* y, const int* done, const int*, int, hipStream_t st) override {
         launch_spmv(rowptr, cols, vals, M, nnz, fmt, plan, p, y, done, st);
         return NKSR_OK;
     }
-    void bytes(double* a, double* ph) override { spmv_bytes(M, nnz, fmt, a, ph); }
+    void bytes(double* a, double* ph, double* sv) override { spmv_bytes(M, nnz, fmt, a, ph); *sv = *a; }
 };
 
 extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, const float* diag, int32_t M,

@@ -25,6 +25,16 @@ def world():
     return (dist.get_rank(), dist.get_world_size()) if is_dist() else (0, 1)
 
 
+def active():
+    """True when the collectives below really run: a process group of more than one rank -- or of ONE rank with
+    NKSR_DIST_FORCE=1, which pushes the whole exchange / gather path through the backend (RCCL on a single GPU: the
+    first time RCCL touches these buffers must not be an 8-GPU run)."""
+    import os
+    if not is_dist():
+        return False
+    return world()[1] > 1 or os.environ.get('NKSR_DIST_FORCE', '') == '1'
+
+
 def _morton3(x, y, z):
     k = 0
     for b in range(21):
@@ -91,7 +101,7 @@ def all_gather_tensors(tensors):
     tensors, on the device of the inputs."""
     import torch.distributed as dist
     rank, ws = world()
-    if ws == 1:
+    if not active():
         return [list(tensors)]
     src_dev = tensors[0].device
     dev = _comm_device(tensors[0])
@@ -127,7 +137,7 @@ def gather_tensors(tensors, dst=0):
     transfers (batched isend / irecv) -- the other ranks receive nothing.  Returns the per-rank lists on ``dst``, None elsewhere."""
     import torch.distributed as dist
     rank, ws = world()
-    if ws == 1:
+    if not active():
         return [list(tensors)]
     src_dev = tensors[0].device
     dev = _comm_device(tensors[0])
@@ -156,7 +166,7 @@ def exchange_payloads(local, expected_ids=None):
     """``local``: {chunk_id: (int64 tensor, float32 tensor)} for the chunks this rank owns.
     Returns the same dict for ALL chunks on every rank (one size collective + one byte collective)."""
     rank, ws = world()
-    if ws == 1:
+    if not active():
         return dict(local)
     ids = sorted(local)
     dev = local[ids[0]][0].device if ids else _default_device()     # an idle rank still takes part in the collectives
@@ -222,7 +232,7 @@ def gather_meshes(v, f, vkey, axis, dst=0):
     """Gathers the per-rank mesh pieces on rank ``dst`` ONLY (point-to-point, after one size collective); ``dst`` merges
     the seams and returns the full mesh, the other ranks keep their own piece."""
     rank, ws = world()
-    if ws == 1:
+    if not active():
         return v, f
     got = gather_tensors([v.reshape(-1).contiguous(), f.reshape(-1).contiguous(), vkey.contiguous(), axis.to(torch.int8).contiguous()], dst)
     if rank != dst:

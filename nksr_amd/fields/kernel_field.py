@@ -18,13 +18,46 @@ import time
 import torch
 
 from .. import _lib, ops
-from .._lib import CoarsePrecondT, FusedOpT, HierT, SiteSetT, call, ptr, stream
+from .._lib import PC_MAX_STEPS, CoarsePrecondT, FusedOpT, HierT, SegmentsT, SiteSetT, call, ptr, stream
 from .base_field import BaseField, EvaluationResult
 
 
 def pack_interpolator(interp):
     """Flat fp32 weights W1[H,K] b1[H] W2[H,H] b2[H] W3[K,H] b3[K] of one level."""
     return interp.packed()
+
+
+class Segments:
+    """Independent diagonal blocks of ONE hierarchy (nksr_segments_t): the chunks of a batched chunk solve.  Segment i owns
+    the Morton key range [key_lo[i], key_hi[i]) of the finest level (an aligned cube of the lattice: its ancestors' ranges are the
+    shifted ones), hence one contiguous run of voxels per level and one contiguous run of the Morton-sorted sites.  Everything is
+    derived on the device (searchsorted), no host sync."""
+
+    def __init__(self, svh, key_lo, key_hi, ids=None):
+        dev = svh.device
+        self.key_lo, self.key_hi = key_lo.to(dev, torch.int64).contiguous(), key_hi.to(dev, torch.int64).contiguous()
+        self.nseg, self.nranges = int(self.key_lo.numel()), svh.depth
+        self.ids = list(ids) if ids is not None else list(range(self.nseg))
+        off = svh.offsets
+        lo, hi, segs = [], [], []
+        for d in range(svh.depth):
+            k = svh.level(d).keys
+            a = torch.searchsorted(k, self.key_lo >> (3 * d))
+            b = torch.searchsorted(k, self.key_hi >> (3 * d))
+            lo.append(a + off[d])
+            hi.append(b + off[d])
+            segs.append(torch.bucketize(k, self.key_lo >> (3 * d), right=True) - 1)
+        self.lo = torch.stack(lo, 1).to(torch.int32).contiguous()          # [nseg, L]
+        self.hi = torch.stack(hi, 1).to(torch.int32).contiguous()
+        self.unknown_seg = torch.cat(segs).to(torch.int32).contiguous()     # [M]
+        self.info = torch.zeros((self.nseg, 2), dtype=torch.float64, device=dev)
+        self.c = SegmentsT()
+        self.c.nseg, self.c.nranges = self.nseg, self.nranges
+        self.c.lo, self.c.hi, self.c.info = ptr(self.lo), ptr(self.hi), ptr(self.info)
+
+    def of_keys(self, keys0):
+        """segment of level-0 Morton keys"""
+        return torch.bucketize(keys0, self.key_lo, right=True) - 1
 
 
 class KernelField(BaseField):
@@ -49,9 +82,27 @@ class KernelField(BaseField):
             call('nksr_voxel_psi', ptr(f), n, self.kdim, self.hidden, ptr(self._mlp[d]), ptr(psi), stream())
             self._feat.append(f)
             self._psi.append(psi)
+        self._apsi_key = None
         self.alpha = torch.zeros(svh.num_unknowns, dtype=torch.float32, device=dev)
         self._hier = self._make_hier()
         self.matrix = None  # (rowptr, cols, vals, diag) of the last non-fused solve
+
+    # alpha is written by HIP kernels through raw pointers (no torch version bump) and the caching allocator recycles
+    # addresses, so the evaluation cache (_alpha_hier) is keyed on ASSIGNMENT: every ``fld.alpha = ...`` drops it
+    @property
+    def alpha(self):
+        return self._alpha
+
+    @alpha.setter
+    def alpha(self, value):
+        self._alpha = value
+        self._apsi_key = None
+        self._apsi = self._apsi_hier = None
+
+    def invalidate_alpha_cache(self):
+        """Call after writing into ``alpha``'s storage in place (kernels, ``alpha[...] = ``)."""
+        self._apsi_key = None
+        self._apsi = self._apsi_hier = None
 
     # ---- C struct describing the hierarchy + features ------------------------------------------
     def _make_hier(self):
@@ -75,7 +126,7 @@ class KernelField(BaseField):
         n, L = xyz.shape[0], self.svh.depth
         val = torch.empty((n, L, 27), dtype=torch.float32, device=self.device) if values else None
         dval = torch.empty((n, 3, L, 27), dtype=torch.float32, device=self.device) if grad else None
-        call('nksr_kernel_rows', C.byref(hier if hier is not None else self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), 0, None, None,
+        call('nksr_kernel_rows', C.byref(hier if hier is not None else self._hier), ptr(xyz), n, int(self.approx_kernel_grad), float(scale), None, 0, None, None,
              ptr(val), ptr(dval), stream())
         return val, dval
 
@@ -91,11 +142,11 @@ class KernelField(BaseField):
                 h.lv[d].offset = off[d] - off[c0]
         return h
 
-    def kernel_rows_level_major(self, xyz, grad, scale, out, level_stride, row_index=None, row_cells=None):
+    def kernel_rows_level_major(self, xyz, grad, scale, out, level_stride, row_index=None, row_cells=None, site_scale=None):
         """Rows of the sites ``xyz`` written LEVEL-MAJOR into ``out`` ([L, level_stride, 27]): position rows (grad=False, one per
         site) or gradient rows (three per site), site i at row ``row_index[i]`` (default i * rows-per-site); ``row_cells``
         [L, level_stride] receives the level-d cell (global unknown index) of every row written."""
-        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), xyz.shape[0], int(self.approx_kernel_grad), float(scale), int(level_stride),
+        call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), xyz.shape[0], int(self.approx_kernel_grad), float(scale), ptr(site_scale), int(level_stride),
              ptr(row_index), ptr(row_cells), None if grad else ptr(out), ptr(out) if grad else None, stream())
 
     def _sorted_sites(self, xyz):
@@ -260,7 +311,7 @@ class KernelField(BaseField):
 
     # ---- matrix-free ("fused") solve ---------------------------------------------------------------------
     def fused_operator(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, pos_sorted_keys=None, normal_sorted_keys=None,
-                       pos_value=None):
+                       pos_value=None, segments=None):
         """Everything the matrix-free operator needs (csrc/fused.hip, nksr_fused_op_t): the level-major kernel rows of both
         site sets in one array (pre-multiplied by sqrt(weight)), their targets, the global neighbour table and the work
         items.  Returns a dict; ``keep`` holds the buffers the C struct points into."""
@@ -274,7 +325,8 @@ class KernelField(BaseField):
                                                  (normal_xyz, normal_value, normal_weight, 3, normal_sorted_keys)):
             if xyz is None or xyz.shape[0] == 0:
                 continue
-            if not float(weight) >= 0.0:
+            per_site = torch.is_tensor(weight)            # batched chunks: every site carries its own chunk's sqrt(weight)
+            if not per_site and not float(weight) >= 0.0:
                 raise RuntimeError('solver weights must be >= 0')
             xyz = xyz.to(dev, torch.float32).contiguous()
             if pre is not None:
@@ -282,21 +334,46 @@ class KernelField(BaseField):
             else:
                 ks, perm = self._sorted_sites(xyz)
                 xs = xyz[perm].contiguous()
-            specs.append((xs, ks, perm, target, float(weight) ** 0.5, ncomp))
+            if per_site:
+                sw = weight.to(dev, torch.float32)
+                sw = (sw[perm] if perm is not None else sw).contiguous()
+            else:
+                sw = float(weight) ** 0.5
+            specs.append((xs, ks, perm, target, sw, ncomp))
         if not specs:
             raise RuntimeError('no constraint sites')
         # ONE Morton-ordered row list for all site sets (stable sort of the sites' level-0 keys; a position site owns one row, a
         # normal site three): the rows of a cell -- of both sets -- are then one contiguous run at every level
         counts_s = [sp[0].shape[0] for sp in specs]
         rows_total = sum(n * sp[5] for n, sp in zip(counts_s, specs))
-        if len(specs) == 1:
+        nsite = sum(counts_s)
+        pad_rows = item_seg = None
+        if len(specs) == 1 and segments is None:
             row_index = [torch.arange(counts_s[0], dtype=torch.int32, device=dev) * specs[0][5]]
         else:
-            nsite = sum(counts_s)
-            _, order = ops.sort_pairs(torch.cat([sp[1] for sp in specs]), torch.arange(nsite, dtype=torch.int32, device=dev))
+            ks_all, order = ops.sort_pairs(torch.cat([sp[1] for sp in specs]), torch.arange(nsite, dtype=torch.int32, device=dev))
             order = order.long()
             ncomp_site = torch.cat([torch.full((n,), sp[5], dtype=torch.int32, device=dev) for n, sp in zip(counts_s, specs)])
-            first_row = ops.exclusive_sum_i32(torch.cat([ncomp_site[order], ncomp_site.new_zeros(1)]))[:nsite]
+            first_row = ops.exclusive_sum_i32(torch.cat([ncomp_site[order], ncomp_site.new_zeros(1)]))       # [nsite + 1]
+            if segments is not None:
+                # every segment's rows start on a work-item boundary (32 rows): the partial blocks of a cell -- and with them every
+                # summation order of the operator -- are then the same whether the segment is solved alone or with others.
+                # Pad rows have no cell (row_cells = -1) and zero values.
+                sb = torch.searchsorted(ks_all, torch.cat([segments.key_lo, segments.key_hi[-1:]]))            # site bounds [nseg + 1]
+                sb[-1] = nsite
+                rb = first_row[sb].long()                                                                       # unpadded row bounds
+                rows_seg = rb[1:] - rb[:-1]
+                pad = (-rows_seg) % 32
+                pad_before = torch.cumsum(pad, 0) - pad
+                first_row = first_row[:nsite] + pad_before[segments.of_keys(ks_all)].to(torch.int32)
+                ends = rb[1:] + pad_before                                                                      # first pad row of every segment
+                pad_rows = (ends[:, None] + torch.arange(31, device=dev)[None])[torch.arange(31, device=dev)[None] < pad[:, None]]
+                rows_total = rows_total + int(pad.sum().item())
+                # segment of every 32-row work item (the solve skips the items of converged segments)
+                item_start = (rb[:-1] + pad_before) // 32
+                item_seg = (torch.bucketize(torch.arange(rows_total // 32 + 2, device=dev), item_start, right=True) - 1).clamp_(0, segments.nseg - 1).to(torch.int32)
+            else:
+                first_row = first_row[:nsite]
             row_of_site = torch.empty(nsite, dtype=torch.int32, device=dev)
             row_of_site[order] = first_row
             row_index = list(torch.split(row_of_site, counts_s))
@@ -305,13 +382,20 @@ class KernelField(BaseField):
         rows_all[L * rows_total * 27:].zero_()
         row_cells = torch.empty((L, rows_total), dtype=torch.int32, device=dev)
         targets_all = torch.zeros(rows_total, dtype=torch.float32, device=dev)
+        if pad_rows is not None and pad_rows.numel():
+            row_cells[:, pad_rows] = -1
+            rows_all[:L * rows_total * 27].view(L, rows_total, 27)[:, pad_rows] = 0.0
         keep = [rows_all, targets_all, row_cells]
         for (xs, ks, perm, target, sw, ncomp), ri in zip(specs, row_index):
             ri = ri.contiguous()
-            self.kernel_rows_level_major(xs, ncomp == 3, sw, rows_all, rows_total, ri, row_cells)
+            if torch.is_tensor(sw):
+                self.kernel_rows_level_major(xs, ncomp == 3, 1.0, rows_all, rows_total, ri, row_cells, site_scale=sw)
+            else:
+                self.kernel_rows_level_major(xs, ncomp == 3, sw, rows_all, rows_total, ri, row_cells)
             if target is not None:
                 tgt = target.detach().to(dev, torch.float32)
-                tgt = ((tgt[perm] if perm is not None else tgt) * sw).reshape(xs.shape[0], ncomp)      # row order (site, component)
+                tgt = (tgt[perm] if perm is not None else tgt).reshape(xs.shape[0], ncomp)
+                tgt = tgt * (sw[:, None] if torch.is_tensor(sw) else sw)                               # row order (site, component)
                 targets_all[(ri.long()[:, None] + torch.arange(ncomp, device=dev)[None]).reshape(-1)] = tgt.reshape(-1)
             keep += [xs, ri]
         # work items = runs of 32 rows; a cell owns one partial block per item its rows touch
@@ -334,6 +418,9 @@ class KernelField(BaseField):
         # neighbours, B-spline support ends): the set-up pass counts the non-zero slots on its way (read back on demand)
         nnz_counter = torch.zeros(1, dtype=torch.int64, device=dev)
         op.nnz_counter = ptr(nnz_counter)
+        if item_seg is not None:
+            op.item_seg, op.unknown_seg = ptr(item_seg), ptr(segments.unknown_seg)
+            keep += [item_seg, segments.unknown_seg]
         keep += [nbr32, offsets, multi, ws, cell_sums, nnz_counter]
         return {'op': op, 'nsets': len(specs), 'nblocks': nblocks, 'rows_total': rows_total, 'n_multi': int(multi.numel()),
                 'nnz_counter': nnz_counter, 'keep': keep, 'span': span, 'rows_all': rows_all}
@@ -356,10 +443,11 @@ class KernelField(BaseField):
         call('nksr_fused_apply', C.byref(op['op']), float(reg_weight), ptr(x.contiguous()), ptr(y), stream())
         return y
 
-    def _coarse_precond(self, op, reg_weight):
+    def _coarse_precond(self, op, reg_weight, segments=None):
         """Block preconditioner of the coarse levels (nksr_coarse_precond_t, csrc/pcg.hip): the diagonal block of the levels >= c0
-        assembled as a small plain CSR + its largest Jacobi-scaled eigenvalue.  solver_config['coarse_precond']: None = automatic
-        (see solve_fused), False = off, or a dict {'first_level', 'steps', 'ratio'}."""
+        assembled as a small plain CSR + the largest Jacobi-scaled eigenvalue of every segment's block (left on the device: no
+        host sync).  solver_config['coarse_precond']: None = automatic (see solve_fused), False = off, or a dict
+        {'first_level', 'steps', 'ratio'}."""
         cfg = self.solver_config.get('coarse_precond')
         L = self.svh.depth
         if cfg is False:
@@ -374,26 +462,31 @@ class KernelField(BaseField):
         if not 0 < c0 < L or M - off[c0] < 1:
             return None
         n = M - off[c0]
+        nseg = segments.nseg if segments is not None else 1
         rowptr, cols, vals, diag, _ = self.assemble(None, None, None, 1.0, 1.0, reg_weight, coarse_from=c0, fused_op=op)
         work = torch.empty(3 * n, dtype=torch.float32, device=self.device)
-        lam = torch.empty(1, dtype=torch.float32, device=self.device)
-        call('nksr_coarse_lambda_max', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), n, 8, ptr(work), ptr(lam), stream())
-        lmax = 1.1 * float(lam.item())          # eight power-iteration steps from the all-ones vector land within ~1 % (measured): 10 % margin
-        if not (lmax > 0.0 and lmax < float('inf')):        # degenerate block (no constraint rows on these levels): Jacobi only
-            return None
+        lam = torch.empty(nseg, dtype=torch.float32, device=self.device)
+        coef = torch.empty(nseg * (1 + 2 * PC_MAX_STEPS), dtype=torch.float32, device=self.device)
+        row_seg = segments.unknown_seg[off[c0]:].contiguous() if segments is not None else None
+        # eight power-iteration steps from the all-ones vector land within ~1 % (measured): 10 % margin.  A segment whose block is
+        # degenerate (no constraint rows on these levels: lambda <= 0) keeps Jacobi -- decided on the device (k_cheb_coeffs)
+        call('nksr_coarse_lambda_max', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), n, 8, ptr(work), ptr(lam),
+             C.byref(segments.c) if segments is not None else None, off[c0], stream())
         pc = CoarsePrecondT()
-        pc.first, pc.n, pc.steps, pc.lambda_max, pc.ratio = off[c0], n, int(cfg.get('steps', 8)), lmax, float(cfg.get('ratio', 100.0))
+        pc.first, pc.n, pc.steps, pc.lambda_scale, pc.ratio = off[c0], n, int(cfg.get('steps', 8)), 1.1, float(cfg.get('ratio', 100.0))
+        pc.lambda_, pc.row_seg, pc.coef = ptr(lam), ptr(row_seg), ptr(coef)
         pc.rowptr, pc.cols, pc.vals, pc.diag, pc.work = ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), ptr(work)
-        return {'pc': pc, 'first_level': c0, 'unknowns': n, 'nnz': int(cols.numel()), 'steps': int(pc.steps), 'lambda_max': lmax,
-                'keep': (rowptr, cols, vals, diag, work)}
+        return {'pc': pc, 'first_level': c0, 'unknowns': n, 'nnz': int(cols.numel()), 'steps': int(pc.steps), 'lambda': lam,
+                'keep': (rowptr, cols, vals, diag, work, lam, coef, row_seg)}
 
     def solve_fused(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0,
-                    pos_sorted_keys=None, normal_sorted_keys=None):
+                    pos_sorted_keys=None, normal_sorted_keys=None, segments=None):
         """Matrix-free Jacobi-PCG on the normal equations: no assembly, ~8 bytes per dense kernel-row slot per
         iteration (examples/recons_waymo.py:33 ``fused_mode=True``).  Same system, same stopping rule as
         solve_non_fused; the iterates agree to fp32 rounding (different summation order)."""
         t0 = time.perf_counter()
-        op = self.fused_operator(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, pos_sorted_keys, normal_sorted_keys)
+        op = self.fused_operator(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, pos_sorted_keys, normal_sorted_keys,
+                                 segments=segments)
         dev = self.device
         M = self.svh.num_unknowns
         b, diag = self.fused_rhs_diag(op, reg_weight)
@@ -403,18 +496,26 @@ class KernelField(BaseField):
         # needs ~47 iterations per tree_depth-5 chunk); shallower ones start with Jacobi -- the 1M-point headline converges in 11
         # iterations, a set-up would not pay -- and switch after one unconverged round of check_every iterations (sparse /
         # sensor-only inputs and adaptive_depth 2 take 100+ Jacobi iterations at depth 4 too).
-        auto = cfg.get('coarse_precond') is None
-        pc = self._coarse_precond(op, reg_weight) if (not auto or self.svh.depth >= 5) else None
+        # Batched chunk solves (``segments``) always take the block at once: a restart decided on the joint residual would make a
+        # chunk's iterates depend on its batch mates.
+        auto = cfg.get('coarse_precond') is None and segments is None
+        pc = self._coarse_precond(op, reg_weight, segments) if (not auto or self.svh.depth >= 5) else None
         if cfg.get('verbose') or cfg.get('sync_timing'):
             torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
-        pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=dev)
+        nseg = segments.nseg if segments is not None else 1
+        pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes_seg(M, nseg, self.svh.depth if segments is not None else 1)),
+                          dtype=torch.uint8, device=dev)
 
         def pcg(rhs, rtol, iters, precond):
             sol = torch.empty(M, dtype=torch.float32, device=dev)
             inf = (C.c_double * 2)()
             call('nksr_pcg_solve_fused', C.byref(op['op']), float(reg_weight), ptr(diag), ptr(rhs), ptr(sol), float(rtol), int(iters),
-                 check_every, ptr(pws), C.byref(precond['pc']) if precond else None, inf, stream())
+                 check_every, ptr(pws), C.byref(precond['pc']) if precond else None, C.byref(segments.c) if segments is not None else None,
+                 inf, stream())
+            if inf[1] < 0:      # a segment stopped on r.z <= 0: the Chebyshev block lost definiteness (eigenvalue bound too small)
+                raise RuntimeError('PCG breakdown (r.z <= 0 after %d iterations, relative residual %.3e): coarse-level preconditioner '
+                                   'is not positive definite -- set solver_config["coarse_precond"] = False' % (int(inf[0]), -inf[1]))
             return sol, int(inf[0]), float(inf[1])
         if pc is not None or not auto or max_iter <= check_every:
             x, iters, rel = pcg(b, tol, max_iter, pc)
@@ -440,7 +541,8 @@ class KernelField(BaseField):
         self.nnz = 0
         self.solve_info = {'iters': int(info[0]), 'rel_residual': float(info[1]), 'M': int(M), 'nnz': 0, 'fused': True,
                            'kernel_row_slots': 27 * self.svh.depth * op['rows_total'], 'partial_blocks': op['nblocks'],
-                           'coarse_precond': ({k: pc[k] for k in ('first_level', 'unknowns', 'nnz', 'steps', 'lambda_max')} if pc else None),
+                           'coarse_precond': ({k: pc[k] for k in ('first_level', 'unknowns', 'nnz', 'steps', 'lambda')} if pc else None),
+                           'segments': nseg, 'segment_info': segments.info if segments is not None else None,
                            't_assemble': t1 - t0, 't_pcg': t2 - t1}
         if self.solver_config.get('verbose'):
             print('[KernelField] fused: M=%d rows=%d iters=%d rel=%.3e rows+rhs=%.3fs pcg=%.3fs' % (
@@ -465,7 +567,7 @@ class KernelField(BaseField):
         pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=self.device)
         info = (C.c_double * 2)()
         call('nksr_pcg_solve_fused', C.byref(self._fused_op['op']), self._fused_reg, ptr(self.diag), ptr(rhs.contiguous()), ptr(x), float(cfg['tol']),
-             int(cfg['max_iter']), int(cfg['check_every']), ptr(pws), None, info, stream())
+             int(cfg['max_iter']), int(cfg['check_every']), ptr(pws), None, None, info, stream())
         return x
 
     def _theta(self):
@@ -527,13 +629,15 @@ class KernelField(BaseField):
         return [gr if gr is not None else torch.zeros_like(t) for gr, t in zip(grads, theta)]
 
     def solve(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0, fused_mode=True,
-              pos_sorted_keys=None, normal_sorted_keys=None):
+              pos_sorted_keys=None, normal_sorted_keys=None, segments=None):
         """``fused_mode=True`` (the reference's memory-lean operator, examples/recons_waymo.py:33): matrix-free solve,
         no assembly; ``False``: assemble the CSR and stream it (solve_non_fused -- the path the training code needs,
         models/nksr_net.py:105-112).  DESIGN.md section 3.5 has the cost model of the two."""
         if fused_mode:
             return self.solve_fused(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight,
-                                    pos_sorted_keys, normal_sorted_keys)
+                                    pos_sorted_keys, normal_sorted_keys, segments=segments)
+        if segments is not None and segments.nseg > 1:
+            raise RuntimeError('batched chunk solves run through the matrix-free solve (fused_mode=True)')
         return self.solve_non_fused(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight,
                                     pos_sorted_keys, normal_sorted_keys)
 
@@ -547,8 +651,8 @@ class KernelField(BaseField):
     def _alpha_hier(self, alpha):
         """A copy of the hierarchy whose psi arrays hold alpha_j psi_j: evaluation then gathers ONE 16-byte value per neighbour
         (these per-point kernels are bound by the number of gather instructions).  Rebuilt when alpha changes."""
-        key = (alpha.data_ptr(), alpha._version, self.device)
-        if getattr(self, '_apsi_key', None) != key:
+        key = (alpha.data_ptr(), alpha._version, str(self.device))
+        if self._apsi_key != key:
             off = self.svh.offsets
             self._apsi = [(self._psi[d] * alpha[off[d]:off[d] + self._psi[d].shape[0], None]).contiguous() for d in range(self.svh.depth)]
             h = HierT.from_buffer_copy(self._hier)
@@ -582,8 +686,9 @@ class KernelField(BaseField):
         self._feat = [t.to(device) for t in self._feat]
         self._psi = [t.to(device) for t in self._psi]
         self._mlp = [t.to(device) for t in self._mlp]
-        self.alpha = self.alpha.to(device)
+        self.alpha = self.alpha.to(device)           # (the setter drops the evaluation cache: it points into the old arrays)
         self.matrix = None
+        self._fused_op = None
         if device.type == 'cuda':
             self._hier = self._make_hier()
         if self.mask_field is not None:

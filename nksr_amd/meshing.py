@@ -44,35 +44,39 @@ def _extract(field, mise_iter, grid_upsample, max_points):
     empty = MeshingResult(torch.zeros((0, 3), dtype=torch.float32, device=dev), torch.zeros((0, 3), dtype=torch.int64, device=dev))
     empty.edge_vkey = torch.zeros(0, dtype=torch.int64, device=dev)
     empty.edge_axis = torch.zeros(0, dtype=torch.int8, device=dev)
-    if g0.num_voxels == 0:
-        return empty
     batch = max_points if (max_points is not None and max_points > 0) else (1 << 22)
     if U < 1 or mise_iter < 0:
         raise RuntimeError('grid_upsample must be >= 1 and mise_iter >= 0')
+    owned_only = hasattr(field, 'base_cell_mask') and getattr(field, 'world_size', 1) > 1
+    # levels whose dual cells are meshed: the finest, and -- LayerField(dec_svh, adaptive_depth), models/nksr_net.py:132 -- the coarser
+    # ones below adaptive_depth, which cover what the finest level leaves open (a structure head that stops at level 1, or input
+    # sparser than the finest voxels): their extent at the SAME lattice resolution -- one uniform lattice over the adaptive
+    # support, so there are no level transitions to stitch
+    adaptive = max(1, min(int(getattr(field, 'meshing_depth', 1)), svh.depth))
+    levels = [d for d in range(adaptive) if svh.level(d).num_voxels > 0]
+    if not levels:
+        return empty
     # lattice / cell keys are 21-bit-per-axis Morton codes biased by 2^20 (csrc/meshing.hip): the refined lattice
     # coordinate ijk * U * 2^mise_iter (+ one cell) must stay inside, or keys would wrap silently
-    reach = (int(g0.ijk.abs().max()) + 4) * U * (1 << int(mise_iter)) + 2
+    reach = max(((int(svh.level(d).ijk.abs().max()) + 4) << d) for d in levels) * U * (1 << int(mise_iter)) + 2
     if reach >= (1 << 20):
         raise RuntimeError('mesh lattice out of range: |ijk| * grid_upsample * 2^mise_iter = %d >= 2^20; recentre the cloud '
                            '(or lower mise_iter / grid_upsample)' % reach)
 
-    flags = torch.empty(g0.num_voxels, dtype=torch.int32, device=dev)
-    call('nksr_base_cell_flags', ptr(g0.nbr), g0.num_voxels, ptr(flags), stream())
-    owned_only = hasattr(field, 'base_cell_mask') and getattr(field, 'world_size', 1) > 1
-    if owned_only:      # distributed fields: cells this rank owns + a one-cell halo (evaluated, not meshed)
-        flags = (flags * field.base_cell_halo_mask(g0.ijk).to(torch.int32)).contiguous()
-    sel = ops.compact(flags)
-    raw = torch.empty(sel.numel() * U ** 3, dtype=torch.int64, device=dev)
-    if sel.numel():
-        call('nksr_base_cell_keys', ptr(g0.ijk), ptr(sel), sel.numel(), U, ptr(raw), stream())
-    # dual cells of the coarser levels below adaptive_depth cover what the finest level leaves open (a structure head that
-    # stops at level 1, or input sparser than the finest voxels): their extent, at the SAME lattice resolution -- one
-    # uniform lattice over the adaptive support, so there are no level transitions to stitch
-    adaptive = 1 if owned_only else min(int(getattr(field, 'meshing_depth', 1)), svh.depth)
-    for d in range(1, adaptive):
-        gd = svh.level(d)
-        if gd.num_voxels == 0:
+    raw = torch.empty(0, dtype=torch.int64, device=dev)
+    if g0.num_voxels:
+        flags = torch.empty(g0.num_voxels, dtype=torch.int32, device=dev)
+        call('nksr_base_cell_flags', ptr(g0.nbr), g0.num_voxels, ptr(flags), stream())
+        if owned_only:      # distributed fields: cells this rank owns + a one-cell halo (evaluated, not meshed)
+            flags = (flags * field.base_cell_halo_mask(g0.ijk).to(torch.int32)).contiguous()
+        sel = ops.compact(flags)
+        raw = torch.empty(sel.numel() * U ** 3, dtype=torch.int64, device=dev)
+        if sel.numel():
+            call('nksr_base_cell_keys', ptr(g0.ijk), ptr(sel), sel.numel(), U, ptr(raw), stream())
+    for d in levels:
+        if d == 0:
             continue
+        gd = svh.level(d)
         fl = torch.empty(gd.num_voxels, dtype=torch.int32, device=dev)
         call('nksr_base_cell_flags', ptr(gd.nbr), gd.num_voxels, ptr(fl), stream())
         sd = ops.compact(fl)
@@ -80,6 +84,10 @@ def _extract(field, mise_iter, grid_upsample, max_points):
             S = U << d
             rd = torch.empty(sd.numel() * S ** 3, dtype=torch.int64, device=dev)
             call('nksr_level_cell_keys', ptr(gd.ijk), ptr(sd), sd.numel(), d, U, ptr(rd), stream())
+            if owned_only:  # the same ownership rule, on the finest voxel that contains the lattice cell
+                gc = torch.empty((rd.numel(), 3), dtype=torch.int32, device=dev)
+                call('nksr_decode_keys', ptr(rd), rd.numel(), -1, ptr(gc), stream())
+                rd = rd[field.base_cell_halo_mask(torch.div(gc, U, rounding_mode='floor').to(torch.int32))]
             raw = torch.cat([raw, rd])
     if raw.numel() == 0:
         return empty

@@ -33,6 +33,10 @@ from .._lib import call, ptr, stream
 from ..svh import SparseFeatureHierarchy, SparseGrid
 
 
+NORMAL_MIN_LENGTH = 1e-2     # a splatted mean normal shorter than this carries no orientation
+NORMAL_MIN_WEIGHT = 1e-3     # nor does the splat of a voxel the cloud barely touches (total trilinear weight)
+
+
 class Interpolator(nn.Module):
     """Per-level MLP  K -> H -> H -> K (ReLU) with a residual skip: phi = t + MLP(t)."""
 
@@ -266,11 +270,16 @@ class StructureUNet(nn.Module):
                     feat.udf_features[d] = pl + self.udf_heads[d](y)
                 # splat on the CANDIDATE grid (it holds every cell that contains a point; the gather
                 # form of the splat walks neighbour voxels), then keep the rows of surviving voxels
-                s, _ = splat_trilinear(cand.level(d), d, enc_svh.inv_w0, enc.keys, enc.xyz, enc.feat)
+                s, ws = splat_trilinear(cand.level(d), d, enc_svh.inv_w0, enc.keys, enc.xyz, enc.feat)
                 if dec_levels[d] is not cand.level(d):
-                    s = gather_rows(s, cand.level(d).hash.query(dec_levels[d].keys))
+                    sel = cand.level(d).hash.query(dec_levels[d].keys)
+                    s, ws = gather_rows(s, sel), ws[sel.long()]
                 nv = s + self.normal_heads[d](y)
-                feat.normal_features[d] = nv / nv.norm(dim=1, keepdim=True).clamp_min(1e-8)
+                # unit length -- unless the splatted normals cancel (|sum w n| < 1e-2 sum w: both sides of a thin sheet in one voxel)
+                # or the voxel is barely touched (sum w < 1e-3: a point on the edge of its stencil weighs 0 or 1e-8 depending on
+                # rounding): that vector is noise; it stays short instead of becoming an arbitrary unit target
+                den = torch.maximum(nv.norm(dim=1), NORMAL_MIN_LENGTH * ws).clamp_min(NORMAL_MIN_WEIGHT)
+                feat.normal_features[d] = nv / den[:, None]
         return feat, dec_svh, dec_svh
 
 

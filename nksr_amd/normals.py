@@ -62,6 +62,25 @@ def choose_cell_size(xyz, k):
     return max(math.sqrt(2.0 * k / (math.pi * rho)), probe / 8)
 
 
+class TooFewPoints(RuntimeError):
+    """Fewer points than the neighbourhood size: chunk mode treats such a chunk as empty (nksr_amd/chunking.py)."""
+
+
+def knn_pca(xyz, knn):
+    """Unoriented kNN-PCA normals: (PointGrid, normal [n,3], r2 [n], valid [n]) in the grid's Morton order (``pg.perm`` maps back).
+    ``r2`` is the squared distance of the k-th nearest neighbour (the point itself included): the neighbour SET of point i is
+    {j : |x_i - x_j|^2 <= r2_i} -- the kernel keeps no index lists, this is what the parity test compares with an exact kd-tree."""
+    n = xyz.shape[0]
+    pg = PointGrid(xyz, choose_cell_size(xyz, knn))
+    nrm = torch.empty((n, 3), dtype=torch.float32, device=xyz.device)
+    r2 = torch.empty(n, dtype=torch.float32, device=xyz.device)
+    valid = torch.empty(n, dtype=torch.int32, device=xyz.device)
+    h = pg.grid.hash
+    call('nksr_knn_pca_normals', ptr(pg.xyz), n, ptr(pg.start), ptr(pg.end), ptr(h.hkeys), ptr(h.hvals), h.cap, pg.cell,
+         pg.inv_cell, int(knn), 6, ptr(nrm), ptr(r2), ptr(valid), stream())
+    return pg, nrm, r2, valid
+
+
 def estimate_normals_knn(xyz, normal, sensor, knn=64, deg=85.0):
     """(xyz, normal=None, sensor) -> (xyz', normal', None), the preprocess_fn contract of
     examples/recons_waymo_cpu.py:21-41."""
@@ -71,14 +90,8 @@ def estimate_normals_knn(xyz, normal, sensor, knn=64, deg=85.0):
         raise RuntimeError('please provide sensor positions for consistent orientations')
     n = xyz.shape[0]
     if n < knn:
-        raise RuntimeError('need at least knn=%d points' % knn)
-    pg = PointGrid(xyz, choose_cell_size(xyz, knn))
-    nrm = torch.empty((n, 3), dtype=torch.float32, device=xyz.device)
-    r2 = torch.empty(n, dtype=torch.float32, device=xyz.device)
-    valid = torch.empty(n, dtype=torch.int32, device=xyz.device)
-    h = pg.grid.hash
-    call('nksr_knn_pca_normals', ptr(pg.xyz), n, ptr(pg.start), ptr(pg.end), ptr(h.hkeys), ptr(h.hvals), h.cap, pg.cell,
-         pg.inv_cell, int(knn), 6, ptr(nrm), ptr(r2), ptr(valid), stream())
+        raise TooFewPoints('need at least knn=%d points' % knn)
+    pg, nrm, r2, valid = knn_pca(xyz, knn)
     xs = pg.xyz
     ss = sensor.to(torch.float32)[pg.perm]
     view = ss - xs

@@ -27,16 +27,12 @@ class Reconstructor:
         self.chunk_tmp_device = self.device
         self.timing = {}
         self.sync_timing = False   # insert stream syncs so that per-stage wall times are exact
-        # chunk mode: chunks can be solved concurrently on this many HIP streams (one host thread each; bit-identical results).
-        # Measured on configs[4] (64 chunks of ~260 k points, one MI355X, matrix-free solve, end of round 2; pairs taken on the same
-        # box): 1 stream 1.08 s, 2 streams 1.08 / 1.26 / 1.20 s, 3 streams 1.00 / 0.94 / 0.91 s, 4 streams 1.02 s -- the kernels
-        # of one chunk fill the GPU less than half the time (chains of short launches with host round trips in between), a third
-        # stream keeps it busy, a fourth adds host-thread contention (GIL, per-stream allocator pools).  Assembled solve:
-        # 1.96 / 1.90 / 2.32 (3 streams) / 6.0 s (4): two of its solves at once already fight over their 11 GB workspaces.
-        # None = 3 for the matrix-free solve, 1 for the assembled one
-        self.chunk_streams = None
+        # chunk mode: ALL chunks of a rank are solved as one block-diagonal system (nksr_amd/chunking.py); chunk_batch_points caps the
+        # points (band included) of one such batch -- ~2 KB of HBM per point at tree_depth 5 -- None = 2^25.  Results do not depend on it.
+        self.chunk_batch_points = None
         self.coarse_precond = None  # matrix-free solve: None = automatic (coarse-level block preconditioner for 5+ levels), False = Jacobi only,
         #                             or {'first_level', 'steps', 'ratio'} (fields/kernel_field.py _coarse_precond)
+        self.keep_solve_inputs = False   # parity tests: the field keeps the site sets / weights of its solve (field._solve_inputs)
         self.col_format = 1        # physical layout of the assembled matrix (include/nksr_hip.h); int32 columns when M > 2^21
 
     # ---- scale selection (NKSR-USAGE.md:129-137) ---------------------------------------------------
@@ -49,7 +45,10 @@ class Reconstructor:
         return scale_for_detail_level(xyz, float(detail_level), self.hparams.voxel_size)
 
     # ---- one chunk: hierarchy -> features -> kernel solve -> mask -------------------------------------
-    def _reconstruct_single(self, xyz, normal, approx_kernel_grad, solver_max_iter, solver_tol, fused_mode):
+    def _reconstruct_single(self, xyz, normal, approx_kernel_grad, solver_max_iter, solver_tol, fused_mode, chunks=None):
+        """``chunks`` = (ids, key_lo, key_hi, frame): the cloud is a batch of chunks in the exploded frame (nksr_amd/chunking.py) -- one
+        hierarchy, one network pass, ONE block-diagonal solve whose diagonal blocks (segments) are the chunks; every chunk keeps
+        the solver weights of its own point / normal-site counts (models/nksr_net.py:103-111)."""
         hp = self.hparams
         t = {}
         tic = time.perf_counter()
@@ -73,11 +72,28 @@ class Reconstructor:
         if self.sync_timing:
             torch.cuda.current_stream().synchronize()
         t['t_network'] = time.perf_counter() - tic
-        field.solve(pos_xyz=enc.xyz, normal_xyz=normal_xyz, normal_value=-normal_value,
-                    pos_weight=hp.solver.pos_weight / xyz.shape[0],
-                    normal_weight=hp.solver.normal_weight / normal_xyz.shape[0] * hp.voxel_size ** 2,
-                    reg_weight=1.0, fused_mode=fused_mode, pos_sorted_keys=enc.keys,
-                    normal_sorted_keys=dec_svh.level(0).keys if hp.adaptive_depth == 1 else None)
+        inputs = dict(pos_xyz=enc.xyz, normal_xyz=normal_xyz, normal_value=-normal_value,
+                      pos_weight=hp.solver.pos_weight / xyz.shape[0],
+                      normal_weight=hp.solver.normal_weight / normal_xyz.shape[0] * hp.voxel_size ** 2,
+                      reg_weight=1.0, pos_sorted_keys=enc.keys,
+                      normal_sorted_keys=dec_svh.level(0).keys if hp.adaptive_depth == 1 else None)
+        if chunks is not None:
+            from .fields.kernel_field import Segments
+            ids, klo, khi, _ = chunks
+            seg = Segments(dec_svh, torch.tensor(klo, dtype=torch.int64), torch.tensor(khi, dtype=torch.int64), ids)
+            # per-site sqrt(weight) of the site's own chunk: pos_weight / N_c and normal_weight / Nn_c * voxel_size^2
+            pseg = seg.of_keys(enc.keys)
+            off = dec_svh.offsets
+            nseg_sites = torch.cat([seg.unknown_seg[off[d]:off[d] + dec_svh.num_voxels(d)] for d in range(hp.adaptive_depth)]).long()
+            n_p = torch.bincount(pseg, minlength=seg.nseg).double().clamp_min(1.0)
+            n_n = torch.bincount(nseg_sites, minlength=seg.nseg).double().clamp_min(1.0)
+            swp = torch.sqrt(float(hp.solver.pos_weight) / n_p).float()
+            swn = torch.sqrt(float(hp.solver.normal_weight) / n_n * hp.voxel_size ** 2).float()
+            inputs.update(pos_weight=swp[pseg].contiguous(), normal_weight=swn[nseg_sites].contiguous(), segments=seg)
+            field.segments = seg
+        field.solve(fused_mode=fused_mode, **inputs)
+        if self.keep_solve_inputs:
+            field._solve_inputs = inputs
         if bool(hp.udf.enabled):          # models/nksr_net.py:124-130
             mask = NeuralField(svh=udf_svh, decoder=self.network.udf_decoder, features=feat.udf_features)
             mask.set_level_set(2 * hp.voxel_size)

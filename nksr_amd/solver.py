@@ -49,10 +49,10 @@ def profile_spmv(enable):
 
 
 def profile_spmv_bytes():
-    """(algorithmic, physical) bytes of the SpMV launches timed since the last call."""
+    """(algorithmic, physical, SURVEY-formula) bytes of the operator applications timed since the last call."""
     a, b = C.c_double(0.0), C.c_double(0.0)
     call('nksr_pcg_profile_bytes', C.byref(a), C.byref(b))
-    return float(a.value), float(b.value)
+    return float(a.value), float(b.value), float(lib.nksr_pcg_profile_survey_bytes())
 
 
 def csr_logical(rowptr, cols, vals):

@@ -12,6 +12,10 @@ in the absent wheel; the specification restated here is SURVEY.md App. B7 / DESI
   * meshing on the union of the chunks' finest levels (one global voxel lattice)
   * mask: plain LayerField of the union grid, or -- with UDF masks -- the OR of the chunk masks over the
     blend support.
+  * the EXPLODED FRAME: chunk c is solved on x' = fl32(x + T_c), T_c = a whole number of coarsest
+    voxels that moves the chunk's data corner into the chunk's own aligned cube of the lattice (the product solves all
+    chunks of a rank as ONE block-diagonal system there); its field is evaluated at fl32(x + T_c), its voxels return to
+    the global lattice by subtracting the integer translation.  Restated here chunk by chunk (the oracle has no batch).
 numpy only; independent of nksr_amd/chunking.py (the product runs this on the GPU).
 """
 import math
@@ -42,12 +46,54 @@ def chunk_ids(xyz, lo, chunk_size, grid):
     return cid
 
 
+SLOT_GAP = 6          # empty coarsest voxels between the data of two slots
+
+
+class Frame:
+    """Slots of the exploded frame: chunk (cx, cy, cz) owns the cube [s 2^S, (s + 1) 2^S)^3 of the finest lattice,
+    s = (cx, cy, cz) - grid // 2, data corner at slot origin + 4 coarsest voxels;  2^S >= that + data extent + 2^depth alignment slack
+    + SLOT_GAP / 2 coarsest voxels."""
+
+    def __init__(self, voxel_size, depth, lo, grid, chunk_size, band):
+        self.w0, self.depth, self.lo, self.grid, self.cs, self.band = float(voxel_size), int(depth), list(lo), list(grid), float(chunk_size), float(band)
+        self.align = 1 << depth
+        self.low = 2 * self.align        # the data starts 4 coarsest voxels inside its slot: every voxel of the chunk lies in the slot
+        need = self.low + int(math.ceil((chunk_size + 2 * band) / voxel_size)) + 2 + self.align + ((SLOT_GAP // 2) << (depth - 1))
+        self.S = depth
+        while (1 << self.S) < need:
+            self.S += 1
+
+    def c3(self, c):
+        g = self.grid
+        return (c // (g[1] * g[2]), (c // g[2]) % g[1], c % g[2])
+
+    def shift_cells(self, c):
+        out = []
+        for a, ca in enumerate(self.c3(c)):
+            data_lo = self.lo[a] + ca * self.cs - self.band if self.grid[a] > 1 else self.lo[a]
+            corner = int(math.floor(math.floor(data_lo / self.w0) / self.align)) * self.align
+            out.append(((ca - self.grid[a] // 2) << self.S) + self.low - corner)
+        return np.asarray(out, np.int64)
+
+    def shift(self, c):
+        return np.asarray([np.float32(float(t) * self.w0) for t in self.shift_cells(c)], np.float32)
+
+
 class ChunkedField:
-    def __init__(self, fields, cores, ov, lo, chunk_size, grid, voxel_size):
+    def __init__(self, fields, cores, ov, lo, chunk_size, grid, voxel_size, frame, adaptive_depth=1):
         self.fields, self.cores, self.ov, self.lo, self.chunk_size, self.grid = fields, cores, float(ov), lo, float(chunk_size), grid
-        self.voxel_size = float(voxel_size)
-        keys = [f['hier'].levels[0].keys for f in fields.values()]
-        self.union = hierarchy.Hierarchy(voxel_size, 1).build_from_keys([np.concatenate(keys) if keys else np.zeros(0, np.int64)])
+        self.voxel_size, self.frame = float(voxel_size), frame
+        from . import spec
+        # union of the chunks' voxels, back on the global lattice (integer translation: T_c is a whole number of voxels at every
+        # level): the finest level and the coarser ones below adaptive_depth (LayerField(dec_svh, adaptive_depth), models/nksr_net.py:132)
+        self.adaptive_depth = max(1, int(adaptive_depth))
+        keys = [[] for _ in range(self.adaptive_depth)]
+        for c, f in fields.items():
+            for d in range(self.adaptive_depth):
+                ld = f['hier'].levels[d]
+                keys[d].append(spec.morton_key(ld.ijk.astype(np.int64) - (frame.shift_cells(c) >> d)[None], d))
+        self.union = hierarchy.Hierarchy(voxel_size, self.adaptive_depth).build_from_keys(
+            [np.concatenate(k) if k else np.zeros(0, np.int64) for k in keys])
 
     def weight(self, c, xyz):
         lo, hi = self.cores[c]
@@ -72,7 +118,7 @@ class ChunkedField:
             sel = np.nonzero(w > 0)[0]
             if len(sel) == 0:
                 continue
-            f, g = pipeline.evaluate(self.fields[c], xyz[sel], grad)
+            f, g = pipeline.evaluate(self.fields[c], (xyz[sel] + self.frame.shift(c)[None]).astype(np.float32), grad)
             num[sel] = (num[sel] + f * w[sel]).astype(np.float32)
             den[sel] = (den[sel] + w[sel]).astype(np.float32)
             if grad:
@@ -91,14 +137,14 @@ class ChunkedField:
                 continue
             sel = np.nonzero(self.weight(c, xyz) > 0)[0]
             if len(sel):
-                d = onet.udf_decode(f['hier'], f['udf_feats'], xyz[sel])
+                d = onet.udf_decode(f['hier'], f['udf_feats'], (xyz[sel] + self.frame.shift(c)[None]).astype(np.float32))
                 keep[sel] |= d < np.float32(f.get('udf_level_set', 2 * f['voxel_size']))
         return keep
 
     def extract_dual_mesh(self, mise_iter=0, grid_upsample=1, info=None):
         has_mask = any(f.get('udf_feats') is not None for f in self.fields.values())
         return meshing.extract(self.voxel_size, self.union.levels[0], lambda p: self.evaluate(p)[0], mise_iter, grid_upsample,
-                               mask_fn=(self.mask if has_mask else None), info=info)
+                               mask_fn=(self.mask if has_mask else None), info=info, coarser=self.union.levels[1:self.adaptive_depth])
 
 
 OV_FLOOR = 1.0        # blend half-width floor, in coarsest voxels        
@@ -124,6 +170,7 @@ def reconstruct_by_chunk(xyz, normal, sensor, chunk_size, overlap_ratio=0.05, pr
         clo = [lo[0] + cx * chunk_size, lo[1] + cy * chunk_size, lo[2] + cz * chunk_size]
         cores[c] = (clo, [clo[a] + chunk_size for a in range(3)])
     counts = np.bincount(chunk_ids(xyz, lo, chunk_size, grid), minlength=nchunk)
+    frame = Frame(voxel_size, depth, lo, grid, chunk_size, band)
     fields = {}
     for c in range(nchunk):
         if counts[c] == 0:
@@ -140,6 +187,7 @@ def reconstruct_by_chunk(xyz, normal, sensor, chunk_size, overlap_ratio=0.05, pr
             raise RuntimeError('oriented input required')
         if cx_.shape[0] < min_points:
             continue
-        fields[c] = pipeline.reconstruct(np.ascontiguousarray(cx_, np.float32), np.ascontiguousarray(cn_, np.float32),
-                                         voxel_size=voxel_size, depth=depth, **kw)
-    return ChunkedField(fields, cores, ov, lo, chunk_size, grid, voxel_size)
+        # preprocess_fn saw the chunk in the caller's coordinates; the solve happens in the chunk's slot of the exploded frame
+        xs = (np.ascontiguousarray(cx_, np.float32) + frame.shift(c)[None]).astype(np.float32)
+        fields[c] = pipeline.reconstruct(xs, np.ascontiguousarray(cn_, np.float32), voxel_size=voxel_size, depth=depth, **kw)
+    return ChunkedField(fields, cores, ov, lo, chunk_size, grid, voxel_size, frame, adaptive_depth=kw.get('adaptive_depth', 1))

@@ -24,10 +24,10 @@ sys.path.insert(0, ROOT)
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 
 CASES = {
-    'street8': dict(preset='carla', overrides={}, n=14000, seed=3, chunk_size=3.1, knn=64, deg=85.0, approx=True, tol=1e-6,
+    'street8': dict(preset='carla', overrides={}, n=14000, seed=3, chunk_size=3.1, knn=64, deg=85.0, approx=True, tol=3e-7,
                     mise_iter=1),
     'terrain5': dict(preset='ks', overrides={'tree_depth': 5}, n=8000, seed=5, chunk_size=5.0 + 1e-3, knn=None, deg=None, approx=False,
-                     tol=1e-6, mise_iter=1),
+                     tol=3e-7, mise_iter=1),
 }
 
 

@@ -20,7 +20,11 @@ def conv3(x, nbr, W, b, relu=True):
     return np.maximum(out, 0) if relu else out
 
 
-def splat(level, xyz, feat, voxel_size_d, mean):
+NORMAL_MIN_LENGTH = 1e-2     # a splatted mean normal shorter than this carries no orientation: not blown up to unit length
+NORMAL_MIN_WEIGHT = 1e-3     # nor is the splat of a voxel the cloud barely touches (total trilinear weight below this)
+
+
+def splat(level, xyz, feat, voxel_size_d, mean, return_weights=False):
     inv_w = np.float32(spec.inv_w0_f32(voxel_size_d))
     p = xyz.astype(np.float32) * inv_w
     base = np.floor(p - np.float32(0.5)).astype(np.int32)
@@ -35,6 +39,8 @@ def splat(level, xyz, feat, voxel_size_d, mean):
         np.add.at(ws, j[ok], w[ok])
     if mean:
         acc = acc / np.where(ws > 0, ws, 1.0)[:, None] * (ws > 0)[:, None]
+    if return_weights:
+        return acc.astype(np.float32), ws.astype(np.float32)
     return acc.astype(np.float32)
 
 
@@ -97,10 +103,14 @@ def forward(P, xyz, normal, voxel_size, depth, kernel_dim, adaptive_depth, udf=F
         y = trunk[d]
         basis.append((y @ P['unet.basis_heads.%d.weight' % d].T + P['unet.basis_heads.%d.bias' % d] + e0v).astype(np.float32))
         if d < adaptive_depth:
-            sN = splat(levels[d], xyz, normal, voxel_size * (1 << d), mean=False)
+            sN, wN = splat(levels[d], xyz, normal, voxel_size * (1 << d), mean=False, return_weights=True)
             nv = sN + (y @ P['unet.normal_heads.%d.weight' % d].T + P['unet.normal_heads.%d.bias' % d]).astype(np.float32)
             normal_norm[d] = np.linalg.norm(nv, axis=1)
-            normals[d] = (nv / np.maximum(normal_norm[d][:, None], np.float32(1e-8))).astype(np.float32)
+            # unit length -- unless the splatted normals cancel (|sum w n| < 1e-2 sum w: opposite sides of a thin sheet in one
+            # voxel) or the voxel is barely touched (sum w < 1e-3: a point ON the edge of its stencil has weight 0 or 1e-8 depending
+            # on rounding): such a vector is noise and stays short instead of becoming an arbitrary unit target
+            den = np.maximum(np.maximum(normal_norm[d], np.float32(NORMAL_MIN_LENGTH) * wN), np.float32(NORMAL_MIN_WEIGHT))
+            normals[d] = (nv / den[:, None]).astype(np.float32)
     forward.last_udf = None
     if udf:     # UDF branch: plane features + the (zero-initialised) learned head
         forward.last_udf = [None] * depth

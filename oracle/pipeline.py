@@ -26,18 +26,22 @@ def default_interpolators(depth, K=4, H=16, seed=0, init_scale=0.0):
     return out
 
 
-def splat_trilinear(level, xyz, feat, voxel_size_d):
+def splat_trilinear(level, xyz, feat, voxel_size_d, return_weights=False):
     """Hat-function splat of per-point features onto the voxels of one level."""
     inv_w = np.float32(spec.inv_w0_f32(voxel_size_d))
     p = xyz.astype(np.float32) * inv_w
     base = np.floor(p - np.float32(0.5)).astype(np.int32)
     acc = np.zeros((level.n, feat.shape[1]), np.float64)
+    ws = np.zeros(level.n, np.float64)
     for co in spec.CORNER_OFFSETS:
         ijk = base + co[None]
         w = np.prod(np.float32(1.0) - np.abs(p - (ijk.astype(np.float32) + np.float32(0.5))), axis=1)
         j = level.lookup(ijk)
         ok = (j >= 0) & (w > 0)
         np.add.at(acc, j[ok], feat[ok].astype(np.float64) * w[ok, None])
+        np.add.at(ws, j[ok], w[ok])
+    if return_weights:
+        return acc.astype(np.float32), ws.astype(np.float32)
     return acc.astype(np.float32)
 
 
@@ -73,8 +77,10 @@ def reconstruct(xyz, normal, voxel_size=0.1, depth=4, adaptive_depth=1, kernel_d
         if net_normals is not None:
             nf = net_normals[d]
         else:
-            s = splat_trilinear(L, xyz, normal, voxel_size * (1 << d))
-            nf = s / np.maximum(np.linalg.norm(s, axis=1, keepdims=True), np.float32(1e-8))
+            # unit mean normal; a cancelled splat (|sum w n| < 1e-2 sum w) or a barely touched voxel (sum w < 1e-3) stays short
+            # (oracle/network.py NORMAL_MIN_LENGTH / NORMAL_MIN_WEIGHT)
+            s, ws = splat_trilinear(L, xyz, normal, voxel_size * (1 << d), return_weights=True)
+            nf = s / np.maximum(np.maximum(np.linalg.norm(s, axis=1), np.float32(1e-2) * ws), np.float32(1e-3))[:, None]
         nxyz.append(L.centers())
         nval.append(nf.astype(np.float32))
     nxyz, nval = np.concatenate(nxyz), np.concatenate(nval)

@@ -18,21 +18,23 @@ def _bench():
 def test_roofline_record_arithmetic_and_keys():
     b = _bench()
     # 220 launches of 0.58 ms each moving 3.01 GB (algorithmic) / 2.50 GB (physical)
-    r = b.roofline_record(220 * 0.58, 220, 220 * 3.01e9, 220 * 2.50e9)
+    r = b.roofline_record(220 * 0.58, 220, 220 * 3.01e9, 220 * 2.50e9, 220 * 3.01e9)
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'achieved_physical', 'frac_physical',
               'bytes_per_launch', 'physical_bytes_per_launch', 'avg_launch_us', 'launches_timed', 'kernel'):
         assert k in r, k
     assert r['bound'] == 'hbm' and r['unit'] == 'GB/s' and r['peak'] == 8000.0
     assert abs(r['achieved'] - 3.01e9 / 0.58e-3 / 1e9) < 1e-6 * r['achieved']
-    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['frac_physical'] < r['frac']
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and r['frac_physical'] < r['frac'] <= 1.0
     assert abs(r['avg_launch_us'] - 580.0) < 1e-6
-    # traffic is only attached when the committed PMC pass was taken on the same matrix, and then names its source
+    # traffic is only attached when the committed PMC pass was taken on the same matrix, and then names its (static) source
     assert (r['traffic'] is None) == (r['traffic_source'] is None)
-    # the matrix-free record has the same keys and the same definitions (achieved = algorithmic bytes / time)
-    f = b.roofline_record(160 * 0.66, 160, 160 * 5.65e9, 160 * 2.71e9, fused=True)
-    assert set(r) == set(f) and 'k_fz_sweep' in f['kernel']
-    assert abs(f['achieved'] - 5.65e9 / 0.66e-3 / 1e9) < 1e-6 * f['achieved'] and abs(f['achieved_physical'] - 2.71e9 / 0.66e-3 / 1e9) < 1e-6 * f['achieved']
-    z = b.roofline_record(0.0, 0, 0.0, 0.0)
+    # the matrix-free record: achieved = the operator's ALGORITHMIC MINIMUM / time (a fraction of the peak, <= 1 by construction:
+    # it is less than what the layout moves); the SURVEY formula's figure travels beside it, labelled, and may exceed 1
+    f = b.roofline_record(160 * 0.56, 160, 160 * 1.60e9, 160 * 2.58e9, 160 * 5.65e9, fused=True)
+    assert set(r) | {'survey_formula_bytes_per_launch', 'survey_formula_frac'} == set(f) and 'k_fz_sweep' in f['kernel']
+    assert abs(f['achieved'] - 1.60e9 / 0.56e-3 / 1e9) < 1e-6 * f['achieved'] and abs(f['achieved_physical'] - 2.58e9 / 0.56e-3 / 1e9) < 1e-6 * f['achieved']
+    assert 0 < f['frac'] < f['frac_physical'] <= 1.0 < f['survey_formula_frac']
+    z = b.roofline_record(0.0, 0, 0.0, 0.0, 0.0)
     assert z['achieved'] == 0.0 and z['traffic'] is None
 
 

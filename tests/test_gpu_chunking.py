@@ -1,6 +1,8 @@
 """Chunked reconstruction (reference call site examples/recons_by_chunk.py:26-30) and its
 multi-rank sharding, on one GPU: (a) seam quality vs the unchunked solve, (b) a simulated
-2-rank run merges to exactly the 1-rank chunked mesh (index-exact topology)."""
+2-rank run merges to exactly the 1-rank chunked mesh (index-exact topology), (c) a chunk's solution
+does not depend on which other chunks share its batch (all chunks of a rank are ONE launch sequence:
+nksr_amd/chunking.py)."""
 import numpy as np
 import pytest
 import torch
@@ -99,9 +101,10 @@ def test_simulated_two_ranks_equal_one_rank(scene):
         for c, f in src.fields.items():
             c3 = (c // (one.grid[1] * one.grid[2]), (c // one.grid[2]) % one.grid[1], c % one.grid[2])
             band = chunking.exchange_band(one.cores[c], c3, one.grid, one.ov, rec.hparams.voxel_size)
-            ints, flts = chunking.pack_field(f, band)
+            ints, flts = chunking.pack_field(f, band)          # (f.chunk_shift: the band is given in scene coordinates)
             assert ints.numel() <= chunking.pack_field(f)[0].numel() * (1.0 if scene == 'small' else 0.6)
             halo[c] = chunking.unpack_field(ints, flts, rec.hparams.voxel_size, rec.network.interpolators, dev)
+            halo[c].solve_info = {}
     pieces = []
     for r, mine in ((0, r0), (1, r1)):
         seen = {c: (mine.fields[c] if c in mine.fields else halo[c]) for c in allf}
@@ -129,9 +132,10 @@ def test_simulated_two_ranks_equal_one_rank(scene):
     assert np.array_equal(fm, f1)                                                  # index-exact topology
 
 
-def test_concurrent_chunk_streams_are_bit_identical():
-    """Reconstructor.chunk_streams: chunks solved concurrently on several HIP streams (one host thread each) give exactly the
-    fields and the mesh of the sequential run."""
+def test_a_chunk_does_not_depend_on_its_batch_mates():
+    """All chunks of a rank are solved as ONE block-diagonal system (one hierarchy, one network pass, one PCG with per-chunk
+    scalars).  Reconstructor.chunk_batch_points cuts the chunks into several such batches: every chunk must come out bit
+    for bit the same whether it is solved with all the others, with a few, or alone -- and so must the mesh."""
     import nksr_amd
     dev = torch.device('cuda:0')
     xyz, nrm = _wide_scene()
@@ -139,17 +143,22 @@ def test_concurrent_chunk_streams_are_bit_identical():
     t = lambda a: torch.from_numpy(a).to(dev)
     ext = float(xyz[:, 0].max() - xyz[:, 0].min())
     out = {}
-    for k in (1, 3):
-        rec.chunk_streams = k
+    for k, budget in (('all', 1 << 30), ('pairs', 90000), ('alone', 1)):
+        rec.chunk_batch_points = budget
         fld = rec.reconstruct(t(xyz), t(nrm), detail_level=None, chunk_size=ext / 4 + 1e-3)
         assert len(fld.fields) >= 4
         out[k] = (fld, fld.extract_dual_mesh(mise_iter=1))
-    a, b = out[1], out[3]
-    assert sorted(a[0].fields) == sorted(b[0].fields)
-    for c in a[0].fields:
-        assert torch.equal(a[0].fields[c].alpha, b[0].fields[c].alpha), 'chunk %d' % c
-        assert all(torch.equal(a[0].fields[c].svh.level(d).keys, b[0].fields[c].svh.level(d).keys) for d in range(4))
-    assert torch.equal(a[1].v, b[1].v) and torch.equal(a[1].f, b[1].f)
+    assert len(out['all'][0].parts) == 1 and len(out['alone'][0].parts) == len(out['alone'][0].fields) >= len(out['pairs'][0].parts) > 1
+    a = out['all']
+    for k in ('pairs', 'alone'):
+        b = out[k]
+        assert sorted(a[0].fields) == sorted(b[0].fields)
+        for c in a[0].fields:
+            fa, fb = a[0].fields[c], b[0].fields[c]
+            assert all(torch.equal(fa.svh.level(d).keys, fb.svh.level(d).keys) for d in range(4)), 'chunk %d' % c
+            assert torch.equal(fa.alpha, fb.alpha), 'chunk %d: alpha depends on the batch (%s)' % (c, k)
+            assert fa.solve_info['iters'] == fb.solve_info['iters']
+        assert torch.equal(a[1].v, b[1].v) and torch.equal(a[1].f, b[1].f)
 
 
 def test_chunked_udf_mask_travels_with_the_chunks():

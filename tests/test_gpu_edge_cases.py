@@ -141,10 +141,14 @@ def test_bench_contract_line():
     for k in ('traffic', 'traffic_source', 'bytes_per_launch', 'avg_launch_us', 'launches_timed', 'kernel'):
         assert k in r, k
     assert (r['traffic'] is None) == (r['traffic_source'] is None)
-    assert d['config']['fused_mode'] is True and 'k_fz_sweep' in r['kernel'] and r['frac_physical'] < r['frac']
-    # algorithmic bytes = 16 per stored entry of G and Q (counted on the device) + the vectors
-    se = d['config']['stored_entries_G_Q']
-    assert 0 < se <= d['config']['kernel_row_slots'] and abs(r['bytes_per_launch'] - (16.0 * se + 12.0 * d['config']['unknowns_M'] + 4)) < 1.0
+    # a roofline fraction is a fraction: algorithmic minimum <= what the layout moves <= what the HBM could stream
+    assert d['config']['fused_mode'] is True and 'k_fz_sweep' in r['kernel'] and 0 < r['frac'] < r['frac_physical'] <= 1.0
+    # algorithmic minimum of the matrix-free operator: 4 B per stored entry of G and Q (counted on the device) + 4 B per row and
+    # level (row -> cell) + 116 B per unknown (stencil, x, y); SURVEY.md section 8d's formula (16 B per stored entry) beside it
+    se, slots, M = d['config']['stored_entries_G_Q'], d['config']['kernel_row_slots'], d['config']['unknowns_M']
+    assert 0 < se <= slots and abs(r['bytes_per_launch'] - (4.0 * se + 4.0 * slots / 27 + 116.0 * M + 4)) < 1.0
+    assert abs(r['survey_formula_bytes_per_launch'] - (16.0 * se + 12.0 * M + 4)) < 1.0
+    assert d['spmv_csr_roofline']['kernel'].startswith('k_spmv') and 0 < d['spmv_csr_roofline']['frac'] <= 1.0
     o = d['other_solve_mode']          # the assembled CSR solve on the same workload, with the CSR SpMV roofline
     assert o['fused_mode'] is False and o['value'] > 0 and 'k_spmv' in o['roofline']['kernel'] and o['nnz_A'] > 0
     assert 'achieved_physical' in o['roofline'] and o['roofline']['frac_physical'] <= o['roofline']['frac']

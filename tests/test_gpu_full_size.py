@@ -1,5 +1,7 @@
-"""Size-independent properties at BASELINE.json's full single-GPU size (configs[2]: 1 000 000 points,
-detail_level=1.0): the oracle cannot run at this size, the invariants of SURVEY.md section 8c(3) can."""
+"""BASELINE.json's full single-GPU size (configs[2]: 1 000 000 points, detail_level=1.0): size-independent properties
+ and -- what the oracle CAN do at this size -- the voxel hierarchy bit for bit, and kernel rows /
+rows of the normal-equation operator against the oracle on a sample of sites / unknowns."""
+import numpy as np
 import pytest
 import torch
 
@@ -14,8 +16,107 @@ def big():
     xyz, nrm = utils.synth_scene(1_000_000, seed=0)
     xyz, nrm = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
     rec = nksr_amd.Reconstructor(dev)
+    rec.keep_solve_inputs = True
     fld = rec.reconstruct(xyz, nrm, detail_level=1.0, fused_mode=False)      # the assembled system is inspected below
     return rec, fld, xyz, nrm
+
+
+def _ranges(starts, ends):
+    """concatenated aranges [starts[i], ends[i])"""
+    n = (ends - starts).astype(np.int64)
+    tot = int(n.sum())
+    if tot == 0:
+        return np.zeros(0, np.int64)
+    off = np.repeat(np.cumsum(n) - n, n)
+    return np.repeat(starts.astype(np.int64), n) + (np.arange(tot) - off)
+
+
+def test_full_size_hierarchy_rows_and_operator_rows_match_the_oracle(big):
+    """The headline configuration against the oracle where the oracle can go:
+      * the detail_level scale and all four levels of voxel keys, exactly (integer work);
+      * the dense-slot kernel rows of 6 000 sampled position sites and 3 000 sampled normal sites (values and gradients);
+      * rows of y = (w_p G^T G + w_n Q^T Q + reg I) x for sampled unknowns of every level: the oracle evaluates ALL constraint
+        rows in the support of those unknowns (ten thousands of sites for a coarse one) -- against the matrix-free operator
+        (nksr_fused_apply) and the assembled CSR (nksr_spmv_csr), bound 3e-6 * (|A| |x|)_i  (SURVEY.md section 8c asks for fp32 rel-tol 1e-5; measured 5e-8 .. 2.3e-7)."""
+    import parity_util as pu
+    from nksr_amd import solver
+    from oracle import density as odens, hierarchy as ohier, kernel as okern, spec
+    rec, fld, xyz, nrm = big
+    hp = rec.hparams
+    L = hp.tree_depth
+    inp = fld._solve_inputs
+    dev = xyz.device
+    so = odens.scale_for_detail_level(xyz.cpu().numpy(), 1.0, hp.voxel_size)
+    assert fld.scale == so, 'detail_level scale differs from the oracle: %r vs %r' % (fld.scale, so)
+    xs = inp['pos_xyz'].cpu().numpy()                      # scaled, Morton-sorted cloud (what the solve saw)
+    H0, _ = spec.half_index(xs, hp.voxel_size)
+    pk0 = spec.morton_key(H0 >> 1, 0)
+    assert (np.diff(pk0) >= 0).all()
+    # (1) hierarchy: one representative point per occupied finest cell defines the same neighbourhood hierarchy (I_d = I_0 >> d)
+    first = np.concatenate([[True], pk0[1:] != pk0[:-1]])
+    oh = ohier.Hierarchy(hp.voxel_size, L).build_point_neighborhood(xs[first])
+    for d in range(L):
+        assert np.array_equal(fld.svh.level(d).keys.cpu().numpy(), oh.levels[d].keys), 'level %d voxel keys' % d
+    M = oh.num_unknowns
+    assert M == fld.svh.num_unknowns
+    # (2) kernel rows at sampled sites, features / interpolator weights as the product holds them
+    feats = [f.cpu().numpy() for f in fld._feat]
+    interps = []
+    for d in range(L):
+        m = rec.network.interpolators[d]
+        interps.append(okern.Interpolator(*[getattr(m, k).detach().cpu().numpy() for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')]))
+    psis = [okern.voxel_psi(feats[d], interps[d]) for d in range(L)]
+    for d in range(L):
+        np.testing.assert_allclose(fld._psi[d].cpu().numpy(), psis[d], rtol=1e-5, atol=1e-6)
+    rs = np.random.RandomState(0)
+    nxyz = inp['normal_xyz'].cpu().numpy()
+    ps = np.sort(rs.choice(xs.shape[0], 6000, replace=False))
+    qs = np.sort(rs.choice(nxyz.shape[0], 3000, replace=False))
+    _, ov, _ = okern.kernel_rows(oh, feats, interps, psis, xs[ps], False, False)
+    hv, _ = fld.kernel_rows(torch.from_numpy(xs[ps]).to(dev), grad=False)
+    pu.check('full_size:position_rows', np.abs(hv.cpu().numpy() - ov).max() / np.abs(ov).max(), 3e-6)      # measured 2.1e-7 (round 3)
+    _, _, od = okern.kernel_rows(oh, feats, interps, psis, nxyz[qs], True, False)
+    _, hd = fld.kernel_rows(torch.from_numpy(nxyz[qs]).to(dev), grad=True, values=False)
+    pu.check('full_size:gradient_rows', np.abs(hd.cpu().numpy() - od).max() / np.abs(od).max(), 3e-6)      # measured 1.1e-7
+    # (3) operator rows on sampled unknowns
+    nk0 = fld.svh.level(0).keys.cpu().numpy()              # normal sites = finest voxel centres (adaptive_depth 1), sorted
+    assert hp.adaptive_depth == 1 and nxyz.shape[0] == nk0.shape[0]
+    sample = {0: 800, 1: 200, 2: 8, 3: 3}
+    U, psel, qsel = [], [], []
+    for d, cnt in sample.items():
+        lv = oh.levels[d]
+        j = np.sort(rs.choice(lv.n, min(cnt, lv.n), replace=False))
+        U.append(j + oh.offsets[d])
+        cells = (lv.ijk[j][:, None, :] + spec.NBR_OFFSETS[None]).reshape(-1, 3)
+        ck = np.unique(spec.morton_key(cells, d))
+        for keys_d, out in ((pk0 >> (3 * d), psel), (nk0 >> (3 * d), qsel)):
+            out.append(_ranges(np.searchsorted(keys_d, ck, 'left'), np.searchsorted(keys_d, ck, 'right')))
+    U = np.concatenate(U)
+    psel, qsel = np.unique(np.concatenate(psel)), np.unique(np.concatenate(qsel))
+    gc, gv, _ = okern.kernel_rows(oh, feats, interps, psis, xs[psel], False, False)
+    qc, _, qd = okern.kernel_rows(oh, feats, interps, psis, nxyz[qsel], True, False)
+    import scipy.sparse as sp
+    G = okern.rows_to_csr(gc, gv, M).astype(np.float64)
+    Q = sp.vstack([okern.rows_to_csr(qc, qd[:, a], M) for a in range(3)]).tocsr().astype(np.float64)
+    wp, wn, reg = float(inp['pos_weight']), float(inp['normal_weight']), float(inp['reg_weight'])
+    x = rs.randn(M).astype(np.float32)
+    x64 = x.astype(np.float64)
+    y = wp * (G.T @ (G @ x64)) + wn * (Q.T @ (Q @ x64)) + reg * x64
+    mag = wp * (abs(G).T @ (abs(G) @ np.abs(x64))) + wn * (abs(Q).T @ (abs(Q) @ np.abs(x64))) + reg * np.abs(x64)
+    xt = torch.from_numpy(x).to(dev)
+    op = fld.fused_operator(inp['pos_xyz'], inp['normal_xyz'], inp['normal_value'], inp['pos_weight'], inp['normal_weight'],
+                            inp['pos_sorted_keys'], inp['normal_sorted_keys'])
+    yf = fld.fused_apply(op, xt, reg).cpu().numpy().astype(np.float64)
+    rowptr, cols_p, vals_p, _ = fld.matrix
+    yc = solver.spmv(rowptr, cols_p, vals_p, xt).cpu().numpy().astype(np.float64)
+    pu.report('full_size:operator_rows', unknowns=int(U.size), pos_sites=int(psel.size), normal_sites=int(qsel.size))
+    pu.check('full_size:fused_apply_rows', (np.abs(yf[U] - y[U]) / mag[U]).max(), 3e-6)       # measured 5.2e-8
+    pu.check('full_size:spmv_csr_rows', (np.abs(yc[U] - y[U]) / mag[U]).max(), 3e-6)         # measured 2.3e-7
+    # the right-hand side rows of the same unknowns: b = w_n Q^T n
+    tgt = inp['normal_value'].cpu().numpy()[qsel]
+    b = wn * (Q.T @ np.concatenate([tgt[:, a] for a in range(3)]).astype(np.float64))
+    bmag = wn * (abs(Q).T @ np.abs(np.concatenate([tgt[:, a] for a in range(3)])).astype(np.float64))
+    pu.check('full_size:rhs_rows', (np.abs(fld.rhs.cpu().numpy()[U] - b[U]) / np.maximum(bmag[U], 1e-30)).max(), 3e-6)       # measured 2.3e-7
 
 
 def test_hierarchy_is_sorted_and_nested(big):

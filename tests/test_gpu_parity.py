@@ -623,7 +623,7 @@ def test_coarse_block_preconditioner_same_solution_fewer_iterations():
         out[name] = (fld.alpha.clone(), fld.solve_info['iters'], fld.solve_info['coarse_precond'])
     (aj, itj, _), (ac, itc, info), (ac2, itc2, _) = out['jacobi'], out['coarse'], out['coarse2']
     assert torch.equal(ac, ac2) and itc == itc2
-    assert info['first_level'] == 2 and info['unknowns'] > 0 and 1.0 < info['lambda_max'] < 100.0
+    assert info['first_level'] == 2 and info['unknowns'] > 0 and 1.0 < 1.1 * float(info['lambda'].max()) < 100.0
     pu.report('coarse_precond:iters', with_block=itc, jacobi_only=itj)
     assert itc * 2 <= itj, (itc, itj)
     pu.check('coarse_precond:alpha_vs_jacobi_rel', float((ac - aj).abs().max() / aj.abs().max()), pu.ALPHA_TOL)

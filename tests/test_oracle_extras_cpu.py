@@ -41,7 +41,7 @@ def test_oracle_chunk_blend_is_a_partition_of_unity_and_closes_the_seam():
     # the blended field matches each chunk's own field where only that chunk weighs
     f, _ = cf.evaluate(xyz)
     only0 = (cf.weight(1, xyz) == 0)
-    f0, _ = pipeline.evaluate(cf.fields[0], xyz[only0])
+    f0, _ = pipeline.evaluate(cf.fields[0], (xyz[only0] + cf.frame.shift(0)[None]).astype(np.float32))      # chunk 0 lives in its slot of the exploded frame
     np.testing.assert_allclose(f[only0], f0, rtol=1e-6, atol=1e-9)
     v, t = cf.extract_dual_mesh(0)
     pu.assert_closed(t, 'chunked oracle mesh')
