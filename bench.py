@@ -191,6 +191,7 @@ def main():
         solver.profile_spmv(True)
         solver.profile_spmv_bytes()
         fence()
+        ms0 = torch.cuda.memory_stats(dev)
         t0 = time.perf_counter()
         out = None
         for _ in range(steps):
@@ -200,6 +201,10 @@ def main():
             out = step(stage_acc)
         fence()
         dt = time.perf_counter() - t0
+        ms1 = torch.cuda.memory_stats(dev)
+        # hipMalloc / hipFree calls inside the timed region (0 in the steady state: the caching allocator serves every step from its pool)
+        stage_acc['device_allocs'] = float(ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)) * steps
+        stage_acc['device_frees'] = float(ms1.get('num_device_free', 0) - ms0.get('num_device_free', 0)) * steps
         ms, launches = solver.profile_spmv(False)
         alg, phys, survey = solver.profile_spmv_bytes()
         if dist is not None:

@@ -218,10 +218,12 @@ int nksr_spmv_set_variant(int v);
 /* Scratch bytes required by nksr_pcg_solve. */
 size_t nksr_pcg_workspace_bytes(int32_t M, int64_t nnz);
 /* Jacobi-PCG, x0 = 0.  info_out (host, may be NULL): [0]=iterations [1]=relative residual.
- * Checks convergence every `check_every` iterations (one stream sync each) -- syncs. */
+ * Checks convergence every `check_every` iterations (one stream sync each) -- syncs.
+ * coarse_precond (struct nksr_coarse_precond_t, declared below; NULL = Jacobi only): the diagonal block of the coarse levels. */
+struct nksr_coarse_precond_s;
 int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, const float* diag, int32_t M,
                    int64_t nnz, int col_format, const float* b, float* x, float tol, int max_iter, int check_every,
-                   void* workspace, double* info_out, void* stream);
+                   void* workspace, const struct nksr_coarse_precond_s* coarse_precond, double* info_out, void* stream);
 /* Live profiling of the SpMV launches inside nksr_pcg_solve (HIP events on the solve's stream).
  * Returns and resets the accumulated milliseconds / launch count, then sets the enable flag. */
 int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out);
@@ -253,7 +255,7 @@ typedef struct {
     double* info;              /* device [nseg * 2] or NULL: iterations, relative residual (negated when the segment stopped on
                                 * r.z <= 0) of every segment, refreshed at every convergence check */
 } nksr_segments_t;
-typedef struct {
+typedef struct nksr_coarse_precond_s {
     int32_t first, n, steps, reserved;
     float lambda_scale, ratio; /* the eigenvalue bound of segment c is lambda_scale * lambda[c] (safety margin, ~1.1)          */
     const float* lambda;       /* device [nseg]: nksr_coarse_lambda_max; <= 0 / non-finite: that segment keeps plain Jacobi     */
@@ -321,7 +323,9 @@ int nksr_pcg_solve_fused(const nksr_fused_op_t* op, float reg, const float* diag
  * max_ring cells. */
 int nksr_knn_pca_normals(const float* xyz_sorted, int64_t n, const int32_t* start, const int32_t* end,
                          const int64_t* hkeys, const int32_t* hvals, int32_t hcap, float cell, float inv_cell, int k,
-                         int max_ring, float* normal_out, float* radius2_out, int32_t* valid_out, void* stream);
+                         int max_ring, float* normal_out, float* radius2_out, int32_t* valid_out,
+                         int32_t* todo_work /* [n] ints: one wavefront per query (candidates through LDS); NULL: one thread per query */,
+                         void* stream);
 /* Signed distance of arbitrary queries to an oriented cloud from their k = nb_points nearest reference points: the training
  * ground truth ext.sdfgen.sdf_from_points(queries, ref_xyz, ref_normal, nb_points, stdv, compute_grad, imls, adaptive_knn)
  * (ext/sdfgen/sdf_from_points.cu:32-235; models/loss.py:85, dataset/av_gt_geometry.py:72).  imls = 0: nearest-neighbour magnitude

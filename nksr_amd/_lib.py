@@ -119,7 +119,7 @@ _PROTOS = {
     'nksr_spmv_plan': [_vp, _i32, _i64, C.c_int, _vp, _vp],
     'nksr_pack_cols21': [_vp, _i64, _vp, _vp],
     'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _vp, _vp],
-    'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(C.c_double), _vp],
+    'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(C.c_double), _vp],
     'nksr_fused_block_counts': [_i32, _i32, _i64, _vp, _vp, _vp, _vp],
     'nksr_fused_tables': [_P(HierT), _vp, _vp, _vp, _vp],
     'nksr_fused_rhs_diag': [_P(FusedOpT), _f32, _vp, _vp, _vp],
@@ -128,7 +128,7 @@ _PROTOS = {
     'nksr_coarse_lambda_max': [_vp, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _P(SegmentsT), _i32, _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
     'nksr_pcg_profile_bytes': [_P(C.c_double), _P(C.c_double)],
-    'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp],
+    'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
     'nksr_nearest_index': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, _vp, _vp],
     'nksr_sdf_from_points': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp],
     'nksr_knn_mean_dist': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp],

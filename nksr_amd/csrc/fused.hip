@@ -319,7 +319,6 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
         // (one serial chain over hundreds of blocks was the critical path of the pass), then the eight partial sums in order
         __shared__ float partial[8][32];
         const int cell = A.multi[blockIdx.x], h = threadIdx.x >> 5;
-        if (LIST && fz_seg_done(A, A.unknown_seg, cell)) return;
         const int b0 = A.offsets[cell], n = A.offsets[cell + 1] - b0;
         const float* p = part + (int64_t)(b0 + h) * 32 + s;
         float acc = 0.f;
@@ -348,7 +347,7 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
 #pragma unroll
     for (int k = 0; k < FZ_GI; ++k) {
         b0[k] = A.offsets[cell[k]];
-        n[k] = (i0 + k < ncell && !(LIST && fz_seg_done(A, A.unknown_seg, cell[k]))) ? A.offsets[cell[k] + 1] - b0[k] : 0;
+        n[k] = i0 + k < ncell ? A.offsets[cell[k] + 1] - b0[k] : 0;
     }
     float acc[FZ_GI], a1[FZ_GI];
 #pragma unroll
@@ -363,7 +362,7 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
         int b = 2;
         for (; b + 4 <= n[k]; b += 4, p += 128) acc[k] += (p[0] + p[32]) + (p[64] + p[96]);
         for (; b < n[k]; ++b, p += 32) acc[k] += p[0];
-        if (i0 + k < ncell && (!LIST || n[k] > 0)) cellp[(int64_t)cell[k] * 32 + s] = acc[k];
+        if (i0 + k < ncell) cellp[(int64_t)cell[k] * 32 + s] = acc[k];
     }
 }
 
@@ -382,17 +381,14 @@ __global__ void __launch_bounds__(256) k_fz_gather(FusedArgs A, int per_xcd, con
     if (j0 >= A.M) return;
     const int sp = threadIdx.x & 31;
     int c[FZ_GI];
-    bool live[FZ_GI];
 #pragma unroll
-    for (int k = 0; k < FZ_GI; ++k) live[k] = j0 + k < A.M && !(MODE == 0 && fz_seg_done(A, A.unknown_seg, j0 + k));
-#pragma unroll
-    for (int k = 0; k < FZ_GI; ++k) c[k] = (sp < 27 && live[k]) ? A.nbr32[(int64_t)(j0 + k) * 32 + sp] : -1;
+    for (int k = 0; k < FZ_GI; ++k) c[k] = (sp < 27 && j0 + k < A.M) ? A.nbr32[(int64_t)(j0 + k) * 32 + sp] : -1;
     float v[FZ_GI];
 #pragma unroll
     for (int k = 0; k < FZ_GI; ++k) v[k] = c[k] >= 0 ? cellp[(int64_t)c[k] * 32 + (26 - sp)] : 0.f;
     const float r = half_sum4(v[0], v[1], v[2], v[3], sp);           // lanes 8 k .. 8 k + 7 hold the total of unknown k
     const int k = sp >> 3;
-    if ((sp & 7) == 0 && j0 + k < A.M && !(MODE == 0 && fz_seg_done(A, A.unknown_seg, j0 + k))) y[j0 + k] = r + (MODE == 0 ? reg * x[j0 + k] : (MODE == 2 ? reg : 0.f));
+    if ((sp & 7) == 0 && j0 + k < A.M) y[j0 + k] = r + (MODE == 0 ? reg * x[j0 + k] : (MODE == 2 ? reg : 0.f));
 }
 static void fz_gather_dims(int M, dim3& grid, int& per_xcd) {
     per_xcd = ((M + 7) / 8 + 8 * FZ_GI - 1) / (8 * FZ_GI) * (8 * FZ_GI);        // whole workgroups (8 half-waves x FZ_GI unknowns)

@@ -102,9 +102,10 @@ __device__ void smallest_eigvec(double a[3][3], float nrm[3]) {
 
 __global__ void __launch_bounds__(128) k_knn_pca_normals(KnnGrid g, int64_t n, int k, int max_ring,
                                                          float* __restrict__ normal, float* __restrict__ radius2,
-                                                         int32_t* __restrict__ valid) {
+                                                         int32_t* __restrict__ valid, const int32_t* __restrict__ todo) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (todo && !todo[i]) return;          // (fallback pass: only the queries the wave-per-query kernel handed back)
     const float q[3] = {g.xyz[i * 3], g.xyz[i * 3 + 1], g.xyz[i * 3 + 2]};
     int c[3];
     cell_of(g, q, c);
@@ -201,6 +202,175 @@ __global__ void __launch_bounds__(128) k_knn_pca_normals(KnnGrid g, int64_t n, i
     }
     radius2[i] = r2;
     valid[i] = 1;
+}
+
+// ---- one WAVEFRONT per query (the default) -------------------------------------------------------------------------------------
+// The thread-per-query kernel above walks ~36 times over the ~400 candidates of its block, one dependent load after the other:
+// fine when a million queries hide each other's latency, 52 ms for the 10 000-point scan of examples/recons_waymo_cpu.py (40
+// wavefronts on 256 CUs).  Here the 64 lanes of a wavefront share one query: the candidates of the (2R+1)^3 block are gathered ONCE
+// into LDS as (squared distance, point index) -- lane = cell of the block, offsets from a wave prefix sum over the cells' point
+// counts, so the candidate order is the cell order: deterministic -- and every later pass (ring count, the 32-step bit-pattern
+// bisection, the fp64 ranking of the candidates within a few ulps of the k-th distance, mean, covariance) strides over that list
+// with ballot / fixed-tree reductions.  Same selection rule, same r2, same neighbour SET as the thread-per-query kernel (which
+// stays as the fallback for a query whose block holds more than KW_CAP candidates: `todo`).
+#define KW_CAP 2048
+#define KW_WAVES 4
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(64 * KW_WAVES) k_knn_pca_wave(KnnGrid g, int64_t n, int k, int max_ring, float* __restrict__ normal,
+                                                               float* __restrict__ radius2, int32_t* __restrict__ valid,
+                                                               int32_t* __restrict__ todo) {
+    __shared__ float cd[KW_WAVES][KW_CAP];
+    __shared__ int32_t ci[KW_WAVES][KW_CAP];
+    __shared__ double amb[KW_WAVES][16];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * KW_WAVES + wave;
+    if (i >= n) return;
+    float* d2 = cd[wave];
+    int32_t* idx = ci[wave];
+    const float q[3] = {g.xyz[i * 3], g.xyz[i * 3 + 1], g.xyz[i * 3 + 2]};
+    int c[3];
+    cell_of(g, q, c);
+    int ncand = 0, R = 1;
+    float rmax2 = 0.f;
+    bool ok = false, overflow = false;
+    for (; R <= max_ring; ++R) {
+        const int side = 2 * R + 1, ncell = side * side * side;
+        ncand = 0;
+        for (int base = 0; base < ncell && !overflow; base += 64) {
+            const int cc = base + lane;
+            int s0 = 0, s1 = 0;
+            if (cc < ncell) {
+                const int dx = cc / (side * side) - R, dy = (cc / side) % side - R, dz = cc % side - R;
+                const int cell = hash_find(g.hkeys, g.hvals, g.hcap, morton_biased(c[0] + dx, c[1] + dy, c[2] + dz, NKSR_BIAS0));
+                if (cell >= 0) { s0 = g.start[cell]; s1 = g.end[cell]; }
+            }
+            int cnt = s1 - s0, off = cnt;                          // inclusive prefix sum over the lanes (= the cells, in block order)
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(off, o);
+                if (lane >= o) off += t;
+            }
+            const int total = __shfl(off, 63);
+            if (ncand + total > KW_CAP) { overflow = true; break; }
+            int w = ncand + off - cnt;
+            for (int p = s0; p < s1; ++p, ++w) {
+                const float ex = g.xyz[(int64_t)p * 3] - q[0], ey = g.xyz[(int64_t)p * 3 + 1] - q[1], ez = g.xyz[(int64_t)p * 3 + 2] - q[2];
+                d2[w] = knn_d2(ex, ey, ez);
+                idx[w] = p;
+            }
+            ncand += total;
+        }
+        if (overflow) break;
+        __builtin_amdgcn_wave_barrier();
+        const float rr = (float)R * g.cell;
+        rmax2 = rr * rr;
+        int cnt = 0;
+        for (int j = lane; j - lane < ncand; j += 64) cnt += __popcll(__ballot(j < ncand && d2[j] <= rmax2));
+        if (cnt >= k) { ok = true; break; }
+    }
+    if (overflow) {                 // too many candidates for the LDS list: the thread-per-query kernel takes this query
+        if (lane == 0) todo[i] = 1;
+        return;
+    }
+    if (lane == 0) todo[i] = 0;
+    if (!ok) {   // fewer than k points within max_ring cells: isolated point
+        if (lane == 0) {
+            valid[i] = 0;
+            normal[i * 3] = normal[i * 3 + 1] = 0.f;
+            normal[i * 3 + 2] = 1.f;
+            radius2[i] = 0.f;
+        }
+        return;
+    }
+    // exact k-th smallest squared distance: bisection on the bit pattern
+    unsigned lo = 0u, hi = __float_as_uint(rmax2);
+    while (lo < hi) {
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        const float m = __uint_as_float(mid);
+        int cnt = 0;
+        for (int j = lane; j - lane < ncand; j += 64) cnt += __popcll(__ballot(j < ncand && d2[j] <= m));
+        if (cnt >= k) hi = mid; else lo = mid + 1;
+    }
+    const float r2 = __uint_as_float(lo);
+    // candidates with an fp32 distance well below r2 are neighbours; the ones within a few ulps of it are ranked in fp64
+    const float r2_lo = r2 * (1.0f - 2e-6f), r2_hi = r2 * (1.0f + 2e-6f);
+    int n_in = 0, n_amb = 0;
+    for (int j = lane; j - lane < ncand; j += 64) {
+        const bool in = j < ncand;
+        const float d = in ? d2[j] : 3.4e38f;
+        n_in += __popcll(__ballot(in && d < r2_lo));
+        const bool am = in && d >= r2_lo && d <= r2_hi;
+        const unsigned long long mask = __ballot(am);
+        if (am) {
+            const int slot = n_amb + __popcll(mask & ((1ull << lane) - 1ull));
+            if (slot < 16) {
+                const int p = idx[j];
+                const double fx = (double)g.xyz[(int64_t)p * 3] - (double)q[0], fy = (double)g.xyz[(int64_t)p * 3 + 1] - (double)q[1],
+                             fz = (double)g.xyz[(int64_t)p * 3 + 2] - (double)q[2];
+                amb[wave][slot] = fx * fx + fy * fy + fz * fz;
+            }
+        }
+        n_amb += __popcll(mask);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (n_amb > 16) n_amb = 16;                  // (more than 16 candidates within 2e-6 of the k-th distance: degenerate input)
+    int need = k - n_in;
+    if (need > n_amb) need = n_amb;
+    double thr64 = -1.0;
+    if (need > 0) {                              // the need-th smallest of <= 16 values: every lane ranks them (uniform result)
+        double best = -1.0;
+        for (int a = 0; a < n_amb; ++a) {
+            const double v = amb[wave][a];
+            int rank = 0;
+            for (int b = 0; b < n_amb; ++b) rank += (amb[wave][b] < v) || (amb[wave][b] == v && b < a);
+            if (rank == need - 1) best = v;
+        }
+        thr64 = best;
+    }
+    // mean and covariance of the neighbour set (fp64, lane-strided partial sums + a fixed reduction tree)
+    double m[3] = {0, 0, 0};
+    int cntn = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0;
+        int cl = 0;
+        for (int j = lane; j < ncand; j += 64) {
+            const float d = d2[j];
+            if (d > r2_hi) continue;
+            const int p = idx[j];
+            const float px = g.xyz[(int64_t)p * 3], py = g.xyz[(int64_t)p * 3 + 1], pz = g.xyz[(int64_t)p * 3 + 2];
+            if (d >= r2_lo) {
+                const double fx = (double)px - (double)q[0], fy = (double)py - (double)q[1], fz = (double)pz - (double)q[2];
+                if (fx * fx + fy * fy + fz * fz > thr64) continue;
+            }
+            if (pass == 0) { a0 += px; a1 += py; a2 += pz; ++cl; }
+            else {
+                const double e0 = px - m[0], e1 = py - m[1], e2 = pz - m[2];
+                a0 += e0 * e0; a1 += e0 * e1; a2 += e0 * e2; a3 += e1 * e1; a4 += e1 * e2; a5 += e2 * e2;
+            }
+        }
+        a0 = wave_sum_d(a0); a1 = wave_sum_d(a1); a2 = wave_sum_d(a2);
+        if (pass == 0) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cl += __shfl_xor(cl, o);
+            cntn = cl;
+            m[0] = a0 / cntn; m[1] = a1 / cntn; m[2] = a2 / cntn;
+        } else {
+            a3 = wave_sum_d(a3); a4 = wave_sum_d(a4); a5 = wave_sum_d(a5);
+            if (lane == 0) {
+                double cov[3][3] = {{a0, a1, a2}, {a1, a3, a4}, {a2, a4, a5}};
+                float nv[3];
+                smallest_eigvec(cov, nv);
+                normal[i * 3] = nv[0]; normal[i * 3 + 1] = nv[1]; normal[i * 3 + 2] = nv[2];
+                radius2[i] = r2;
+                valid[i] = 1;
+            }
+        }
+    }
 }
 
 __global__ void __launch_bounds__(128) k_nearest_index(KnnGrid g, const float* __restrict__ query, int64_t nq, int max_ring,
@@ -379,12 +549,19 @@ static KnnGrid make_grid(const float* xyz_sorted, const int32_t* start, const in
 
 extern "C" int nksr_knn_pca_normals(const float* xyz_sorted, int64_t n, const int32_t* start, const int32_t* end,
                                     const int64_t* hkeys, const int32_t* hvals, int32_t hcap, float cell, float inv_cell, int k, int max_ring,
-                                    float* normal_out, float* radius2_out, int32_t* valid_out, void* stream) {
+                                    float* normal_out, float* radius2_out, int32_t* valid_out, int32_t* todo_work, void* stream) {
     if (n <= 0) return NKSR_OK;
     if (k < 3) return nksr_set_error(NKSR_ERR_ARG, "knn must be >= 3");
     KnnGrid g = make_grid(xyz_sorted, start, end, hkeys, hvals, hcap, cell, inv_cell);
-    hipLaunchKernelGGL(k_knn_pca_normals, dim3(nksr_blocks(n, 128)), dim3(128), 0, (hipStream_t)stream, g, n, k, max_ring,
-                       normal_out, radius2_out, valid_out);
+    if (!todo_work || k > KW_CAP) {        // no work array: thread-per-query for all
+        hipLaunchKernelGGL(k_knn_pca_normals, dim3(nksr_blocks(n, 128)), dim3(128), 0, (hipStream_t)stream, g, n, k, max_ring,
+                           normal_out, radius2_out, valid_out, (const int32_t*)nullptr);
+    } else {
+        hipLaunchKernelGGL(k_knn_pca_wave, dim3(nksr_blocks(n, KW_WAVES)), dim3(64 * KW_WAVES), 0, (hipStream_t)stream, g, n, k, max_ring,
+                           normal_out, radius2_out, valid_out, todo_work);
+        hipLaunchKernelGGL(k_knn_pca_normals, dim3(nksr_blocks(n, 128)), dim3(128), 0, (hipStream_t)stream, g, n, k, max_ring,
+                           normal_out, radius2_out, valid_out, (const int32_t*)todo_work);
+    }
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }

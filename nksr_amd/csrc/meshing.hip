@@ -124,9 +124,13 @@ __global__ void k_lattice_positions(const int64_t* __restrict__ vkeys, int64_t n
     if (i >= n) return;
     int x, y, z;
     morton_decode_biased(vkeys[i], NKSR_BIAS0, x, y, z);
-    xyz[i * 3] = __fadd_rn(__fmul_rn((float)x, h), half_w0);
-    xyz[i * 3 + 1] = __fadd_rn(__fmul_rn((float)y, h), half_w0);
-    xyz[i * 3 + 2] = __fadd_rn(__fmul_rn((float)z, h), half_w0);
+    // g * h + w0 / 2 with TWO fp32 roundings (contraction is off in this file).  Plain operators on purpose:
+    // __fadd_rn(__fmul_rn(..)) are inline header functions compiled with contraction allowed, the pair still fused into one fma and
+    // every lattice position sat one ulp off the oracle's -- 3e-7 of field difference at the mesh vertices (found in round 3)
+    const float px = (float)x * h, py = (float)y * h, pz = (float)z * h;
+    xyz[i * 3] = px + half_w0;
+    xyz[i * 3 + 1] = py + half_w0;
+    xyz[i * 3 + 2] = pz + half_w0;
 }
 
 __global__ void k_cell_config(const int32_t* __restrict__ corner_idx, const float* __restrict__ f, int64_t ncell,
@@ -177,9 +181,11 @@ __global__ void k_mc_vertices(const int64_t* __restrict__ edge_keys, int64_t ned
     const int64_t k1 = morton_biased(g[0], g[1], g[2], NKSR_BIAS0);
     const int v1 = hash_find(hkeys, hvals, hcap, k1);          // the far end of an emitted edge is a lattice vertex
     float f0 = f[v0], f1 = f[v1 >= 0 ? v1 : v0];
-    float t = __fdiv_rn(f0, __fsub_rn(f0, f1));
+    const float df = f0 - f1;
+    const float t = f0 / df;
     float p[3] = {vpos[v0 * 3], vpos[v0 * 3 + 1], vpos[v0 * 3 + 2]};
-    p[axis] = __fadd_rn(p[axis], __fmul_rn(t, h));
+    const float th = t * h;                 // (rounded product, then rounded sum: contraction is off in this file)
+    p[axis] = p[axis] + th;
     verts[i * 3] = p[0];
     verts[i * 3 + 1] = p[1];
     verts[i * 3 + 2] = p[2];

@@ -834,7 +834,7 @@ struct CsrOperator : PcgOperator {
 
 extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, const float* diag, int32_t M,
                               int64_t nnz, int col_format, const float* b, float* x, float tol, int max_iter, int check_every,
-                              void* workspace, double* info_out, void* stream) {
+                              void* workspace, const nksr_coarse_precond_t* pc, double* info_out, void* stream) {
     if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
     if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     void* spmv_ws = (char*)workspace + pcg_vector_bytes(M);
@@ -843,5 +843,5 @@ extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const flo
     CsrOperator A;
     A.rowptr = rowptr; A.cols = cols; A.vals = vals; A.M = M; A.nnz = nnz; A.fmt = col_format;
     A.plan = carve_spmv(spmv_ws, nnz, col_format);
-    return nksr_pcg_run(A, diag, M, b, x, tol, max_iter, check_every, workspace, info_out, (hipStream_t)stream);
+    return nksr_pcg_run(A, diag, M, b, x, tol, max_iter, check_every, workspace, info_out, (hipStream_t)stream, pc);
 }

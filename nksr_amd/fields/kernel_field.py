@@ -291,17 +291,26 @@ class KernelField(BaseField):
         t0 = time.perf_counter()
         rowptr, cols, vals, diag, b = self.assemble(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight,
                                                     pos_sorted_keys, normal_sorted_keys)
-        if self.solver_config.get('verbose') or self.solver_config.get('sync_timing'):
+        # the same preconditioner policy as the matrix-free solve: hierarchies of 5+ levels (Jacobi needs ~47 iterations per
+        # tree_depth-5 chunk, the coarse-level block ~13) or an explicit solver_config['coarse_precond']
+        cfg = self.solver_config
+        pc = None
+        if cfg.get('coarse_precond') is not False and (isinstance(cfg.get('coarse_precond'), dict) or self.svh.depth >= 5):
+            pc = self._coarse_precond(None, reg_weight, sites=dict(pos_xyz=pos_xyz, normal_xyz=normal_xyz, normal_value=normal_value,
+                                                                   pos_weight=pos_weight, normal_weight=normal_weight,
+                                                                   pos_sorted_keys=pos_sorted_keys, normal_sorted_keys=normal_sorted_keys))
+        if cfg.get('verbose') or cfg.get('sync_timing'):
             torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
-        x, iters, rel = solver.pcg_solve(rowptr, cols, vals, diag, b, tol=self.solver_config['tol'],
-                                         max_iter=self.solver_config['max_iter'], check_every=self.solver_config['check_every'])
+        x, iters, rel = solver.pcg_solve(rowptr, cols, vals, diag, b, tol=cfg['tol'], max_iter=cfg['max_iter'], check_every=cfg['check_every'],
+                                         precond=pc['pc'] if pc else None)
         t2 = time.perf_counter()
         self.alpha = x
         self.matrix = (rowptr, cols, vals, diag)
         self._fused_op = None
         self.rhs, self.diag = b, diag
         self.solve_info = {'iters': iters, 'rel_residual': rel, 'M': int(b.numel()), 'nnz': int(self.nnz),
+                           'coarse_precond': ({k: pc[k] for k in ('first_level', 'unknowns', 'nnz', 'steps', 'lambda')} if pc else None),
                            't_assemble': t1 - t0, 't_pcg': t2 - t1}
         self._attach_autograd(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight)
         if self.solver_config.get('verbose'):
@@ -443,7 +452,7 @@ class KernelField(BaseField):
         call('nksr_fused_apply', C.byref(op['op']), float(reg_weight), ptr(x.contiguous()), ptr(y), stream())
         return y
 
-    def _coarse_precond(self, op, reg_weight, segments=None):
+    def _coarse_precond(self, op, reg_weight, segments=None, sites=None):
         """Block preconditioner of the coarse levels (nksr_coarse_precond_t, csrc/pcg.hip): the diagonal block of the levels >= c0
         assembled as a small plain CSR + the largest Jacobi-scaled eigenvalue of every segment's block (left on the device: no
         host sync).  solver_config['coarse_precond']: None = automatic (see solve_fused), False = off, or a dict
@@ -463,7 +472,10 @@ class KernelField(BaseField):
             return None
         n = M - off[c0]
         nseg = segments.nseg if segments is not None else 1
-        rowptr, cols, vals, diag, _ = self.assemble(None, None, None, 1.0, 1.0, reg_weight, coarse_from=c0, fused_op=op)
+        if op is not None:      # from the kernel rows the matrix-free operator already holds
+            rowptr, cols, vals, diag, _ = self.assemble(None, None, None, 1.0, 1.0, reg_weight, coarse_from=c0, fused_op=op)
+        else:                   # the assembled solve: the same block from the site sets (rows of the masked hierarchy)
+            rowptr, cols, vals, diag, _ = self.assemble(reg_weight=reg_weight, coarse_from=c0, **sites)
         work = torch.empty(3 * n, dtype=torch.float32, device=self.device)
         lam = torch.empty(nseg, dtype=torch.float32, device=self.device)
         coef = torch.empty(nseg * (1 + 2 * PC_MAX_STEPS), dtype=torch.float32, device=self.device)

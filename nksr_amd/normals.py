@@ -75,9 +75,10 @@ def knn_pca(xyz, knn):
     nrm = torch.empty((n, 3), dtype=torch.float32, device=xyz.device)
     r2 = torch.empty(n, dtype=torch.float32, device=xyz.device)
     valid = torch.empty(n, dtype=torch.int32, device=xyz.device)
+    todo = torch.empty(n, dtype=torch.int32, device=xyz.device)       # one wavefront per query; the queries it hands back (too many candidates)
     h = pg.grid.hash
     call('nksr_knn_pca_normals', ptr(pg.xyz), n, ptr(pg.start), ptr(pg.end), ptr(h.hkeys), ptr(h.hvals), h.cap, pg.cell,
-         pg.inv_cell, int(knn), 6, ptr(nrm), ptr(r2), ptr(valid), stream())
+         pg.inv_cell, int(knn), 6, ptr(nrm), ptr(r2), ptr(valid), ptr(todo), stream())
     return pg, nrm, r2, valid
 
 

@@ -26,8 +26,9 @@ def spmv(rowptr, cols, vals, x):
     return y
 
 
-def pcg_solve(rowptr, cols, vals, diag, b, tol=1e-5, max_iter=2000, check_every=16, workspace=None):
-    """Returns (x, iterations, relative residual).  x0 = 0, stop on ||r|| <= tol ||b||."""
+def pcg_solve(rowptr, cols, vals, diag, b, tol=1e-5, max_iter=2000, check_every=16, workspace=None, precond=None):
+    """Returns (x, iterations, relative residual).  x0 = 0, stop on ||r|| <= tol ||b||.  ``precond``: a CoarsePrecondT
+    (KernelField._coarse_precond) -- Chebyshev steps on the coarse levels' diagonal block instead of Jacobi there."""
     M = b.numel()
     nnz = int(rowptr[M].item())
     x = torch.empty(M, dtype=torch.float32, device=b.device)
@@ -36,7 +37,9 @@ def pcg_solve(rowptr, cols, vals, diag, b, tol=1e-5, max_iter=2000, check_every=
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
     info = (C.c_double * 2)()
     call('nksr_pcg_solve', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), M, nnz, col_format(cols), ptr(b), ptr(x), float(tol), int(max_iter),
-         int(check_every), ptr(workspace), info, stream())
+         int(check_every), ptr(workspace), C.byref(precond) if precond is not None else None, info, stream())
+    if info[1] < 0:
+        raise RuntimeError('PCG breakdown (r.z <= 0): the coarse-level preconditioner is not positive definite')
     return x, int(info[0]), float(info[1])
 
 

@@ -4,15 +4,19 @@ import sqlite3
 import sys
 
 
-def summarise(db_path, top=40):
+def summarise(db_path, top=40, tail_ms=0.0):
     db = sqlite3.connect(db_path)
     cur = db.cursor()
     tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
     kd = [t for t in tabs if t.startswith('rocpd_kernel_dispatch')][0]
     ks = [t for t in tabs if t.startswith('rocpd_info_kernel_symbol')][0]
+    where = ''
+    if tail_ms > 0:      # only the last tail_ms milliseconds (the last timed step of a bench run)
+        t_end = list(cur.execute('select max(end) from %s' % kd))[0][0]
+        where = 'where d.start >= %d ' % int(t_end - tail_ms * 1e6)
     q = ("select s.kernel_name, count(*), sum(d.end-d.start)/1e6, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3, "
          "max(d.end-d.start)/1e3, s.arch_vgpr_count, s.sgpr_count, s.group_segment_size, s.private_segment_size "
-         "from %s d join %s s on d.kernel_id=s.id group by s.kernel_name order by 3 desc" % (kd, ks))
+         "from %s d join %s s on d.kernel_id=s.id %sgroup by s.kernel_name order by 3 desc" % (kd, ks, where))
     rows = list(cur.execute(q))
     tot = sum(r[2] for r in rows)
     lines = ['| kernel | calls | total ms | % | avg us | min us | max us | vgpr | sgpr | lds B | scratch B |', '|---|---|---|---|---|---|---|---|---|---|---|']
@@ -23,7 +27,8 @@ def summarise(db_path, top=40):
 
 
 if __name__ == '__main__':
-    out = summarise(sys.argv[1])
+    import os
+    out = summarise(sys.argv[1], top=int(os.environ.get('KSTATS_ROWS', 40)), tail_ms=float(os.environ.get('KSTATS_TAIL_MS', 0)))
     if len(sys.argv) > 2:
         open(sys.argv[2], 'w').write(out + '\n')
     print(out)

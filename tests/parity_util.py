@@ -176,7 +176,10 @@ def compare_meshes(name, gv, gf, gvkey, gaxis, ref, delta_f, w0=0.1, max_tainted
     if exact:   # identical triangle sets: the ORDER must be identical too (cell-major, table order) => index-exact faces
         assert np.array_equal(tg, to), '%s: same triangles in a different order' % name
         assert np.array_equal(np.asarray(gf, np.int64), np.asarray(of, np.int64)), '%s: face indices differ' % name
-    assert (dv <= bound).all(), '%s: vertex off by %.3e voxel' % (name, float((dv / w0).max()))
+    if not (dv <= bound).all():
+        w = int(np.argmax(dv / bound))
+        raise AssertionError('%s: %d vertices beyond their bound; worst: off by %.3e voxel, bound %.3e voxel, |f0 - f1| = %.3e, at %s (oracle %s)' % (
+            name, int((dv > bound).sum()), dv[w] / w0, bound[w] / w0, float(ref['vert_df'][io][w]), gv[ig][w], ov[io][w]))
     stats['exact'] = exact
     return stats
 
