@@ -251,6 +251,9 @@ def main():
                'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]),
                'parallelism': 'none' if world == 1 else 'chunks sharded over %d ranks (Morton-contiguous), sharded input, no collective in the solve, '
                                                         'one halo exchange, mesh gather + stitch on rank 0' % world}
+        from nksr_amd.fields import kernel_field as _kf
+        if _kf.DETAIL_TIMES:
+            cfg['detail_ms_total'] = {k: round(v * 1e3, 1) for k, v in sorted(_kf.DETAIL_TIMES.items()) if k != '_'}
         return dt, n_scene, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}
 
     # ---- configs[2]: the roofline workload ---------------------------------------------------------------------------

@@ -256,7 +256,7 @@ typedef struct {
                                 * r.z <= 0) of every segment, refreshed at every convergence check */
 } nksr_segments_t;
 typedef struct nksr_coarse_precond_s {
-    int32_t first, n, steps, reserved;
+    int32_t first, n, steps, format;   /* format 0: plain CSR (rowptr / cols / vals / diag);  1: packed, see below */
     float lambda_scale, ratio; /* the eigenvalue bound of segment c is lambda_scale * lambda[c] (safety margin, ~1.1)          */
     const float* lambda;       /* device [nseg]: nksr_coarse_lambda_max; <= 0 / non-finite: that segment keeps plain Jacobi     */
     const int32_t* row_seg;    /* device [n]: segment of every coarse row; NULL with one segment                                */
@@ -264,9 +264,25 @@ typedef struct nksr_coarse_precond_s {
     const int32_t* cols;       /* [nnz_c] local column indices */
     const float* vals;         /* [nnz_c] */
     const float* diag;         /* [n] diagonal of A_cc */
-    float* work;               /* [3 n] floats */
+    float* work;               /* [3 n] floats ([4 n] with format 1) */
     float* coef;               /* [nseg * (1 + 2 * NKSR_PC_MAX_STEPS)] floats: the solve writes the Chebyshev coefficients here */
+    /* format 1 (nksr_coarse_pack): the Jacobi-scaled block S = D^-1/2 A_cc D^-1/2 without its unit diagonal, 4 bytes per entry --
+     * (half-precision value << 16) | column local to the row's segment -- over the coarse unknowns renumbered segment-major; needs
+     * < 2^16 coarse unknowns per segment.  row_seg is then in the NEW order.  The preconditioner stays a fixed symmetric positive
+     * operator (all a CG preconditioner must be); a Chebyshev step streams half the bytes. */
+    const uint32_t* packed;    /* [nnz_c - n] */
+    const int32_t* packed_rowptr; /* [n + 1] new order */
+    const float* dis;          /* [n] D^-1/2, new order */
+    const int32_t* old_of_new; /* [n] coarse row (PCG order) of every new row */
+    const int32_t* seg_base;   /* [nseg + 1] first new row of every segment */
 } nksr_coarse_precond_t;
+/* format-1 block from the plain CSR: new_of_old / old_of_new = the segment-major renumbering, row_seg_new / seg_base in the new
+ * order, packed_rowptr = exclusive sum of (row length - 1) in the new order.  Writes packed_out and dis_out. */
+int nksr_coarse_pack(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n,
+                     const int32_t* old_of_new, const int32_t* new_of_old, const int32_t* row_seg_new, const int32_t* seg_base,
+                     const int32_t* packed_rowptr, uint32_t* packed_out, float* dis_out, void* stream);
+/* eigenvalue bounds of a format-1 block (power iteration on S, work: 2 n floats): lambda_out [nseg] */
+int nksr_coarse_lambda_max_packed(const nksr_coarse_precond_t* pc, int32_t nseg, int iters, float* work, float* lambda_out, void* stream);
 /* power iteration (iters steps from the all-ones vector, work: 2 n floats): lambda_out (device, [nseg]) = ||v_k|| / ||v_{k-1}||
  * over the coarse rows of every segment (`first` = unknown index of coarse row 0; the ranges below it are skipped). */
 int nksr_coarse_lambda_max(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n, int iters,

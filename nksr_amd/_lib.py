@@ -34,8 +34,9 @@ class SegmentsT(C.Structure):
 
 
 class CoarsePrecondT(C.Structure):
-    _fields_ = [('first', _i32), ('n', _i32), ('steps', _i32), ('reserved', _i32), ('lambda_scale', _f32), ('ratio', _f32),
-                ('lambda_', _vp), ('row_seg', _vp), ('rowptr', _vp), ('cols', _vp), ('vals', _vp), ('diag', _vp), ('work', _vp), ('coef', _vp)]
+    _fields_ = [('first', _i32), ('n', _i32), ('steps', _i32), ('format', _i32), ('lambda_scale', _f32), ('ratio', _f32),
+                ('lambda_', _vp), ('row_seg', _vp), ('rowptr', _vp), ('cols', _vp), ('vals', _vp), ('diag', _vp), ('work', _vp), ('coef', _vp),
+                ('packed', _vp), ('packed_rowptr', _vp), ('dis', _vp), ('old_of_new', _vp), ('seg_base', _vp)]
 
 
 PC_MAX_STEPS = 16
@@ -126,6 +127,8 @@ _PROTOS = {
     'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(SegmentsT), _P(C.c_double), _vp],
     'nksr_coarse_lambda_max': [_vp, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _P(SegmentsT), _i32, _vp],
+    'nksr_coarse_pack': [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'nksr_coarse_lambda_max_packed': [_P(CoarsePrecondT), _i32, C.c_int, _vp, _vp, _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
     'nksr_pcg_profile_bytes': [_P(C.c_double), _P(C.c_double)],
     'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],

@@ -728,10 +728,185 @@ extern "C" int nksr_coarse_lambda_max(const int32_t* rowptr, const int32_t* cols
     return NKSR_OK;
 }
 
+// ---- packed coarse block (nksr_coarse_precond_t.format 1) -----------------------------------------------------------------------
+// A Chebyshev step streams the whole block: 8 bytes per entry (fp32 value + int32 column) x 4.2e8 entries x 8 steps per PCG
+// iteration on the 64-chunk scene -- a third of the iteration.  The preconditioner only has to be a FIXED symmetric positive
+// operator, so the block is stored Jacobi-scaled, S = D^-1/2 A_cc D^-1/2 (unit diagonal, |S_ij| <= 1): an entry is a 16-bit
+// half-precision value and a 16-bit column LOCAL to the row's segment -- the coarse unknowns are renumbered segment-major
+// (old_of_new), so a chunk's columns span < 2^16 -- i.e. 4 bytes.  The recurrence runs in the scaled variables
+//   res' = D^-1/2 res,  d' = D^1/2 d:   t = S d';  y' += d';  res' -= t;  d' <- a d' + b res';      z = D^-1/2 y'
+// (the same polynomial in D^-1 A_cc, up to the rounding of S to half precision: S_ij = half(v_ij * (dis_i * dis_j)) is bitwise symmetric).
+#include <hip/hip_fp16.h>
+
+__global__ void __launch_bounds__(256) k_cc_pack(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                 const float* __restrict__ vals, const float* __restrict__ diag,
+                                                 const int32_t* __restrict__ old_of_new, const int32_t* __restrict__ new_of_old,
+                                                 const int32_t* __restrict__ row_seg, const int32_t* __restrict__ seg_base,
+                                                 const int32_t* __restrict__ prow, uint32_t* __restrict__ pk, float* __restrict__ dis) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const int j = old_of_new[i];
+    const int k0 = rowptr[j], k1 = rowptr[j + 1] - 1;          // the diagonal closes every row: it is dropped (unit diagonal)
+    const float di = 1.f / sqrtf(diag[j]);
+    const int base = seg_base[row_seg[i]], o = prow[i];
+    if (lane == 0) dis[i] = di;
+    for (int k = k0 + lane; k < k1; k += 64) {
+        const int c = cols[k];
+        const float dj = 1.f / sqrtf(diag[c]);
+        const __half hv = __float2half_rn(vals[k] * (di * dj));
+        pk[o + (k - k0)] = ((uint32_t)__half_as_ushort(hv) << 16) | (uint32_t)(new_of_old[c] - base);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_cheb16_init(int n, const float* __restrict__ r, const int32_t* __restrict__ old_of_new,
+                                                     const float* __restrict__ dis, const float* __restrict__ coef,
+                                                     const int32_t* __restrict__ row_seg, float* __restrict__ res, float* __restrict__ d0,
+                                                     float* __restrict__ y, const SegScalars* __restrict__ sc) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int seg = row_seg[i];
+    if (sc && sc[seg].done) return;
+    const float rs = r[old_of_new[i]] * dis[i];
+    res[i] = rs;
+    d0[i] = rs * (coef ? coef[(int64_t)seg * CHEB_STRIDE] : 1.f);
+    y[i] = 0.f;
+}
+
+// One wavefront per CHEB16_ROWS consecutive rows; LAST: the step also leaves z = D^-1/2 (y' + d') in the PCG's order.  POWER: out = S v
+// only (eigenvalue bound).  A row holds ~240 entries -- one trip of four 64-entry groups: with a wavefront per row the step was a chain
+// of three dependent round trips per wavefront (row pointers -> entries -> gathered d) and ran at the latency, not the bandwidth
+// (0.69 ms per step on the 64-chunk scene with 8-byte AND with 4-byte entries).  Four rows per wavefront put 16 entry loads and then
+// 16 gathers in flight at once.
+#define CHEB16_ROWS 4
+template <bool POWER>
+__global__ void __launch_bounds__(256) k_cheb16_step(int n, const int32_t* __restrict__ prow, const uint32_t* __restrict__ pk,
+                                                     const float* __restrict__ coef, int step, const int32_t* __restrict__ row_seg,
+                                                     const int32_t* __restrict__ seg_base, float* __restrict__ res,
+                                                     const float* __restrict__ d_old, float* __restrict__ d_new, float* __restrict__ y,
+                                                     const SegScalars* __restrict__ sc, int last, float* __restrict__ z,
+                                                     const int32_t* __restrict__ old_of_new, const float* __restrict__ dis) {
+    const int i0 = ((blockIdx.x * 256 + threadIdx.x) >> 6) * CHEB16_ROWS, lane = threadIdx.x & 63;
+    if (i0 >= n) return;
+    // per-row scalars: lane r (< CHEB16_ROWS) owns row i0 + r; the row pointers come as one load of CHEB16_ROWS + 1 lanes
+    const int ir = i0 + (lane < CHEB16_ROWS ? lane : 0), irc = ir < n ? ir : n - 1;
+    const int pl = prow[(i0 + lane <= n && lane <= CHEB16_ROWS) ? i0 + lane : n];
+    const int sg = row_seg[irc];
+    const bool live_l = lane < CHEB16_ROWS && ir < n && (POWER || !sc || !sc[sg].done);
+    const int sb = seg_base[sg];
+    const float dj = d_old[irc];
+    float rs = 0.f, yj = 0.f, ca = 0.f, cb = 0.f;
+    if (!POWER) {
+        rs = res[irc]; yj = y[irc];
+        ca = coef[(int64_t)sg * CHEB_STRIDE + 1 + 2 * step]; cb = coef[(int64_t)sg * CHEB_STRIDE + 2 + 2 * step];
+    }
+    int k0[CHEB16_ROWS], k1[CHEB16_ROWS], base_r[CHEB16_ROWS];
+    bool live[CHEB16_ROWS];
+    int maxlen = 0;
+#pragma unroll
+    for (int r = 0; r < CHEB16_ROWS; ++r) {
+        k0[r] = __builtin_amdgcn_readlane(pl, r);
+        k1[r] = __builtin_amdgcn_readlane(pl, r + 1);
+        base_r[r] = __builtin_amdgcn_readlane(sb, r);
+        live[r] = __builtin_amdgcn_readlane((int)live_l, r) != 0;
+        if (!live[r]) k1[r] = k0[r];
+        maxlen = (k1[r] - k0[r]) > maxlen ? (k1[r] - k0[r]) : maxlen;
+    }
+    float t[CHEB16_ROWS][4];
+#pragma unroll
+    for (int r = 0; r < CHEB16_ROWS; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[r][q] = 0.f;
+    for (int b = 0; b < maxlen; b += 256) {
+        uint32_t w[CHEB16_ROWS][4];
+#pragma unroll
+        for (int r = 0; r < CHEB16_ROWS; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = k0[r] + b + 64 * q + lane;
+                const int kc = k < k1[r] ? k : (k1[r] > k0[r] ? k1[r] - 1 : 0);          // clamped address, value masked below
+                w[r][q] = pk[kc];
+                if (k >= k1[r]) w[r][q] = 0u;                                              // value +0.0, column 0 of the segment
+            }
+#pragma unroll
+        for (int r = 0; r < CHEB16_ROWS; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                t[r][q] = fmaf(__half2float(__ushort_as_half((unsigned short)(w[r][q] >> 16))), d_old[base_r[r] + (int)(w[r][q] & 0xFFFFu)], t[r][q]);
+    }
+    float tot = 0.f;                                                     // lane r ends up with the sum of row r
+#pragma unroll
+    for (int r = 0; r < CHEB16_ROWS; ++r) {
+        float tt = (t[r][0] + t[r][1]) + (t[r][2] + t[r][3]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tt += __shfl_xor(tt, o);
+        if (lane == r) tot = tt;
+    }
+    if (live_l) {
+        tot += dj;                                                        // the unit diagonal
+        if (POWER) { d_new[ir] = tot; return; }
+        const float rj = rs - tot;
+        res[ir] = rj;
+        d_new[ir] = fmaf(ca, dj, cb * rj);
+        if (last) z[old_of_new[ir]] = (yj + dj) * dis[ir];
+        else y[ir] = yj + dj;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fill1(int n, float* __restrict__ v) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = 1.f;
+}
+// out[c] = ||b|| / ||a|| over the rows [seg_base[c], seg_base[c + 1]) (segment-major order): one workgroup per segment
+__global__ void __launch_bounds__(PCG_BLOCK) k_norm_ratio_seg(const int32_t* __restrict__ seg_base, const float* __restrict__ a,
+                                                              const float* __restrict__ b, float* __restrict__ out) {
+    __shared__ double sm[PCG_BLOCK / 64];
+    const int c = blockIdx.x;
+    double sa = 0.0, sb = 0.0;
+    for (int i = seg_base[c] + threadIdx.x; i < seg_base[c + 1]; i += PCG_BLOCK) { sa += (double)a[i] * a[i]; sb += (double)b[i] * b[i]; }
+    const double ta = block_sum(sa, sm), tb = block_sum(sb, sm);
+    if (threadIdx.x == 0) out[c] = ta > 0.0 ? (float)sqrt(tb / ta) : 0.f;
+}
+
+extern "C" int nksr_coarse_pack(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n,
+                                const int32_t* old_of_new, const int32_t* new_of_old, const int32_t* row_seg_new, const int32_t* seg_base,
+                                const int32_t* packed_rowptr, uint32_t* packed_out, float* dis_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (!rowptr || !cols || !vals || !diag || !old_of_new || !new_of_old || !row_seg_new || !seg_base || !packed_rowptr || !packed_out || !dis_out)
+        return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    hipLaunchKernelGGL(k_cc_pack, dim3(nksr_blocks((int64_t)n * 64, 256)), dim3(256), 0, (hipStream_t)stream, n, rowptr, cols, vals, diag,
+                       old_of_new, new_of_old, row_seg_new, seg_base, packed_rowptr, packed_out, dis_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+extern "C" int nksr_coarse_lambda_max_packed(const nksr_coarse_precond_t* pc, int32_t nseg, int iters, float* work, float* lambda_out, void* stream) {
+    if (!pc || pc->n <= 0) return NKSR_OK;
+    if (pc->format != 1 || !pc->packed || !pc->packed_rowptr || !pc->row_seg || !pc->seg_base || !work || !lambda_out)
+        return nksr_set_error(NKSR_ERR_ARG, "packed coarse block has NULL arrays");
+    if (iters < 2) iters = 2;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = pc->n;
+    float* v[2] = {work, work + n};
+    hipLaunchKernelGGL(k_fill1, dim3(nksr_blocks(n, 256)), dim3(256), 0, st, n, v[0]);
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL((k_cheb16_step<true>), dim3(nksr_blocks(((int64_t)n + CHEB16_ROWS - 1) / CHEB16_ROWS * 64, 256)), dim3(256), 0, st, n, pc->packed_rowptr, pc->packed,
+                           (const float*)nullptr, 0, pc->row_seg, pc->seg_base, (float*)nullptr, (const float*)v[i & 1], v[(i + 1) & 1], (float*)nullptr,
+                           (const SegScalars*)nullptr, 0, (float*)nullptr, (const int32_t*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL(k_norm_ratio_seg, dim3(nseg), dim3(PCG_BLOCK), 0, st, pc->seg_base, (const float*)v[(iters - 1) & 1], (const float*)v[iters & 1], lambda_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
 static int cheb_check(const nksr_coarse_precond_t* pc, int nseg) {
     if (pc->n <= 0 || pc->steps < 1 || pc->steps > NKSR_PC_MAX_STEPS) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: 1..%d steps", NKSR_PC_MAX_STEPS);
     if (!(pc->lambda_scale > 0.f) || !(pc->ratio > 1.f)) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: lambda_scale > 0, ratio > 1");
-    if (!pc->rowptr || !pc->cols || !pc->vals || !pc->diag || !pc->work || !pc->lambda || !pc->coef) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner has NULL arrays");
+    if (!pc->work || !pc->lambda || !pc->coef) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner has NULL arrays");
+    if (pc->format == 1) {
+        if (!pc->packed || !pc->packed_rowptr || !pc->dis || !pc->old_of_new || !pc->seg_base || !pc->row_seg)
+            return nksr_set_error(NKSR_ERR_ARG, "packed coarse block has NULL arrays");
+        return NKSR_OK;
+    }
+    if (!pc->rowptr || !pc->cols || !pc->vals || !pc->diag) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner has NULL arrays");
     if (nseg > 1 && !pc->row_seg) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: row_seg is required with more than one segment");
     return NKSR_OK;
 }
@@ -739,6 +914,16 @@ static int cheb_check(const nksr_coarse_precond_t* pc, int nseg) {
 static void cheb_apply(const nksr_coarse_precond_t* pc, const float* r, float* z, const SegScalars* sc, hipStream_t st) {
     const int n = pc->n;
     float *res = pc->work, *d[2] = {pc->work + n, pc->work + 2 * (size_t)n};
+    if (pc->format == 1) {      // packed block: scaled variables, segment-major order; y lives in the work array (z is written by the last step)
+        float* y = pc->work + 3 * (size_t)n;
+        hipLaunchKernelGGL(k_cheb16_init, dim3(nksr_blocks(n, 256)), dim3(256), 0, st, n, r, pc->old_of_new, pc->dis, (const float*)pc->coef, pc->row_seg,
+                           res, d[0], y, sc);
+        for (int i = 0; i < pc->steps; ++i)
+            hipLaunchKernelGGL((k_cheb16_step<false>), dim3(nksr_blocks(((int64_t)n + CHEB16_ROWS - 1) / CHEB16_ROWS * 64, 256)), dim3(256), 0, st, n, pc->packed_rowptr, pc->packed,
+                               (const float*)pc->coef, i, pc->row_seg, pc->seg_base, res, (const float*)d[i & 1], d[(i + 1) & 1], y, sc,
+                               i == pc->steps - 1 ? 1 : 0, z, pc->old_of_new, pc->dis);
+        return;
+    }
     hipLaunchKernelGGL(k_cheb_init, dim3(nksr_blocks(n, 256)), dim3(256), 0, st, n, r, pc->diag, (const float*)pc->coef, pc->row_seg, res, d[0], z, sc);
     for (int i = 0; i < pc->steps; ++i)
         hipLaunchKernelGGL(k_cheb_step, dim3(nksr_blocks((int64_t)n * 64, 256)), dim3(256), 0, st, n, pc->rowptr, pc->cols, pc->vals, pc->diag,

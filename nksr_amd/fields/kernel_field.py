@@ -27,6 +27,20 @@ def pack_interpolator(interp):
     return interp.packed()
 
 
+_DETAIL = os.environ.get('NKSR_TIMING_DETAIL', '') == '1'
+DETAIL_TIMES = {}
+
+
+def _tick(name, t0):
+    """NKSR_TIMING_DETAIL=1: synchronised sub-stage times accumulated in DETAIL_TIMES (diagnostics only)."""
+    if not _DETAIL:
+        return t0
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    DETAIL_TIMES[name] = DETAIL_TIMES.get(name, 0.0) + (t1 - t0)
+    return t1
+
+
 class Segments:
     """Independent diagonal blocks of ONE hierarchy (nksr_segments_t): the chunks of a batched chunk solve.  Segment i owns
     the Morton key range [key_lo[i], key_hi[i]) of the finest level (an aligned cube of the lattice: its ancestors' ranges are the
@@ -232,8 +246,10 @@ class KernelField(BaseField):
         counts = torch.zeros((4, M + 1), dtype=torch.int32, device=dev)
         rowcount, crosscount, samelow, indeg = counts[0], counts[1], counts[2], counts[3]
         ws = torch.empty(int(_lib.lib.nksr_assemble_workspace_bytes(C.byref(hier))), dtype=torch.uint8, device=dev)
+        td = _tick('_', time.perf_counter())
         call('nksr_assemble_count', C.byref(hier), ptr(ws), ptr(rowcount), ptr(crosscount), ptr(samelow), ptr(indeg), stream())
         n_up, n_mir = [int(v) for v in counts[:2].sum(dim=1, dtype=torch.int64).tolist()]
+        td = _tick('asm:count', td)
         nnz = 2 * n_up + M
         if nnz >= 2 ** 31 - 4096:
             raise RuntimeError('assembled system too large for one chunk (M=%d, nnz=%d >= 2^31): use the matrix-free solve '
@@ -267,6 +283,7 @@ class KernelField(BaseField):
         split = torch.empty(split_bytes, dtype=torch.uint8, device=dev) if split_bytes else None
         call('nksr_assemble', C.byref(hier), sets, nsets, float(reg_weight), col_bits, ptr(ws), ptr(rowptr), ptr(indeg),
              ptr(samelow), ptr(mir_off), fmt, ptr(cols), ptr(vals), ptr(diag), ptr(mir_k), ptr(mir_v), ptr(b), ptr(split), split_bytes, stream())
+        td = _tick('asm:blocks+fill', td)
         del split
         del ws
         ks, vs = ops.sort_pairs(mir_k, mir_v.view(torch.int32), end_bit=col_bits)   # stable, destination-row bits only
@@ -274,6 +291,7 @@ class KernelField(BaseField):
         call('nksr_place_mirrors', ptr(ks), ptr(vs.view(torch.float32)), n_mir, col_bits, ptr(rowptr), ptr(mirptr), fmt, ptr(cols),
              ptr(vals), stream())
         del ks, vs
+        td = _tick('asm:mirrors', td)
         if fmt == 1:
             packed = torch.empty(npad // 3, dtype=torch.int64, device=dev)
             call('nksr_pack_cols21', ptr(cols), npad, ptr(packed), stream())
@@ -386,6 +404,7 @@ class KernelField(BaseField):
             row_of_site = torch.empty(nsite, dtype=torch.int32, device=dev)
             row_of_site[order] = first_row
             row_index = list(torch.split(row_of_site, counts_s))
+        td = _tick('_', time.perf_counter())
         pad = 64 * 27      # (the operator's loads are unconditional: the last wavefront reads up to 63 rows past the end)
         rows_all = torch.empty(L * rows_total * 27 + pad, dtype=torch.float32, device=dev)
         rows_all[L * rows_total * 27:].zero_()
@@ -395,6 +414,7 @@ class KernelField(BaseField):
             row_cells[:, pad_rows] = -1
             rows_all[:L * rows_total * 27].view(L, rows_total, 27)[:, pad_rows] = 0.0
         keep = [rows_all, targets_all, row_cells]
+        td = _tick('op:alloc', td)
         for (xs, ks, perm, target, sw, ncomp), ri in zip(specs, row_index):
             ri = ri.contiguous()
             if torch.is_tensor(sw):
@@ -407,6 +427,7 @@ class KernelField(BaseField):
                 tgt = tgt * (sw[:, None] if torch.is_tensor(sw) else sw)                               # row order (site, component)
                 targets_all[(ri.long()[:, None] + torch.arange(ncomp, device=dev)[None]).reshape(-1)] = tgt.reshape(-1)
             keep += [xs, ri]
+        td = _tick('op:kernel_rows', td)
         # work items = runs of 32 rows; a cell owns one partial block per item its rows touch
         span = torch.empty((2, M), dtype=torch.int32, device=dev)
         counts = torch.empty(M + 1, dtype=torch.int32, device=dev)
@@ -431,6 +452,7 @@ class KernelField(BaseField):
             op.item_seg, op.unknown_seg = ptr(item_seg), ptr(segments.unknown_seg)
             keep += [item_seg, segments.unknown_seg]
         keep += [nbr32, offsets, multi, ws, cell_sums, nnz_counter]
+        td = _tick('op:tables', td)
         return {'op': op, 'nsets': len(specs), 'nblocks': nblocks, 'rows_total': rows_total, 'n_multi': int(multi.numel()),
                 'nnz_counter': nnz_counter, 'keep': keep, 'span': span, 'rows_all': rows_all}
 
@@ -472,24 +494,60 @@ class KernelField(BaseField):
             return None
         n = M - off[c0]
         nseg = segments.nseg if segments is not None else 1
+        td = _tick('_', time.perf_counter())
         if op is not None:      # from the kernel rows the matrix-free operator already holds
             rowptr, cols, vals, diag, _ = self.assemble(None, None, None, 1.0, 1.0, reg_weight, coarse_from=c0, fused_op=op)
         else:                   # the assembled solve: the same block from the site sets (rows of the masked hierarchy)
             rowptr, cols, vals, diag, _ = self.assemble(reg_weight=reg_weight, coarse_from=c0, **sites)
-        work = torch.empty(3 * n, dtype=torch.float32, device=self.device)
+        td = _tick('pc:assemble', td)
         lam = torch.empty(nseg, dtype=torch.float32, device=self.device)
         coef = torch.empty(nseg * (1 + 2 * PC_MAX_STEPS), dtype=torch.float32, device=self.device)
         row_seg = segments.unknown_seg[off[c0]:].contiguous() if segments is not None else None
+        pc = CoarsePrecondT()
+        pc.first, pc.n, pc.steps, pc.lambda_scale, pc.ratio = off[c0], n, int(cfg.get('steps', 8)), 1.1, float(cfg.get('ratio', 100.0))
+        pc.lambda_, pc.coef = ptr(lam), ptr(coef)
+        nnz = int(cols.numel())
+        info = {'first_level': c0, 'unknowns': n, 'nnz': nnz, 'steps': int(pc.steps), 'lambda': lam}
+        # packed form (csrc/pcg.hip, format 1): Jacobi-scaled half-precision values + 16-bit segment-local columns, 4 bytes per entry
+        # instead of 8 -- when every segment holds fewer than 2^16 coarse unknowns (chunks do; a large single field does not)
+        rs = row_seg if row_seg is not None else torch.zeros(n, dtype=torch.int32, device=self.device)
+        counts = torch.bincount(rs.long(), minlength=nseg)
+        if cfg.get('packed', os.environ.get('NKSR_PC_PACKED', '1') != '0') and int(counts.max()) < 65536:
+            ar = torch.arange(n, dtype=torch.int64, device=self.device)
+            old_of_new = torch.argsort(rs.long() * n + ar)
+            new_of_old = torch.empty_like(old_of_new)
+            new_of_old[old_of_new] = ar
+            seg_base = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).to(torch.int32)
+            row_seg_new = rs[old_of_new].contiguous()
+            rp = rowptr.long()
+            lens = (rp[1:] - rp[:-1] - 1)[old_of_new]
+            prow = ops.exclusive_sum_i32(torch.cat([lens, lens.new_zeros(1)]).to(torch.int32))
+            packed = torch.empty(max(nnz - n, 1), dtype=torch.int32, device=self.device)
+            dis = torch.empty(n, dtype=torch.float32, device=self.device)
+            o2n, n2o = old_of_new.to(torch.int32), new_of_old.to(torch.int32)
+            call('nksr_coarse_pack', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), n, ptr(o2n), ptr(n2o), ptr(row_seg_new), ptr(seg_base), ptr(prow),
+                 ptr(packed), ptr(dis), stream())
+            work = torch.empty(4 * n, dtype=torch.float32, device=self.device)
+            # twelve steps instead of eight: a packed step costs a third of a plain one (four rows per wavefront, half the bytes), and
+            # every PCG iteration saved is a sweep over all kernel rows (configs[4], one GPU: 12.8 -> 11.1 iterations per chunk)
+            if 'steps' not in cfg:
+                pc.steps = 12
+                info['steps'] = 12
+            pc.format, pc.row_seg, pc.work = 1, ptr(row_seg_new), ptr(work)
+            pc.packed, pc.packed_rowptr, pc.dis, pc.old_of_new, pc.seg_base = ptr(packed), ptr(prow), ptr(dis), ptr(o2n), ptr(seg_base)
+            call('nksr_coarse_lambda_max_packed', C.byref(pc), nseg, 8, ptr(work), ptr(lam), stream())
+            info.update(packed=True, keep=(packed, prow, dis, o2n, seg_base, row_seg_new, work, lam, coef))
+            td = _tick('pc:pack+lambda', td)
+            return dict(info, pc=pc)
+        work = torch.empty(3 * n, dtype=torch.float32, device=self.device)
         # eight power-iteration steps from the all-ones vector land within ~1 % (measured): 10 % margin.  A segment whose block is
         # degenerate (no constraint rows on these levels: lambda <= 0) keeps Jacobi -- decided on the device (k_cheb_coeffs)
         call('nksr_coarse_lambda_max', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), n, 8, ptr(work), ptr(lam),
              C.byref(segments.c) if segments is not None else None, off[c0], stream())
-        pc = CoarsePrecondT()
-        pc.first, pc.n, pc.steps, pc.lambda_scale, pc.ratio = off[c0], n, int(cfg.get('steps', 8)), 1.1, float(cfg.get('ratio', 100.0))
-        pc.lambda_, pc.row_seg, pc.coef = ptr(lam), ptr(row_seg), ptr(coef)
-        pc.rowptr, pc.cols, pc.vals, pc.diag, pc.work = ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), ptr(work)
-        return {'pc': pc, 'first_level': c0, 'unknowns': n, 'nnz': int(cols.numel()), 'steps': int(pc.steps), 'lambda': lam,
-                'keep': (rowptr, cols, vals, diag, work, lam, coef, row_seg)}
+        pc.format, pc.row_seg, pc.work = 0, ptr(row_seg), ptr(work)
+        pc.rowptr, pc.cols, pc.vals, pc.diag = ptr(rowptr), ptr(cols), ptr(vals), ptr(diag)
+        info.update(packed=False, keep=(rowptr, cols, vals, diag, work, lam, coef, row_seg))
+        return dict(info, pc=pc)
 
     def solve_fused(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0,
                     pos_sorted_keys=None, normal_sorted_keys=None, segments=None):
@@ -497,11 +555,14 @@ class KernelField(BaseField):
         iteration (examples/recons_waymo.py:33 ``fused_mode=True``).  Same system, same stopping rule as
         solve_non_fused; the iterates agree to fp32 rounding (different summation order)."""
         t0 = time.perf_counter()
+        td = _tick('_', t0)
         op = self.fused_operator(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, pos_sorted_keys, normal_sorted_keys,
                                  segments=segments)
+        td = _tick('fused_operator', td)
         dev = self.device
         M = self.svh.num_unknowns
         b, diag = self.fused_rhs_diag(op, reg_weight)
+        td = _tick('rhs_diag', td)
         cfg, tol = self.solver_config, float(self.solver_config['tol'])
         max_iter, check_every = int(cfg['max_iter']), int(cfg['check_every'])
         # Preconditioner policy (coarse_precond = None): hierarchies of 5+ levels get the coarse-level block at once (Jacobi alone
@@ -512,6 +573,7 @@ class KernelField(BaseField):
         # chunk's iterates depend on its batch mates.
         auto = cfg.get('coarse_precond') is None and segments is None
         pc = self._coarse_precond(op, reg_weight, segments) if (not auto or self.svh.depth >= 5) else None
+        td = _tick('coarse_precond', td)
         if cfg.get('verbose') or cfg.get('sync_timing'):
             torch.cuda.current_stream().synchronize()
         t1 = time.perf_counter()
