@@ -331,6 +331,36 @@ int nksr_pcg_solve_fused(const nksr_fused_op_t* op, float reg, const float* diag
                          int check_every, void* pcg_workspace, const nksr_coarse_precond_t* coarse_precond /* or NULL: Jacobi */,
                          const nksr_segments_t* segments /* or NULL */, double* info_out, void* stream);
 
+/* ---- chunk plumbing of reconstruct(chunk_size=...) (csrc/chunks.hip; examples/recons_by_chunk.py:29) ---------------------------
+ * The chunk grid: chunk id = (cx * grid[1] + cy) * grid[2] + cz; along a split axis (grid[a] > 1) chunk j has the core [lo_j, hi_j),
+ * solves the points with  lo_sel[a][j] <= x < hi_sel[a][j]  (= fp32(lo_j - band), fp32(hi_j + band)) and weighs
+ * w = prod_a clamp((x - lo_w[a][j]) * inv_2ov, 0, 1) * clamp((hi_w[a][j] - x) * inv_2ov, 0, 1)  (lo_w = fp32(lo_j - ov), hi_w = fp32(hi_j + ov),
+ * factors multiplied in the order up_x, dn_x, up_y, ...; an axis that is not split contributes nothing).  Candidates of a point: the
+ * chunks within `reach` of its home chunk floor((x - origin) * inv_cs). */
+typedef struct {
+    int32_t grid[3];
+    int32_t reach;
+    float origin[3];
+    float inv_cs, inv_2ov;
+    const float* lo_sel[3];    /* device, [grid[a]] each; may be NULL for an axis that is not split */
+    const float* hi_sel[3];
+    const float* lo_w[3];
+    const float* hi_w[3];
+    const float* shift;        /* device [nchunk, 3]: translation of every chunk into its slot of the exploded frame (mode 1) */
+} nksr_chunk_grid_t;
+/* mode 0: (point, chunk) pairs of the solve's input; mode 1: pairs with a positive blend weight.  chunk_flag [nchunk] >= 0: the chunk
+ * takes part.  Count pass -> exclusive scan (offsets, n + 1 entries) -> fill pass: pairs of a point in ascending chunk order;
+ * mode 1 also writes the weight and the translated position x + shift[chunk] (one fp32 rounding). */
+int nksr_chunk_pair_counts(const nksr_chunk_grid_t* grid, int mode, const float* xyz, int64_t n, const int32_t* chunk_flag,
+                           int32_t* counts_out, void* stream);
+int nksr_chunk_pair_fill(const nksr_chunk_grid_t* grid, int mode, const float* xyz, int64_t n, const int32_t* chunk_flag,
+                         const int32_t* offsets, int64_t* pair_point_out, int32_t* pair_chunk_out, float* pair_w_out,
+                         float* pair_xyz_out, void* stream);
+/* f = sum_k w_k f_k / max(sum_k w_k, 1e-20) over the pairs [offsets[i], offsets[i + 1]) of query i, in that order (+ the same for the
+ * gradient when pair_grad / grad_out are given). */
+int nksr_chunk_blend(int64_t n, const int32_t* offsets, const float* pair_w, const float* pair_f, const float* pair_grad,
+                     float* f_out, float* grad_out, void* stream);
+
 /* ---- grid-hash nearest neighbours (csrc/knn.hip) ----------------------------------------------------
  * Points Morton-sorted by a uniform grid of size `cell` (keys from nksr_point_keys with inv_w0 =
  * inv_cell); start/end = nksr_site_ranges of the occupied cells; hkeys/hvals = their hash. */

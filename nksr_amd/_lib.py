@@ -29,6 +29,11 @@ class FusedOpT(C.Structure):
                 ('nnz_counter', _vp), ('workspace', _vp), ('cell_sums', _vp), ('item_seg', _vp), ('unknown_seg', _vp)]
 
 
+class ChunkGridT(C.Structure):
+    _fields_ = [('grid', _i32 * 3), ('reach', _i32), ('origin', _f32 * 3), ('inv_cs', _f32), ('inv_2ov', _f32),
+                ('lo_sel', _vp * 3), ('hi_sel', _vp * 3), ('lo_w', _vp * 3), ('hi_w', _vp * 3), ('shift', _vp)]
+
+
 class SegmentsT(C.Structure):
     _fields_ = [('nseg', _i32), ('nranges', _i32), ('lo', _vp), ('hi', _vp), ('info', _vp)]
 
@@ -131,6 +136,9 @@ _PROTOS = {
     'nksr_coarse_lambda_max_packed': [_P(CoarsePrecondT), _i32, C.c_int, _vp, _vp, _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
     'nksr_pcg_profile_bytes': [_P(C.c_double), _P(C.c_double)],
+    'nksr_chunk_pair_counts': [_P(ChunkGridT), C.c_int, _vp, _i64, _vp, _vp, _vp],
+    'nksr_chunk_pair_fill': [_P(ChunkGridT), C.c_int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'nksr_chunk_blend': [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
     'nksr_nearest_index': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, _vp, _vp],
     'nksr_sdf_from_points': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp],

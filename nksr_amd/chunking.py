@@ -27,6 +27,7 @@ given either the same full cloud or -- ``sharded_input=True`` -- only the points
 collective on the solve path, one all_gather of the chunk HALOS before meshing, one point-to-point gather of the
 mesh pieces to rank 0 after it.
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -34,7 +35,7 @@ import torch
 
 from . import dist as D
 from . import ops
-from ._lib import call, ptr, stream
+from ._lib import ChunkGridT, call, ptr, stream
 from .fields.base_field import BaseField, EvaluationResult
 from .fields.kernel_field import KernelField, Segments
 from .fields.mask_fields import LayerField, NeuralField
@@ -284,6 +285,38 @@ class ChunkPart:
         return g
 
 
+def chunk_grid_struct(origin, grid, chunk_size, sel_band, w_band, device, shift=None):
+    """nksr_chunk_grid_t (include/nksr_hip.h) + the device arrays it points to (keep both alive).  Bounds are rounded to fp32 once,
+    on the host: lo_sel/hi_sel = core -+ sel_band (membership of the solve), lo_w/hi_w = core -+ w_band (blend ramps)."""
+    G = ChunkGridT()
+    keep = []
+    reach = 1
+    for b in (sel_band, w_band):
+        if b is not None:
+            reach = max(reach, int(math.ceil(b / chunk_size)))
+    for a in range(3):
+        G.grid[a] = int(grid[a])
+        G.origin[a] = float(origin[a])
+        if grid[a] <= 1:
+            continue
+        for band, lo_name, hi_name in ((sel_band, 'lo_sel', 'hi_sel'), (w_band, 'lo_w', 'hi_w')):
+            if band is None:
+                continue
+            lo_t = torch.tensor([np.float32(origin[a] + j * chunk_size - band) for j in range(grid[a])], dtype=torch.float32, device=device)
+            hi_t = torch.tensor([np.float32(origin[a] + j * chunk_size + chunk_size + band) for j in range(grid[a])], dtype=torch.float32, device=device)
+            keep += [lo_t, hi_t]
+            getattr(G, lo_name)[a] = ptr(lo_t)
+            getattr(G, hi_name)[a] = ptr(hi_t)
+    G.reach = reach
+    G.inv_cs = float(np.float32(1.0) / np.float32(chunk_size))
+    if w_band is not None:
+        G.inv_2ov = float(np.float32(1.0) / np.float32(2 * w_band))
+    if shift is not None:
+        keep.append(shift)
+        G.shift = ptr(shift)
+    return G, keep
+
+
 class _ChunkViews:
     """``multi.fields``: per-chunk KernelFields, built on demand from the batch (the batch is what evaluates)."""
 
@@ -327,15 +360,20 @@ class ChunkUnionMask(BaseField):
 
     def evaluate_mask(self, xyz_model):
         m = self.multi
+        xyz_model = xyz_model.contiguous()
         keep = torch.zeros(xyz_model.shape[0], dtype=torch.bool, device=xyz_model.device)
-        for q, cid, w, xq in m._pairs(xyz_model):
-            for pi, part in enumerate(m.parts):
-                if part.field.mask_field is None or not isinstance(part.field.mask_field, NeuralField):
-                    continue
-                s = torch.nonzero(m._part_lut[cid] == pi).reshape(-1) if len(m.parts) > 1 else None
-                qq, xx = (q, xq) if s is None else (q[s], xq[s].contiguous())
-                if qq.numel():
-                    keep[qq] |= part.field.mask_field.evaluate_mask(xx)
+        if xyz_model.shape[0] == 0:
+            return keep
+        _, q, cid, _, xq = m._pairs(xyz_model)
+        pl = m._part_lut[cid.long()] if len(m.parts) > 1 else None
+        for pi, part in enumerate(m.parts):
+            if part.field.mask_field is None or not isinstance(part.field.mask_field, NeuralField):
+                continue
+            s = torch.nonzero(pl == pi).reshape(-1) if pl is not None else None
+            qq, xx = (q, xq) if s is None else (q[s], xq[s].contiguous())
+            if qq.numel():
+                kq = part.field.mask_field.evaluate_mask(xx)
+                keep[qq[kq]] = True          # a query may appear once per chunk: "any chunk keeps it"
         return keep
 
     def to_(self, device):
@@ -367,6 +405,8 @@ class MultiChunkField(BaseField):
             cells[c] = frame.shift_cells(c)
         self._part_lut = lut.to(device)
         self._shift = torch.from_numpy(shifts).to(device)
+        self._chunk_flag = self._part_lut.to(torch.int32)
+        self._cgrid, self._cgrid_keep = chunk_grid_struct(origin, grid, chunk_size, None, self.ov, device, shift=self._shift)
         # union of the chunks' voxels on the GLOBAL lattice (integer translation back; T_c is a whole number of voxels at every
         # level): the dual grid that is meshed -- the finest level and, below adaptive_depth, the coarser ones (LayerField(dec_svh,
         # adaptive_depth), models/nksr_net.py:132; 2 in the carla preset, configs/carla/train.yaml:6)
@@ -408,97 +448,53 @@ class MultiChunkField(BaseField):
                 out.append({'chunk': c, 'M': sum(h - l for l, h in rg[c]), 'iters': int(si[i][0]), 'rel_residual': float(si[i][1])})
         return out
 
-    # ---- blend weights ------------------------------------------------------------------------
-    def _weight(self, c, xyz):
-        lo, hi = self.cores[c]
-        w = torch.ones(xyz.shape[0], dtype=torch.float32, device=xyz.device)
-        inv = float(np.float32(1.0) / np.float32(2 * self.ov))
-        for a in range(3):
-            x = xyz[:, a]
-            if self.grid[a] > 1:          # no ramp along an axis that is not split
-                w = (w * ((x - float(np.float32(lo[a] - self.ov))) * inv).clamp(0, 1)) * ((float(np.float32(hi[a] + self.ov)) - x) * inv).clamp(0, 1)
-        return w
-
+    # ---- blend ------------------------------------------------------------------------------------
     def _pairs(self, xyz):
-        """(query index, chunk, weight, translated position) of every (query, chunk) with a positive blend weight, as a list of
-        groups in ASCENDING chunk order per query (a query appears at most once per group): adding the groups in order is the
-        fixed summation order of the blend.  A chunk's weight is supported on core +- ov, so only the chunks around a query's
-        home chunk are candidates."""
+        """(offsets [n + 1] int32, query index, chunk, weight, translated position) of every (query, chunk) with a positive blend
+        weight, the pairs of a query in ASCENDING chunk order -- the fixed summation order of the blend (csrc/chunks.hip).  A
+        chunk's weight is supported on core +- ov, so only the chunks around a query's home chunk are candidates."""
         n = xyz.shape[0]
         dev = xyz.device
-        if n == 0:
-            return []
-        g = self.grid
-        inv = float(np.float32(1.0) / np.float32(2 * self.ov))
-        reach = max(1, int(math.ceil(self.ov / self.chunk_size)))
-        home, wax = [], []
-        for a in range(3):
-            x = xyz[:, a]
-            if g[a] > 1:
-                i = torch.floor((x - self.origin[a]) / self.chunk_size).long().clamp_(0, g[a] - 1)
-                lo_t = torch.tensor([np.float32(self.origin[a] + j * self.chunk_size - self.ov) for j in range(g[a])], dtype=torch.float32, device=dev)
-                hi_t = torch.tensor([np.float32(self.origin[a] + j * self.chunk_size + self.chunk_size + self.ov) for j in range(g[a])], dtype=torch.float32, device=dev)
-                ws = {}
-                for o in range(-reach, reach + 1):
-                    j = i + o
-                    ok = (j >= 0) & (j < g[a])
-                    jc = j.clamp(0, g[a] - 1)
-                    up = torch.where(ok, ((x - lo_t[jc]) * inv).clamp(0, 1), torch.zeros_like(x))
-                    ws[o] = (up, ((hi_t[jc] - x) * inv).clamp(0, 1))
-                home.append(i)
-                wax.append(ws)
-            else:
-                home.append(torch.zeros(n, dtype=torch.long, device=dev))
-                wax.append({0: None})
-        out = []
-        for ox in sorted(wax[0]):
-            for oy in sorted(wax[1]):
-                for oz in sorted(wax[2]):
-                    w = torch.ones(n, dtype=torch.float32, device=dev)
-                    for a, o in ((0, ox), (1, oy), (2, oz)):
-                        if wax[a][o] is not None:
-                            w = (w * wax[a][o][0]) * wax[a][o][1]          # the order of _weight(): ((w up_x) dn_x) up_y ...
-                    cid = ((home[0] + ox).clamp(0, g[0] - 1) * g[1] + (home[1] + oy).clamp(0, g[1] - 1)) * g[2] + (home[2] + oz).clamp(0, g[2] - 1)
-                    sel = torch.nonzero((w > 0) & (self._part_lut[cid] >= 0)).reshape(-1)
-                    if sel.numel():
-                        cs = cid[sel]
-                        out.append((sel, cs, w[sel], (xyz[sel] + self._shift[cs]).contiguous()))
-        return out
+        counts = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        counts[n:] = 0
+        call('nksr_chunk_pair_counts', C.byref(self._cgrid), 1, ptr(xyz), n, ptr(self._chunk_flag), ptr(counts), stream())
+        offs = ops.exclusive_sum_i32(counts)
+        m = int(offs[n].item())
+        q = torch.empty(m, dtype=torch.int64, device=dev)
+        cid = torch.empty(m, dtype=torch.int32, device=dev)
+        w = torch.empty(m, dtype=torch.float32, device=dev)
+        xq = torch.empty((m, 3), dtype=torch.float32, device=dev)
+        if m:
+            call('nksr_chunk_pair_fill', C.byref(self._cgrid), 1, ptr(xyz), n, ptr(self._chunk_flag), ptr(offs), ptr(q), ptr(cid), ptr(w),
+                 ptr(xq), stream())
+        return offs, q, cid, w, xq
 
     def _evaluate_f_model(self, xyz, grad, max_points=1 << 22):
         n = xyz.shape[0]
-        num = torch.zeros(n, dtype=torch.float32, device=xyz.device)
-        den = torch.zeros(n, dtype=torch.float32, device=xyz.device)
-        gnum = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if grad else None
-        groups = self._pairs(xyz)
-        if groups:
-            # one evaluation call per part for ALL groups; the blend then adds the groups in their fixed order
-            sizes = [gq[0].numel() for gq in groups]
-            xq = torch.cat([gq[3] for gq in groups])
-            cid = torch.cat([gq[1] for gq in groups])
-            f = torch.empty(xq.shape[0], dtype=torch.float32, device=xyz.device)
-            gr = torch.empty((xq.shape[0], 3), dtype=torch.float32, device=xyz.device) if grad else None
-            if len(self.parts) == 1:
-                res = self.parts[0].field._evaluate_f_model(xq, grad, max_points)
-                f, gr = res.value, res.gradient
-            else:
-                pl = self._part_lut[cid]
-                for pi, part in enumerate(self.parts):
-                    s = torch.nonzero(pl == pi).reshape(-1)
-                    if s.numel():
-                        res = part.field._evaluate_f_model(xq[s].contiguous(), grad, max_points)
-                        f[s] = res.value
-                        if grad:
-                            gr[s] = res.gradient
-            o = 0
-            for (q, _, w, _), m in zip(groups, sizes):
-                num[q] = num[q] + f[o:o + m] * w
-                den[q] = den[q] + w
-                if grad:   # the gradient of the weights is ignored (they are flat outside the seams)
-                    gnum[q] = gnum[q] + gr[o:o + m] * w[:, None]
-                o += m
-        den = den.clamp_min(1e-20)
-        return EvaluationResult(num / den, gnum / den[:, None] if grad else None)
+        xyz = xyz.contiguous()
+        f_out = torch.zeros(n, dtype=torch.float32, device=xyz.device)
+        g_out = torch.zeros((n, 3), dtype=torch.float32, device=xyz.device) if grad else None
+        if n == 0:
+            return EvaluationResult(f_out, g_out)
+        offs, _, cid, w, xq = self._pairs(xyz)
+        m = xq.shape[0]
+        if len(self.parts) == 1 or m == 0:        # one evaluation call per part for ALL pairs
+            res = self.parts[0].field._evaluate_f_model(xq, grad, max_points)
+            f, gr = res.value.contiguous(), (res.gradient.contiguous() if grad else None)
+        else:
+            f = torch.empty(m, dtype=torch.float32, device=xyz.device)
+            gr = torch.empty((m, 3), dtype=torch.float32, device=xyz.device) if grad else None
+            pl = self._part_lut[cid.long()]
+            for pi, part in enumerate(self.parts):
+                s = torch.nonzero(pl == pi).reshape(-1)
+                if s.numel():
+                    res = part.field._evaluate_f_model(xq[s].contiguous(), grad, max_points)
+                    f[s] = res.value
+                    if grad:
+                        gr[s] = res.gradient
+        # f = sum w f_c / max(sum w, 1e-20); the gradient of the weights is ignored (they are flat outside the seams)
+        call('nksr_chunk_blend', n, ptr(offs), ptr(w), ptr(f), ptr(gr) if grad else None, ptr(f_out), ptr(g_out) if grad else None, stream())
+        return EvaluationResult(f_out, g_out)
 
     # ---- ownership of dual cells ----------------------------------------------------------------
     def chunk_of(self, xyz):
@@ -583,45 +579,25 @@ def select_chunk_points(xyz, lo, grid, chunk_size, band, wanted):
     dev = xyz.device
     n = xyz.shape[0]
     nchunk = grid[0] * grid[1] * grid[2]
-    reach = max(1, int(math.ceil(band / chunk_size)))
-    home, inside = [], []
-    for a in range(3):
-        if grid[a] > 1:
-            x = xyz[:, a]
-            i = torch.floor((x - lo[a]) / chunk_size).long().clamp_(0, grid[a] - 1)
-            lo_t = torch.tensor([np.float32(lo[a] + j * chunk_size - band) for j in range(grid[a])], dtype=torch.float32, device=dev)
-            hi_t = torch.tensor([np.float32(lo[a] + j * chunk_size + chunk_size + band) for j in range(grid[a])], dtype=torch.float32, device=dev)
-            ms = {}
-            for o in range(-reach, reach + 1):
-                j = i + o
-                jc = j.clamp(0, grid[a] - 1)
-                ms[o] = (j >= 0) & (j < grid[a]) & (x >= lo_t[jc]) & (x < hi_t[jc])
-            home.append(i)
-            inside.append(ms)
-        else:
-            home.append(torch.zeros(n, dtype=torch.long, device=dev))
-            inside.append({0: None})
-    want = torch.as_tensor(wanted, dtype=torch.bool, device=dev)
-    idxs, cids = [], []
-    for ox in sorted(inside[0]):
-        for oy in sorted(inside[1]):
-            for oz in sorted(inside[2]):
-                m = None
-                for a, o in ((0, ox), (1, oy), (2, oz)):
-                    if inside[a][o] is not None:
-                        m = inside[a][o] if m is None else (m & inside[a][o])
-                cid = ((home[0] + ox).clamp(0, grid[0] - 1) * grid[1] + (home[1] + oy).clamp(0, grid[1] - 1)) * grid[2] + (home[2] + oz).clamp(0, grid[2] - 1)
-                m = want[cid] if m is None else (m & want[cid])
-                sel = torch.nonzero(m).reshape(-1)
-                if sel.numel():
-                    idxs.append(sel)
-                    cids.append(cid[sel])
-    if not idxs:
-        z = torch.zeros(0, dtype=torch.long, device=dev)
+    z = torch.zeros(0, dtype=torch.long, device=dev)
+    if n == 0:
         return z, z, [0] * nchunk
-    idx, cid = torch.cat(idxs), torch.cat(cids)
+    xyz = xyz.contiguous()
+    G, keep = chunk_grid_struct(lo, grid, chunk_size, band, None, dev)
+    flag = torch.tensor([0 if w else -1 for w in wanted], dtype=torch.int32, device=dev)
+    cnt = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    cnt[n:] = 0
+    call('nksr_chunk_pair_counts', C.byref(G), 0, ptr(xyz), n, ptr(flag), ptr(cnt), stream())
+    offs = ops.exclusive_sum_i32(cnt)
+    m = int(offs[n].item())
+    if m == 0:
+        return z, z, [0] * nchunk
+    idx = torch.empty(m, dtype=torch.int64, device=dev)
+    cid = torch.empty(m, dtype=torch.int32, device=dev)
+    call('nksr_chunk_pair_fill', C.byref(G), 0, ptr(xyz), n, ptr(flag), ptr(offs), ptr(idx), ptr(cid), None, None, stream())
+    cid = cid.long()
     if nchunk > 1:
-        ks, order = ops.sort_pairs(cid * max(n, 1) + idx, torch.arange(idx.numel(), dtype=torch.int32, device=dev))
+        ks, order = ops.sort_pairs(cid * max(n, 1) + idx, torch.arange(m, dtype=torch.int32, device=dev))
         order = order.long()
         idx, cid = idx[order], cid[order]
     counts = torch.bincount(cid, minlength=nchunk).tolist()

@@ -31,6 +31,7 @@ struct PcgGlobal {          // what the host reads back every check_every iterat
     int done_all;
     int done_count;
     int nblocks;            // reduction blocks in use (k_seg_fill)
+    int min_iter;           // fewest iterations any segment has taken so far (= all segments were still iterating up to here)
 };
 
 struct PcgWork {
@@ -428,22 +429,24 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spcg_pupdate(PcgWork w, int parit
 // what the host reads every check_every iterations (+ the per-segment results, when asked for)
 __global__ void __launch_bounds__(PCG_BLOCK) k_spcg_summary(PcgWork w, double* __restrict__ seg_info) {
     __shared__ double smr[PCG_BLOCK];
-    __shared__ int smi[PCG_BLOCK], smb[PCG_BLOCK];
+    __shared__ int smi[PCG_BLOCK], smb[PCG_BLOCK], smn[PCG_BLOCK];
     double mr = 0.0;
-    int mi = 0, nbk = 0;
+    int mi = 0, nbk = 0, mn = 0x7fffffff;
     for (int c = threadIdx.x; c < w.nseg; c += PCG_BLOCK) {
         const SegScalars& s = w.sc[c];
         mr = s.rel > mr ? s.rel : mr;
         mi = s.iter > mi ? s.iter : mi;
+        mn = s.iter < mn ? s.iter : mn;
         nbk += s.done == 2;
         if (seg_info) { seg_info[2 * c] = (double)s.iter; seg_info[2 * c + 1] = s.done == 2 ? -s.rel : s.rel; }
     }
-    smr[threadIdx.x] = mr; smi[threadIdx.x] = mi; smb[threadIdx.x] = nbk;
+    smr[threadIdx.x] = mr; smi[threadIdx.x] = mi; smb[threadIdx.x] = nbk; smn[threadIdx.x] = mn;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int t = 1; t < PCG_BLOCK; ++t) { mr = smr[t] > mr ? smr[t] : mr; mi = smi[t] > mi ? smi[t] : mi; nbk += smb[t]; }
+        for (int t = 1; t < PCG_BLOCK; ++t) { mr = smr[t] > mr ? smr[t] : mr; mi = smi[t] > mi ? smi[t] : mi; nbk += smb[t]; mn = smn[t] < mn ? smn[t] : mn; }
         w.g->max_rel = nbk ? -mr : mr;         // negative: some segment broke down (r.z <= 0)
         w.g->max_iter = mi;
+        w.g->min_iter = mn;
     }
 }
 
@@ -963,31 +966,37 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
             NKSR_CHECK_HIP(hipEventCreate(&e));
             g_prof_events.push_back(e);
         }
+    // (Tried in round 3 and removed: capturing two iterations into a hipGraph and replaying it for small systems -- configs[1] and the
+    // 10 000-point bunny sequence spend 5 / 8 ms in 42 / 93 iterations of 6-20 tiny launches.  No change (5.07 vs 4.56 ms, 8.76 vs 8.30):
+    // the bound is the dependency latency between consecutive tiny kernels on the device, ~15 us each, not the host enqueue.)
+    auto iterate = [&](int parity, int c) -> int {
+        if (prof) (void)hipEventRecord(g_prof_events[2 * c], st);
+        if (int rc = A.apply(w.p, w.y, &w.g->done_all, w.nseg > 1 ? &w.sc[0].done : nullptr, (int)(sizeof(SegScalars) / sizeof(int)), st)) return rc;
+        if (prof) (void)hipEventRecord(g_prof_events[2 * c + 1], st);
+        hipLaunchKernelGGL(k_spcg_dot, gb, blkd, 0, st, w);
+        hipLaunchKernelGGL(k_spcg_update, gb, blkd, 0, st, w, diag, x, parity);
+        if (pc) {
+            cheb_apply(pc, w.r + pc->first, w.z + pc->first, w.sc, st);
+            hipLaunchKernelGGL(k_spcg_rz, gb, blkd, 0, st, w, 0);
+        }
+        hipLaunchKernelGGL(k_spcg_pupdate, gb, blkd, 0, st, w, parity, tol);
+        return NKSR_OK;
+    };
     while (launched < max_iter) {
         int chunk = check_every < (max_iter - launched) ? check_every : (max_iter - launched);
-        for (int c = 0; c < chunk; ++c) {
-            const int parity = (launched + c) & 1;
-            if (prof) (void)hipEventRecord(g_prof_events[2 * c], st);
-            if (int rc = A.apply(w.p, w.y, &w.g->done_all, w.nseg > 1 ? &w.sc[0].done : nullptr, (int)(sizeof(SegScalars) / sizeof(int)), st)) return rc;
-            if (prof) (void)hipEventRecord(g_prof_events[2 * c + 1], st);
-            hipLaunchKernelGGL(k_spcg_dot, gb, blkd, 0, st, w);
-            hipLaunchKernelGGL(k_spcg_update, gb, blkd, 0, st, w, diag, x, parity);
-            if (pc) {
-                cheb_apply(pc, w.r + pc->first, w.z + pc->first, w.sc, st);
-                hipLaunchKernelGGL(k_spcg_rz, gb, blkd, 0, st, w, 0);
-            }
-            hipLaunchKernelGGL(k_spcg_pupdate, gb, blkd, 0, st, w, parity, tol);
-        }
+        for (int c = 0; c < chunk; ++c)
+            if (int rc = iterate((launched + c) & 1, c)) return rc;
         hipLaunchKernelGGL(k_spcg_summary, dim3(1), blkd, 0, st, w, seg ? seg->info : (double*)nullptr);
         NKSR_CHECK_LAUNCH();
         NKSR_CHECK_HIP(hipMemcpyAsync(&host, w.g, sizeof(host), hipMemcpyDeviceToHost, st));
         NKSR_CHECK_HIP(hipStreamSynchronize(st));
         if (prof) {
-            // only applications that did real work (the done flag turns later ones into no-ops)
+            // only applications in which EVERY segment was still iterating (the done flag turns later launches into no-ops, and the
+            // operator skips the rows of segments that have converged: those move fewer bytes than A.bytes() says)
             double ba, bp, bs;
             A.bytes(&ba, &bp, &bs);
             std::lock_guard<std::mutex> lock(g_prof_mutex);
-            for (int c = 0; c < chunk && launched + c < host.max_iter; ++c) {
+            for (int c = 0; c < chunk && launched + c < host.min_iter; ++c) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, g_prof_events[2 * c], g_prof_events[2 * c + 1]) == hipSuccess) {
                     g_prof_ms += ms;

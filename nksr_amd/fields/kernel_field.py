@@ -530,7 +530,8 @@ class KernelField(BaseField):
             work = torch.empty(4 * n, dtype=torch.float32, device=self.device)
             # twelve steps instead of eight: a packed step costs a third of a plain one (four rows per wavefront, half the bytes), and
             # every PCG iteration saved is a sweep over all kernel rows (configs[4], one GPU: 12.8 -> 11.1 iterations per chunk)
-            if 'steps' not in cfg:
+            # (small blocks are bound by the number of launches, not by bytes: they keep eight)
+            if 'steps' not in cfg and n >= 100000:
                 pc.steps = 12
                 info['steps'] = 12
             pc.format, pc.row_seg, pc.work = 1, ptr(row_seg_new), ptr(work)
