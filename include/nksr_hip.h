@@ -270,17 +270,20 @@ typedef struct nksr_coarse_precond_s {
      * (half-precision value << 16) | column local to the row's segment -- over the coarse unknowns renumbered segment-major; needs
      * < 2^16 coarse unknowns per segment.  row_seg is then in the NEW order.  The preconditioner stays a fixed symmetric positive
      * operator (all a CG preconditioner must be); a Chebyshev step streams half the bytes. */
-    const uint32_t* packed;    /* [nnz_c - n] */
+    const uint32_t* packed;    /* [packed_rowptr[n]] */
     const int32_t* packed_rowptr; /* [n + 1] new order */
     const float* dis;          /* [n] D^-1/2, new order */
     const int32_t* old_of_new; /* [n] coarse row (PCG order) of every new row */
     const int32_t* seg_base;   /* [nseg + 1] first new row of every segment */
 } nksr_coarse_precond_t;
 /* format-1 block from the plain CSR: new_of_old / old_of_new = the segment-major renumbering, row_seg_new / seg_base in the new
- * order, packed_rowptr = exclusive sum of (row length - 1) in the new order.  Writes packed_out and dis_out. */
+ * order, packed_rowptr = exclusive sum of the kept entries per row (nksr_coarse_pack_count) in the new order.  Off-diagonal entries
+ * with |S_ij| < drop_tol are left out (0 keeps all; S_ij = S_ji bitwise, so the block stays symmetric).  Writes packed_out, dis_out. */
+int nksr_coarse_pack_count(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n,
+                           const int32_t* old_of_new, float drop_tol, int32_t* lens_out, void* stream);
 int nksr_coarse_pack(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n,
                      const int32_t* old_of_new, const int32_t* new_of_old, const int32_t* row_seg_new, const int32_t* seg_base,
-                     const int32_t* packed_rowptr, uint32_t* packed_out, float* dis_out, void* stream);
+                     const int32_t* packed_rowptr, float drop_tol, uint32_t* packed_out, float* dis_out, void* stream);
 /* eigenvalue bounds of a format-1 block (power iteration on S, work: 2 n floats): lambda_out [nseg] */
 int nksr_coarse_lambda_max_packed(const nksr_coarse_precond_t* pc, int32_t nseg, int iters, float* work, float* lambda_out, void* stream);
 /* power iteration (iters steps from the all-ones vector, work: 2 n floats): lambda_out (device, [nseg]) = ||v_k|| / ||v_{k-1}||

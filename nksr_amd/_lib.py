@@ -132,7 +132,8 @@ _PROTOS = {
     'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(SegmentsT), _P(C.c_double), _vp],
     'nksr_coarse_lambda_max': [_vp, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _P(SegmentsT), _i32, _vp],
-    'nksr_coarse_pack': [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'nksr_coarse_pack_count': [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp],
+    'nksr_coarse_pack': [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp],
     'nksr_coarse_lambda_max_packed': [_P(CoarsePrecondT), _i32, C.c_int, _vp, _vp, _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
     'nksr_pcg_profile_bytes': [_P(C.c_double), _P(C.c_double)],

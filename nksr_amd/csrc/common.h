@@ -65,14 +65,30 @@ __device__ __forceinline__ uint32_t hash_mix(int64_t k) {
     h ^= h >> 33;
     return (uint32_t)h;
 }
+// The eight children of a parent cell (keys that agree above their low three bits) share one 64-byte line of the table: the 27
+// neighbours of a voxel then touch ~8 lines instead of 27, and Morton-sorted inserts / queries walk the table coherently (the
+// neighbour tables of a 17 M-voxel level were bound by the 64-byte sectors a fully random slot fetches).  A collision moves to
+// ANOTHER line (triangular steps over the lines, same place within the line): walking on within the line would run through the
+// siblings, and a miss -- half the 27 neighbours of a surface voxel -- would pay for the whole cluster.
+__device__ __forceinline__ uint32_t hash_slot(int64_t key, int hcap) {
+    return ((hash_mix(key >> 3) << 3) | ((uint32_t)key & 7u)) & (uint32_t)(hcap - 1);
+}
+// probe = 1, 2, ...: the step that follows try number probe.  Triangular steps visit every line once per hcap / 8 tries; a key set
+// whose low three bits are all alike (it can only use one place of every line) then moves on to the next place: hcap tries see
+// every slot of the table.
+__device__ __forceinline__ uint32_t hash_next(uint32_t slot, int probe, int hcap) {
+    slot = (slot + ((uint32_t)probe << 3)) & (uint32_t)(hcap - 1);
+    if (((uint32_t)probe & (uint32_t)((hcap >> 3) - 1)) == 0u) slot = (slot & ~7u) | ((slot + 1u) & 7u);
+    return slot;
+}
 __device__ __forceinline__ int hash_find(const int64_t* __restrict__ hkeys, const int32_t* __restrict__ hvals,
                                          int hcap, int64_t key) {
-    uint32_t slot = hash_mix(key) & (uint32_t)(hcap - 1);
-    for (int probe = 0; probe < hcap; ++probe) {
+    uint32_t slot = hash_slot(key, hcap);
+    for (int probe = 1; probe <= hcap; ++probe) {
         int64_t k = hkeys[slot];
         if (k == key) return hvals[slot];
         if (k == -1) return -1;
-        slot = (slot + 1) & (uint32_t)(hcap - 1);
+        slot = hash_next(slot, probe, hcap);
     }
     return -1;
 }

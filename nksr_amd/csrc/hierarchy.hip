@@ -58,15 +58,15 @@ __global__ void k_hash_build(const int64_t* __restrict__ keys, int n, int64_t* h
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int64_t key = keys[i];
-    uint32_t slot = hash_mix(key) & (uint32_t)(hcap - 1);
-    for (int probe = 0; probe < hcap; ++probe) {
+    uint32_t slot = hash_slot(key, hcap);
+    for (int probe = 1; probe <= hcap; ++probe) {
         unsigned long long prev = atomicCAS((unsigned long long*)&hkeys[slot], 0xFFFFFFFFFFFFFFFFull,
                                             (unsigned long long)key);
         if (prev == 0xFFFFFFFFFFFFFFFFull || prev == (unsigned long long)key) {
             hvals[slot] = i;  // keys are unique: exactly one writer per slot
             return;
         }
-        slot = (slot + 1) & (uint32_t)(hcap - 1);
+        slot = hash_next(slot, probe, hcap);
     }
 }
 

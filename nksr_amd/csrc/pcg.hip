@@ -741,23 +741,53 @@ extern "C" int nksr_coarse_lambda_max(const int32_t* rowptr, const int32_t* cols
 // (the same polynomial in D^-1 A_cc, up to the rounding of S to half precision: S_ij = half(v_ij * (dis_i * dis_j)) is bitwise symmetric).
 #include <hip/hip_fp16.h>
 
+// Entries with |S_ij| < drop are left out (drop = 0 keeps all): the far corners of the 5 x 5 x 5 stencil carry 1e-2 .. 1e-6 of
+// the diagonal and most of the bytes; the dropped matrix is still symmetric (S_ij and S_ji are the same bits) and the polynomial of
+// it is still a fixed symmetric positive operator.
+__device__ __forceinline__ __half cc_scaled(float v, float di, float dj) { return __float2half_rn(v * (di * dj)); }
+__device__ __forceinline__ bool cc_keep(__half hv, float drop) { return fabsf(__half2float(hv)) >= drop; }
+
+__global__ void __launch_bounds__(256) k_cc_count(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                  const float* __restrict__ vals, const float* __restrict__ diag,
+                                                  const int32_t* __restrict__ old_of_new, float drop, int32_t* __restrict__ lens) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const int j = old_of_new[i];
+    const int k0 = rowptr[j], k1 = rowptr[j + 1] - 1;
+    const float di = 1.f / sqrtf(diag[j]);
+    int cnt = 0;
+    for (int k = k0 + lane; k < k1; k += 64) cnt += cc_keep(cc_scaled(vals[k], di, 1.f / sqrtf(diag[cols[k]])), drop) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (lane == 0) lens[i] = cnt;
+}
+
 __global__ void __launch_bounds__(256) k_cc_pack(int n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
                                                  const float* __restrict__ vals, const float* __restrict__ diag,
                                                  const int32_t* __restrict__ old_of_new, const int32_t* __restrict__ new_of_old,
                                                  const int32_t* __restrict__ row_seg, const int32_t* __restrict__ seg_base,
-                                                 const int32_t* __restrict__ prow, uint32_t* __restrict__ pk, float* __restrict__ dis) {
+                                                 const int32_t* __restrict__ prow, float drop, uint32_t* __restrict__ pk, float* __restrict__ dis) {
     const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= n) return;
     const int j = old_of_new[i];
     const int k0 = rowptr[j], k1 = rowptr[j + 1] - 1;          // the diagonal closes every row: it is dropped (unit diagonal)
     const float di = 1.f / sqrtf(diag[j]);
-    const int base = seg_base[row_seg[i]], o = prow[i];
+    const int base = seg_base[row_seg[i]];
+    int o = prow[i];
     if (lane == 0) dis[i] = di;
-    for (int k = k0 + lane; k < k1; k += 64) {
-        const int c = cols[k];
-        const float dj = 1.f / sqrtf(diag[c]);
-        const __half hv = __float2half_rn(vals[k] * (di * dj));
-        pk[o + (k - k0)] = ((uint32_t)__half_as_ushort(hv) << 16) | (uint32_t)(new_of_old[c] - base);
+    for (int kb = k0; kb < k1; kb += 64) {                      // kept entries keep their order
+        const int k = kb + lane;
+        bool keep = false;
+        uint32_t word = 0u;
+        if (k < k1) {
+            const int c = cols[k];
+            const __half hv = cc_scaled(vals[k], di, 1.f / sqrtf(diag[c]));
+            keep = cc_keep(hv, drop);
+            word = ((uint32_t)__half_as_ushort(hv) << 16) | (uint32_t)(new_of_old[c] - base);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) pk[o + __popcll(m & ((1ull << lane) - 1ull))] = word;
+        o += __popcll(m);
     }
 }
 
@@ -870,14 +900,26 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_norm_ratio_seg(const int32_t* __r
     if (threadIdx.x == 0) out[c] = ta > 0.0 ? (float)sqrt(tb / ta) : 0.f;
 }
 
+extern "C" int nksr_coarse_pack_count(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n,
+                                      const int32_t* old_of_new, float drop_tol, int32_t* lens_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (!rowptr || !cols || !vals || !diag || !old_of_new || !lens_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    if (!(drop_tol >= 0.f) || drop_tol >= 1.f) return nksr_set_error(NKSR_ERR_ARG, "drop_tol must be in [0, 1)");
+    hipLaunchKernelGGL(k_cc_count, dim3(nksr_blocks((int64_t)n * 64, 256)), dim3(256), 0, (hipStream_t)stream, n, rowptr, cols, vals, diag, old_of_new,
+                       drop_tol, lens_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
 extern "C" int nksr_coarse_pack(const int32_t* rowptr, const int32_t* cols, const float* vals, const float* diag, int32_t n,
                                 const int32_t* old_of_new, const int32_t* new_of_old, const int32_t* row_seg_new, const int32_t* seg_base,
-                                const int32_t* packed_rowptr, uint32_t* packed_out, float* dis_out, void* stream) {
+                                const int32_t* packed_rowptr, float drop_tol, uint32_t* packed_out, float* dis_out, void* stream) {
     if (n <= 0) return NKSR_OK;
     if (!rowptr || !cols || !vals || !diag || !old_of_new || !new_of_old || !row_seg_new || !seg_base || !packed_rowptr || !packed_out || !dis_out)
         return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    if (!(drop_tol >= 0.f) || drop_tol >= 1.f) return nksr_set_error(NKSR_ERR_ARG, "drop_tol must be in [0, 1)");
     hipLaunchKernelGGL(k_cc_pack, dim3(nksr_blocks((int64_t)n * 64, 256)), dim3(256), 0, (hipStream_t)stream, n, rowptr, cols, vals, diag,
-                       old_of_new, new_of_old, row_seg_new, seg_base, packed_rowptr, packed_out, dis_out);
+                       old_of_new, new_of_old, row_seg_new, seg_base, packed_rowptr, drop_tol, packed_out, dis_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }

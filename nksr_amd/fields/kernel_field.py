@@ -27,6 +27,7 @@ def pack_interpolator(interp):
     return interp.packed()
 
 
+PC_DROP_TOL = 0.005        # packed coarse block: off-diagonal entries below this fraction of the (unit) diagonal are left out
 _DETAIL = os.environ.get('NKSR_TIMING_DETAIL', '') == '1'
 DETAIL_TIMES = {}
 
@@ -519,14 +520,18 @@ class KernelField(BaseField):
             new_of_old[old_of_new] = ar
             seg_base = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)]).to(torch.int32)
             row_seg_new = rs[old_of_new].contiguous()
-            rp = rowptr.long()
-            lens = (rp[1:] - rp[:-1] - 1)[old_of_new]
-            prow = ops.exclusive_sum_i32(torch.cat([lens, lens.new_zeros(1)]).to(torch.int32))
-            packed = torch.empty(max(nnz - n, 1), dtype=torch.int32, device=self.device)
-            dis = torch.empty(n, dtype=torch.float32, device=self.device)
             o2n, n2o = old_of_new.to(torch.int32), new_of_old.to(torch.int32)
+            drop = float(cfg.get('drop', os.environ.get('NKSR_PC_DROP', PC_DROP_TOL)))
+            lens = torch.empty(n + 1, dtype=torch.int32, device=self.device)
+            lens[n:] = 0
+            call('nksr_coarse_pack_count', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), n, ptr(o2n), drop, ptr(lens), stream())
+            prow = ops.exclusive_sum_i32(lens)
+            kept = int(prow[n].item())
+            info.update(nnz_kept=kept + n, drop=drop)
+            packed = torch.empty(max(kept, 1), dtype=torch.int32, device=self.device)
+            dis = torch.empty(n, dtype=torch.float32, device=self.device)
             call('nksr_coarse_pack', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), n, ptr(o2n), ptr(n2o), ptr(row_seg_new), ptr(seg_base), ptr(prow),
-                 ptr(packed), ptr(dis), stream())
+                 drop, ptr(packed), ptr(dis), stream())
             work = torch.empty(4 * n, dtype=torch.float32, device=self.device)
             # twelve steps instead of eight: a packed step costs a third of a plain one (four rows per wavefront, half the bytes), and
             # every PCG iteration saved is a sweep over all kernel rows (configs[4], one GPU: 12.8 -> 11.1 iterations per chunk)
