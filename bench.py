@@ -194,11 +194,19 @@ def main():
         ms0 = torch.cuda.memory_stats(dev)
         t0 = time.perf_counter()
         out = None
+        diag = os.environ.get('NKSR_BENCH_STEP_TIMES', '') == '1'      # diagnostics only: a device sync after every step
         for _ in range(steps):
             # the previous result is released first: every step then has the memory footprint of the warm-up step and
             # the caching allocator serves it from its pool
             out = None
+            ts = time.perf_counter()
             out = step(stage_acc)
+            if diag:
+                torch.cuda.synchronize()
+                m = torch.cuda.memory_stats(dev)
+                print('[step] %.1f ms, device allocs so far %d, frees %d, reserved %.1f GB, peak allocated %.1f GB' % (
+                    (time.perf_counter() - ts) * 1e3, m.get('num_device_alloc', 0), m.get('num_device_free', 0),
+                    m.get('reserved_bytes.all.current', 0) / 1e9, m.get('allocated_bytes.all.peak', 0) / 1e9), file=sys.stderr)
         fence()
         dt = time.perf_counter() - t0
         ms1 = torch.cuda.memory_stats(dev)

@@ -29,6 +29,7 @@ mesh pieces to rank 0 after it.
 """
 import ctypes as C
 import math
+import weakref
 
 import numpy as np
 import torch
@@ -318,29 +319,31 @@ def chunk_grid_struct(origin, grid, chunk_size, sel_band, w_band, device, shift=
 
 
 class _ChunkViews:
-    """``multi.fields``: per-chunk KernelFields, built on demand from the batch (the batch is what evaluates)."""
+    """``multi.fields``: per-chunk KernelFields, built on demand from the batch (the batch is what evaluates).  Holds the parts, not
+    the MultiChunkField: a reference back to it would be a cycle, and the field (GBs of device memory) would then live until
+    the cyclic collector happens to run instead of until its last reference goes."""
 
-    def __init__(self, multi):
-        self._m, self._cache = multi, {}
+    def __init__(self, parts, part_of, interpolators):
+        self._parts, self._part_of, self._interp, self._cache = parts, part_of, interpolators, {}
 
     def _ids(self):
-        return sorted(self._m.part_of)
+        return sorted(self._part_of)
 
     def __iter__(self):
         return iter(self._ids())
 
     def __len__(self):
-        return len(self._m.part_of)
+        return len(self._part_of)
 
     def __contains__(self, c):
-        return c in self._m.part_of
+        return c in self._part_of
 
     def keys(self):
         return self._ids()
 
     def __getitem__(self, c):
         if c not in self._cache:
-            self._cache[c] = self._m.parts[self._m.part_of[c]].chunk_view(c, self._m.interpolators)
+            self._cache[c] = self._parts[self._part_of[c]].chunk_view(c, self._interp)
         return self._cache[c]
 
     def values(self):
@@ -356,10 +359,12 @@ class ChunkUnionMask(BaseField):
 
     def __init__(self, multi):
         super().__init__(multi.svh)
-        self.multi = multi
+        self._multi = weakref.ref(multi)          # the field owns its mask, not the other way round (no reference cycle)
 
     def evaluate_mask(self, xyz_model):
-        m = self.multi
+        m = self._multi()
+        if m is None:
+            raise RuntimeError('the chunked field this mask belongs to has been released')
         xyz_model = xyz_model.contiguous()
         keep = torch.zeros(xyz_model.shape[0], dtype=torch.bool, device=xyz_model.device)
         if xyz_model.shape[0] == 0:
@@ -432,7 +437,7 @@ class MultiChunkField(BaseField):
         if any(isinstance(p.field.mask_field, NeuralField) for p in self.parts):
             self.mask_field = ChunkUnionMask(self)
         self.solve_info = {}
-        self.fields = _ChunkViews(self)
+        self.fields = _ChunkViews(self.parts, self.part_of, interpolators)
 
     def chunk_infos(self):
         """[{'chunk', 'M', 'iters', 'rel_residual'}] of the chunks solved here (one host read per part)."""

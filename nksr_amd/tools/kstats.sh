@@ -10,3 +10,4 @@ cd /tmp && export TMPDIR=/tmp
 db=$(find /tmp/prof_$tag -name '*.db' | head -1)
 cd $root && python -m nksr_amd.tools.prof_summary $db gpurun_out/kstats_$tag.md | head -${KSTATS_TOP:-24}
 python -m nksr_amd.tools.prof_gaps $db gpurun_out/kgaps_$tag.md 40 ${KGAPS_TAIL_MS:-0} > /dev/null
+python -m nksr_amd.tools.prof_timeline $db gpurun_out/ktimeline_$tag.md ${KGAPS_TAIL_MS:-0} ${KTIMELINE_BIG_US:-300}
