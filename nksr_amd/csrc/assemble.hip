@@ -22,7 +22,7 @@
 //     the CSR.  Deterministic and exactly symmetric, no float atomics, no full COO.
 #include "common.h"
 
-#define ASM_WAVES 4
+#define ASM_WAVES 1
 
 struct AsmArgs {
     nksr_hier_t hier;
@@ -114,6 +114,7 @@ __device__ __forceinline__ void cell_blocks_finalize(const AsmArgs& A, int d, in
 // the level has enough cells to fill the chip, e.g. all chunks of a rank batched into one system).  The result therefore does
 // not depend on how many other cells share the launch.
 #define ASM_PART_ROWS 128
+#define ASM_TRIP 4
 __host__ __device__ __forceinline__ int asm_level_parts(int d) {          // d = 0..2: 1, 3: 4, 4: 16, 5: 64
     const int k = d >= 2 ? (1 << (2 * (d - 2))) : 1;
     return k > 64 ? 64 : k;
@@ -134,6 +135,69 @@ __device__ __forceinline__ void asm_part_range(int R, int level_parts, int p, in
     if (hi < lo) hi = lo;
 }
 
+// The operator's row list as ONE site set (level-major rows, one row per "site", no row index: nksr_amd/fields/kernel_field.py
+// assemble(fused_op=...)): rows [r_lo, r_hi) of the list, same products in the same order as asm_accumulate_rows.  Every load is
+// unconditional (clamped row, one pointer and one stride per lane and tile: the value of its column, or -- the lane of column T --
+// the target), and the loads of the NEXT trip are requested before the products of this one: the pass ran at the latency of one
+// trip after the other (~20 loads in flight per XCD against 200+ in the operator's sweep).
+__device__ __forceinline__ bool asm_is_row_list(const AsmArgs& A) {
+    return A.nsets == 1 && A.sets[0].level_stride > 0 && A.sets[0].ncomp == 1 && !A.sets[0].row_index;
+}
+template <int NT>
+struct AsmLanePtr { const float* p[NT]; int mul[NT]; bool on[NT]; };
+template <int NT>
+__device__ __forceinline__ void asm_lm_load(const AsmLanePtr<NT>& P, int r0, int r_lo, int r_hi, int half, float (&b)[ASM_TRIP][NT]) {
+#pragma unroll
+    for (int u = 0; u < ASM_TRIP; ++u) {
+        const int r = r0 + 2 * u + half;
+        const int rc = r < r_hi ? r : r_lo;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) b[u][n] = P.p[n][(int64_t)rc * P.mul[n]];
+    }
+}
+template <int NT>
+__device__ __forceinline__ void asm_lm_mfma(const AsmLanePtr<NT>& P, int r0, int r_hi, int half, int j, float w, float (&b)[ASM_TRIP][NT], asm_f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int u = 0; u < ASM_TRIP; ++u) {
+        const bool ok = r0 + 2 * u + half < r_hi;
+        float v[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) v[n] = (ok && P.on[n]) ? b[u][n] : 0.f;
+        const float a = (j < 27) ? w * v[0] : 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[n], acc[n], 0, 0, 0);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void asm_accumulate_lm(const AsmArgs& A, int d, int r_lo, int r_hi, int lane, asm_f32x16 (&acc)[NT]) {
+    if (r_hi <= r_lo) return;
+    const nksr_siteset_t& S = A.sets[0];
+    const int L = A.hier.depth;
+    const int T = (L - d) * 27;
+    const int j = lane & 31, half = lane >> 5;
+    AsmLanePtr<NT> P;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int col = 32 * n + j;
+        const int dd = col / 27, sl = col - dd * 27;
+        P.on[n] = col < T || (col == T && S.target);
+        P.mul[n] = (col == T && S.target) ? 1 : 27;
+        P.p[n] = (col == T && S.target) ? S.target : S.val + (col < T ? (int64_t)(d + dd) * S.level_stride * 27 + sl : 0);
+    }
+    const float w = S.weight;
+    float bA[ASM_TRIP][NT], bB[ASM_TRIP][NT];
+    asm_lm_load<NT>(P, r_lo, r_lo, r_hi, half, bA);
+    for (int r0 = r_lo; r0 < r_hi; r0 += 4 * ASM_TRIP) {
+        const int r1 = r0 + 2 * ASM_TRIP, r2 = r0 + 4 * ASM_TRIP;
+        if (r1 < r_hi) asm_lm_load<NT>(P, r1, r_lo, r_hi, half, bB);
+        asm_lm_mfma<NT>(P, r0, r_hi, half, j, w, bA, acc);
+        if (r1 < r_hi) {
+            if (r2 < r_hi) asm_lm_load<NT>(P, r2, r_lo, r_hi, half, bA);
+            asm_lm_mfma<NT>(P, r1, r_hi, half, j, w, bB, acc);
+        }
+    }
+}
+
 // acc += the Gram products of rows [lo, hi) of cell c (row numbering: set 0's rows, then set 1's)
 template <int NT>
 __device__ __forceinline__ void asm_accumulate_rows(const AsmArgs& A, int d, int c, int lo, int hi, int lane, asm_f32x16 (&acc)[NT]) {
@@ -148,11 +212,12 @@ __device__ __forceinline__ void asm_accumulate_rows(const AsmArgs& A, int d, int
         const int m_lo = lo > base ? lo - base : 0, m_hi = hi - base < nrows ? hi - base : nrows;      // this set's rows of the part
         const int64_t q0 = (int64_t)k0 * S.ncomp;
         const float w = S.weight;
-        // four row pairs per trip: their loads go out together (one pair per trip left the wavefront waiting on every load)
-        for (int m0 = m_lo; m0 < m_hi; m0 += 8) {
-            float b[4][NT];
+        // ASM_TRIP row pairs per trip: their loads go out together (one pair per trip left the wavefront waiting on every load;
+        // the pass is bound by the loads in flight -- 20 per XCD at four pairs, against 200+ in the operator's sweep)
+        for (int m0 = m_lo; m0 < m_hi; m0 += 2 * ASM_TRIP) {
+            float b[ASM_TRIP][NT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < ASM_TRIP; ++u) {
                 const int m = m0 + 2 * u + half;
                 const bool valid = m < m_hi;
                 const int64_t q = q0 + (valid ? m : m_lo);
@@ -166,7 +231,7 @@ __device__ __forceinline__ void asm_accumulate_rows(const AsmArgs& A, int d, int
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < ASM_TRIP; ++u) {
                 const float a = (j < 27) ? w * b[u][0] : 0.f;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][n], acc[n], 0, 0, 0);
@@ -190,7 +255,8 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks_part(AsmArgs A, 
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     int lo, hi;
     asm_part_range(asm_cell_rows(A, d, c), nsplit, p, lo, hi);
-    asm_accumulate_rows<NT>(A, d, c, lo, hi, lane, acc);
+    if (asm_is_row_list(A)) asm_accumulate_lm<NT>(A, d, A.sets[0].start[d][c] + lo, A.sets[0].start[d][c] + hi, lane, acc);
+    else asm_accumulate_rows<NT>(A, d, c, lo, hi, lane, acc);
     float* out = scratch + idx * (NT * 16 * 64) + lane;
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -240,7 +306,10 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks_seq(AsmArgs A, i
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-        if (hi > lo) asm_accumulate_rows<NT>(A, d, c, lo, hi, lane, acc);
+        if (hi > lo) {
+            if (asm_is_row_list(A)) asm_accumulate_lm<NT>(A, d, A.sets[0].start[d][c] + lo, A.sets[0].start[d][c] + hi, lane, acc);
+            else asm_accumulate_rows<NT>(A, d, c, lo, hi, lane, acc);
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -267,6 +336,13 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
     int total = 0;
+    if (LM && asm_is_row_list(A)) {
+        const int k0 = A.sets[0].start[d][c], k1 = A.sets[0].end[d][c];
+        total = k1 > k0 ? k1 - k0 : 0;
+        asm_accumulate_lm<NT>(A, d, k0, k1, lane, acc);
+        cell_blocks_finalize<NT>(A, d, c, lane, acc, total);
+        return;
+    }
     for (int si = 0; si < A.nsets; ++si) {
         const nksr_siteset_t& S = A.sets[si];
         const int k0 = S.start[d][c], k1 = S.end[d][c];
@@ -303,11 +379,11 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
             }
             continue;
         }
-        // level-major rows (coarse block of the preconditioner: cells of 60+ rows): two row pairs per trip, loads issued together
-        for (int m0 = 0; m0 < nrows; m0 += 4) {
-            float b[2][NT];
+        // level-major rows (coarse block of the preconditioner: cells of 60+ rows): ASM_TRIP row pairs per trip, loads issued together
+        for (int m0 = 0; m0 < nrows; m0 += 2 * ASM_TRIP) {
+            float b[ASM_TRIP][NT];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < ASM_TRIP; ++u) {
                 const int m = m0 + 2 * u + half;
                 const bool valid = m < nrows;
                 const int64_t q = q0 + (valid ? m : 0);
@@ -321,7 +397,7 @@ __global__ void __launch_bounds__(ASM_WAVES * 64) k_cell_blocks(AsmArgs A, int d
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < ASM_TRIP; ++u) {
                 const float a = (j < 27) ? w * b[u][0] : 0.f;
 #pragma unroll
                 for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[u][n], acc[n], 0, 0, 0);

@@ -1,0 +1,90 @@
+"""Hardware counters of the heavy kernels of the 64-chunk scene step (or any bench flags), one rocprofv3 --pmc pass per counter
+group (never combined with a trace domain other than --kernel-trace).  Run on the GPU box:
+    python -m nksr_amd.tools.scene_pmc <out.json> [bench flags ...]
+Per kernel (by name fragment) the dispatch with the LONGEST duration is reported: its duration under the counters and every
+counter of every group.  FETCH_SIZE is in KiB and, on gfx950, counts the 128-byte requests of a coalesced stream at 64 bytes
+(MI355X_MICROARCH.md, HBM section): fetch_bytes = 2 * 1024 * FETCH_SIZE."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+GROUPS = [
+    ['SQ_WAVES', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_VMEM_RD'],
+    ['SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_VMEM', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_MFMA', 'SQ_INST_LEVEL_VMEM', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS',
+     'GRBM_GUI_ACTIVE'],
+    ['FETCH_SIZE'],
+    ['TCC_HIT_sum', 'TCC_MISS_sum'],
+    ['TCP_TOTAL_CACHE_ACCESSES_sum', 'TCP_TCC_READ_REQ_sum', 'TCP_PENDING_STALL_CYCLES_sum', 'TA_TA_BUSY_sum'],
+    ['TA_ADDR_STALLED_BY_TC_CYCLES_sum', 'TA_DATA_STALLED_BY_TC_CYCLES_sum', 'TCP_TCP_TA_DATA_STALL_CYCLES_sum', 'TD_TD_BUSY_sum'],
+]
+KERNELS = ['k_cell_blocks', 'k_fz_sweep', 'k_cheb16_step', 'k_kernel_rows', 'k_sparse_conv3', 'k_splat_mean32', 'k_splat_trilinear',
+           'k_fz_gather', 'k_fz_cellsum', 'k_evaluate_f', 'k_build_nbr', 'k_row_count', 'k_row_fill']
+
+
+def short(name):
+    i = name.find('k_')
+    return name[i:i + 40] if i >= 0 else name[:40]
+
+
+def run_pass(counters, flags, tag):
+    out = '/tmp/pmc_%s' % tag
+    subprocess.run(['rm', '-rf', out])
+    env = dict(os.environ, TMPDIR='/tmp')
+    root = os.environ.get('GRAFT_REPO_ROOT', os.getcwd())
+    cmd = ['rocprofv3', '--pmc'] + counters + ['--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(root, 'bench.py')] + flags
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd='/tmp')
+    dur = {}
+    for f in glob.glob(out + '/**/*kernel_trace.csv', recursive=True):
+        for row in csv.DictReader(open(f)):
+            dur[row.get('Dispatch_Id')] = (int(row['End_Timestamp']) - int(row['Start_Timestamp'])) / 1e3
+    per = {}          # kernel -> dispatch id -> {counter: value}
+    for f in glob.glob(out + '/**/*counter_collection.csv', recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = row.get('Kernel_Name', '')
+            if not any(k in name for k in KERNELS):
+                continue
+            d = per.setdefault(short(name), {}).setdefault(row.get('Dispatch_Id'), {})
+            d[row.get('Counter_Name')] = d.get(row.get('Counter_Name'), 0.0) + float(row['Counter_Value'])
+    res = {}
+    for k, disp in per.items():
+        best = max(disp, key=lambda i: dur.get(i, 0.0))
+        res[k] = dict(disp[best], us=dur.get(best, 0.0), dispatches=len(disp))
+    if not res:
+        sys.stderr.write('pass %s gave no counters: %s\n' % (tag, r.stderr[-600:]))
+    return res
+
+
+def main():
+    out = sys.argv[1]
+    flags = sys.argv[2:] or ['--scene', 'terrain', '--steps', '1', '--warmup', '0', '--no-cpu-baseline']
+    rec = {'command': 'bench.py ' + ' '.join(flags), 'kernels': {}}
+    for gi, g in enumerate(GROUPS):
+        res = run_pass(g, flags, 'g%d' % gi)
+        for k, v in res.items():
+            e = rec['kernels'].setdefault(k, {})
+            e['us_pass%d' % gi] = v.pop('us')
+            e['dispatches'] = v.pop('dispatches')
+            e.update(v)
+    for k, e in rec['kernels'].items():
+        if 'FETCH_SIZE' in e:
+            e['fetch_bytes'] = 2.0 * 1024.0 * e['FETCH_SIZE']
+            e['fetch_TBps'] = e['fetch_bytes'] / e.get('us_pass2', 1e9) / 1e6
+        if e.get('SQ_WAVE_CYCLES'):
+            for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY'):
+                if c in e:
+                    e[c + '_frac'] = e[c] / e['SQ_WAVE_CYCLES']
+        if e.get('TCC_HIT_sum') is not None and e.get('TCC_MISS_sum') is not None and e['TCC_HIT_sum'] + e['TCC_MISS_sum'] > 0:
+            e['l2_hit'] = e['TCC_HIT_sum'] / (e['TCC_HIT_sum'] + e['TCC_MISS_sum'])
+    json.dump(rec, open(out, 'w'), indent=1, sort_keys=True)
+    for k in sorted(rec['kernels'], key=lambda k: -rec['kernels'][k].get('us_pass0', 0)):
+        e = rec['kernels'][k]
+        print('%-42s %8.0f us  fetch %.2f TB/s  l2hit %.2f  wait %.2f  stall %.2f  active %.2f  waves %d' % (
+            k, e.get('us_pass0', 0), e.get('fetch_TBps', 0), e.get('l2_hit', 0), e.get('SQ_WAIT_ANY_frac', 0), e.get('SQ_WAIT_INST_ANY_frac', 0),
+            e.get('SQ_ACTIVE_INST_ANY_frac', 0), e.get('SQ_WAVES', 0)))
+
+
+if __name__ == '__main__':
+    main()
