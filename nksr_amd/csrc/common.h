@@ -110,6 +110,70 @@ __device__ __forceinline__ void bspline3(float u, float w[3], float dw[3]) {
     dw[2] = u;
 }
 
+// ---- the points that weigh at a voxel, in a fixed order (trilinear splats: hierarchy.hip, nn.hip) --------------------------------
+// One 32-lane half-wave per voxel, lane s < 27 = neighbour cell c (-1: none).  Every lane walks the points of ITS cell and keeps
+// those with a positive trilinear weight at the voxel centre (cx, cy, cz; voxel units), at most SPLAT_CAP per round; the kept
+// (point, weight) pairs of the 27 lanes are compacted -- cell after cell, points in their order -- into a list in LDS, and
+// `consume(k[4], w[4])` gets them four at a time (missing ones: weight 0, point 0), so that the caller's loads of four points go
+// out together and one row of a point is read by the whole half-wave at once.  (Round 3: every lane fetched the feature rows of
+// its own cell's points inside the branchy walk -- 8 x 16 bytes per lane and point, one dependent round trip per point.)
+// lk / lw: SPLAT_LIST ints / floats of LDS owned by this half-wave.  Rounds repeat until every cell is exhausted.
+#define SPLAT_CAP 4
+#define SPLAT_LIST 128
+typedef float splat_f32x3 __attribute__((ext_vector_type(3), aligned(4)));
+template <typename F>
+__device__ __forceinline__ void splat_for_each_point(const float* __restrict__ xyz, const int32_t* __restrict__ start,
+                                                     const int32_t* __restrict__ end, int c, float cx, float cy, float cz, float inv_w,
+                                                     int s, int* lk, float* lw, F&& consume) {
+#pragma clang fp contract(off)          // the weights are the oracle's: x * inv_w rounded before the subtraction
+    int k = c >= 0 ? start[c] : 0;
+    const int k1 = c >= 0 ? end[c] : 0;
+    while (true) {
+        // SPLAT_CAP candidates per round, their coordinates requested together (clamped index: point 0 exists whenever a cell does)
+        splat_f32x3 pt[SPLAT_CAP];
+#pragma unroll
+        for (int i = 0; i < SPLAT_CAP; ++i) pt[i] = *reinterpret_cast<const splat_f32x3*>(xyz + (int64_t)(k + i < k1 ? k + i : 0) * 3);
+        float wv[SPLAT_CAP];
+        int rank[SPLAT_CAP], cnt = 0;
+#pragma unroll
+        for (int i = 0; i < SPLAT_CAP; ++i) {
+            const float wx = 1.f - fabsf(pt[i].x * inv_w - cx), wy = 1.f - fabsf(pt[i].y * inv_w - cy), wz = 1.f - fabsf(pt[i].z * inv_w - cz);
+            const bool keep = k + i < k1 && wx > 0.f && wy > 0.f && wz > 0.f;
+            wv[i] = keep ? wx * wy * wz : 0.f;
+            rank[i] = keep ? cnt : -1;
+            cnt += keep ? 1 : 0;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int t = __shfl_up(incl, o, 32);
+            if (s >= o) incl += t;
+        }
+        const int off = incl - cnt, P = __shfl(incl, 31, 32);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // the reads of the previous round are done
+#pragma unroll
+        for (int i = 0; i < SPLAT_CAP; ++i)
+            if (rank[i] >= 0) { lk[off + rank[i]] = k + i; lw[off + rank[i]] = wv[i]; }
+        k = k + SPLAT_CAP < k1 ? k + SPLAT_CAP : k1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int Po = __shfl_xor(P, 32, 64), Pw = P > Po ? P : Po;     // the two halves of the wavefront loop together
+        for (int p = 0; p < Pw; p += 4) {
+            int kq[4];
+            float wq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = p + i < P;
+                const int kv = lk[(p + i) & (SPLAT_LIST - 1)];
+                const float wv = lw[(p + i) & (SPLAT_LIST - 1)];
+                kq[i] = ok ? kv : 0;
+                wq[i] = ok ? wv : 0.f;
+            }
+            consume(kq, wq);
+        }
+        if (__ballot(k < k1) == 0ull) break;
+    }
+}
+
 // ---- reductions over the 32 lanes of a half-wavefront (fixed trees: deterministic) ------------------------------------------------
 __device__ __forceinline__ float half_sum(float p) {      // sum over the 32 lanes of this half-wave, fixed tree
     p += __shfl_xor(p, 16, 32);

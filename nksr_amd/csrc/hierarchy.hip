@@ -188,38 +188,29 @@ __global__ void __launch_bounds__(256) k_splat_trilinear(const float* __restrict
                                                          const int32_t* __restrict__ start, const int32_t* __restrict__ end,
                                                          const int32_t* __restrict__ nbr, const int32_t* __restrict__ ijk, int n,
                                                          float inv_w, float* __restrict__ out, float* __restrict__ wsum_out) {
-    const int j = (blockIdx.x * 256 + threadIdx.x) >> 5, s = threadIdx.x & 31;
-    if (j >= n) return;
+    __shared__ int lk[8][SPLAT_LIST];
+    __shared__ float lw[8][SPLAT_LIST];
+    const int j = (blockIdx.x * 256 + threadIdx.x) >> 5, s = threadIdx.x & 31, h = threadIdx.x >> 5;
+    const bool live = j < n;
+    const int jc = live ? j : n - 1;
     // fp64 accumulators: the splat of the input normals is normalised afterwards, and where the normals of a voxel's points nearly
     // cancel (both sides of a thin sheet) fp32 sums left 1e-4 of noise in the unit target (round 3: sites with |sum w n| ~ 0.1 sum w
-    // differed by 7e-5 from the fp64 oracle); the products w * f are exact in fp64, so only the order of the additions is left
-    double acc[8];
+    // differed by 7e-5 from the fp64 oracle); the products w * f are exact in fp64, so only the order of the additions is left.
+    // The points that weigh at the voxel are listed first (common.h: splat_for_each_point, lane = neighbour cell), then lane =
+    // channel sums them in list order.
+    double acc = 0.0, wsum = 0.0;
+    const float cx = (float)ijk[jc * 3] + 0.5f, cy = (float)ijk[jc * 3 + 1] + 0.5f, cz = (float)ijk[jc * 3 + 2] + 0.5f;
+    const int c = (live && s < 27) ? nbr[(int64_t)jc * 27 + s] : -1;
+    const int ch = s < C ? s : 0;
+    splat_for_each_point(xyz, start, end, c, cx, cy, cz, inv_w, s, lk[h], lw[h], [&](const int (&kq)[4], const float (&wq)[4]) {
+        float f[4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.0;
-    double wsum = 0.0;
-    const float cx = (float)ijk[j * 3] + 0.5f, cy = (float)ijk[j * 3 + 1] + 0.5f, cz = (float)ijk[j * 3 + 2] + 0.5f;
-    const int c = s < 27 ? nbr[(int64_t)j * 27 + s] : -1;
-    if (c >= 0) {
-        for (int k = start[c], k1 = end[c]; k < k1; ++k) {
-            const float wx = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3], inv_w) - cx);
-            const float wy = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 1], inv_w) - cy);
-            const float wz = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 2], inv_w) - cz);
-            if (wx <= 0.f || wy <= 0.f || wz <= 0.f) continue;
-            const float w = wx * wy * wz;
-            wsum += (double)w;
+        for (int i = 0; i < 4; ++i) f[i] = feat[(int64_t)kq[i] * C + ch];
 #pragma unroll
-            for (int c2 = 0; c2 < 8; ++c2)
-                if (c2 < C) acc[c2] = fma((double)w, (double)feat[(int64_t)k * C + c2], acc[c2]);
-        }
-    }
-    wsum = half_sum_d(wsum);
-#pragma unroll
-    for (int c2 = 0; c2 < 8; ++c2)
-        if (c2 < C) {
-            const double t = half_sum_d(acc[c2]);
-            if (s == 0) out[(int64_t)j * C + c2] = (float)t;
-        }
-    if (s == 0) wsum_out[j] = (float)wsum;
+        for (int i = 0; i < 4; ++i) { wsum += (double)wq[i]; acc = fma((double)wq[i], (double)f[i], acc); }
+    });
+    if (live && s < C) out[(int64_t)j * C + s] = (float)acc;
+    if (live && s == 0) wsum_out[j] = (float)wsum;
 }
 
 extern "C" int nksr_splat_trilinear(const float* xyz_sorted, const float* feat_sorted, int C, const int32_t* start,

@@ -92,51 +92,30 @@ __global__ void k_splat_mean_c(const float* __restrict__ xyz, const float* __res
     for (int c2 = 0; c2 < nc; ++c2) out[(int64_t)j * C + c0 + c2] = acc[c2] * inv;
 }
 
-// C = 32 specialisation: one 32-lane half-wave per voxel, lane = neighbour cell (the 27 chains cell -> point range ->
-// coordinates -> feature row run side by side; a thread per voxel walked them one after the other: 0.69 ms at 7.8e5 voxels),
-// 32 accumulators per lane, then eight transposing butterflies (four channels each) over the lanes and one coalesced 128-byte
-// store per voxel.
+// C = 32 specialisation: one 32-lane half-wave per voxel.  The points that weigh at the voxel are listed first (common.h:
+// splat_for_each_point, lane = neighbour cell), then lane = CHANNEL: four points per trip, each feature row one coalesced 128-byte
+// read of the half-wave; the sum runs over the points in list order (cell after cell), the same in every lane -- no reduction
+// over the lanes, one coalesced 128-byte store per voxel.
 __global__ void __launch_bounds__(256) k_splat_mean32(const float* __restrict__ xyz, const float* __restrict__ feat,
                                                       const int32_t* __restrict__ start, const int32_t* __restrict__ end,
                                                       const int32_t* __restrict__ nbr, const int32_t* __restrict__ ijk, int n,
                                                       float inv_w, float* __restrict__ out) {
-    const int j = (blockIdx.x * 256 + threadIdx.x) >> 5, s = threadIdx.x & 31;
-    if (j >= n) return;
-    float acc[32];
+    __shared__ int lk[8][SPLAT_LIST];
+    __shared__ float lw[8][SPLAT_LIST];
+    const int j = (blockIdx.x * 256 + threadIdx.x) >> 5, s = threadIdx.x & 31, h = threadIdx.x >> 5;
+    const bool live = j < n;                                         // (a dead half-wave walks an empty list next to its partner)
+    const int jc = live ? j : n - 1;
+    const float cx = (float)ijk[jc * 3] + 0.5f, cy = (float)ijk[jc * 3 + 1] + 0.5f, cz = (float)ijk[jc * 3 + 2] + 0.5f;
+    const int c = (live && s < 27) ? nbr[(int64_t)jc * 27 + s] : -1;
+    float acc = 0.f, wsum = 0.f;
+    splat_for_each_point(xyz, start, end, c, cx, cy, cz, inv_w, s, lk[h], lw[h], [&](const int (&kq)[4], const float (&wq)[4]) {
+        float f[4];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] = 0.f;
-    float wsum = 0.f;
-    const float cx = (float)ijk[j * 3] + 0.5f, cy = (float)ijk[j * 3 + 1] + 0.5f, cz = (float)ijk[j * 3 + 2] + 0.5f;
-    const int c = s < 27 ? nbr[(int64_t)j * 27 + s] : -1;
-    if (c >= 0) {
-        for (int k = start[c], k1 = end[c]; k < k1; ++k) {
-            const float wx = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3], inv_w) - cx);
-            const float wy = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 1], inv_w) - cy);
-            const float wz = 1.f - fabsf(__fmul_rn(xyz[(int64_t)k * 3 + 2], inv_w) - cz);
-            if (wx <= 0.f || wy <= 0.f || wz <= 0.f) continue;
-            const float w = wx * wy * wz;
-            wsum += w;
-            const float4* f = reinterpret_cast<const float4*>(feat + (int64_t)k * 32);
+        for (int i = 0; i < 4; ++i) f[i] = feat[(int64_t)kq[i] * 32 + s];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float4 t = f[q];
-                acc[4 * q] = fmaf(w, t.x, acc[4 * q]); acc[4 * q + 1] = fmaf(w, t.y, acc[4 * q + 1]);
-                acc[4 * q + 2] = fmaf(w, t.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(w, t.w, acc[4 * q + 3]);
-            }
-        }
-    }
-    wsum = half_sum(wsum);
-    const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
-    // butterfly q leaves channel 4 q + g in the lanes 8 g .. 8 g + 7; lane L wants channel L = 4 (L >> 2) + (L & 3): the value of
-    // butterfly L >> 2, taken from lane 8 (L & 3)
-    float mine = 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float r = half_sum4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3], s);
-        const float v = __shfl(r, 8 * (s & 3), 32);
-        if ((s >> 2) == q) mine = v;
-    }
-    out[(int64_t)j * 32 + s] = mine * inv;
+        for (int i = 0; i < 4; ++i) { wsum += wq[i]; acc = fmaf(wq[i], f[i], acc); }
+    });
+    if (live) out[(int64_t)j * 32 + s] = acc * (wsum > 0.f ? 1.f / wsum : 0.f);
 }
 
 // ---- UDF mask branch (NeuralField, models/nksr_net.py:124-130) -------------------------------------------------
