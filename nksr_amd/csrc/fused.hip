@@ -89,9 +89,22 @@ struct FusedArgs {               // uniform scalars and base pointers only
     const int32_t* unknown_seg;
     const int* seg_done;         // device flags of the PCG: segment c finished <=> seg_done[c * seg_stride] != 0 (may be NULL)
     int seg_stride;
+    const int* seg_done_count;   // device: finished segments so far (may be NULL); the per-cell sums and the gather look at their
+    int seg_gate;                // unknowns' segments only once >= seg_gate have finished (the look-up costs ~20 % of those passes)
 };
 __device__ __forceinline__ bool fz_seg_done(const FusedArgs& A, const int32_t* seg_of, int64_t i) {
     return A.seg_done && seg_of && A.seg_done[(int64_t)seg_of[i] * A.seg_stride] != 0;
+}
+// true when the FZ_GI (four) consecutive unknowns i0 .. of this half-wave all belong to finished segments (gated, see seg_gate);
+// `idx` non-NULL: the unknowns are idx[i0 ..] (the cell list of the per-cell sums).  n: valid entries from i0 on.
+__device__ __forceinline__ bool fz_group_done(const FusedArgs& A, const int32_t* idx, int64_t i0, int n, int lane32, bool upper) {
+    if (!A.seg_done || !A.unknown_seg || !A.seg_done_count || *A.seg_done_count < A.seg_gate) return false;
+    bool dn = true;
+    if (lane32 < 4 && lane32 < n) {
+        const int64_t j = idx ? idx[i0 + lane32] : i0 + lane32;
+        dn = A.seg_done[(int64_t)A.unknown_seg[j] * A.seg_stride] != 0;
+    }
+    return (unsigned)(__ballot(dn) >> (upper ? 32 : 0)) == 0xFFFFFFFFu;
 }
 
 // lane `l` of the caller's own half-wave, l uniform: two scalar lane reads + a select (no crossbar)
@@ -319,6 +332,8 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
         // (one serial chain over hundreds of blocks was the critical path of the pass), then the eight partial sums in order
         __shared__ float partial[8][32];
         const int cell = A.multi[blockIdx.x], h = threadIdx.x >> 5;
+        if (A.seg_done && A.unknown_seg && A.seg_done_count && *A.seg_done_count >= A.seg_gate &&
+            A.seg_done[(int64_t)A.unknown_seg[cell] * A.seg_stride] != 0) return;          // uniform over the workgroup
         const int b0 = A.offsets[cell], n = A.offsets[cell + 1] - b0;
         const float* p = part + (int64_t)(b0 + h) * 32 + s;
         float acc = 0.f;
@@ -338,6 +353,7 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
     const int first = LIST ? A.n_big : 0, ncell = (LIST ? A.n_multi : A.M) - first;
     const int i0 = (((LIST ? (int)blockIdx.x - A.n_big : (int)blockIdx.x) * 256 + (int)threadIdx.x) >> 5) * FZ_GI;
     if (i0 >= ncell) return;
+    if (fz_group_done(A, LIST ? A.multi + first : nullptr, i0, ncell - i0, s, (threadIdx.x & 32) != 0)) return;
     int cell[FZ_GI], b0[FZ_GI], n[FZ_GI];
 #pragma unroll
     for (int k = 0; k < FZ_GI; ++k) {
@@ -380,6 +396,7 @@ __global__ void __launch_bounds__(256) k_fz_gather(FusedArgs A, int per_xcd, con
     const int j0 = xcd * per_xcd + local;
     if (j0 >= A.M) return;
     const int sp = threadIdx.x & 31;
+    if (fz_group_done(A, nullptr, j0, A.M - j0, sp, (threadIdx.x & 32) != 0)) return;
     int c[FZ_GI];
 #pragma unroll
     for (int k = 0; k < FZ_GI; ++k) c[k] = (sp < 27 && j0 + k < A.M) ? A.nbr32[(int64_t)(j0 + k) * 32 + sp] : -1;
@@ -529,10 +546,13 @@ extern "C" int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* 
 
 struct FusedOperator : PcgOperator {
     FusedArgs A; float reg; FusedWork w;
-    int apply(const float* p, float* y, const int* done, const int* seg_done, int seg_stride, hipStream_t st) override {
+    int apply(const float* p, float* y, const int* done, const int* seg_done, int seg_stride, const int* seg_done_count, int seg_count,
+              hipStream_t st) override {
         FusedArgs B = A;
         B.seg_done = (A.item_seg && A.unknown_seg) ? seg_done : nullptr;
         B.seg_stride = seg_stride;
+        B.seg_done_count = seg_done_count;
+        B.seg_gate = seg_count / 4 > 1 ? seg_count / 4 : 1;
         return fz_apply(B, reg, w, p, y, done, st);
     }
     void bytes(double* alg, double* phys, double* survey) override {

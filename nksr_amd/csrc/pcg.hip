@@ -1013,7 +1013,7 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
     // the bound is the dependency latency between consecutive tiny kernels on the device, ~15 us each, not the host enqueue.)
     auto iterate = [&](int parity, int c) -> int {
         if (prof) (void)hipEventRecord(g_prof_events[2 * c], st);
-        if (int rc = A.apply(w.p, w.y, &w.g->done_all, w.nseg > 1 ? &w.sc[0].done : nullptr, (int)(sizeof(SegScalars) / sizeof(int)), st)) return rc;
+        if (int rc = A.apply(w.p, w.y, &w.g->done_all, w.nseg > 1 ? &w.sc[0].done : nullptr, (int)(sizeof(SegScalars) / sizeof(int)), &w.g->done_count, w.nseg, st)) return rc;
         if (prof) (void)hipEventRecord(g_prof_events[2 * c + 1], st);
         hipLaunchKernelGGL(k_spcg_dot, gb, blkd, 0, st, w);
         hipLaunchKernelGGL(k_spcg_update, gb, blkd, 0, st, w, diag, x, parity);
@@ -1061,7 +1061,7 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
 
 struct CsrOperator : PcgOperator {
     const int32_t* rowptr; const void* cols; const float* vals; int M; int64_t nnz; int fmt; SpmvPlan plan;
-    int apply(const float* p, float* y, const int* done, const int*, int, hipStream_t st) override {
+    int apply(const float* p, float* y, const int* done, const int*, int, const int*, int, hipStream_t st) override {
         launch_spmv(rowptr, cols, vals, M, nnz, fmt, plan, p, y, done, st);
         return NKSR_OK;
     }

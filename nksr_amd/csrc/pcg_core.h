@@ -6,8 +6,10 @@
 struct PcgOperator {
     // enqueue y = A p on `st`; `done` (device flag) != 0 must turn the launches into no-ops.  seg_done (may be NULL): device
     // flags, segment c's at seg_done[c * seg_stride] -- an operator that knows its segments (nksr_fused_op_t.item_seg /
-    // unknown_seg) may skip the rows and unknowns of finished ones (their y is never read again)
-    virtual int apply(const float* p, float* y, const int* done, const int* seg_done, int seg_stride, hipStream_t st) = 0;
+    // unknown_seg) may skip the rows and unknowns of finished ones (their y is never read again); seg_done_count (device, may be
+    // NULL): how many segments have finished, seg_count: how many there are
+    virtual int apply(const float* p, float* y, const int* done, const int* seg_done, int seg_stride, const int* seg_done_count, int seg_count,
+                      hipStream_t st) = 0;
     // bytes one application moves: the algorithmic minimum of THIS operator's data (what `roofline.achieved` is priced on), what the
     // layout really streams, and the figure of SURVEY.md section 8d's formula (CSR: equal to the first)
     virtual void bytes(double* algorithmic, double* physical, double* survey_formula) = 0;
