@@ -327,6 +327,7 @@ class KernelField(BaseField):
         self.alpha = x
         self.matrix = (rowptr, cols, vals, diag)
         self._fused_op = None
+        self._pc = pc if self._wants_grad(normal_value) else None      # the adjoint solve of the backward pass takes the same preconditioner (_solve_system)
         self.rhs, self.diag = b, diag
         self.solve_info = {'iters': iters, 'rel_residual': rel, 'M': int(b.numel()), 'nnz': int(self.nnz),
                            'coarse_precond': ({k: pc[k] for k in ('first_level', 'unknowns', 'nnz', 'steps', 'lambda')} if pc else None),
@@ -616,6 +617,7 @@ class KernelField(BaseField):
         self.alpha = x
         self.matrix = None
         self._fused_op, self._fused_reg = op, float(reg_weight)
+        self._pc = pc if segments is None else None      # (a batched solve's block needs its segments: not kept)
         self._stored_entries = op['nnz_counter']
         self.rhs, self.diag = b, diag
         self.nnz = 0
@@ -628,18 +630,21 @@ class KernelField(BaseField):
             print('[KernelField] fused: M=%d rows=%d iters=%d rel=%.3e rows+rhs=%.3fs pcg=%.3fs' % (
                 M, op['rows_total'], int(info[0]), float(info[1]), t1 - t0, t2 - t1))
         if not self._wants_grad(normal_value):
-            self._fused_op = None          # only the backward pass needs the operator again: do not pin ~2 GB of rows
+            self._fused_op = self._pc = None          # only the backward pass needs the operator again: do not pin ~2 GB of rows
         self._attach_autograd(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight)
         return self
 
     # ---- differentiable solve (training path, models/nksr_net.py:105-112) ---------------------------------------
     def _solve_system(self, rhs):
-        """A^-1 rhs with the system of the last solve (assembled CSR or matrix-free operator), same tolerance."""
+        """A^-1 rhs with the system of the last solve (assembled CSR or matrix-free operator), same tolerance, same
+        preconditioner (the coarse-level block of the forward solve, when it had one)."""
         from .. import solver
         cfg = self.solver_config
+        pc = getattr(self, '_pc', None)
         if self.matrix is not None:
             rowptr, cols, vals, diag = self.matrix
-            return solver.pcg_solve(rowptr, cols, vals, diag, rhs.contiguous(), tol=cfg['tol'], max_iter=cfg['max_iter'], check_every=cfg['check_every'])[0]
+            return solver.pcg_solve(rowptr, cols, vals, diag, rhs.contiguous(), tol=cfg['tol'], max_iter=cfg['max_iter'], check_every=cfg['check_every'],
+                                    precond=pc['pc'] if pc else None)[0]
         if getattr(self, '_fused_op', None) is None:
             raise RuntimeError('the system of the last solve is gone: call solve*() under torch.enable_grad() with normal_value.requires_grad')
         M = self.svh.num_unknowns
@@ -647,7 +652,9 @@ class KernelField(BaseField):
         pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=self.device)
         info = (C.c_double * 2)()
         call('nksr_pcg_solve_fused', C.byref(self._fused_op['op']), self._fused_reg, ptr(self.diag), ptr(rhs.contiguous()), ptr(x), float(cfg['tol']),
-             int(cfg['max_iter']), int(cfg['check_every']), ptr(pws), None, None, info, stream())
+             int(cfg['max_iter']), int(cfg['check_every']), ptr(pws), C.byref(pc['pc']) if pc else None, None, info, stream())
+        if info[1] < 0:
+            raise RuntimeError('PCG breakdown in the adjoint solve (r.z <= 0): set solver_config["coarse_precond"] = False')
         return x
 
     def _theta(self):
@@ -768,7 +775,7 @@ class KernelField(BaseField):
         self._mlp = [t.to(device) for t in self._mlp]
         self.alpha = self.alpha.to(device)           # (the setter drops the evaluation cache: it points into the old arrays)
         self.matrix = None
-        self._fused_op = None
+        self._fused_op = self._pc = None
         if device.type == 'cuda':
             self._hier = self._make_hier()
         if self.mask_field is not None:

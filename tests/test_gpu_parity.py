@@ -332,6 +332,37 @@ def _level_keys(svh, xyz, d):
     return keys
 
 
+@pytest.mark.parametrize('fused', [False, True])
+def test_adjoint_solve_takes_the_forward_preconditioner(fused):
+    """ADVICE.md (round 2): the backward pass's A^-1 g ignored the coarse-level block the forward solve had used (4x the
+    iterations at depth 5).  With the block the adjoint solve gives the same vector as with Jacobi alone."""
+    from nksr_amd.fields import KernelField
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=1200, init_scale=0.3)
+    net.to(_dev())
+    t = lambda a: torch.from_numpy(a).to(_dev())
+    fld = KernelField(svh, net.interpolators, [t(f) for f in feats], approx_kernel_grad=True)
+    fld.solver_config.update({'tol': 1e-7, 'max_iter': 4000, 'coarse_precond': {'first_level': max(1, svh.depth - 2)}})
+    nxyz = oh.levels[0].centers()
+    rs = np.random.RandomState(3)
+    nval = t(rs.randn(len(nxyz), 3).astype(np.float32)).requires_grad_(True)
+    wp, wn = 1e4 / len(xyz), 1e4 / len(nxyz) * 0.01
+    with torch.enable_grad():
+        (fld.solve if fused else fld.solve_non_fused)(t(xyz), t(nxyz), nval, wp, wn, 1.0)
+    assert fld._pc is not None and fld.solve_info['coarse_precond'] is not None
+    g = t(rs.randn(svh.num_unknowns).astype(np.float32))
+    with_block = fld._solve_system(g)
+    pc, fld._pc = fld._pc, None
+    jacobi = fld._solve_system(g)
+    fld._pc = pc
+    pu.check('adjoint_precond[fused=%s]' % fused, float((with_block - jacobi).abs().max() / jacobi.abs().max()), 1e-4)
+    # and the gradient through it is the one of the Jacobi-only adjoint
+    loss = (fld.alpha * g).sum()
+    ga = torch.autograd.grad(loss, nval, retain_graph=True)[0]
+    fld._pc = None
+    gb = torch.autograd.grad(loss, nval)[0]
+    pu.check('adjoint_precond[fused=%s]:grad' % fused, float((ga - gb).abs().max() / gb.abs().max()), 1e-4)
+
+
 @pytest.mark.parametrize('approx,fused', [(False, False), (True, False), (True, True)])
 def test_solve_is_differentiable_wrt_features_and_interpolators(approx, fused):
     """models/nksr_net.py:105-112 back-propagates through solve_non_fused into the basis features and the
