@@ -146,8 +146,10 @@ int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int appr
  * of the matrix-free solve (nksr_fused_op_t.rows_all): row_index lets several site sets share one Morton-ordered row list;
  * row_cells [L, level_stride] (may be NULL) receives the global unknown index of the level-d cell of every row written (-1 = none). */
 /* f(x) (and gradient if grad_out != NULL): field.evaluate_f, models/loss.py:189-198.  alpha == NULL: the hierarchy's psi arrays
- * already hold alpha_j psi_j (one gather per neighbour instead of two). */
-int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx,
+ * already hold alpha_j psi_j (one gather per neighbour instead of two).  A query outside every active cell of a level still sees the
+ * voxels whose support covers it (hash lookups); active_only != 0 drops those levels instead -- the support of nksr_kernel_rows,
+ * which is what the training path's backward differentiates. */
+int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx, int active_only,
                     float* f_out, float* grad_out, void* stream);
 
 /* ---- normal-equation assembly (KernelField.solve_non_fused, models/nksr_net.py:105-112) */

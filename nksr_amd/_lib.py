@@ -117,7 +117,7 @@ _PROTOS = {
     'nksr_udf_decode': [_P(LevelT), C.c_int, _vp, _vp, _i64, _f32, _f32, C.c_int, _vp, _vp],
     'nksr_voxel_psi': [_vp, _i32, C.c_int, C.c_int, _vp, _vp, _vp],
     'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
-    'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, _vp, _vp, _vp],
+    'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp],
     'nksr_assemble_count': [_P(HierT), _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'nksr_place_mirrors': [_vp, _vp, _i64, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp],

@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
 // ---- f(x) = sum_d sum_s alpha_j K_d(x, c_j) ---------------------------------------------------
 template <int K, int H, bool GRAD, bool JAC>
 __global__ void __launch_bounds__(128) k_evaluate_f(nksr_hier_t hier, const float* __restrict__ alpha, const float* __restrict__ xyz,
-                             int64_t n, float* __restrict__ fout, float* __restrict__ gout) {
+                             int64_t n, float* __restrict__ fout, float* __restrict__ gout, int active_only) {
     extern __shared__ __attribute__((aligned(16))) float wall[];
     const int L = hier.depth;
     for (int d = 0; d < L; ++d)
@@ -283,6 +283,7 @@ __global__ void __launch_bounds__(128) k_evaluate_f(nksr_hier_t hier, const floa
         const nksr_level_t& lv = hier.lv[d];
         if (lv.n == 0) continue;
         SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
+        if (active_only && sc.cell < 0) continue;      // the support of the kernel ROWS (training path: forward = what backward differentiates)
         float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
         float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
         trilerp_feat<K, JAC, true>(lv, d, sc, inv_w, t, Jt);
@@ -364,16 +365,16 @@ extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t 
     return NKSR_OK;
 }
 
-extern "C" int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx,
+extern "C" int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx, int active_only,
                                float* f_out, float* grad_out, void* stream) {
     if (n <= 0) return NKSR_OK;
     if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
     dim3 grid(nksr_blocks(n, 128)), block(128);
     DISPATCH_KH(h->kdim, h->hidden, {
         size_t lds = (size_t)h->depth * MlpView<K, H>::SIZE * sizeof(float);
-        if (!grad_out) hipLaunchKernelGGL((k_evaluate_f<K, H, false, false>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out);
-        else if (approx) hipLaunchKernelGGL((k_evaluate_f<K, H, true, false>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out);
-        else hipLaunchKernelGGL((k_evaluate_f<K, H, true, true>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out);
+        if (!grad_out) hipLaunchKernelGGL((k_evaluate_f<K, H, false, false>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out, active_only);
+        else if (approx) hipLaunchKernelGGL((k_evaluate_f<K, H, true, false>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out, active_only);
+        else hipLaunchKernelGGL((k_evaluate_f<K, H, true, true>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out, active_only);
     })
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;

@@ -748,7 +748,7 @@ class KernelField(BaseField):
             self._apsi_hier, self._apsi_key = h, key
         return self._apsi_hier
 
-    def _evaluate_raw(self, alpha, xyz, grad, max_points=1 << 22):
+    def _evaluate_raw(self, alpha, xyz, grad, max_points=1 << 22, active_only=False):
         n = xyz.shape[0]
         xyz = xyz.to(self.device)
         alpha = alpha.detach().contiguous()
@@ -763,7 +763,7 @@ class KernelField(BaseField):
             xs = xyz[s:e].contiguous()
             fs = f[s:e]
             gs = g[s:e] if grad else None
-            call('nksr_evaluate_f', C.byref(hier), ptr(alpha_arg), ptr(xs), e - s, int(self.approx_kernel_grad),
+            call('nksr_evaluate_f', C.byref(hier), ptr(alpha_arg), ptr(xs), e - s, int(self.approx_kernel_grad), int(bool(active_only)),
                  ptr(fs), ptr(gs), stream())
         return EvaluationResult(f, g)
 
@@ -819,14 +819,15 @@ class _SolveFunction(torch.autograd.Function):
 class _EvaluateFunction(torch.autograd.Function):
     """f(x) and grad f(x) as functions of alpha (linear) and theta: dL/dalpha = G_x^T g_f + Q_x^T g_grad, the set-up pass of the
     matrix-free operator over the kernel rows of the query points; dL/dtheta = sum_x dR_x . (g alpha) (KernelField._theta_vjp).
-    Query points are not differentiated; points outside every active cell of a level contribute nothing at that level here
-    (evaluate_f itself looks their neighbours up in the hash)."""
+    Query points are not differentiated.  Support: the kernel rows exist only where the query lies in an active cell of the
+    level, so the FORWARD of this (training) path is evaluated with the same support (nksr_evaluate_f active_only) -- the
+    inference path (no autograd) also adds the levels whose neighbours a query outside every active cell still touches."""
 
     @staticmethod
     def forward(ctx, field, alpha, xyz, want_grad, max_points, *theta):
         ctx.field, ctx.xyz, ctx.want_grad, ctx.n_theta = field, xyz, want_grad, len(theta)
         ctx.alpha = alpha.detach()
-        res = field._evaluate_raw(alpha, xyz, want_grad, max_points)
+        res = field._evaluate_raw(alpha, xyz, want_grad, max_points, active_only=True)
         g = res.gradient if want_grad else torch.zeros((0, 3), dtype=torch.float32, device=res.value.device)
         return res.value, g
 
@@ -834,6 +835,9 @@ class _EvaluateFunction(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g_f, g_grad):
         fld = ctx.field
+        if ctx.xyz.shape[0] == 0:           # no queries: zero gradients
+            th = fld._theta()[:ctx.n_theta]
+            return (None, torch.zeros_like(ctx.alpha), None, None, None) + tuple(torch.zeros_like(q) for q in th)
         use_g = ctx.want_grad and g_grad is not None and g_grad.numel() > 0
         g_f = g_f if g_f is not None else torch.zeros(ctx.xyz.shape[0], device=fld.device)
         op = fld.fused_operator(ctx.xyz, ctx.xyz if use_g else None, g_grad if use_g else None, 1.0, 1.0, pos_value=g_f)

@@ -332,6 +332,53 @@ def _level_keys(svh, xyz, d):
     return keys
 
 
+def test_training_path_forward_and_backward_share_their_support():
+    """ADVICE.md (round 2): evaluate_f looks the neighbours of a query OUTSIDE every active cell up in the hash, the kernel rows the
+    backward differentiates exist only inside active cells -- for samples near the support boundary dL/dalpha disagreed with
+    the forward.  Under autograd the forward now uses the rows' support: f is linear in alpha, so dL/dalpha . v must equal
+    L(alpha + v) - L(alpha) for queries just outside the active voxels; an empty query batch gives zero gradients."""
+    from nksr_amd.fields import KernelField
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=1500, init_scale=0.3)
+    net.to(_dev())
+    t = lambda a: torch.from_numpy(a).to(_dev())
+    fld = KernelField(svh, net.interpolators, [t(f) for f in feats], approx_kernel_grad=False)
+    rs = np.random.RandomState(5)
+    # queries: input points pushed outwards by 0.5 .. 2.5 finest voxels along their normals (many leave the finest level's cells)
+    q = (xyz[:800] + nrm[:800] * (rs.uniform(0.5, 2.5, (800, 1)) * oh.voxel_size).astype(np.float32)).astype(np.float32)
+    qt = t(q)
+    outside0 = svh.level(0).hash.query(_level_keys(svh, qt, 0)) < 0
+    assert int(outside0.sum()) > 50, 'the probe must contain queries outside the finest level'
+    a0 = t(rs.randn(svh.num_unknowns).astype(np.float32))
+    v = t(rs.randn(svh.num_unknowns).astype(np.float32))
+    c1, c3 = t(rs.randn(800).astype(np.float32)), t(rs.randn(800, 3).astype(np.float32))
+
+    def loss_of(alpha):
+        fld.alpha = alpha
+        r = fld.evaluate_f(qt, grad=True)
+        return (c1 * r.value).sum() + (c3 * r.gradient).sum()
+    with torch.enable_grad():
+        al = a0.clone().requires_grad_(True)
+        L0 = loss_of(al)
+        g, = torch.autograd.grad(L0, al)
+        L1 = loss_of((a0 + v).requires_grad_(True))
+        # no queries: zero gradient, no exception
+        fld.alpha = al
+        e = fld.evaluate_f(torch.zeros((0, 3), device=_dev()), grad=True)
+        ge, = torch.autograd.grad(e.value.sum() + e.gradient.sum() + 0.0 * al.sum(), al, allow_unused=True)
+    assert ge is None or float(ge.abs().max()) == 0.0
+    lin, dif = float((g * v).sum()), float(L1 - L0)
+    pu.check('training_support:dL/dalpha.v vs L(alpha+v)-L(alpha)', abs(lin - dif) / max(abs(dif), 1e-12), 2e-4)
+    # the inference path still sees the fallback neighbours: on this probe it differs from the training forward
+    with torch.no_grad():
+        fld.alpha = a0
+        inf = fld.evaluate_f(qt).value
+    with torch.enable_grad():
+        fld.alpha = a0.clone().requires_grad_(True)
+        trn = fld.evaluate_f(qt).value.detach()
+    d = (inf - trn).abs()
+    assert float(d.max()) > 0
+
+
 @pytest.mark.parametrize('fused', [False, True])
 def test_adjoint_solve_takes_the_forward_preconditioner(fused):
     """ADVICE.md (round 2): the backward pass's A^-1 g ignored the coarse-level block the forward solve had used (4x the
