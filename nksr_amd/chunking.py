@@ -483,7 +483,9 @@ class MultiChunkField(BaseField):
             return EvaluationResult(f_out, g_out)
         offs, _, cid, w, xq = self._pairs(xyz)
         m = xq.shape[0]
-        if len(self.parts) == 1 or m == 0:        # one evaluation call per part for ALL pairs
+        if m == 0:                                 # no chunk weighs at any query: f = 0
+            return EvaluationResult(f_out, g_out)
+        if len(self.parts) == 1:                   # one evaluation call per part for ALL pairs
             res = self.parts[0].field._evaluate_f_model(xq, grad, max_points)
             f, gr = res.value.contiguous(), (res.gradient.contiguous() if grad else None)
         else:
