@@ -24,6 +24,9 @@
 #include "pcg_core.h"
 
 #define FZ_RC 32
+// (round 3: reading the kernel rows with the non-temporal hint made the sweep 9-13 % SLOWER -- a 108-byte row shares its cache lines
+// with its neighbours in the list, which the four rows of a trip and the next trip fetch again)
+#define FZ_ROW_LOAD(p) (*(p))
 #define FZ_BLOCK 256
 
 // ---- tables ----------------------------------------------------------------------------------------------------------------
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
         for (int u = 0; u < U; ++u) {
             const int row = rr + u < nrows ? rr + u : lastrow;
 #pragma unroll
-            for (int d = 0; d < D; ++d) w[u][d] = A.rows_all[((int64_t)d * A.rows_total + R0 + row) * 27 + sc];
+            for (int d = 0; d < D; ++d) w[u][d] = FZ_ROW_LOAD(A.rows_all + ((int64_t)d * A.rows_total + R0 + row) * 27 + sc);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
