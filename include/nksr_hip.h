@@ -84,7 +84,9 @@ int nksr_footprint_keys_dedup(const float* xyz, const int64_t* cell_keys, int64_
 int nksr_point_keys(const float* xyz, int64_t n, float inv_w0, int64_t* keys_out, void* stream);
 int nksr_decode_keys(const int64_t* keys, int64_t n, int level, int32_t* ijk_out, void* stream);
 int nksr_encode_keys(const int32_t* ijk, int64_t n, int level, int64_t* keys_out, void* stream);
-/* hkeys must be pre-filled with 0xFF bytes. */
+/* Open-addressing table Morton key -> value (the key's rank): hcap a power of two >= max(8, 2 n); hkeys must be pre-filled with 0xFF
+ * bytes.  The eight children of a cell (keys equal above their low three bits) share one 64-byte line of hkeys; a collision moves to
+ * another line (csrc/common.h: hash_slot / hash_next). */
 int nksr_hash_build(const int64_t* keys, int32_t n, int64_t* hkeys, int32_t* hvals, int32_t hcap, void* stream);
 int nksr_hash_query(const int64_t* q, int64_t nq, const int64_t* hkeys, const int32_t* hvals, int32_t hcap,
                     int32_t* idx_out, void* stream);

@@ -143,12 +143,14 @@ extern "C" int nksr_encode_keys(const int32_t* ijk, int64_t n, int level, int64_
     return NKSR_OK;
 }
 extern "C" int nksr_hash_build(const int64_t* keys, int32_t n, int64_t* hkeys, int32_t* hvals, int32_t hcap, void* stream) {
-    if (hcap <= 0 || (hcap & (hcap - 1)) || hcap < 2 * n) return nksr_set_error(NKSR_ERR_ARG, "hash capacity must be a power of two >= 2n");
+    // (>= 8: a line of the table holds the eight children of a cell, common.h hash_slot / hash_next)
+    if (hcap < 8 || (hcap & (hcap - 1)) || hcap < 2 * n) return nksr_set_error(NKSR_ERR_ARG, "hash capacity must be a power of two >= max(8, 2n)");
     LAUNCH1D(k_hash_build, n, stream, keys, n, hkeys, hvals, hcap);
     return NKSR_OK;
 }
 extern "C" int nksr_hash_query(const int64_t* q, int64_t nq, const int64_t* hkeys, const int32_t* hvals, int32_t hcap,
                                int32_t* idx_out, void* stream) {
+    if (nq > 0 && (hcap < 8 || (hcap & (hcap - 1)))) return nksr_set_error(NKSR_ERR_ARG, "hash capacity must be a power of two >= 8");
     LAUNCH1D(k_hash_query, nq, stream, q, nq, hkeys, hvals, hcap, idx_out);
     return NKSR_OK;
 }

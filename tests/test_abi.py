@@ -127,6 +127,8 @@ def test_c_abi_argument_errors_without_a_gpu():
     op = _lib.FusedOpT()
     op.depth, op.M = 4, 10
     assert lib.nksr_fused_apply(C.byref(op), C.c_float(1.0), null, null, null) != 0 and 'NULL' in err()
+    assert lib.nksr_hash_build(null, C.c_int32(2), null, null, C.c_int32(4), null) != 0 and 'power of two' in err()
+    assert lib.nksr_hash_query(null, C.c_int64(2), null, null, C.c_int32(12), null, null) != 0 and 'power of two' in err()
     # round-2 entry points: argument errors are reported before anything is launched
     hh = _lib.HierT()
     hh.depth = 4
