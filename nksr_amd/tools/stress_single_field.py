@@ -35,7 +35,7 @@ def main():
     on = fld.evaluate_f(xyz[:: max(1, n // 200_000)].contiguous()).value.abs()
     print('N=%d M=%d stored entries of G,Q=%d iters=%d rel=%.2e alpha finite=%s  %.1f ms (%.1f M points/s)  V=%d F=%d open edges=%d non-manifold=%d  '
           'mean |f| at the input points=%.3e  peak mem %.1f GB' % (
-              n, info['M'], info.get('nnz', -1), info['iters'], info['rel_residual'], bool(torch.isfinite(fld.alpha).all()), dt * 1e3, n / dt / 1e6,
+              n, info['M'], fld.stored_entries() or 0, info['iters'], info['rel_residual'], bool(torch.isfinite(fld.alpha).all()), dt * 1e3, n / dt / 1e6,
               V, f.shape[0], int((cnt == 1).sum()), int((cnt > 2).sum()), float(on.mean()), torch.cuda.max_memory_allocated() / 1e9))
 
 
