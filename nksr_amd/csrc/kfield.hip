@@ -108,7 +108,8 @@ __device__ __forceinline__ int nbr_of(const nksr_level_t& lv, int level, const S
                      morton_biased(sc.I[0] + s / 9 - 1, sc.I[1] + (s / 3) % 3 - 1, sc.I[2] + s % 3 - 1, NKSR_BIAS0 >> level));
 }
 
-__device__ __forceinline__ SiteCell locate_site(const nksr_level_t& lv, int level, float inv_w0, const float x[3]) {
+// the containing cell's integer coordinates, half bits and local coordinates (no table look-up)
+__device__ __forceinline__ SiteCell site_geometry(int level, float inv_w0, const float x[3]) {
     SiteCell sc;
     float scale = __int_as_float((127 - level) << 23);  // 2^-level
 #pragma unroll
@@ -119,8 +120,26 @@ __device__ __forceinline__ SiteCell locate_site(const nksr_level_t& lv, int leve
         sc.hb[a] = Hd & 1;
         sc.u[a] = p * scale - (float)sc.I[a];
     }
+    sc.cell = -1;
+    return sc;
+}
+__device__ __forceinline__ SiteCell locate_site(const nksr_level_t& lv, int level, float inv_w0, const float x[3]) {
+    SiteCell sc = site_geometry(level, inv_w0, x);
     sc.cell = hash_find(lv.hkeys, lv.hvals, lv.hcap, morton_biased(sc.I[0], sc.I[1], sc.I[2], NKSR_BIAS0 >> level));
     return sc;
+}
+// hash_find whose FIRST probe (key and value of the home slot) was fetched by the caller: k0 / v0
+__device__ __forceinline__ int hash_find_after(const int64_t* __restrict__ hkeys, const int32_t* __restrict__ hvals, int hcap, int64_t key,
+                                               uint32_t slot, int64_t k0, int v0) {
+    if (k0 == key) return v0;
+    if (k0 == -1) return -1;
+    for (int probe = 1; probe < hcap; ++probe) {
+        slot = hash_next(slot, probe, hcap);
+        const int64_t k = hkeys[slot];
+        if (k == key) return hvals[slot];
+        if (k == -1) return -1;
+    }
+    return -1;
 }
 
 // trilinear interpolation of the level's basis features (+ spatial tangents in world units)
@@ -279,10 +298,35 @@ __global__ void __launch_bounds__(128) k_evaluate_f(nksr_hier_t hier, const floa
     if (i >= n) return;
     float x[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
     float f = 0.f, gr[3] = {0.f, 0.f, 0.f};
-    for (int d = 0; d < L; ++d) {
+    // the containing cell at EVERY level first: the home-slot probes of all levels go out together (one round trip instead of one per
+    // level at the head of each level's chain  cell -> neighbour row -> features / psi)
+    int cellv[NKSR_MAX_DEPTH];
+    {
+        int64_t key[NKSR_MAX_DEPTH], k0[NKSR_MAX_DEPTH];
+        uint32_t slot[NKSR_MAX_DEPTH];
+        int v0[NKSR_MAX_DEPTH];
+#pragma unroll
+        for (int d = 0; d < NKSR_MAX_DEPTH; ++d) {
+            key[d] = 0; k0[d] = -1; slot[d] = 0; v0[d] = -1;
+            if (d < L && hier.lv[d].n > 0) {               // uniform
+                const SiteCell g = site_geometry(d, hier.inv_w0, x);
+                key[d] = morton_biased(g.I[0], g.I[1], g.I[2], NKSR_BIAS0 >> d);
+                slot[d] = hash_slot(key[d], hier.lv[d].hcap);
+                k0[d] = hier.lv[d].hkeys[slot[d]];
+                v0[d] = hier.lv[d].hvals[slot[d]];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < NKSR_MAX_DEPTH; ++d)
+            cellv[d] = (d < L && hier.lv[d].n > 0) ? hash_find_after(hier.lv[d].hkeys, hier.lv[d].hvals, hier.lv[d].hcap, key[d], slot[d], k0[d], v0[d]) : -1;
+    }
+#pragma unroll
+    for (int d = 0; d < NKSR_MAX_DEPTH; ++d) {
+        if (d >= L) break;
         const nksr_level_t& lv = hier.lv[d];
         if (lv.n == 0) continue;
-        SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
+        SiteCell sc = site_geometry(d, hier.inv_w0, x);
+        sc.cell = cellv[d];
         if (active_only && sc.cell < 0) continue;      // the support of the kernel ROWS (training path: forward = what backward differentiates)
         float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
         float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
