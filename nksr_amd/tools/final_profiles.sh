@@ -9,5 +9,5 @@ timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_
 KSTATS_TOP=6 timeout 300 bash nksr_amd/tools/kstats.sh ${tag}_fused --no-scale-scene --no-other-mode > /dev/null
 KSTATS_TOP=6 timeout 300 bash nksr_amd/tools/kstats.sh ${tag}_csr --non-fused --no-scale-scene --no-other-mode > /dev/null
 KSTATS_TAIL_MS=${SCENE_TAIL_MS:-420} KGAPS_TAIL_MS=${SCENE_TAIL_MS:-420} KSTATS_TOP=6 timeout 300 bash nksr_amd/tools/kstats.sh ${tag}_scene --scene terrain --steps 2 > /dev/null
-timeout 400 python -m nksr_amd.tools.scene_pmc gpurun_out/${tag}_scene_pmc.json > gpurun_out/${tag}_scene_pmc.txt 2>&1
+timeout 400 python -m nksr_amd.tools.scene_pmc gpurun_out/${tag}_scene_fused_pmc.json > gpurun_out/${tag}_scene_fused_pmc.txt 2>&1
 ls -la gpurun_out | grep ${tag}_

@@ -16,10 +16,12 @@ GROUPS = [
     ['SQ_ACTIVE_INST_VALU', 'SQ_ACTIVE_INST_VMEM', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_INSTS_MFMA', 'SQ_INST_LEVEL_VMEM', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS',
      'GRBM_GUI_ACTIVE'],
     ['FETCH_SIZE'],
+    ['WRITE_SIZE'],
     ['TCC_HIT_sum', 'TCC_MISS_sum'],
     ['TCP_TOTAL_CACHE_ACCESSES_sum', 'TCP_TCC_READ_REQ_sum', 'TCP_PENDING_STALL_CYCLES_sum', 'TA_TA_BUSY_sum'],
     ['TA_ADDR_STALLED_BY_TC_CYCLES_sum', 'TA_DATA_STALLED_BY_TC_CYCLES_sum', 'TCP_TCP_TA_DATA_STALL_CYCLES_sum', 'TD_TD_BUSY_sum'],
 ]
+LAST_BENCH_LINE = None
 KERNELS = ['k_cell_blocks', 'k_fz_sweep', 'k_cheb16_step', 'k_kernel_rows', 'k_sparse_conv3', 'k_splat_mean32', 'k_splat_trilinear',
            'k_fz_gather', 'k_fz_cellsum', 'k_evaluate_f', 'k_build_nbr', 'k_row_count', 'k_row_fill']
 
@@ -36,6 +38,10 @@ def run_pass(counters, flags, tag):
     root = os.environ.get('GRAFT_REPO_ROOT', os.getcwd())
     cmd = ['rocprofv3', '--pmc'] + counters + ['--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(root, 'bench.py')] + flags
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, cwd='/tmp')
+    global LAST_BENCH_LINE
+    for line in r.stdout.splitlines():
+        if line.startswith('{'):
+            LAST_BENCH_LINE = line
     dur = {}
     for f in glob.glob(out + '/**/*kernel_trace.csv', recursive=True):
         for row in csv.DictReader(open(f)):
@@ -72,12 +78,27 @@ def main():
         if 'FETCH_SIZE' in e:
             e['fetch_bytes'] = 2.0 * 1024.0 * e['FETCH_SIZE']
             e['fetch_TBps'] = e['fetch_bytes'] / e.get('us_pass2', 1e9) / 1e6
+        if 'WRITE_SIZE' in e:
+            e['write_bytes'] = 1024.0 * e['WRITE_SIZE']
         if e.get('SQ_WAVE_CYCLES'):
             for c in ('SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY'):
                 if c in e:
                     e[c + '_frac'] = e[c] / e['SQ_WAVE_CYCLES']
         if e.get('TCC_HIT_sum') is not None and e.get('TCC_MISS_sum') is not None and e['TCC_HIT_sum'] + e['TCC_MISS_sum'] > 0:
             e['l2_hit'] = e['TCC_HIT_sum'] / (e['TCC_HIT_sum'] + e['TCC_MISS_sum'])
+    # the operator application with every chunk still iterating = the longest dispatch of each of its three kernels
+    op = [k for k in rec['kernels'] if k.startswith(('k_fz_sweep<0', 'k_fz_cellsum<true', 'k_fz_gather<0'))]
+    if len(op) == 3 and all('fetch_bytes' in rec['kernels'][k] and 'write_bytes' in rec['kernels'][k] for k in op):
+        rec['operator_application'] = {k: {'fetch_bytes': rec['kernels'][k]['fetch_bytes'], 'write_bytes': rec['kernels'][k]['write_bytes'],
+                                           'us': rec['kernels'][k].get('us_pass2')} for k in op}
+        rec['hbm_bytes_per_application'] = sum(rec['kernels'][k]['fetch_bytes'] + rec['kernels'][k]['write_bytes'] for k in op)
+        if LAST_BENCH_LINE:
+            try:
+                rec['physical_bytes_per_application'] = json.loads(LAST_BENCH_LINE)['roofline']['physical_bytes_per_launch']
+                rec['algorithmic_bytes_per_application'] = json.loads(LAST_BENCH_LINE)['roofline']['bytes_per_launch']
+            except Exception:
+                pass
+        rec['correction'] = 'KiB units; gfx950 FETCH_SIZE counts the 128-B requests of a coalesced stream at 64 B: doubled; WRITE_SIZE uncorrected'
     json.dump(rec, open(out, 'w'), indent=1, sort_keys=True)
     for k in sorted(rec['kernels'], key=lambda k: -rec['kernels'][k].get('us_pass0', 0)):
         e = rec['kernels'][k]
