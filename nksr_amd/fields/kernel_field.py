@@ -27,6 +27,8 @@ def pack_interpolator(interp):
     return interp.packed()
 
 
+PC_RATIO = 40.0          # Chebyshev interval [lambda_max / PC_RATIO, lambda_max] of the coarse block (100 until late round 3: 11.16 -> 10.9
+#                          PCG iterations per chunk of the 64-chunk scene at the same step count; 10..20 are worse again, 200 much worse)
 PC_DROP_TOL = 0.005        # packed coarse block: off-diagonal entries below this fraction of the (unit) diagonal are left out
 _DETAIL = os.environ.get('NKSR_TIMING_DETAIL', '') == '1'
 DETAIL_TIMES = {}
@@ -506,7 +508,7 @@ class KernelField(BaseField):
         coef = torch.empty(nseg * (1 + 2 * PC_MAX_STEPS), dtype=torch.float32, device=self.device)
         row_seg = segments.unknown_seg[off[c0]:].contiguous() if segments is not None else None
         pc = CoarsePrecondT()
-        pc.first, pc.n, pc.steps, pc.lambda_scale, pc.ratio = off[c0], n, int(cfg.get('steps', 8)), 1.1, float(cfg.get('ratio', 100.0))
+        pc.first, pc.n, pc.steps, pc.lambda_scale, pc.ratio = off[c0], n, int(cfg.get('steps', 8)), 1.1, float(cfg.get('ratio', PC_RATIO))
         pc.lambda_, pc.coef = ptr(lam), ptr(coef)
         nnz = int(cols.numel())
         info = {'first_level': c0, 'unknowns': n, 'nnz': nnz, 'steps': int(pc.steps), 'lambda': lam}
@@ -534,12 +536,13 @@ class KernelField(BaseField):
             call('nksr_coarse_pack', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), n, ptr(o2n), ptr(n2o), ptr(row_seg_new), ptr(seg_base), ptr(prow),
                  drop, ptr(packed), ptr(dis), stream())
             work = torch.empty(4 * n, dtype=torch.float32, device=self.device)
-            # twelve steps instead of eight: a packed step costs a third of a plain one (four rows per wavefront, half the bytes), and
-            # every PCG iteration saved is a sweep over all kernel rows (configs[4], one GPU: 12.8 -> 11.1 iterations per chunk)
-            # (small blocks are bound by the number of launches, not by bytes: they keep eight)
+            # ten steps instead of eight on large blocks: a packed step costs a third of a plain one (four rows per wavefront, half the
+            # bytes, no tails), and every PCG iteration saved is a sweep over all kernel rows (configs[4], one GPU, ratio 40:
+            # 8 / 10 / 12 steps -> 11.19 / 10.91 / 10.72 iterations per chunk, 390.7 / 392.5 / 395.7 ms per step: flat);
+            # small blocks are bound by the number of launches, not by bytes: they keep eight
             if 'steps' not in cfg and n >= 100000:
-                pc.steps = 12
-                info['steps'] = 12
+                pc.steps = 10
+                info['steps'] = 10
             pc.format, pc.row_seg, pc.work = 1, ptr(row_seg_new), ptr(work)
             pc.packed, pc.packed_rowptr, pc.dis, pc.old_of_new, pc.seg_base = ptr(packed), ptr(prow), ptr(dis), ptr(o2n), ptr(seg_base)
             call('nksr_coarse_lambda_max_packed', C.byref(pc), nseg, 8, ptr(work), ptr(lam), stream())
