@@ -604,9 +604,10 @@ def select_chunk_points(xyz, lo, grid, chunk_size, band, wanted):
     call('nksr_chunk_pair_fill', C.byref(G), 0, ptr(xyz), n, ptr(flag), ptr(offs), ptr(idx), ptr(cid), None, None, stream())
     cid = cid.long()
     if nchunk > 1:
-        ks, order = ops.sort_pairs(cid * max(n, 1) + idx, torch.arange(m, dtype=torch.int32, device=dev))
+        # the fill order is (point, chunk): a STABLE sort on the chunk bits alone gives (chunk, point) -- one radix pass over 6-8 bits
+        ks, order = ops.sort_pairs(cid, torch.arange(m, dtype=torch.int32, device=dev), end_bit=ops._bits(nchunk))
         order = order.long()
-        idx, cid = idx[order], cid[order]
+        idx, cid = idx[order], ks
     counts = torch.bincount(cid, minlength=nchunk).tolist()
     return idx, cid, counts
 
