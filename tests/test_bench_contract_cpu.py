@@ -65,3 +65,23 @@ def test_terrain_tiles_are_deterministic_and_exactly_sized():
     np.testing.assert_allclose(np.linalg.norm(na, axis=1), 1.0, atol=1e-5)
     c, _ = utils.terrain_tile((2, 6), 20000, 125.0, seed=0)
     assert not np.array_equal(a, c)
+
+
+def test_committed_pmc_records_feed_the_traffic_field():
+    """``roofline.traffic`` is taken from the committed rocprofv3 --pmc passes (static: the bench does not run counters) and only when
+    the pass was taken on the same system: the committed bench line names the files it used, they exist, and the loaders find them."""
+    import json
+    b = _bench()
+    line = json.loads(open(os.path.join(ROOT, 'profiles', 'r03_bench.json')).read().strip().splitlines()[-1])
+    recs = [('headline', line['roofline'], True), ('csr', line['spmv_csr_roofline'], False), ('scene', line['scale_scene']['roofline'], True)]
+    for name, r, fused in recs:
+        assert 0.0 < r['frac'] <= 1.0 and r['frac'] <= r['frac_physical'] * 1.3, name
+        assert r['traffic'] is not None and r['traffic_source'].startswith('static: profiles/'), name
+        src = os.path.join(ROOT, r['traffic_source'][len('static: '):])
+        assert os.path.exists(src), src
+        got, f = (b.load_traffic_fused(r['physical_bytes_per_launch']) if fused else b.load_traffic(r['bytes_per_launch']))
+        assert f is not None and abs(got - r['traffic']) <= 5e-3 * r['traffic'], name      # (the PMC file may be a later pass of the same command)
+        # the counters agree with the byte model the physical fraction is priced on: no hidden re-reads
+        model = r['physical_bytes_per_launch']
+        assert 0.85 * model <= r['traffic'] <= 1.20 * model, (name, r['traffic'], model)
+    assert line['scale_scene']['ms_per_step'] < 420.0 and line['n_gpus'] == 1 and line['config']['workload'].startswith('configs[2]')
