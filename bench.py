@@ -1,27 +1,33 @@
 #!/usr/bin/env python
 """Headline benchmark (driver contract):  python bench.py --gpus N --steps K --warmup W
 
-metric  : reconstructed points/sec (solve + mesh); CG SpMV HBM GB/s        (BASELINE.json)
-N = 1   : BASELINE.json configs[2] -- synthetic 1M-point oriented cloud, detail_level=1.0, reconstruct() +
-          extract_dual_mesh(mise_iter=1): the configuration the SpMV roofline is quoted on.  One "step" = one full pass
-          of the hot path over the resident cloud.  The line also carries
-            scale_scene  : configs[4] (below) on this one GPU, warm -- the N=1 point of the scaling curve
-            cpu_baseline : the reference's examples/recons_waymo_cpu.py call sequence on assets/bunny.ply on the host
-                           cores (oracle port, oracle/waymo_cpu.py), the GPU on the same input beside it, and a bounded
-                           crop of the configs[2] cloud through the oracle
-N > 1   : BASELINE.json configs[4] -- the north_star scaling scene: synthetic 10M-point km-scale terrain (8 x 8 tiles of
-          125 m, tree_depth=5), recons_by_chunk over 64 chunks, STRONG scaling: the same scene on 1/2/4/8 ranks.  Every
-          rank generates only the tiles of its own chunks and their neighbours (sharded input), solves its chunks with no
-          collective, exchanges chunk halos once (RCCL), meshes its cells; rank 0 gathers + stitches the mesh.
-roofline: the operator application inside the PCG loop.  achieved = ALGORITHMIC bytes per application (SURVEY.md section 8d:
-          assembled CSR 8 nnz + 12 M + 4; matrix-free 2 x 8 bytes per stored entry of G and Q + 12 M + 4) / average duration,
-          measured live with HIP events on the solve stream inside the timed region; ``achieved_physical`` counts the bytes
-          the layout really moves (packed columns / index-free rows read once).
+metric  : reconstructed points/sec (solve + mesh) at 1/2/4/8 MI355X; CG SpMV HBM GB/s        (BASELINE.json)
+workload: at EVERY N the top-level ``value`` is BASELINE.json configs[4] -- the north_star scaling scene: synthetic 10M-point
+          km-scale terrain (8 x 8 tiles of 125 m, tree_depth=5), recons_by_chunk over 64 chunks (examples/recons_by_chunk.py:26-29
+          semantics: every chunk solved independently, blended), reconstruct(chunk_size=) + extract_dual_mesh(mise_iter=1).  The
+          scene is the same at every N (STRONG scaling): with N ranks every rank generates only the tiles of its own chunks and
+          their neighbours (sharded input), solves its chunks with no collective, exchanges chunk halos once (RCCL), meshes its
+          cells; rank 0 gathers + stitches the mesh.  One "step" = one full pass of the hot path over the resident scene.
+launch  : ``python bench.py --gpus N`` spawns its N ranks itself (torch.distributed.run, 127.0.0.1 rendezvous, one process per GPU,
+          backend nccl = RCCL; NKSR_DIST_BACKEND=gloo lets the ranks share GPUs in tests) and fails loudly when fewer than N GPUs are
+          visible; under an external ``torch.distributed.run`` (RANK / WORLD_SIZE in the environment) it joins that group instead.
+roofline: the operator application inside the PCG loop of the timed region, measured live with HIP events on the solve stream.
+          achieved = ALGORITHMIC bytes per application / average duration; ``achieved_physical`` counts the
+          bytes the layout really moves.
+N = 1 adds the sub-records the scene does not cover:
+          cloud_1m          : configs[2] (synthetic 1M-point oriented cloud, detail_level=1.0, ONE field) with its operator roofline,
+                              and the same workload through the assembled solve -> ``spmv_csr_roofline`` (north_star's SpMV KPI:
+                              SURVEY.md section 8d, 8 nnz + 12 M + 4 bytes per launch, target 0.70 of 8 TB/s)
+          small_inputs      : configs[0] / configs[1] latencies on the GPU (10 000-point bunny scan sequence, 3 000-point ShapeNet recipe)
+          cpu_baseline      : the reference's examples/recons_waymo_cpu.py call sequence on assets/bunny.ply on the host cores
+                              (oracle port, oracle/waymo_cpu.py), the GPU on the same input beside it
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -37,39 +43,53 @@ sys.path.insert(0, ROOT)
 HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
 TILE = 125.0       # metres, configs[4]: 8 x 8 chunks of 125 m
 TILES = 8
+PROFILES_DIR = os.path.join(ROOT, 'profiles')
+
+
+# ---- committed PMC records -> roofline.traffic ----------------------------------------------------------------------------
+def kernel_source_hash(kind):
+    """Hash of the sources that define the roofline kernels (nksr_amd/build.py: kernel_hash) -- a committed PMC record is only
+    attached to a bench line when it was taken on the same kernel code."""
+    from nksr_amd import build
+    return build.kernel_hash(kind)
+
+
+def _load_pmc(suffix, match_key, value_key, bytes_per_launch, kind):
+    """(bytes, source file, note).  A record qualifies when it was taken on the same system (its byte model within 2 % of this
+    run's) AND on the same kernel sources (``kernel_source_hash``); the newest qualifying file wins.  A record of the same system
+    from OTHER kernel sources is refused: traffic stays null and the note says which file was stale."""
+    pdir = PROFILES_DIR
+    best, stale = (None, None), None
+    try:
+        want = kernel_source_hash(kind)
+    except Exception:
+        want = None
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if not f.endswith(suffix):
+                continue
+            try:
+                rec = json.load(open(os.path.join(pdir, f)))
+            except Exception:
+                continue
+            if abs(rec.get(match_key, 0) - bytes_per_launch) >= 0.02 * bytes_per_launch:
+                continue
+            if want is not None and rec.get('kernel_source_hash') != want:
+                stale = 'profiles/' + f
+                continue
+            best = (rec.get(value_key), 'profiles/' + f)
+    note = None if best[0] is not None or stale is None else 'refused %s: taken on other kernel sources' % stale
+    return best[0], best[1], note
 
 
 def load_traffic(bytes_per_launch):
-    """HBM bytes per SpMV launch from the committed rocprofv3 --pmc pass (profiles/*_spmv_pmc.json), used only when
-    that pass was taken on the same matrix as this run (same algorithmic bytes).  Returns (bytes, source file)."""
-    best = (None, None)
-    pdir = os.path.join(ROOT, 'profiles')
-    if os.path.isdir(pdir):
-        for f in sorted(os.listdir(pdir)):
-            if f.endswith('_spmv_pmc.json'):
-                try:
-                    rec = json.load(open(os.path.join(pdir, f)))
-                    if abs(rec.get('algorithmic_bytes_per_launch', 0) - bytes_per_launch) < 0.02 * bytes_per_launch:
-                        best = (rec.get('hbm_bytes_per_launch'), 'profiles/' + f)
-                except Exception:
-                    pass
-    return best
+    """HBM bytes per SpMV launch from the committed rocprofv3 --pmc pass (profiles/*_spmv_pmc.json)."""
+    return _load_pmc('_spmv_pmc.json', 'algorithmic_bytes_per_launch', 'hbm_bytes_per_launch', bytes_per_launch, 'spmv')
 
 
 def load_traffic_fused(bytes_per_launch):
     """Same for the matrix-free operator (profiles/*_fused_pmc.json, matched on the operator's physical bytes)."""
-    best = (None, None)
-    pdir = os.path.join(ROOT, 'profiles')
-    if os.path.isdir(pdir):
-        for f in sorted(os.listdir(pdir)):
-            if f.endswith('_fused_pmc.json'):
-                try:
-                    rec = json.load(open(os.path.join(pdir, f)))
-                    if abs(rec.get('physical_bytes_per_application', 0) - bytes_per_launch) < 0.02 * bytes_per_launch:
-                        best = (rec.get('hbm_bytes_per_application'), 'profiles/' + f)
-                except Exception:
-                    pass
-    return best
+    return _load_pmc('_fused_pmc.json', 'physical_bytes_per_application', 'hbm_bytes_per_application', bytes_per_launch, 'fused')
 
 
 def roofline_record(ms, launches, alg, phys, survey, fused=False):
@@ -83,21 +103,24 @@ def roofline_record(ms, launches, alg, phys, survey, fused=False):
     survey_formula_*  = the same launches priced by SURVEY.md section 8d's matrix-free formula (2 x 8 B per stored entry + 12 M + 4):
                         the operator holds no column indices and reads every row once, so this exceeds what it moves -- kept for
                         comparison with round 2's line, NOT a utilisation figure.
-    traffic           = HBM bytes per application from the committed rocprofv3 --pmc pass of the same system (static: not measured in
-                        this run; ``traffic_source`` names the file)."""
+    traffic           = HBM bytes per application from the committed rocprofv3 --pmc pass of the same system AND the same kernel
+                        sources (static: counters are not collected in this run; ``traffic_source`` names the file, ``traffic_note``
+                        says when a stale record was refused)."""
     avg_s = (ms / max(launches, 1)) * 1e-3
     a = alg / max(launches, 1)
     p = phys / max(launches, 1)
     sv = survey / max(launches, 1)
     rate = lambda b: (b / avg_s if avg_s > 0 else 0.0)
-    traffic, src = ((load_traffic_fused(p) if fused else load_traffic(a)) if launches else (None, None))
+    traffic, src, note = ((load_traffic_fused(p) if fused else load_traffic(a)) if launches else (None, None, None))
     rec = {'bound': 'hbm',
-           'kernel': ('k_fz_sweep + k_fz_cellsum + k_fz_gather (matrix-free normal-equation operator inside the PCG loop, fused_mode=True)' if fused else
+           'kernel': ('k_fz_sweep + k_fz_gather (+ k_fz_cellsum) (matrix-free normal-equation operator inside the PCG loop, fused_mode=True)' if fused else
                       'k_spmv<3,0> + k_spmv_fixup (packed-column CSR SpMV inside the PCG loop, fused_mode=False)'),
            'achieved': rate(a) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(a) / HBM_PEAK,
            'achieved_physical': rate(p) / 1e9, 'frac_physical': rate(p) / HBM_PEAK,
            'traffic': traffic, 'traffic_source': ('static: ' + src) if traffic is not None else None,
            'bytes_per_launch': a, 'physical_bytes_per_launch': p, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
+    if note:
+        rec['traffic_note'] = note
     if fused:
         rec['survey_formula_bytes_per_launch'] = sv
         rec['survey_formula_frac'] = rate(sv) / HBM_PEAK
@@ -136,13 +159,41 @@ def terrain_setup(rec, dev, n_total, rank, world):
     return xyz, nrm, scale, owner, bounds, n_scene, len(need)
 
 
+# ---- launch: one process per GPU ----------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv, probe=False):
+    """``python bench.py --gpus N`` without a process group: re-exec through torch.distributed.run, one rank per GPU.  Returns the
+    exit code.  RCCL needs one device per rank: fewer than N visible GPUs is an error, not a silent 1-GPU run."""
+    backend = os.environ.get('NKSR_DIST_BACKEND', 'nccl')
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if backend != 'gloo' and have < n:
+        print('bench.py: --gpus %d needs %d visible MI355X devices for RCCL (one process per GPU); torch sees %d.  Nothing was run.  '
+              '(NKSR_DIST_BACKEND=gloo lets the ranks share devices: a protocol test, not a measurement.)' % (n, n, have), file=sys.stderr)
+        return 2
+    if have < 1 and not (probe and backend == 'gloo'):
+        print('bench.py: no GPU visible to PyTorch-ROCm', file=sys.stderr)
+        return 2
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, NKSR_BENCH_SPAWNED='1')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--points', type=int, default=1_000_000, help='configs[2] cloud size (N=1 headline)')
-    ap.add_argument('--scene-points', type=int, default=10_000_000, help='configs[4] scene size')
+    ap.add_argument('--points', type=int, default=1_000_000, help='configs[2] cloud size (cloud_1m sub-record)')
+    ap.add_argument('--scene-points', type=int, default=10_000_000, help='configs[4] scene size (the headline)')
     ap.add_argument('--mise-iter', type=int, default=1)
     ap.add_argument('--detail-level', type=float, default=1.0)
     ap.add_argument('--cpu-sample', type=int, default=10000, help='points of the configs[2] crop every CPU worker solves')
@@ -150,28 +201,48 @@ def main():
     ap.add_argument('--cpu-repeats', type=int, default=4)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--chunk-batch-points', type=int, default=0, help='chunk mode: points per batched solve (0 = the Reconstructor default, all chunks of a rank in one batch up to 2^25 points)')
-    ap.add_argument('--no-scale-scene', action='store_true')
-    ap.add_argument('--no-other-mode', action='store_true')
-    ap.add_argument('--non-fused', action='store_true', help='configs[2] headline through the assembled CSR solve (fused_mode=False)')
-    ap.add_argument('--scene', choices=['auto', 'cloud', 'terrain'], default='auto',
-                    help="'terrain' runs configs[4] as the headline at N=1 too")
+    ap.add_argument('--no-cloud', action='store_true', help='skip the configs[2] sub-record (and with it spmv_csr_roofline)')
+    ap.add_argument('--no-other-mode', action='store_true', help='skip the assembled-solve leg of the configs[2] sub-record')
+    ap.add_argument('--no-small-inputs', action='store_true')
+    ap.add_argument('--cloud-steps', type=int, default=3)
+    ap.add_argument('--dist-probe', action='store_true', help='launch check only: start the N ranks, run the handshake collectives over the '
+                                                              'backend, print the ``dist`` record and exit (no reconstruction)')
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        print('bench.py: --gpus must be >= 1', file=sys.stderr)
+        return 2
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:], probe=args.dist_probe)
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        print('bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE): they must agree' % (args.gpus, world), file=sys.stderr)
+        return 2
     dist = None
-    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    backend = os.environ.get('NKSR_DIST_BACKEND', 'nccl')
+    ndev = max(torch.cuda.device_count(), 1)
+    if args.dist_probe:
+        return dist_probe(rank, local_rank, world, backend)
+    if world > 1 and backend != 'gloo' and ndev < world:
+        print('bench.py: %d ranks but %d visible GPUs: RCCL needs one device per rank' % (world, ndev), file=sys.stderr)
+        return 2
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)            # before the process group: RCCL binds to the current device
     dev = torch.device('cuda', local_rank)
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # backend "nccl" is RCCL on ROCm; NKSR_DIST_BACKEND=gloo lets two ranks share one GPU in tests
-        dist.init_process_group(os.environ.get('NKSR_DIST_BACKEND', 'nccl'), rank=rank, world_size=world)
-        # create the communicator (RCCL ring / peer mappings) now, outside every timed region
-        warm = torch.zeros(1, device=dev if dist.get_backend() != 'gloo' else 'cpu')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        # create the communicator (RCCL ring / peer mappings) now, outside every timed region; the sum of ones over the backend
+        # is the number of ranks that really took part
+        warm = torch.ones(1, device=dev if dist.get_backend() != 'gloo' else 'cpu')
         dist.all_reduce(warm)
+        ranks_seen = int(round(float(warm.item())))
         dist.all_gather([torch.zeros_like(warm) for _ in range(world)], warm)
 
     import nksr_amd
@@ -211,19 +282,20 @@ def main():
         dt = time.perf_counter() - t0
         ms1 = torch.cuda.memory_stats(dev)
         # hipMalloc / hipFree calls inside the timed region (0 in the steady state: the caching allocator serves every step from its pool)
-        stage_acc['device_allocs'] = float(ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)) * steps
-        stage_acc['device_frees'] = float(ms1.get('num_device_free', 0) - ms0.get('num_device_free', 0)) * steps
+        alloc = {'device_allocs_per_step': (ms1.get('num_device_alloc', 0) - ms0.get('num_device_alloc', 0)) / steps,
+                 'device_frees_per_step': (ms1.get('num_device_free', 0) - ms0.get('num_device_free', 0)) / steps,
+                 'reserved_GB': ms1.get('reserved_bytes.all.current', 0) / 1e9, 'peak_allocated_GB': ms1.get('allocated_bytes.all.peak', 0) / 1e9}
         ms, launches = solver.profile_spmv(False)
         alg, phys, survey = solver.profile_spmv_bytes()
         if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() != 'gloo' else 'cpu')
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, out, (ms, launches, alg, phys, survey)
+        return dt, out, (ms, launches, alg, phys, survey), alloc
 
-    def acc_stages(acc, rec, tm):
+    def acc_stages(acc, timing, extra):
         if acc is not None:
-            for k, v in list(rec.timing.items()) + [('t_mesh', tm)]:
+            for k, v in list(timing.items()) + list(extra.items()):
                 acc[k] = acc.get(k, 0.0) + v
 
     # ---- configs[4]: strong-scaling scene ----------------------------------------------------------------------------
@@ -241,14 +313,14 @@ def main():
             t0 = time.perf_counter()
             mesh = field.extract_dual_mesh(mise_iter=args.mise_iter)
             torch.cuda.synchronize()
-            acc_stages(acc, rec, time.perf_counter() - t0)
+            acc_stages(acc, rec.timing, {'t_mesh': time.perf_counter() - t0, 't_gather': getattr(field, 'last_gather_s', 0.0)})
             return field, mesh
 
         acc = {}
-        dt, (field, mesh), prof = timed_loop(step, steps, warmup, acc)
+        dt, (field, mesh), prof, alloc = timed_loop(step, steps, warmup, acc)
         infos = field.chunk_infos()
         cfg = {'workload': 'configs[4]: synthetic %d-point km-scale terrain + boxes (8x8 tiles of 125 m), tree_depth=5, chunk_size=125 m '
-                           '(64 chunks), reconstruct(chunk_size=)+extract_dual_mesh(mise_iter=%d), STRONG scaling' % (n_scene, args.mise_iter),
+                           '(64 chunks), reconstruct(chunk_size=)+extract_dual_mesh(mise_iter=%d), the same scene at every N (strong scaling)' % (n_scene, args.mise_iter),
                'scene_points': n_scene, 'fused_mode': fused, 'tree_depth': 5, 'kernel_dim': rec.hparams.kernel_dim, 'global_scale': scale,
                'chunks': TILES * TILES, 'batched_solves_this_rank': len([p for p in field.parts if p.solved]), 'chunks_this_rank': sum(1 for c in owner if c == rank), 'tiles_loaded_this_rank': ntiles,
                'points_resident_this_rank': int(xyz.shape[0]),
@@ -262,9 +334,9 @@ def main():
         from nksr_amd.fields import kernel_field as _kf
         if _kf.DETAIL_TIMES:
             cfg['detail_ms_total'] = {k: round(v * 1e3, 1) for k, v in sorted(_kf.DETAIL_TIMES.items()) if k != '_'}
-        return dt, n_scene, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}
+        return dt, n_scene, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}, alloc
 
-    # ---- configs[2]: the roofline workload ---------------------------------------------------------------------------
+    # ---- configs[2]: the single-field roofline workload -----------------------------------------------------------------
     def run_cloud(steps, warmup, fused):
         rec = nksr_amd.Reconstructor(dev)
         rec.sync_timing = True
@@ -276,89 +348,165 @@ def main():
             t0 = time.perf_counter()
             mesh = field.extract_dual_mesh(mise_iter=args.mise_iter)
             torch.cuda.synchronize()
-            acc_stages(acc, rec, time.perf_counter() - t0)
+            acc_stages(acc, rec.timing, {'t_mesh': time.perf_counter() - t0})
             return field, mesh
 
         acc = {}
-        dt, (field, mesh), prof = timed_loop(step, steps, warmup, acc)
+        dt, (field, mesh), prof, alloc = timed_loop(step, steps, warmup, acc)
         info = field.solve_info
         cfg = {'workload': 'configs[2]: synthetic %d-point oriented cloud (8 spheres/tori in a 40x40x10 box, sigma=0.01), '
                            'detail_level=%.1f, reconstruct()+extract_dual_mesh(mise_iter=%d)' % (args.points, args.detail_level, args.mise_iter),
                'points': args.points, 'fused_mode': fused, 'tree_depth': rec.hparams.tree_depth, 'kernel_dim': rec.hparams.kernel_dim,
                'unknowns_M': info['M'], 'nnz_A': info['nnz'], 'kernel_row_slots': info.get('kernel_row_slots'),
                'stored_entries_G_Q': field.stored_entries() if fused else None, 'pcg_iters': info['iters'], 'pcg_rel_residual': info['rel_residual'],
-               'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]), 'global_scale': field.scale,
-               'parallelism': 'none'}
-        return dt, args.points, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}, (rec, xyz_np, nrm_np, field.scale)
+               'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]), 'global_scale': field.scale}
+        return dt, args.points, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}, alloc, (rec, xyz_np, nrm_np, field.scale)
 
-    terrain_headline = world > 1 or args.scene == 'terrain'
-    extra = None
-    # Both workloads run through the API default, fused_mode=True (what the reference's examples pass): the matrix-free solve
-    # skips the assembly and its operator (one pass over the index-free kernel rows) is about as fast per application as the CSR
-    # SpMV; the other mode is measured and reported next to each (DESIGN.md section 3.5 has the cost model).
-    fused = (not args.non_fused) if not terrain_headline else True      # chunk mode = the batched matrix-free solve
-    if terrain_headline:
-        dt, npts, cfg, prof, stages = run_terrain(args.steps, args.warmup, fused)
-    else:
-        dt, npts, cfg, prof, stages, extra = run_cloud(args.steps, args.warmup, fused)
+    # The headline runs through the API default, fused_mode=True (what the reference's examples pass): chunk mode = the batched
+    # matrix-free solve.
+    dt, npts, cfg, prof, stages, alloc = run_terrain(args.steps, args.warmup, True)
     out = {
         'metric': 'reconstructed points/sec (solve+mesh)', 'value': npts * args.steps / dt, 'unit': 'points/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'strong' if terrain_headline else 'weak', 'vs_baseline': None, 'dtype': 'f32',
-        'data': 'synthetic', 'config': cfg, 'roofline': roofline_record(*prof, fused=fused), 'stages_s_per_step': stages,
+        'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic', 'config': cfg, 'roofline': roofline_record(*prof, fused=True), 'stages_s_per_step': stages, 'allocator': alloc,
+        'dist': {'backend': (dist.get_backend() if dist is not None else None), 'world_size': world, 'rccl_ranks_seen': ranks_seen,
+                 'launcher': 'bench.py self-spawn (torch.distributed.run)' if os.environ.get('NKSR_BENCH_SPAWNED') else ('external' if world > 1 else 'single process')},
     }
-    if not terrain_headline and not args.no_other_mode:
-        # the same workload through the other solve: assembled CSR + streaming SpMV (solve_non_fused, the path training needs)
-        odt, _, ocfg, oprof, ostages, _ = run_cloud(2, 1, not fused)
-        out['other_solve_mode'] = {'fused_mode': not fused, 'value': npts * 2 / odt, 'unit': 'points/s', 'ms_per_step': odt / 2 * 1e3, 'steps': 2,
-                                   'warmup': 1, 'unknowns_M': ocfg['unknowns_M'], 'nnz_A': ocfg['nnz_A'], 'pcg_iters': ocfg['pcg_iters'],
-                                   'roofline': roofline_record(*oprof, fused=not fused), 'stages_s_per_step': ostages}
-        # north_star's KPI, in every line: the CSR SpMV roofline (target 0.70 of 8 TB/s), whichever solve the headline ran
-        out['spmv_csr_roofline'] = out['other_solve_mode']['roofline'] if fused else out['roofline']
-    if not terrain_headline and not args.no_scale_scene:
-        # the same scene the N > 1 runs solve, on this one GPU (1 warm-up + 2 timed steps): the N=1 point of the curve
+    if dist is not None:
+        # per-rank stage times (seconds per step): what every rank spent where, incl. the halo exchange and the mesh gather
+        mine = {'rank': rank, 'chunks': cfg['chunks_this_rank'], 'points_resident': cfg['points_resident_this_rank']}
+        mine.update({k: round(v, 5) for k, v in stages.items()})
+        per = [None] * world
+        dist.all_gather_object(per, mine)
+        out['dist']['per_rank'] = per
+    if world == 1 and not args.no_cloud:
         torch.cuda.empty_cache()
-        sdt, sn, scfg, sprof, sstages = run_terrain(2, 1, True)
-        out['scale_scene'] = {'value': sn * 2 / sdt, 'unit': 'points/s', 'ms_per_step': sdt / 2 * 1e3, 'steps': 2, 'warmup': 1,
-                              'config': scfg, 'roofline': roofline_record(*sprof, fused=True), 'stages_s_per_step': sstages}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and extra is not None:
-        from oracle import waymo_cpu
+        cdt, cn, ccfg, cprof, cstages, calloc, extra = run_cloud(args.cloud_steps, 1, True)
+        cloud = {'value': cn * args.cloud_steps / cdt, 'unit': 'points/s', 'ms_per_step': cdt / args.cloud_steps * 1e3, 'steps': args.cloud_steps, 'warmup': 1,
+                 'config': ccfg, 'roofline': roofline_record(*cprof, fused=True), 'stages_s_per_step': cstages, 'allocator': calloc}
+        if not args.no_other_mode:
+            # the same workload through the other solve: assembled CSR + streaming SpMV (solve_non_fused, the path training needs)
+            odt, _, ocfg, oprof, ostages, oalloc, _ = run_cloud(2, 1, False)
+            cloud['other_solve_mode'] = {'fused_mode': False, 'value': cn * 2 / odt, 'unit': 'points/s', 'ms_per_step': odt / 2 * 1e3, 'steps': 2,
+                                         'warmup': 1, 'unknowns_M': ocfg['unknowns_M'], 'nnz_A': ocfg['nnz_A'], 'pcg_iters': ocfg['pcg_iters'],
+                                         'roofline': roofline_record(*oprof, fused=False), 'stages_s_per_step': ostages, 'allocator': oalloc}
+            # north_star's KPI at the top level of every N = 1 line: the CSR SpMV roofline (target 0.70 of 8 TB/s)
+            out['spmv_csr_roofline'] = cloud['other_solve_mode']['roofline']
+        out['cloud_1m'] = cloud
+    else:
+        extra = None
+    if world == 1 and not args.no_small_inputs:
+        out['small_inputs'] = small_inputs(dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(dev, args, extra)
+    elif rank == 0:
+        out['cpu_baseline'] = None
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+def dist_probe(rank, local_rank, world, backend):
+    """The launch path without the workload: every rank joins the group, the handshake collectives of the real run go over the
+    backend (all_reduce of ones = ranks seen, all_gather, a point-to-point ring), rank 0 prints the record."""
+    import torch.distributed as dist
+    on_gpu = backend != 'gloo' and torch.cuda.is_available()
+    if on_gpu:
+        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    dev = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
+    rec = {'dist_probe': True, 'n_gpus': world, 'backend': backend, 'rccl_ranks_seen': 1, 'launcher': 'bench.py self-spawn (torch.distributed.run)' if os.environ.get('NKSR_BENCH_SPAWNED') else 'external'}
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        rec['rccl_ranks_seen'] = int(round(float(one.item())))
+        got = [torch.zeros(1, device=dev) for _ in range(world)]
+        dist.all_gather(got, torch.full((1,), float(rank), device=dev))
+        rec['all_gather_ranks'] = [int(g.item()) for g in got]
+        # point-to-point ring (the mesh gather's transport): rank r sends r to r + 1
+        recv = torch.full((1,), -1.0, device=dev)
+        ops = [dist.P2POp(dist.isend, torch.full((1,), float(rank), device=dev), (rank + 1) % world),
+               dist.P2POp(dist.irecv, recv, (rank - 1) % world)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        ok = torch.tensor([1.0 if int(recv.item()) == (rank - 1) % world else 0.0], device=dev)
+        dist.all_reduce(ok)
+        rec['p2p_ring_ok'] = int(round(float(ok.item()))) == world
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps(rec))
+        sys.stdout.flush()
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+def _latency(fn, repeats):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        r = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / repeats * 1e3, r
+
+
+def small_inputs(dev):
+    """configs[1] on the GPU: the ShapeNet-3K-noise recipe (3 000 points, sigma 0.005, preset snet-n3k-wnormal) end to end --
+    launch-latency bound, reported as a latency."""
+    import nksr_amd
+    from nksr_amd import utils
+    xyz, nrm = utils.synth_sphere(3000, 0.45, 0.005, 0)
+    x, n = torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev)
+    rec = nksr_amd.Reconstructor(dev, config='snet-n3k-wnormal')
+    st = {}
+
+    def seq():
+        f = rec.reconstruct(x, n, detail_level=None)
+        st['iters'] = f.solve_info['iters']
+        return f.extract_dual_mesh(mise_iter=1)
+    ms, m = _latency(seq, 10)
+    return {'configs1_shapenet_3k': {'ms': ms, 'points': 3000, 'pcg_iters': st['iters'], 'mesh_triangles': int(m.f.shape[0]),
+                                     'sample': 'sphere r=0.45, N=3000, sigma=0.005, preset snet-n3k-wnormal, reconstruct(detail_level=None)+extract_dual_mesh(mise_iter=1), mean of 10'}}
+
+
+def cpu_baseline(dev, args, extra):
+    import nksr_amd
+    from oracle import waymo_cpu
+    crop = None
+    if extra is not None:
         rec, xyz_np, nrm_np, scale = extra
         # bounded crop of the configs[2] cloud (model units), one per CPU worker
         c = xyz_np[0]
         idx = np.argsort(np.abs(xyz_np - c).max(1))[:args.cpu_sample]
         crop = os.path.join(tempfile.gettempdir(), 'nksr_bench_crop_%d.npz' % os.getpid())
         np.savez(crop, xyz=(xyz_np[idx] * np.float32(scale)).astype(np.float32), normal=nrm_np[idx], mise_iter=args.mise_iter)
-        try:
-            cb = waymo_cpu.measure(cores=args.cpu_cores or min(os.cpu_count() or 1, 64), repeats=args.cpu_repeats, crop=crop)
-        finally:
-            if os.path.exists(crop):
-                os.remove(crop)
-        # the GPU on the same input (same call sequence, sensor-only, through the product's preprocess_fn)
-        d = np.load(waymo_cpu.BUNNY)
-        bx = torch.from_numpy(d['xyz']).to(dev)
-        bs = torch.from_numpy(waymo_cpu.synth_sensors(d['xyz'], d['normal'])).to(dev)
-        fn = nksr_amd.get_estimate_normal_preprocess_fn(64, 85.0)
+    else:
+        rec = nksr_amd.Reconstructor(dev)
+    try:
+        cb = waymo_cpu.measure(cores=args.cpu_cores or min(os.cpu_count() or 1, 64), repeats=args.cpu_repeats, crop=crop)
+    finally:
+        if crop and os.path.exists(crop):
+            os.remove(crop)
+    # the GPU on the same input (same call sequence, sensor-only, through the product's preprocess_fn)
+    d = np.load(waymo_cpu.BUNNY)
+    bx = torch.from_numpy(d['xyz']).to(dev)
+    bs = torch.from_numpy(waymo_cpu.synth_sensors(d['xyz'], d['normal'])).to(dev)
+    fn = nksr_amd.get_estimate_normal_preprocess_fn(64, 85.0)
 
-        def gpu_seq():
-            f = rec.reconstruct(bx, sensor=bs, detail_level=None, approx_kernel_grad=True, solver_tol=1e-4, fused_mode=True, preprocess_fn=fn)
-            return f.extract_dual_mesh(mise_iter=1)
-        gpu_seq()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5):
-            m = gpu_seq()
-        torch.cuda.synchronize()
-        cb['gpu_same_input'] = {'value': 5 * bx.shape[0] / (time.perf_counter() - t0), 'unit': 'points/s', 'mesh_triangles': int(m.f.shape[0]),
-                                'note': 'one 10 000-point scan at a time on one MI355X: launch-latency bound, not a throughput figure'}
-        out['cpu_baseline'] = cb
-    elif rank == 0:
-        out['cpu_baseline'] = None
-    if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    def gpu_seq():
+        f = rec.reconstruct(bx, sensor=bs, detail_level=None, approx_kernel_grad=True, solver_tol=1e-4, fused_mode=True, preprocess_fn=fn)
+        return f.extract_dual_mesh(mise_iter=1)
+    ms, m = _latency(gpu_seq, 5)
+    cb['gpu_same_input'] = {'value': bx.shape[0] / (ms * 1e-3), 'unit': 'points/s', 'ms': ms, 'mesh_triangles': int(m.f.shape[0]),
+                            'note': 'one 10 000-point scan at a time on one MI355X: launch-latency bound, not a throughput figure'}
+    return cb
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -38,6 +38,21 @@ def source_hash():
     return h.hexdigest()
 
 
+KERNEL_SOURCES = {'fused': ['fused.hip', 'pcg_core.h', 'common.h'],      # k_fz_sweep / k_fz_gather / k_fz_cellsum
+                  'spmv': ['pcg.hip', 'pcg_core.h', 'common.h']}         # k_spmv / k_spmv_fixup
+
+
+def kernel_hash(kind):
+    """Hash of the sources (+ flags) that define one of the roofline kernels: the counter records under profiles/ carry it, and
+    bench.py attaches a record to a line only when it was taken on the same kernel code."""
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for f in KERNEL_SOURCES[kind]:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     """Stale when the library is missing or was built from other sources / flags.  Content hash, not mtimes: a
     snapshot copied to another box (gpurun) does not preserve them."""

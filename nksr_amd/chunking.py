@@ -560,7 +560,12 @@ class MultiChunkField(BaseField):
     def finalize_mesh(self, res):
         if self.world_size == 1 and not self.distributed:
             return res
+        import time
+        torch.cuda.current_stream().synchronize()
+        t0 = time.perf_counter()
         v, f = D.gather_meshes(res.v, res.f, res.edge_vkey, res.edge_axis)
+        torch.cuda.current_stream().synchronize()
+        self.last_gather_s = time.perf_counter() - t0      # mesh gather (point-to-point to rank 0) + seam merge
         res.v, res.f = v, f
         res.c = self.texture_field.evaluate_color(v) if self.texture_field is not None else None
         return res
@@ -767,6 +772,7 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
         parts.append(ChunkPart(fld, ids, frame))
     rec.timing = timing
     interps = rec.network.interpolators
+    t_x = _now(rec)
     if active:
         # the exchange carries the halo of every chunk (the voxels other ranks can touch), not the whole field; which
         # chunks were actually solved travels with it (a sparse chunk may have been skipped by its owner)
@@ -785,12 +791,20 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
             if remote.mask_field is None:
                 remote.set_mask_field(LayerField(remote.svh, hp.adaptive_depth))
             parts.append(ChunkPart(remote, sorted(need, key=lambda c: frame.key_range(c)[0]), frame, solved=False))
+        timing['t_exchange'] = _now(rec) - t_x          # halo exchange: pack, size + byte collectives, the remote field's tables
     else:
         for p in parts:
             if p.field.device != dev:
                 p.field.to_(dev)          # meshing runs on the GPU: bring the parked batches back
     return MultiChunkField(parts, cores, ov, lo, chunk_size, grid, owner, rank, ws, frame, interps, dev, distributed=active,
                            adaptive_depth=int(hp.adaptive_depth))
+
+
+def _now(rec):
+    import time
+    if getattr(rec, 'sync_timing', False):
+        torch.cuda.current_stream().synchronize()
+    return time.perf_counter()
 
 
 def needed_chunks(cores, margin, grid, owned, candidates):

@@ -38,6 +38,45 @@ def test_roofline_record_arithmetic_and_keys():
     assert z['achieved'] == 0.0 and z['traffic'] is None
 
 
+def _run_bench(args, env=None, timeout=300):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.pop('WORLD_SIZE', None)
+    e.pop('RANK', None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def test_gpus_n_without_n_devices_fails_loudly():
+    """``python bench.py --gpus N`` (the driver's command, no torchrun around it) must never degrade to a 1-GPU run: with fewer than
+    N visible devices it runs nothing, says why, and exits non-zero."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip('needs a box with fewer than 2 GPUs')
+    r = _run_bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], env={'NKSR_DIST_BACKEND': 'nccl'})
+    assert r.returncode == 2 and 'needs 2 visible' in r.stderr and 'Nothing was run' in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+    # a launcher that started another number of ranks than --gpus says is refused too
+    r = _run_bench(['--gpus', '4', '--dist-probe'], env={'WORLD_SIZE': '2', 'RANK': '0'})
+    assert r.returncode == 2 and 'must agree' in r.stderr
+
+
+def test_gpus_n_spawns_its_own_ranks():
+    """The self-spawn path end to end on CPU (gloo): ``--gpus 2 --dist-probe`` starts two ranks through torch.distributed.run on
+    127.0.0.1, the handshake collectives of the real run (all_reduce of ones = ranks seen, all_gather, a point-to-point ring) go
+    over the backend, rank 0 prints one record with n_gpus = 2."""
+    import json
+    r = _run_bench(['--gpus', '2', '--dist-probe'], env={'NKSR_DIST_BACKEND': 'gloo'})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_ranks_seen'] == 2 and d['all_gather_ranks'] == [0, 1] and d['p2p_ring_ok'] is True
+    assert 'self-spawn' in d['launcher'] and d['backend'] == 'gloo'
+
+
 def test_strong_scaling_partition_is_compact_and_balanced():
     from nksr_amd import dist as D
     for world in (1, 2, 4, 8):
@@ -67,21 +106,51 @@ def test_terrain_tiles_are_deterministic_and_exactly_sized():
     assert not np.array_equal(a, c)
 
 
-def test_committed_pmc_records_feed_the_traffic_field():
-    """``roofline.traffic`` is taken from the committed rocprofv3 --pmc passes (static: the bench does not run counters) and only when
-    the pass was taken on the same system: the committed bench line names the files it used, they exist, and the loaders find them."""
+def test_stale_pmc_records_are_refused(tmp_path):
+    """``roofline.traffic`` comes from a committed rocprofv3 --pmc record only when that record was taken on the same system (byte
+    model within 2 %) AND on the same kernel sources (nksr_amd/build.py: kernel_hash): a record from older kernels is refused,
+    traffic stays null and the line says which file was stale."""
     import json
+    from nksr_amd import build
     b = _bench()
-    line = json.loads(open(os.path.join(ROOT, 'profiles', 'r03_bench.json')).read().strip().splitlines()[-1])
-    recs = [('headline', line['roofline'], True), ('csr', line['spmv_csr_roofline'], False), ('scene', line['scale_scene']['roofline'], True)]
-    for name, r, fused in recs:
+    b.PROFILES_DIR = str(tmp_path)
+    phys = 2.58e9
+    json.dump({'physical_bytes_per_application': phys, 'hbm_bytes_per_application': 2.57e9, 'kernel_source_hash': 'deadbeef'},
+              open(os.path.join(str(tmp_path), 'r00_fused_pmc.json'), 'w'))
+    got, src, note = b.load_traffic_fused(phys)
+    assert got is None and src is None and 'r00_fused_pmc.json' in note and 'other kernel sources' in note
+    r = b.roofline_record(160 * 0.56, 160, 160 * 1.60e9, 160 * phys, 160 * 5.65e9, fused=True)
+    assert r['traffic'] is None and r['traffic_source'] is None and 'refused' in r['traffic_note']
+    json.dump({'physical_bytes_per_application': phys, 'hbm_bytes_per_application': 2.57e9, 'kernel_source_hash': build.kernel_hash('fused')},
+              open(os.path.join(str(tmp_path), 'r01_fused_pmc.json'), 'w'))
+    got, src, note = b.load_traffic_fused(phys)
+    assert got == 2.57e9 and src == 'profiles/r01_fused_pmc.json' and note is None
+    # another system (other byte model): not attached, nothing to refuse
+    assert b.load_traffic_fused(2.0 * phys) == (None, None, None)
+    assert build.kernel_hash('fused') != build.kernel_hash('spmv') and len(build.kernel_hash('spmv')) == 16
+
+
+def test_committed_bench_line_and_its_pmc_records():
+    """The round's committed bench line (profiles/r04_bench.json): configs[4] is the top-level workload at N = 1, the configs[2]
+    single-field workload and north_star's CSR SpMV KPI travel as sub-records, every roofline fraction is a fraction, and wherever
+    a line carries ``traffic`` the committed PMC record it names exists, carries a kernel source hash and agrees with the byte
+    model the physical fraction is priced on (no hidden re-reads)."""
+    import json
+    import pytest
+    path = os.path.join(ROOT, 'profiles', 'r04_bench.json')
+    if not os.path.exists(path):
+        pytest.skip('profiles/r04_bench.json is committed with the round\'s GPU run')
+    line = json.loads(open(path).read().strip().splitlines()[-1])
+    assert line['n_gpus'] == 1 and line['config']['workload'].startswith('configs[4]') and line['scaling'] == 'strong'
+    assert line['cloud_1m']['config']['workload'].startswith('configs[2]') and line['dist']['rccl_ranks_seen'] == 1
+    recs = [('scene', line['roofline']), ('cloud', line['cloud_1m']['roofline']), ('csr', line['spmv_csr_roofline'])]
+    for name, r in recs:
         assert 0.0 < r['frac'] <= 1.0 and r['frac'] <= r['frac_physical'] * 1.3, name
-        assert r['traffic'] is not None and r['traffic_source'].startswith('static: profiles/'), name
-        src = os.path.join(ROOT, r['traffic_source'][len('static: '):])
-        assert os.path.exists(src), src
-        got, f = (b.load_traffic_fused(r['physical_bytes_per_launch']) if fused else b.load_traffic(r['bytes_per_launch']))
-        assert f is not None and abs(got - r['traffic']) <= 5e-3 * r['traffic'], name      # (the PMC file may be a later pass of the same command)
-        # the counters agree with the byte model the physical fraction is priced on: no hidden re-reads
-        model = r['physical_bytes_per_launch']
-        assert 0.85 * model <= r['traffic'] <= 1.20 * model, (name, r['traffic'], model)
-    assert line['scale_scene']['ms_per_step'] < 420.0 and line['n_gpus'] == 1 and line['config']['workload'].startswith('configs[2]')
+        assert (r['traffic'] is None) == (r['traffic_source'] is None), name
+        if r['traffic'] is not None:
+            src = os.path.join(ROOT, r['traffic_source'][len('static: '):])
+            assert os.path.exists(src), src
+            assert len(json.load(open(src)).get('kernel_source_hash', '')) == 16, src
+            model = r['physical_bytes_per_launch']
+            assert 0.85 * model <= r['traffic'] <= 1.20 * model, (name, r['traffic'], model)
+    assert line['ms_per_step'] < 420.0 and 'device_allocs_per_step' in line['allocator']

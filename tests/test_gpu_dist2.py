@@ -131,3 +131,28 @@ def test_two_ranks_one_gpu_equal_one_rank():
     assert v1.shape == v2.shape and f1.shape == f2.shape
     np.testing.assert_array_equal(v1, v2)          # bit-identical vertex positions
     np.testing.assert_array_equal(f1, f2)          # index-exact topology
+
+
+def test_bench_gpus_2_spawns_two_ranks_on_one_gpu():
+    """The driver's command line, ``python bench.py --gpus 2`` with no launcher around it: bench.py starts its two ranks itself
+    (gloo here so that both can share cuda:0), runs the sharded configs[4] pipeline and prints ONE line with n_gpus = 2, the
+    ranks the backend saw and every rank's stage times incl. the halo exchange and the mesh gather."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NKSR_DIST_BACKEND='gloo')
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--scene-points', '640000'],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['dist']['rccl_ranks_seen'] == 2 and d['dist']['backend'] == 'gloo' and 'self-spawn' in d['dist']['launcher']
+    assert 'configs[4]' in d['config']['workload'] and d['config']['chunks_this_rank'] == 32 and d['scaling'] == 'strong'
+    per = d['dist']['per_rank']
+    assert [p['rank'] for p in per] == [0, 1] and all(p['chunks'] == 32 for p in per)
+    assert all(p['t_exchange'] > 0 and p['t_pcg'] > 0 and p['t_mesh'] > 0 for p in per) and per[0]['t_gather'] > 0
+    assert d['cpu_baseline'] is None and 'cloud_1m' not in d and d['value'] > 0

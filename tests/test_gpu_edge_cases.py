@@ -135,29 +135,33 @@ def test_bench_contract_line():
         assert k in d, k
     assert d['n_gpus'] == 1 and d['steps'] == 1 and d['higher_is_better'] is True and d['vs_baseline'] is None
     assert 'workload' in d['config'] and d['value'] > 0
-    assert 'configs[2]' in d['config']['workload'] and d['scaling'] == 'weak'
+    # configs[4] is the top-level workload at every N (the curve's N = 1 point), the same scene = strong scaling
+    assert 'configs[4]' in d['config']['workload'] and d['scaling'] == 'strong' and d['config']['chunks'] == 64 and d['config']['tree_depth'] == 5
+    assert d['dist']['world_size'] == 1 and d['dist']['rccl_ranks_seen'] == 1 and 'device_allocs_per_step' in d['allocator']
+    assert set(d['stages_s_per_step']) >= {'t_network', 't_assemble', 't_pcg', 't_mesh'}
     r = d['roofline']
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
     for k in ('traffic', 'traffic_source', 'bytes_per_launch', 'avg_launch_us', 'launches_timed', 'kernel'):
         assert k in r, k
-    assert (r['traffic'] is None) == (r['traffic_source'] is None)
+    assert (r['traffic'] is None) == (r['traffic_source'] is None) and r['launches_timed'] > 0
     # a roofline fraction is a fraction: algorithmic minimum <= what the layout moves <= what the HBM could stream
     assert d['config']['fused_mode'] is True and 'k_fz_sweep' in r['kernel'] and 0 < r['frac'] < r['frac_physical'] <= 1.0
+    c2 = d['cloud_1m']                 # configs[2]: one field, the operator roofline + the assembled solve's CSR SpMV roofline
+    assert 'configs[2]' in c2['config']['workload'] and c2['value'] > 0
+    rc = c2['roofline']
     # algorithmic minimum of the matrix-free operator: 4 B per stored entry of G and Q (counted on the device) + 4 B per row and
     # level (row -> cell) + 116 B per unknown (stencil, x, y); SURVEY.md section 8d's formula (16 B per stored entry) beside it
-    se, slots, M = d['config']['stored_entries_G_Q'], d['config']['kernel_row_slots'], d['config']['unknowns_M']
-    assert 0 < se <= slots and abs(r['bytes_per_launch'] - (4.0 * se + 4.0 * slots / 27 + 116.0 * M + 4)) < 1.0
-    assert abs(r['survey_formula_bytes_per_launch'] - (16.0 * se + 12.0 * M + 4)) < 1.0
+    se, slots, M = c2['config']['stored_entries_G_Q'], c2['config']['kernel_row_slots'], c2['config']['unknowns_M']
+    assert 0 < se <= slots and abs(rc['bytes_per_launch'] - (4.0 * se + 4.0 * slots / 27 + 116.0 * M + 4)) < 1.0
+    assert abs(rc['survey_formula_bytes_per_launch'] - (16.0 * se + 12.0 * M + 4)) < 1.0
     assert d['spmv_csr_roofline']['kernel'].startswith('k_spmv') and 0 < d['spmv_csr_roofline']['frac'] <= 1.0
-    o = d['other_solve_mode']          # the assembled CSR solve on the same workload, with the CSR SpMV roofline
+    o = c2['other_solve_mode']          # the assembled CSR solve on the same workload, with the CSR SpMV roofline
     assert o['fused_mode'] is False and o['value'] > 0 and 'k_spmv' in o['roofline']['kernel'] and o['nnz_A'] > 0
     assert 'achieved_physical' in o['roofline'] and o['roofline']['frac_physical'] <= o['roofline']['frac']
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['cores'] == 2 and c['value'] > 0 and 'recons_waymo_cpu.py' in c['sample']
-    assert c['gpu_same_input']['value'] > 0 and c['workload_crop']['value'] > 0
-    s = d['scale_scene']           # the N=1 point of the configs[4] strong-scaling curve
-    assert 'configs[4]' in s['config']['workload'] and s['value'] > 0 and s['config']['chunks'] == 64
-    assert s['config']['tree_depth'] == 5 and s['roofline']['launches_timed'] > 0
+    assert c['gpu_same_input']['value'] > 0 and c['gpu_same_input']['ms'] > 0 and c['workload_crop']['value'] > 0
+    assert d['small_inputs']['configs1_shapenet_3k']['ms'] > 0
 
 
 def test_reconstruct_is_bitwise_deterministic():
