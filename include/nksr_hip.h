@@ -221,7 +221,9 @@ int nksr_pack_cols21(const int32_t* cols32, int64_t n_padded, uint64_t* packed_o
 int nksr_spmv_set_variant(int v);
 /* Scratch bytes required by nksr_pcg_solve. */
 size_t nksr_pcg_workspace_bytes(int32_t M, int64_t nnz);
-/* Jacobi-PCG, x0 = 0.  info_out (host, may be NULL): [0]=iterations [1]=relative residual.
+/* Jacobi-PCG, x0 = 0.  info_out (host, 3 doubles, may be NULL): [0]=iterations [1]=relative residual (negated on a hard failure:
+ * r.z <= 0 with the Jacobi preconditioner, or NaN) [2]=segments whose coarse-level block lost definiteness (r.z <= 0) and that went on
+ * with Jacobi alone from the current iterate (a restart on the device, no error).
  * Checks convergence every `check_every` iterations (one stream sync each) -- syncs.
  * coarse_precond (struct nksr_coarse_precond_t, declared below; NULL = Jacobi only): the diagonal block of the coarse levels. */
 struct nksr_coarse_precond_s;
@@ -279,7 +281,11 @@ typedef struct nksr_coarse_precond_s {
     const float* dis;          /* [n] D^-1/2, new order */
     const int32_t* old_of_new; /* [n] coarse row (PCG order) of every new row */
     const int32_t* seg_base;   /* [nseg + 1] first new row of every segment */
+    const float* gersh;        /* device [nseg] or NULL: Gershgorin bound of the same spectrum (nksr_coarse_gershgorin); the interval's upper
+                                * end is min(lambda_scale * lambda[c], gersh[c]) */
 } nksr_coarse_precond_t;
+/* Gershgorin bound per segment of the Jacobi-scaled block described by pc (either format; work: n floats): gersh_out [nseg]. */
+int nksr_coarse_gershgorin(const nksr_coarse_precond_t* pc, int32_t nseg, float* work, float* gersh_out, void* stream);
 /* format-1 block from the plain CSR: new_of_old / old_of_new = the segment-major renumbering, row_seg_new / seg_base in the new
  * order, packed_rowptr = exclusive sum of the kept entries per row (nksr_coarse_pack_count) in the new order.  Off-diagonal entries
  * with |S_ij| < drop_tol are left out (0 keeps all; S_ij = S_ji bitwise, so the block stays symmetric).  Writes packed_out, dis_out. */
@@ -330,8 +336,8 @@ int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* b_out, floa
 /* y = (sum_s R_s^T R_s + reg I) x */
 int nksr_fused_apply(const nksr_fused_op_t* op, float reg, const float* x, float* y, void* stream);
 /* Jacobi-PCG with that operator; pcg_workspace: nksr_pcg_vector_workspace_bytes(M), or ..._seg(M, nseg, nranges) with segments.
- * Syncs like nksr_pcg_solve.  info_out: [0] = iterations (max over the segments), [1] = relative residual (max; negated if a
- * segment stopped on r.z <= 0). */
+ * Syncs like nksr_pcg_solve.  info_out (3 doubles): [0] = iterations (max over the segments), [1] = relative residual (max; negated if a
+ * segment failed hard), [2] = segments that fell back to Jacobi (see nksr_pcg_solve). */
 size_t nksr_pcg_vector_workspace_bytes(int32_t M);
 size_t nksr_pcg_vector_workspace_bytes_seg(int32_t M, int32_t nseg, int32_t nranges);
 int nksr_pcg_solve_fused(const nksr_fused_op_t* op, float reg, const float* diag, const float* b, float* x, float tol, int max_iter,

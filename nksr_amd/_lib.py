@@ -41,7 +41,7 @@ class SegmentsT(C.Structure):
 class CoarsePrecondT(C.Structure):
     _fields_ = [('first', _i32), ('n', _i32), ('steps', _i32), ('format', _i32), ('lambda_scale', _f32), ('ratio', _f32),
                 ('lambda_', _vp), ('row_seg', _vp), ('rowptr', _vp), ('cols', _vp), ('vals', _vp), ('diag', _vp), ('work', _vp), ('coef', _vp),
-                ('packed', _vp), ('packed_rowptr', _vp), ('dis', _vp), ('old_of_new', _vp), ('seg_base', _vp)]
+                ('packed', _vp), ('packed_rowptr', _vp), ('dis', _vp), ('old_of_new', _vp), ('seg_base', _vp), ('gersh', _vp)]
 
 
 PC_MAX_STEPS = 16
@@ -135,6 +135,7 @@ _PROTOS = {
     'nksr_coarse_pack_count': [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp],
     'nksr_coarse_pack': [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp],
     'nksr_coarse_lambda_max_packed': [_P(CoarsePrecondT), _i32, C.c_int, _vp, _vp, _vp],
+    'nksr_coarse_gershgorin': [_P(CoarsePrecondT), _i32, _vp, _vp, _vp],
     'nksr_pcg_profile': [C.c_int, _P(C.c_double), _P(_i64)],
     'nksr_pcg_profile_bytes': [_P(C.c_double), _P(C.c_double)],
     'nksr_chunk_pair_counts': [_P(ChunkGridT), C.c_int, _vp, _i64, _vp, _vp, _vp],

@@ -23,7 +23,9 @@ struct SegScalars {
     double bb;
     double rel;
     int iter;
-    int done;
+    int done;               // 1: converged (or empty right-hand side), 2: hard failure (r.z <= 0 with the Jacobi preconditioner too, NaN)
+    int jacobi;             // 1: the coarse-level block lost definiteness for this segment (r.z <= 0): it went on with Jacobi alone
+    int pad;
 };
 struct PcgGlobal {          // what the host reads back every check_every iterations
     double max_rel;
@@ -32,12 +34,14 @@ struct PcgGlobal {          // what the host reads back every check_every iterat
     int done_count;
     int nblocks;            // reduction blocks in use (k_seg_fill)
     int min_iter;           // fewest iterations any segment has taken so far (= all segments were still iterating up to here)
+    int fallbacks;          // segments that dropped the coarse-level block and went on with Jacobi
+    int pad;
 };
 
 struct PcgWork {
     float *r, *z, *p, *y;
     double* part1;          // [nb_max]
-    double* part2;          // [2 * nb_max]
+    double* part2;          // [3 * nb_max]: r.r, r.z with the preconditioner in use, r.z with plain Jacobi (the fallback's)
     int32_t *blk_lo, *blk_hi, *blk_seg;   // [nb_max] reduction blocks: unknown range + segment
     int32_t* seg_blk;       // [nseg + 1] first block of every segment
     SegScalars* sc;         // [nseg]
@@ -53,7 +57,7 @@ static int spcg_nb_max(int32_t M, int nseg, int nranges) { return (M + SPCG_BS -
 
 static size_t pcg_vector_bytes_seg(int32_t M, int nseg, int nranges) {
     const size_t vec = align_up((size_t)M * sizeof(float), 256), nb = (size_t)spcg_nb_max(M, nseg, nranges);
-    return 4 * vec + align_up(3 * nb * sizeof(double), 256) + align_up(3 * nb * sizeof(int32_t), 256) + align_up(((size_t)nseg + 1) * sizeof(int32_t), 256) +
+    return 4 * vec + align_up(4 * nb * sizeof(double), 256) + align_up(3 * nb * sizeof(int32_t), 256) + align_up(((size_t)nseg + 1) * sizeof(int32_t), 256) +
            align_up((size_t)nseg * sizeof(SegScalars), 256) + 256;
 }
 static size_t pcg_vector_bytes(int32_t M) { return pcg_vector_bytes_seg(M, 1, 1); }
@@ -81,7 +85,7 @@ static PcgWork carve(void* ws, int M, const nksr_segments_t* seg) {
     w.p = (float*)p; p += vec;
     w.y = (float*)p; p += vec;
     w.part1 = (double*)p;
-    w.part2 = w.part1 + nb; p += align_up(3 * nb * sizeof(double), 256);
+    w.part2 = w.part1 + nb; p += align_up(4 * nb * sizeof(double), 256);
     w.blk_lo = (int32_t*)p;
     w.blk_hi = w.blk_lo + nb;
     w.blk_seg = w.blk_hi + nb; p += align_up(3 * nb * sizeof(int32_t), 256);
@@ -351,25 +355,35 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spcg_init(PcgWork w, const float*
     const double t0 = block_sum(bb, sm);
     const double t1 = block_sum(rz, sm);
     if (threadIdx.x == 0) {
-        w.part2[2 * blk] = t0;
-        w.part2[2 * blk + 1] = t1;
+        w.part2[3 * blk] = t0;
+        w.part2[3 * blk + 1] = t1;
+        w.part2[3 * blk + 2] = t1;
     }
 }
 
-__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_init_finish(PcgWork w) {      // one workgroup per segment
+// one workgroup per segment.  r.z <= 0 with the coarse-level block in z (the Chebyshev polynomial lost definiteness: eigenvalue
+// bound too small) while the Jacobi r.z is positive: the segment starts with Jacobi alone (p = z = r / diag) instead of failing.
+__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_init_finish(PcgWork w, const float* __restrict__ diag) {
     __shared__ double sm[PCG_BLOCK / 64];
     const int c = blockIdx.x, b0 = w.seg_blk[c], nb = w.seg_blk[c + 1] - b0;
-    const double bb = reduce_partials(w.part2 + 2 * (int64_t)b0, nb, 2, sm);
-    const double rz = reduce_partials(w.part2 + 2 * (int64_t)b0 + 1, nb, 2, sm);
+    const double bb = reduce_partials(w.part2 + 3 * (int64_t)b0, nb, 3, sm);
+    const double rz = reduce_partials(w.part2 + 3 * (int64_t)b0 + 1, nb, 3, sm);
+    const double rzj = reduce_partials(w.part2 + 3 * (int64_t)b0 + 2, nb, 3, sm);
+    const bool fall = bb != 0.0 && !(rz > 0.0) && rzj > 0.0;
+    if (fall)
+        for (int k = 0; k < nb; ++k)
+            for (int i = w.blk_lo[b0 + k] + threadIdx.x; i < w.blk_hi[b0 + k]; i += PCG_BLOCK) { const float zi = w.r[i] / diag[i]; w.z[i] = zi; w.p[i] = zi; }
     if (threadIdx.x == 0) {
         SegScalars& s = w.sc[c];
         s.bb = bb;
-        s.rz[0] = rz;
+        s.rz[0] = fall ? rzj : rz;
         s.rz[1] = 0.0;
         s.rel = bb == 0.0 ? 0.0 : 1.0;
         s.iter = 0;
         s.done = 0;
-        if (bb == 0.0 || !(rz > 0.0)) { s.done = bb == 0.0 ? 1 : 2; seg_retire(w); }      // empty / zero right-hand side; 2 = breakdown
+        s.jacobi = fall ? 1 : 0;
+        s.pad = 0;
+        if (bb == 0.0 || !(s.rz[0] > 0.0)) { s.done = bb == 0.0 ? 1 : 2; seg_retire(w); }      // empty / zero right-hand side; 2 = breakdown
     }
 }
 
@@ -403,14 +417,16 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spcg_update(PcgWork w, const floa
     const double t0 = block_sum(rr, sm);
     const double t1 = block_sum(rz, sm);
     if (threadIdx.x == 0) {
-        w.part2[2 * blk] = t0;
-        w.part2[2 * blk + 1] = t1;
+        w.part2[3 * blk] = t0;
+        w.part2[3 * blk + 1] = t1;
+        w.part2[3 * blk + 2] = t1;      // r.z with z = r / diag everywhere: what a fallback to Jacobi continues with
     }
 }
 
 // partial r.z again (second column of part2) after the coarse slice of z changed; init: p = z as well
 __global__ void __launch_bounds__(PCG_BLOCK) k_spcg_rz(PcgWork w, int copy_p) {
     SPCG_BLOCK_PROLOGUE(!copy_p)
+    if (!copy_p && w.sc[seg].jacobi) return;      // this segment's z is the Jacobi one of k_spcg_update: its partial is in place
     double rz = 0.0;
     for (int i = lo + threadIdx.x; i < hi; i += PCG_BLOCK) {
         const float zi = w.z[i];
@@ -418,52 +434,67 @@ __global__ void __launch_bounds__(PCG_BLOCK) k_spcg_rz(PcgWork w, int copy_p) {
         rz += (double)w.r[i] * zi;
     }
     const double t = block_sum(rz, sm);
-    if (threadIdx.x == 0) w.part2[2 * blk + 1] = t;
+    if (threadIdx.x == 0) w.part2[3 * blk + 1] = t;
 }
 
 // p = z + beta p ; the first block of a segment publishes the scalars of its finished iteration
-__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_pupdate(PcgWork w, int parity, float tol) {
+// Breakdown (r.z <= 0: the Chebyshev polynomial of the coarse-level block lost definiteness -- its eigenvalue bound was too small --
+// or the residual ran away): the segment RESTARTS its conjugate gradients from the current x with Jacobi alone, p = z = r / diag,
+// r.z from the third column of the partials (k_spcg_update); from then on the Chebyshev kernels skip it (SegScalars.jacobi).
+// Every block of the segment takes the same decision from the same reduced numbers -- no flag is read here, so nothing races with
+// the first block's write.  With Jacobi already in use the two r.z columns are equal, i.e. r.z <= 0 there is a hard failure.
+__global__ void __launch_bounds__(PCG_BLOCK) k_spcg_pupdate(PcgWork w, const float* __restrict__ diag, int parity, float tol) {
     SPCG_BLOCK_PROLOGUE(true)
     const int b0 = w.seg_blk[seg], nb = w.seg_blk[seg + 1] - b0;
-    const double rr = reduce_partials(w.part2 + 2 * (int64_t)b0, nb, 2, sm);
-    const double rz_new = reduce_partials(w.part2 + 2 * (int64_t)b0 + 1, nb, 2, sm);
+    const double rr = reduce_partials(w.part2 + 3 * (int64_t)b0, nb, 3, sm);
+    const double rz_new = reduce_partials(w.part2 + 3 * (int64_t)b0 + 1, nb, 3, sm);
+    const double rz_jac = reduce_partials(w.part2 + 3 * (int64_t)b0 + 2, nb, 3, sm);
     const double rz_old = w.sc[seg].rz[parity];
     const double bb = w.sc[seg].bb;
-    const float beta = (float)(rz_new / rz_old);
-    for (int i = lo + threadIdx.x; i < hi; i += PCG_BLOCK) w.p[i] = fmaf(beta, w.p[i], w.z[i]);
+    const double rel = sqrt(rr / bb);
+    const bool bad = !(rz_new > 0.0) || !(rel < 1e4);
+    const bool fall = bad && rz_jac > 0.0 && rz_jac != rz_new && rel < 1e30;
+    if (fall) {
+        for (int i = lo + threadIdx.x; i < hi; i += PCG_BLOCK) { const float zi = w.r[i] / diag[i]; w.z[i] = zi; w.p[i] = zi; }
+    } else {
+        const float beta = (float)(rz_new / rz_old);
+        for (int i = lo + threadIdx.x; i < hi; i += PCG_BLOCK) w.p[i] = fmaf(beta, w.p[i], w.z[i]);
+    }
     __syncthreads();
     if (blk == b0 && threadIdx.x == 0) {
         SegScalars& s = w.sc[seg];
-        const double rel = sqrt(rr / bb);
-        s.rz[parity ^ 1] = rz_new;
+        s.rz[parity ^ 1] = fall ? rz_jac : rz_new;
         s.rel = rel;
         s.iter += 1;
+        if (fall) s.jacobi = 1;
         if (rel <= (double)tol) { s.done = 1; seg_retire(w); }
-        else if (!(rz_new > 0.0) || !(rel < 1e30)) { s.done = 2; seg_retire(w); }      // r.z <= 0: the preconditioner lost definiteness (or NaN)
+        else if (!fall && (!(rz_new > 0.0) || !(rel < 1e30))) { s.done = 2; seg_retire(w); }      // r.z <= 0 with Jacobi (or NaN): nothing left to fall back to
     }
 }
 
 // what the host reads every check_every iterations (+ the per-segment results, when asked for)
 __global__ void __launch_bounds__(PCG_BLOCK) k_spcg_summary(PcgWork w, double* __restrict__ seg_info) {
     __shared__ double smr[PCG_BLOCK];
-    __shared__ int smi[PCG_BLOCK], smb[PCG_BLOCK], smn[PCG_BLOCK];
+    __shared__ int smi[PCG_BLOCK], smb[PCG_BLOCK], smn[PCG_BLOCK], smf[PCG_BLOCK];
     double mr = 0.0;
-    int mi = 0, nbk = 0, mn = 0x7fffffff;
+    int mi = 0, nbk = 0, mn = 0x7fffffff, nfb = 0;
     for (int c = threadIdx.x; c < w.nseg; c += PCG_BLOCK) {
         const SegScalars& s = w.sc[c];
         mr = s.rel > mr ? s.rel : mr;
         mi = s.iter > mi ? s.iter : mi;
         mn = s.iter < mn ? s.iter : mn;
         nbk += s.done == 2;
+        nfb += s.jacobi != 0;
         if (seg_info) { seg_info[2 * c] = (double)s.iter; seg_info[2 * c + 1] = s.done == 2 ? -s.rel : s.rel; }
     }
-    smr[threadIdx.x] = mr; smi[threadIdx.x] = mi; smb[threadIdx.x] = nbk; smn[threadIdx.x] = mn;
+    smr[threadIdx.x] = mr; smi[threadIdx.x] = mi; smb[threadIdx.x] = nbk; smn[threadIdx.x] = mn; smf[threadIdx.x] = nfb;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int t = 1; t < PCG_BLOCK; ++t) { mr = smr[t] > mr ? smr[t] : mr; mi = smi[t] > mi ? smi[t] : mi; nbk += smb[t]; mn = smn[t] < mn ? smn[t] : mn; }
+        for (int t = 1; t < PCG_BLOCK; ++t) { mr = smr[t] > mr ? smr[t] : mr; mi = smi[t] > mi ? smi[t] : mi; nbk += smb[t]; mn = smn[t] < mn ? smn[t] : mn; nfb += smf[t]; }
         w.g->max_rel = nbk ? -mr : mr;         // negative: some segment broke down (r.z <= 0)
         w.g->max_iter = mi;
         w.g->min_iter = mn;
+        w.g->fallbacks = nfb;
     }
 }
 
@@ -608,11 +639,15 @@ extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_ou
 
 // coef[c] = { 1 / theta, a_0, b_0, a_1, b_1, ... } for the interval [lmax / ratio, lmax], lmax = scale * lambda[c]; a segment without
 // a usable bound (no constraint rows on its coarse levels) gets { 1, 0, 0, ... }: one Jacobi step
-__global__ void k_cheb_coeffs(int nseg, const float* __restrict__ lambda, float scale, float ratio, int steps, float* __restrict__ coef) {
+// gersh (may be NULL): a Gershgorin bound of the same spectrum (nksr_coarse_gershgorin) -- a true upper bound, so the margin on the
+// power estimate never has to carry the interval beyond it
+__global__ void k_cheb_coeffs(int nseg, const float* __restrict__ lambda, const float* __restrict__ gersh, float scale, float ratio, int steps,
+                              float* __restrict__ coef) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= nseg) return;
     float* o = coef + (int64_t)c * CHEB_STRIDE;
-    const double lmax = (double)scale * (double)lambda[c];
+    double lmax = (double)scale * (double)lambda[c];
+    if (gersh && gersh[c] > 0.f && (double)gersh[c] < lmax) lmax = (double)gersh[c];
     if (!(lmax > 0.0) || !(lmax < 1e30)) {
         o[0] = 1.f;
         for (int i = 0; i < steps; ++i) { o[1 + 2 * i] = 0.f; o[2 + 2 * i] = 0.f; }
@@ -636,7 +671,7 @@ __global__ void __launch_bounds__(256) k_cheb_init(int n, const float* __restric
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const int seg = row_seg ? row_seg[j] : 0;
-    if (sc && sc[seg].done) return;
+    if (sc && (sc[seg].done || sc[seg].jacobi)) return;
     const float rj = r[j];
     res[j] = rj;
     d0[j] = rj / diag[j] * (coef ? coef[(int64_t)seg * CHEB_STRIDE] : 1.f);
@@ -651,7 +686,7 @@ __global__ void __launch_bounds__(256) k_cheb_step(int n, const int32_t* __restr
     const int j = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (j >= n) return;
     const int seg = row_seg ? row_seg[j] : 0;
-    if (sc && sc[seg].done) return;
+    if (sc && (sc[seg].done || sc[seg].jacobi)) return;
     // a wavefront's time is a chain of dependent load latencies (the block streams from L2 / HBM): everything that does not depend on
     // the row's entries is requested up front, and four 64-entry groups (rows hold ~190 entries) are in flight at once -- clamped
     // addresses instead of predicated loads, so that the compiler does not serialise them
@@ -815,7 +850,7 @@ __global__ void __launch_bounds__(256) k_cheb16_init(int n, const float* __restr
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int seg = row_seg[i];
-    if (sc && sc[seg].done) return;
+    if (sc && (sc[seg].done || sc[seg].jacobi)) return;
     const float rs = r[old_of_new[i]] * dis[i];
     res[i] = rs;
     d0[i] = rs * (coef ? coef[(int64_t)seg * CHEB_STRIDE] : 1.f);
@@ -841,7 +876,7 @@ __global__ void __launch_bounds__(256) k_cheb16_step(int n, const int32_t* __res
     const int ir = i0 + (lane < CHEB16_ROWS ? lane : 0), irc = ir < n ? ir : n - 1;
     const int pl = prow[(i0 + lane <= n && lane <= CHEB16_ROWS) ? i0 + lane : n];
     const int sg = row_seg[irc];
-    const bool live_l = lane < CHEB16_ROWS && ir < n && (POWER || !sc || !sc[sg].done);
+    const bool live_l = lane < CHEB16_ROWS && ir < n && (POWER || !sc || !(sc[sg].done || sc[sg].jacobi));
     const int sb = seg_base[sg];
     const float dj = d_old[irc];
     float rs = 0.f, yj = 0.f, ca = 0.f, cb = 0.f;
@@ -959,6 +994,59 @@ extern "C" int nksr_coarse_lambda_max_packed(const nksr_coarse_precond_t* pc, in
     return NKSR_OK;
 }
 
+// Gershgorin bound of the Jacobi-scaled block per segment: max over the rows of  sum_j |a_ij| / d_i  (format 0, spectrum of D^-1 A_cc)
+// or  1 + sum_j |S_ij|  (format 1: unit diagonal).  2-3x above the true lambda_max on these blocks -- too loose to BE the interval
+// (it costs ~50 % more iterations), right as a cap on margin x power estimate.
+__global__ void __launch_bounds__(256) k_gersh_rows(int n, int format, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ cols,
+                                                    const float* __restrict__ vals, const float* __restrict__ diag,
+                                                    const uint32_t* __restrict__ pk, float* __restrict__ rowsum) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const int k0 = rowptr[i], k1 = rowptr[i + 1];
+    float t = 0.f;
+    if (format == 1) {
+        for (int k = k0 + lane; k < k1; k += 64) t += fabsf(__half2float(__ushort_as_half((unsigned short)(pk[k] >> 16))));
+    } else {
+        for (int k = k0 + lane; k < k1; k += 64) t += fabsf(vals[k]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if (lane == 0) rowsum[i] = format == 1 ? 1.f + t : t / diag[i];
+}
+__global__ void __launch_bounds__(PCG_BLOCK) k_gersh_seg(int n, const int32_t* __restrict__ seg_base, const int32_t* __restrict__ row_seg,
+                                                         int nseg, const float* __restrict__ rowsum, float* __restrict__ out) {
+    __shared__ float sm[PCG_BLOCK];
+    const int c = blockIdx.x;
+    float m = 0.f;
+    if (seg_base) {
+        for (int i = seg_base[c] + threadIdx.x; i < seg_base[c + 1]; i += PCG_BLOCK) m = fmaxf(m, rowsum[i]);
+    } else {
+        for (int i = threadIdx.x; i < n; i += PCG_BLOCK)
+            if (nseg == 1 || !row_seg || row_seg[i] == c) m = fmaxf(m, rowsum[i]);
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = PCG_BLOCK / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = sm[0];
+}
+extern "C" int nksr_coarse_gershgorin(const nksr_coarse_precond_t* pc, int32_t nseg, float* work, float* gersh_out, void* stream) {
+    if (!pc || pc->n <= 0) return NKSR_OK;
+    if (!work || !gersh_out || nseg < 1) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    if (pc->format == 1 ? (!pc->packed || !pc->packed_rowptr || !pc->seg_base) : (!pc->rowptr || !pc->vals || !pc->diag || (nseg > 1 && !pc->row_seg)))
+        return nksr_set_error(NKSR_ERR_ARG, "coarse block has NULL arrays");
+    hipStream_t st = (hipStream_t)stream;
+    const int n = pc->n;
+    hipLaunchKernelGGL(k_gersh_rows, dim3(nksr_blocks((int64_t)n * 64, 256)), dim3(256), 0, st, n, pc->format, pc->format == 1 ? pc->packed_rowptr : pc->rowptr,
+                       pc->cols, pc->vals, pc->diag, pc->packed, work);
+    hipLaunchKernelGGL(k_gersh_seg, dim3(nseg), dim3(PCG_BLOCK), 0, st, n, pc->format == 1 ? pc->seg_base : (const int32_t*)nullptr, pc->row_seg, nseg,
+                       (const float*)work, gersh_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
 static int cheb_check(const nksr_coarse_precond_t* pc, int nseg) {
     if (pc->n <= 0 || pc->steps < 1 || pc->steps > NKSR_PC_MAX_STEPS) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: 1..%d steps", NKSR_PC_MAX_STEPS);
     if (!(pc->lambda_scale > 0.f) || !(pc->ratio > 1.f)) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: lambda_scale > 0, ratio > 1");
@@ -994,7 +1082,7 @@ static void cheb_apply(const nksr_coarse_precond_t* pc, const float* r, float* z
 
 int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, float* x, float tol, int max_iter, int check_every,
                  void* vector_workspace, double* info_out, hipStream_t st, const nksr_coarse_precond_t* pc, const nksr_segments_t* seg) {
-    if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
+    if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; info_out[2] = 0; } return NKSR_OK; }
     if (!vector_workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     if (seg && (seg->nseg < 1 || seg->nranges < 1 || !seg->lo || !seg->hi)) return nksr_set_error(NKSR_ERR_ARG, "bad segments");
     if (check_every < 1) check_every = 1;
@@ -1003,7 +1091,7 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
     if (pc) {
         if (int rc = cheb_check(pc, w.nseg)) return rc;
         if (pc->first < 0 || pc->first + pc->n != M) return nksr_set_error(NKSR_ERR_ARG, "coarse preconditioner: the block must be the last %d unknowns", pc->n);
-        hipLaunchKernelGGL(k_cheb_coeffs, dim3(nksr_blocks(w.nseg, 64)), dim3(64), 0, st, w.nseg, pc->lambda, pc->lambda_scale, pc->ratio, pc->steps, pc->coef);
+        hipLaunchKernelGGL(k_cheb_coeffs, dim3(nksr_blocks(w.nseg, 64)), dim3(64), 0, st, w.nseg, pc->lambda, pc->gersh, pc->lambda_scale, pc->ratio, pc->steps, pc->coef);
     }
     hipLaunchKernelGGL(k_seg_count, dim3(nksr_blocks(w.nseg, 64)), dim3(64), 0, st, w);
     hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1), 0, st, w);
@@ -1013,7 +1101,7 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
         cheb_apply(pc, w.r + pc->first, w.z + pc->first, nullptr, st);
         hipLaunchKernelGGL(k_spcg_rz, gb, blkd, 0, st, w, 1);
     }
-    hipLaunchKernelGGL(k_spcg_init_finish, dim3(w.nseg), blkd, 0, st, w);
+    hipLaunchKernelGGL(k_spcg_init_finish, dim3(w.nseg), blkd, 0, st, w, diag);
     NKSR_CHECK_LAUNCH();
     PcgGlobal host;
     memset(&host, 0, sizeof(host));
@@ -1038,7 +1126,7 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
             cheb_apply(pc, w.r + pc->first, w.z + pc->first, w.sc, st);
             hipLaunchKernelGGL(k_spcg_rz, gb, blkd, 0, st, w, 0);
         }
-        hipLaunchKernelGGL(k_spcg_pupdate, gb, blkd, 0, st, w, parity, tol);
+        hipLaunchKernelGGL(k_spcg_pupdate, gb, blkd, 0, st, w, diag, parity, tol);
         return NKSR_OK;
     };
     while (launched < max_iter) {
@@ -1071,7 +1159,8 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
     }
     if (info_out) {
         info_out[0] = (double)host.max_iter;
-        info_out[1] = host.max_rel;          // negative: a segment stopped on r.z <= 0 (preconditioner lost definiteness)
+        info_out[1] = host.max_rel;          // negative: a segment stopped on r.z <= 0 with Jacobi too, or on NaN (hard failure)
+        info_out[2] = (double)host.fallbacks; // segments whose coarse-level block lost definiteness: they went on with Jacobi alone
     }
     return NKSR_OK;
 }
@@ -1088,7 +1177,7 @@ struct CsrOperator : PcgOperator {
 extern "C" int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, const float* diag, int32_t M,
                               int64_t nnz, int col_format, const float* b, float* x, float tol, int max_iter, int check_every,
                               void* workspace, const nksr_coarse_precond_t* pc, double* info_out, void* stream) {
-    if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; } return NKSR_OK; }
+    if (M <= 0) { if (info_out) { info_out[0] = 0; info_out[1] = 0; info_out[2] = 0; } return NKSR_OK; }
     if (!workspace) return nksr_set_error(NKSR_ERR_ARG, "workspace is NULL");
     void* spmv_ws = (char*)workspace + pcg_vector_bytes(M);
     int rc = nksr_spmv_plan(rowptr, M, nnz, col_format, spmv_ws, stream);

@@ -18,7 +18,7 @@ struct PcgOperator {
 
 // bytes of the vector workspace (r, z, p, y, partial sums, scalars) for M unknowns
 size_t nksr_pcg_vector_bytes(int32_t M);
-// x0 = 0, stop on ||r|| <= tol ||b||; info_out[0] = iterations, [1] = relative residual.  Syncs every check_every iterations.
+// x0 = 0, stop on ||r|| <= tol ||b||; info_out (3 doubles): [0] = iterations, [1] = relative residual, [2] = Jacobi fallbacks.  Syncs every check_every iterations.
 // Preconditioner: Jacobi (diag); with `pc` the unknowns of the coarse levels (the last pc->n) get pc->steps Chebyshev steps on their
 // diagonal block instead (see nksr_coarse_precond_t, include/nksr_hip.h).  `seg`: independent diagonal blocks with their own CG
 // scalars (nksr_segments_t); the workspace is then nksr_pcg_vector_workspace_bytes_seg.

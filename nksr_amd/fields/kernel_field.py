@@ -332,8 +332,8 @@ class KernelField(BaseField):
         self._pc = pc if self._wants_grad(normal_value) else None      # the adjoint solve of the backward pass takes the same preconditioner (_solve_system)
         self.rhs, self.diag = b, diag
         self.solve_info = {'iters': iters, 'rel_residual': rel, 'M': int(b.numel()), 'nnz': int(self.nnz),
-                           'coarse_precond': ({k: pc[k] for k in ('first_level', 'unknowns', 'nnz', 'steps', 'lambda')} if pc else None),
-                           't_assemble': t1 - t0, 't_pcg': t2 - t1}
+                           'coarse_precond': ({k: pc[k] for k in ('first_level', 'unknowns', 'nnz', 'steps', 'lambda', 'gershgorin')} if pc else None),
+                           'jacobi_fallbacks': solver.last_fallbacks, 't_assemble': t1 - t0, 't_pcg': t2 - t1}
         self._attach_autograd(pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight)
         if self.solver_config.get('verbose'):
             print('[KernelField] M=%d nnz=%d iters=%d rel=%.3e assemble=%.3fs pcg=%.3fs' % (
@@ -508,7 +508,11 @@ class KernelField(BaseField):
         coef = torch.empty(nseg * (1 + 2 * PC_MAX_STEPS), dtype=torch.float32, device=self.device)
         row_seg = segments.unknown_seg[off[c0]:].contiguous() if segments is not None else None
         pc = CoarsePrecondT()
-        pc.first, pc.n, pc.steps, pc.lambda_scale, pc.ratio = off[c0], n, int(cfg.get('steps', 8)), 1.1, float(cfg.get('ratio', PC_RATIO))
+        # the interval's upper end: 1.1 x the power-iteration estimate (a LOWER bound of lambda_max, within ~1 % after 8 steps), capped by
+        # the Gershgorin bound (a true upper bound, 2-3x too large to be used by itself).  'lambda_scale' is a test knob: < 1 forces the
+        # polynomial to lose definiteness, which the PCG answers by restarting the segment with Jacobi alone (csrc/pcg.hip)
+        pc.first, pc.n, pc.steps, pc.lambda_scale, pc.ratio = off[c0], n, int(cfg.get('steps', 8)), float(cfg.get('lambda_scale', 1.1)), float(cfg.get('ratio', PC_RATIO))
+        gersh = torch.empty(nseg, dtype=torch.float32, device=self.device)
         pc.lambda_, pc.coef = ptr(lam), ptr(coef)
         nnz = int(cols.numel())
         info = {'first_level': c0, 'unknowns': n, 'nnz': nnz, 'steps': int(pc.steps), 'lambda': lam}
@@ -546,7 +550,9 @@ class KernelField(BaseField):
             pc.format, pc.row_seg, pc.work = 1, ptr(row_seg_new), ptr(work)
             pc.packed, pc.packed_rowptr, pc.dis, pc.old_of_new, pc.seg_base = ptr(packed), ptr(prow), ptr(dis), ptr(o2n), ptr(seg_base)
             call('nksr_coarse_lambda_max_packed', C.byref(pc), nseg, 8, ptr(work), ptr(lam), stream())
-            info.update(packed=True, keep=(packed, prow, dis, o2n, seg_base, row_seg_new, work, lam, coef))
+            call('nksr_coarse_gershgorin', C.byref(pc), nseg, ptr(work), ptr(gersh), stream())
+            pc.gersh = ptr(gersh)
+            info.update(packed=True, gershgorin=gersh, keep=(packed, prow, dis, o2n, seg_base, row_seg_new, work, lam, coef, gersh))
             td = _tick('pc:pack+lambda', td)
             return dict(info, pc=pc)
         work = torch.empty(3 * n, dtype=torch.float32, device=self.device)
@@ -556,7 +562,9 @@ class KernelField(BaseField):
              C.byref(segments.c) if segments is not None else None, off[c0], stream())
         pc.format, pc.row_seg, pc.work = 0, ptr(row_seg), ptr(work)
         pc.rowptr, pc.cols, pc.vals, pc.diag = ptr(rowptr), ptr(cols), ptr(vals), ptr(diag)
-        info.update(packed=False, keep=(rowptr, cols, vals, diag, work, lam, coef, row_seg))
+        call('nksr_coarse_gershgorin', C.byref(pc), nseg, ptr(work), ptr(gersh), stream())
+        pc.gersh = ptr(gersh)
+        info.update(packed=False, gershgorin=gersh, keep=(rowptr, cols, vals, diag, work, lam, coef, row_seg, gersh))
         return dict(info, pc=pc)
 
     def solve_fused(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0,
@@ -593,14 +601,18 @@ class KernelField(BaseField):
 
         def pcg(rhs, rtol, iters, precond):
             sol = torch.empty(M, dtype=torch.float32, device=dev)
-            inf = (C.c_double * 2)()
+            inf = (C.c_double * 3)()
             call('nksr_pcg_solve_fused', C.byref(op['op']), float(reg_weight), ptr(diag), ptr(rhs), ptr(sol), float(rtol), int(iters),
                  check_every, ptr(pws), C.byref(precond['pc']) if precond else None, C.byref(segments.c) if segments is not None else None,
                  inf, stream())
-            if inf[1] < 0:      # a segment stopped on r.z <= 0: the Chebyshev block lost definiteness (eigenvalue bound too small)
-                raise RuntimeError('PCG breakdown (r.z <= 0 after %d iterations, relative residual %.3e): coarse-level preconditioner '
-                                   'is not positive definite -- set solver_config["coarse_precond"] = False' % (int(inf[0]), -inf[1]))
+            # a segment whose Chebyshev block lost definiteness (r.z <= 0: eigenvalue bound too small) restarts with Jacobi alone on
+            # the device (csrc/pcg.hip: k_spcg_pupdate) -- counted, not raised; only r.z <= 0 with Jacobi itself / NaN is an error
+            fallbacks[0] += int(inf[2])
+            if inf[1] < 0:
+                raise RuntimeError('PCG breakdown (r.z <= 0 with the Jacobi preconditioner after %d iterations, relative residual %.3e): '
+                                   'the system is not positive definite (non-finite rows or weights?)' % (int(inf[0]), -inf[1]))
             return sol, int(inf[0]), float(inf[1])
+        fallbacks = [0]
         if pc is not None or not auto or max_iter <= check_every:
             x, iters, rel = pcg(b, tol, max_iter, pc)
         else:
@@ -626,9 +638,9 @@ class KernelField(BaseField):
         self.nnz = 0
         self.solve_info = {'iters': int(info[0]), 'rel_residual': float(info[1]), 'M': int(M), 'nnz': 0, 'fused': True,
                            'kernel_row_slots': 27 * self.svh.depth * op['rows_total'], 'partial_blocks': op['nblocks'],
-                           'coarse_precond': ({k: pc[k] for k in ('first_level', 'unknowns', 'nnz', 'steps', 'lambda')} if pc else None),
+                           'coarse_precond': ({k: pc[k] for k in ('first_level', 'unknowns', 'nnz', 'steps', 'lambda', 'gershgorin')} if pc else None),
                            'segments': nseg, 'segment_info': segments.info if segments is not None else None,
-                           't_assemble': t1 - t0, 't_pcg': t2 - t1}
+                           'jacobi_fallbacks': fallbacks[0], 't_assemble': t1 - t0, 't_pcg': t2 - t1}
         if self.solver_config.get('verbose'):
             print('[KernelField] fused: M=%d rows=%d iters=%d rel=%.3e rows+rhs=%.3fs pcg=%.3fs' % (
                 M, op['rows_total'], int(info[0]), float(info[1]), t1 - t0, t2 - t1))
@@ -653,11 +665,11 @@ class KernelField(BaseField):
         M = self.svh.num_unknowns
         x = torch.empty(M, dtype=torch.float32, device=self.device)
         pws = torch.empty(int(_lib.lib.nksr_pcg_vector_workspace_bytes(M)), dtype=torch.uint8, device=self.device)
-        info = (C.c_double * 2)()
+        info = (C.c_double * 3)()
         call('nksr_pcg_solve_fused', C.byref(self._fused_op['op']), self._fused_reg, ptr(self.diag), ptr(rhs.contiguous()), ptr(x), float(cfg['tol']),
              int(cfg['max_iter']), int(cfg['check_every']), ptr(pws), C.byref(pc['pc']) if pc else None, None, info, stream())
         if info[1] < 0:
-            raise RuntimeError('PCG breakdown in the adjoint solve (r.z <= 0): set solver_config["coarse_precond"] = False')
+            raise RuntimeError('PCG breakdown in the adjoint solve (r.z <= 0 with the Jacobi preconditioner): the system is not positive definite')
         return x
 
     def _theta(self):

@@ -8,6 +8,9 @@ import torch
 from ._lib import call, lib, ptr, stream
 
 
+last_fallbacks = 0      # Jacobi fallbacks of the last pcg_solve (segments whose coarse-level block lost definiteness)
+
+
 def col_format(cols):
     """Physical layout of a matrix from KernelField.assemble (include/nksr_hip.h, col_format): int32 columns in
     256-entry tiles (0) or three 21-bit columns per int64 word in 192-entry tiles (1)."""
@@ -28,18 +31,21 @@ def spmv(rowptr, cols, vals, x):
 
 def pcg_solve(rowptr, cols, vals, diag, b, tol=1e-5, max_iter=2000, check_every=16, workspace=None, precond=None):
     """Returns (x, iterations, relative residual).  x0 = 0, stop on ||r|| <= tol ||b||.  ``precond``: a CoarsePrecondT
-    (KernelField._coarse_precond) -- Chebyshev steps on the coarse levels' diagonal block instead of Jacobi there."""
+    (KernelField._coarse_precond) -- Chebyshev steps on the coarse levels' diagonal block instead of Jacobi there; if that
+    polynomial loses definiteness (r.z <= 0) the solve restarts with Jacobi alone on the device (``last_fallbacks`` counts it)."""
+    global last_fallbacks
     M = b.numel()
     nnz = int(rowptr[M].item())
     x = torch.empty(M, dtype=torch.float32, device=b.device)
     nbytes = int(lib.nksr_pcg_workspace_bytes(M, nnz))
     if workspace is None or workspace.numel() < nbytes:
         workspace = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
-    info = (C.c_double * 2)()
+    info = (C.c_double * 3)()
     call('nksr_pcg_solve', ptr(rowptr), ptr(cols), ptr(vals), ptr(diag), M, nnz, col_format(cols), ptr(b), ptr(x), float(tol), int(max_iter),
          int(check_every), ptr(workspace), C.byref(precond) if precond is not None else None, info, stream())
+    last_fallbacks = int(info[2])
     if info[1] < 0:
-        raise RuntimeError('PCG breakdown (r.z <= 0): the coarse-level preconditioner is not positive definite')
+        raise RuntimeError('PCG breakdown (r.z <= 0 with the Jacobi preconditioner): the system is not positive definite')
     return x, int(info[0]), float(info[1])
 
 

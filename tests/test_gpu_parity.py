@@ -732,6 +732,37 @@ def test_coarse_block_preconditioner_same_solution_fewer_iterations():
     assert abs(Ac - Ac.T).max() <= 1e-6 * abs(ref).max()
 
 
+def test_a_coarse_block_that_loses_definiteness_falls_back_to_jacobi_on_the_device():
+    """The Chebyshev polynomial of the coarse-level block is only positive definite while its interval covers the block's
+    spectrum.  ``lambda_scale`` < 1 forces the bound too small (what a poor power-iteration estimate would do): r.z goes
+    <= 0, and instead of raising the PCG restarts that system with Jacobi alone from the current iterate, on the device
+    (csrc/pcg.hip: k_spcg_pupdate).  The solve still converges to the Jacobi-only solution; the fallback is counted.  The
+    Gershgorin cap never cuts into a sound bound: with the default scale it changes nothing."""
+    import nksr_amd
+    from nksr_amd import configs
+    xyz, nrm = make_cloud('torus', 6000, 0.003, 1)
+    hp = configs.get_hparams('ks', tree_depth=5)
+    t = lambda a: torch.from_numpy(a).to(_dev())
+    out = {}
+    for name, pc in (('jacobi', False), ('sound', None), ('broken', {'lambda_scale': 0.25})):
+        for fused in (True, False):
+            rec = nksr_amd.Reconstructor(_dev(), hparams=hp)
+            rec.coarse_precond = pc
+            fld = rec.reconstruct(t(xyz), t(nrm), voxel_size=0.03, solver_tol=1e-6, fused_mode=fused)
+            assert fld.solve_info['rel_residual'] <= 1e-6, (name, fused, fld.solve_info['rel_residual'])
+            out[(name, fused)] = (fld.alpha.clone(), fld.solve_info['iters'], fld.solve_info['jacobi_fallbacks'], fld.solve_info['coarse_precond'])
+    for fused in (True, False):
+        aj, itj, fbj, _ = out[('jacobi', fused)]
+        a_s, its, fbs, info = out[('sound', fused)]
+        ab, itb, fbb, _ = out[('broken', fused)]
+        assert fbj == 0 and fbs == 0 and fbb == 1, (fused, fbj, fbs, fbb)
+        # Gershgorin is a true upper bound of the spectrum the power iteration estimates from below
+        assert float(info['lambda'].max()) <= float(info['gershgorin'].max()) * (1 + 1e-5)
+        pu.report('coarse_precond:fallback_iters[fused=%s]' % fused, sound=its, broken_then_jacobi=itb, jacobi_only=itj)
+        assert its < itb <= itj + 40
+        pu.check('coarse_precond:fallback_alpha_vs_jacobi_rel[fused=%s]' % fused, float((ab - aj).abs().max() / aj.abs().max()), pu.ALPHA_TOL)
+
+
 def test_shallow_hierarchies_switch_to_the_coarse_block_when_jacobi_stalls():
     """Depth-4 hierarchies start with Jacobi (the dense 1M-point cloud converges in 11 iterations) and restart on the residual with
     the coarse-level block after one unconverged round of check_every iterations: sparse input with normal sites on two levels
