@@ -311,26 +311,29 @@ typedef struct {
     const float* rows_all;     /* LEVEL-MAJOR dense-slot rows [depth][rows_total][27], pre-multiplied by sqrt(w) (nksr_kernel_rows, level_stride, row_index) */
     const float* targets_all;  /* [rows_total] right-hand side values pre-multiplied by sqrt(w) (0 for rows without a target); may be NULL if unused */
     const int32_t* row_cells;  /* [depth][rows_total] GLOBAL unknown index of the row's level-d cell, -1 = none (nksr_kernel_rows) */
-    const int32_t* nbr32;      /* [M, 32]: [0..26] GLOBAL unknown index of every neighbour voxel or -1; [27] block base, [28] single-block flag (nksr_fused_tables) */
+    const int32_t* nbr32;      /* [M, 32]: [0..26] GLOBAL unknown index of every neighbour voxel or -1; [27] block base, [28] / [29] first / last row of
+                                * the cell (nksr_fused_tables) */
+    const int32_t* nbrT;       /* [27, M]: the same neighbour indices SLOT-MAJOR (the second product's gather runs one lane per unknown) */
     const int32_t* offsets;    /* [M + 1] partial blocks of a cell = [offsets[j], offsets[j + 1])                             */
-    const int32_t* multi;      /* [n_multi] the cells with more than one block: first the n_big cells with more than 16 blocks (one
-                                * workgroup each in the per-cell sum), then the others                                        */
+    const int32_t* multi;      /* [n_multi] the cells with partial blocks (cells whose rows span several 256-row workgroups of the sweep):
+                                * first the n_big cells with more than 16 blocks (one workgroup each in the per-cell sum), then the others */
     int64_t nblocks;           /* offsets[M]                                                                                 */
     uint64_t* nnz_counter;     /* device counter or NULL: nksr_fused_rhs_diag leaves the non-zero slots of rows_all here = the
                                 * stored entries of G and Q (roofline accounting) */
-    void* workspace;           /* nksr_fused_workspace_bytes(nblocks)                                                        */
-    float* cell_sums;          /* [M, 32] per-cell block sums, ZERO-INITIALISED by the caller                                */
+    void* workspace;           /* nksr_fused_workspace_bytes(nblocks, M)                                                     */
+    float* cell_sums;          /* [27, M] per-cell block sums, slot-major, ZERO-INITIALISED by the caller (cells without rows are never written) */
     const int32_t* item_seg;   /* batched chunks (nksr_segments_t), both or neither: [ceil(rows_total / 32) + 1] segment of every 32-row work
-                                * item (a segment's rows are padded to whole items) and                                      */
+                                * item (a segment's rows are padded to whole 256-row workgroups) and                          */
     const int32_t* unknown_seg;/* [M] segment of every unknown: the solve skips the rows / unknowns of segments that have converged */
 } nksr_fused_op_t;
-/* Work items are runs of 32 consecutive rows; a cell whose rows touch k items owns k partial blocks.
- * nksr_fused_block_counts: span_out [2, M] (first / last row of every cell, -1 = none), counts_out [M + 1] (last entry 0) ->
- * exclusive scan = offsets -> nksr_fused_tables. */
+/* Work items are runs of 32 consecutive rows, eight of them (256 rows) a workgroup; a cell whose rows lie inside one workgroup is
+ * finished by the sweep, a cell whose rows reach into k > 1 workgroups owns k partial blocks.
+ * nksr_fused_block_counts: span_out [2, M] (first / last row of every cell, -1 = none), counts_out [M + 1] (0 or k; last entry 0) ->
+ * exclusive scan = offsets -> nksr_fused_tables (nbr32_out [M, 32], nbrT_out [27, M]). */
 int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_total, const int32_t* row_cells, int32_t* span_out, int32_t* counts_out,
                             void* stream);
-int nksr_fused_tables(const nksr_hier_t* h, const int32_t* offsets, const int32_t* span, int32_t* nbr32_out, void* stream);
-size_t nksr_fused_workspace_bytes(int64_t nblocks);
+int nksr_fused_tables(const nksr_hier_t* h, const int32_t* offsets, const int32_t* span, int32_t* nbr32_out, int32_t* nbrT_out, void* stream);
+size_t nksr_fused_workspace_bytes(int64_t nblocks, int32_t M);
 /* b = sum_s R_s^T t_s and diag = reg + sum_s diag(R_s^T R_s) (either may be NULL): one sweep over the rows serves both. */
 int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* b_out, float* diag_out, void* stream);
 /* y = (sum_s R_s^T R_s + reg I) x */

@@ -28,6 +28,22 @@
 // with its neighbours in the list, which the four rows of a trip and the next trip fetch again)
 #define FZ_ROW_LOAD(p) (*(p))
 #define FZ_BLOCK 256
+#define FZ_HW (FZ_BLOCK / 32)              // items (half-waves) of a workgroup
+#define FZ_WG_ROWS (FZ_RC * FZ_HW)         // 256 consecutive rows per workgroup
+#define FZ_STAGE0 128                      // level-0 / level-1 cells of a workgroup whose final blocks are staged in LDS (a workgroup holds
+#define FZ_STAGE1 32                       // ~64 / ~8 of them at four rows per level-0 cell; more than fit are written word by word)
+
+// Round 4 -- where the blocks go.  A cell's block P[c][27] is final as soon as all rows of the cell have been seen.  Rounds 2-3
+// wrote one partial block per 32-row item a cell touches, summed them in a second pass (k_fz_cellsum: 15 % of the cells had two
+// blocks) into a cell-major array and gathered that with one lane per neighbour slot (27 scattered lines per unknown).  Now
+//   * a cell that lies inside ONE workgroup's 256 rows is finished there: blocks of cells that cross an item boundary meet in LDS
+//     at the end of the workgroup and are summed in item order -- only cells whose rows span several workgroups (the coarse ones:
+//     ~1 % of the cells) still go through partial blocks (one per workgroup) + k_fz_cellsum;
+//   * the per-cell sums are stored SLOT-MAJOR, ct[s][c]: the second product's gather then runs with one lane per UNKNOWN,
+//     y_j = sum_s' ct[26 - s'][nbrT[s'][j]] -- 27 coalesced loads of the (slot-major) neighbour table and 27 gathers whose 64
+//     lanes hit a few neighbouring lines (consecutive unknowns have consecutive neighbours) instead of 54.
+// Every summation order is fixed and depends on the rows' position inside their segment only (segments are padded to whole
+// workgroups): deterministic, and a chunk's result does not depend on its batch mates.
 
 // ---- tables ----------------------------------------------------------------------------------------------------------------
 // All they need is row_cells[d][r] (written by nksr_kernel_rows next to the rows): the rows of a cell are one contiguous run.
@@ -43,11 +59,17 @@ __global__ void k_fz_spans(int depth, int64_t rows_total, const int32_t* __restr
     if (r == rows_total - 1 || row_cells[lin + 1] != c) last[c] = (int32_t)r;
 }
 
-// partial blocks of a cell: one per 32-row item its rows touch
+// partial blocks of a cell: one per workgroup (256 rows) its rows touch -- if that is more than one; a cell inside one workgroup
+// has none (the sweep finishes it)
 __global__ void k_fz_block_counts(int M, const int32_t* __restrict__ first, const int32_t* __restrict__ last, int32_t* __restrict__ counts) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > M) return;
-    counts[j] = (j < M && first[j] >= 0) ? last[j] / FZ_RC - first[j] / FZ_RC + 1 : 0;
+    int n = 0;
+    if (j < M && first[j] >= 0) {
+        n = last[j] / FZ_WG_ROWS - first[j] / FZ_WG_ROWS + 1;
+        if (n == 1) n = 0;
+    }
+    counts[j] = n;
 }
 
 __device__ __forceinline__ int fz_level(const nksr_hier_t& h, int j) {
@@ -56,10 +78,10 @@ __device__ __forceinline__ int fz_level(const nksr_hier_t& h, int j) {
     return d;
 }
 
-// nbr32[j][0..26]: global unknown index of the neighbour voxels or -1;  [27]: (first block of j) - (first item of j), so that the
-// block of item i is nbr32[j][27] + i;  [28]: 1 if the cell owns exactly one block
+// nbr32[j][0..26]: global unknown index of the neighbour voxels or -1;  [27]: (first block of j) - (first workgroup of j), so that
+// the block of workgroup w is nbr32[j][27] + w;  [28] / [29]: first / last row of the cell (-1: none)
 __global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__ offsets, const int32_t* __restrict__ first,
-                            int32_t* __restrict__ nbr32) {
+                            const int32_t* __restrict__ last, int32_t* __restrict__ nbr32) {
     const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lin >= (int64_t)M * 32) return;
     const int j = (int)(lin >> 5), s = (int)(lin & 31);
@@ -69,11 +91,27 @@ __global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__
         const int nb = hier.lv[d].nbr[(int64_t)c * 27 + s];
         v = nb >= 0 ? nb + hier.lv[d].offset : -1;
     } else if (s == 27) {
-        v = offsets[j] - (first[j] >= 0 ? first[j] / FZ_RC : 0);
+        v = offsets[j] - (first[j] >= 0 ? first[j] / FZ_WG_ROWS : 0);
     } else if (s == 28) {
-        v = offsets[j + 1] - offsets[j] == 1;     // the cell's only block: the operator writes it straight into the per-cell sums
+        v = first[j];
+    } else if (s == 29) {
+        v = last[j];
     }
     nbr32[lin] = v;
+}
+// nbrT[s][j]: the same neighbour indices slot-major (the gather's table), transposed through LDS 64 unknowns at a time
+__global__ void __launch_bounds__(256) k_fz_nbrT(int M, const int32_t* __restrict__ nbr32, int32_t* __restrict__ nbrT) {
+    __shared__ int32_t tile[64][33];
+    const int j0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+        const int jj = i >> 5, s = i & 31;
+        tile[jj][s] = j0 + jj < M ? nbr32[(int64_t)(j0 + jj) * 32 + s] : -1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+        const int s = i >> 6, jj = i & 63;
+        if (j0 + jj < M) nbrT[(int64_t)s * M + j0 + jj] = tile[jj][s];
+    }
 }
 
 // ---- the operator ----------------------------------------------------------------------------------------------------------
@@ -82,10 +120,11 @@ struct FusedArgs {               // uniform scalars and base pointers only
     const float* targets_all;    // [rows_total]
     const int32_t* row_cells;    // [depth][rows_total]
     const int32_t* nbr32;        // [M][32]
-    const int32_t* offsets;      // [M + 1] blocks of a cell
-    const int32_t* multi;        // cells with more than one block: the n_big cells with more than FZ_BIG blocks first
+    const int32_t* nbrT;         // [27][M]
+    const int32_t* offsets;      // [M + 1] partial blocks of a cell
+    const int32_t* multi;        // cells with partial blocks: the n_big cells with more than FZ_BIG blocks first
     int n_multi, n_big, M, depth;
-    int hw_total;                // half-waves = items, rounded up to whole wavefronts
+    int hw_total;                // half-waves = items, rounded up to whole workgroups
     int64_t rows_total, nblocks;
     unsigned long long* nnz_counter;   // the set-up pass (MODE 1) adds the non-zero slots it sees (may be NULL)
     const int32_t* item_seg;     // [hw_total] segment of every 32-row item, [M] segment of every unknown (batched chunks; may be NULL)
@@ -98,12 +137,16 @@ struct FusedArgs {               // uniform scalars and base pointers only
 __device__ __forceinline__ bool fz_seg_done(const FusedArgs& A, const int32_t* seg_of, int64_t i) {
     return A.seg_done && seg_of && A.seg_done[(int64_t)seg_of[i] * A.seg_stride] != 0;
 }
-// true when the FZ_GI (four) consecutive unknowns i0 .. of this half-wave all belong to finished segments (gated, see seg_gate);
-// `idx` non-NULL: the unknowns are idx[i0 ..] (the cell list of the per-cell sums).  n: valid entries from i0 on.
+__device__ __forceinline__ bool fz_gate_open(const FusedArgs& A) {
+    return A.seg_done && A.unknown_seg && A.seg_done_count && *A.seg_done_count >= A.seg_gate;
+}
+// true when the FZ_GI (four) cells idx[i0 ..] of this half-wave all belong to finished segments (gated, see seg_gate).
+// n: valid entries from i0 on.
+#define FZ_GI 4
 __device__ __forceinline__ bool fz_group_done(const FusedArgs& A, const int32_t* idx, int64_t i0, int n, int lane32, bool upper) {
-    if (!A.seg_done || !A.unknown_seg || !A.seg_done_count || *A.seg_done_count < A.seg_gate) return false;
+    if (!fz_gate_open(A)) return false;
     bool dn = true;
-    if (lane32 < 4 && lane32 < n) {
+    if (lane32 < FZ_GI && lane32 < n) {
         const int64_t j = idx ? idx[i0 + lane32] : i0 + lane32;
         dn = A.seg_done[(int64_t)A.unknown_seg[j] * A.seg_stride] != 0;
     }
@@ -117,35 +160,50 @@ __device__ __forceinline__ int half_lane_i(int v, int l, bool upper) {
 }
 __device__ __forceinline__ float half_lane_f(float v, int l, bool upper) { return __int_as_float(half_lane_i(__float_as_int(v), l, upper)); }
 
-// where the block of the current cell goes: the cell's block base (then block = base + item; the base may be negative) or, in
-// MODE 0 for a cell with a single block, the cell's row of the per-cell sums (direct = true, base = the cell)
-template <int MODE>
-__device__ __forceinline__ int fz_block_base(int nbrow, int cell, bool& direct) {
-    direct = MODE == 0 && __shfl(nbrow, 28, 32) != 0;
-    return direct ? cell : __shfl(nbrow, 27, 32);
-}
-
-// MODE 0: the operator (t from x).  MODE 1: the set-up pass -- right-hand side (t = target) into `part`, Jacobi diagonal
-// (P2 += rows^2) into `part2`, and the count of non-zero slots, all in one sweep over the rows.
+// MODE 0: the operator (t from x).  MODE 1: the set-up pass -- right-hand side (t = target) into ct / part, Jacobi diagonal
+// (P2 += rows^2) into ct2 / part2, and the count of non-zero slots, all in one sweep over the rows.
 // U rows per trip.  Levels < NG (the fine ones, where a cell holds a handful of rows) fetch the stencil of EVERY row (neighbour
 // row, then 27 x values: the loads of a trip go out together, nothing to decide); levels >= NG keep the stencil of their current
 // cell in registers and refresh it on the rare trip that crosses a cell boundary -- that trip is processed in two parts, before
 // and after the refresh.  Which rows change cell / have a cell at all is known up front as two 32-bit masks per level.
 template <int MODE, int D, int U, int NG>
-__global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
-                                                      float* __restrict__ part2, float* __restrict__ cellp, const int* __restrict__ done) {
+__global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 5 : 4))) __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
+                                                      float* __restrict__ part2, float* __restrict__ ct, float* __restrict__ ct2,
+                                                      const int* __restrict__ done) {
     if (done && *done) return;
     constexpr int G = NG < D ? NG : D;                               // levels that gather per row
-    const int item = (blockIdx.x * FZ_BLOCK + threadIdx.x) >> 5;
-    if (item >= A.hw_total) return;                                  // whole wavefronts: hw_total is even
-    const int64_t R0 = (int64_t)item * FZ_RC;
-    const int64_t left = A.rows_total - R0;
-    // (the rows of a segment whose conjugate gradients have finished are skipped: an item lies inside ONE segment -- segments
-    // are padded to whole items -- and a half-wave without rows just idles next to its partner)
-    const int nrows = (MODE == 0 && left > 0 && fz_seg_done(A, A.item_seg, item)) ? 0 : (left >= FZ_RC ? FZ_RC : (left > 0 ? (int)left : 0));
+    // blocks of cells that cross an item boundary inside this workgroup: [item][level][0: the item's first cell, which began before
+    // it / 1: its last cell, which goes on after it] -- summed after the row loop (see below)
+    __shared__ float xv[FZ_HW][D][2][32];
+    __shared__ float xv2[MODE == 1 ? FZ_HW : 1][MODE == 1 ? D : 1][2][32];
+    __shared__ int xm[FZ_HW][D][2];                                  // their cells (-1: no entry; bit 30: the cell ends in that item)
+    __shared__ int xmb[FZ_HW][D][2];                                 // their block bases
+    __shared__ int xbase[FZ_HW][D];                                  // block base of the current cell of every level
+    // final blocks of the workgroup's level-0 / level-1 cells, staged so that they leave slot-major in contiguous runs (lane = cell):
+    // written word by word, 27 different lines per block, the per-cell sums cost the sweep 130 us of partial-line writes
+    constexpr int CAP0 = FZ_STAGE0, CAP1 = D > 1 ? FZ_STAGE1 : 1;
+    __shared__ float st0[CAP0 * 27], st1[CAP1 * 27];
+    __shared__ float st0b[MODE == 1 ? CAP0 * 27 : 1], st1b[MODE == 1 ? CAP1 * 27 : 1];
+    __shared__ int stf[CAP0 + CAP1];
+    for (int i = threadIdx.x; i < CAP0 + CAP1; i += FZ_BLOCK) stf[i] = 0;
+    __syncthreads();
+    const int hwi = threadIdx.x >> 5;
+    const int item = blockIdx.x * FZ_HW + hwi;
+    const int R0 = item * FZ_RC;                                    // (rows_total < 2^31 - 256: row numbers fit an int)
+    const int64_t left = A.rows_total - (int64_t)R0;
+    // (the rows of a segment whose conjugate gradients have finished are skipped: a workgroup lies inside ONE segment -- segments
+    // are padded to whole workgroups -- and a half-wave without rows just idles next to its partner)
+    const int nrows = (item >= A.hw_total || (MODE == 0 && left > 0 && fz_seg_done(A, A.item_seg, item))) ? 0
+                      : (left >= FZ_RC ? FZ_RC : (left > 0 ? (int)left : 0));
+    const int Ra = nrows > 0 ? R0 : 0;                               // (addresses of a half-wave without rows stay inside the arrays)
+    const int W0 = blockIdx.x * FZ_WG_ROWS;
+    // first cell of the staged levels with rows in this workgroup (uniform)
+    const int cw0 = __builtin_amdgcn_readfirstlane((int64_t)W0 < A.rows_total ? A.row_cells[W0] : -1);
+    const int cw1 = __builtin_amdgcn_readfirstlane((D > 1 && (int64_t)W0 < A.rows_total) ? A.row_cells[A.rows_total + W0] : -1);
     const int s = threadIdx.x & 31;
     const bool act = s < 27, upper = (threadIdx.x & 32) != 0;
     const int sh = upper ? 32 : 0;
+    if (s < 2 * D) xm[hwi][s >> 1][s & 1] = -1;
     // the cells (and targets) of the item's rows, one row per lane: a single coalesced load each
     int cells[D];
     unsigned chg[D], pos[D];         // bit l: row l lies in another cell than row l - 1 / lies in a cell at all
@@ -157,12 +215,45 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
         pos[d] = (unsigned)(__ballot(cells[d] >= 0) >> sh);
     }
     const float tg = (MODE == 1 && A.targets_all && s < nrows) ? A.targets_all[R0 + s] : 0.f;
-    int fb[D];                       // block base of the current cell (or the cell itself: direct[d])
-    bool direct[D];
+    // of the current cell of every level only two bits are kept: do its rows start / end inside this item (bits 2 d, 2 d + 1)
+    unsigned inside = 0;
     float P[D], P2[MODE == 1 ? D : 1], xs[D];
     bool have[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) { fb[d] = 0; direct[d] = false; P[d] = 0.f; P2[MODE == 1 ? d : 0] = 0.f; xs[d] = 0.f; have[d] = false; }
+    for (int d = 0; d < D; ++d) { P[d] = 0.f; P2[MODE == 1 ? d : 0] = 0.f; xs[d] = 0.f; have[d] = false; }
+    // nbv: the neighbour row of the cell that becomes current at level d (lanes 28 / 29: its first / last row)
+    auto enter = [&](int d, int nbv) {
+        const int first = __shfl(nbv, 28, 32), last = __shfl(nbv, 29, 32);
+        if (s == 27) xbase[hwi][d] = nbv;
+        inside = (inside & ~(3u << (2 * d))) | ((first >= R0 ? 1u : 0u) << (2 * d)) | ((last < R0 + FZ_RC ? 2u : 0u) << (2 * d));
+    };
+    // the final block of a cell that lies inside this workgroup: staged (levels 0 and 1, while there is room) or written word by word
+    auto finish = [&](int d, int cell, float p, float p2) {
+        const int rel = d == 0 ? cell - cw0 : cell - cw1;
+        if (d == 0 && cw0 >= 0 && (unsigned)rel < (unsigned)CAP0) {
+            if (act) { st0[rel * 27 + s] = p; if (MODE == 1) st0b[MODE == 1 ? rel * 27 + s : 0] = p2; }
+            if (s == 0) stf[rel] = 1;
+        } else if (d == 1 && cw1 >= 0 && (unsigned)rel < (unsigned)CAP1) {
+            if (act) { st1[rel * 27 + s] = p; if (MODE == 1) st1b[MODE == 1 ? rel * 27 + s : 0] = p2; }
+            if (s == 0) stf[CAP0 + rel] = 1;
+        } else if (act) {
+            ct[(int64_t)s * A.M + cell] = p;
+            if (MODE == 1) ct2[(int64_t)s * A.M + cell] = p2;
+        }
+    };
+    // the running block of level d leaves (`cell`: its cell): complete (all rows of the cell lie in this item) -> final; otherwise ->
+    // the workgroup exchange
+    auto emit = [&](int d, int cell, float p, float p2) {
+        const unsigned f = (inside >> (2 * d)) & 3u;
+        if (f == 3u) {
+            finish(d, cell, p, p2);
+        } else {
+            const int k = (int)(f & 1u);
+            xv[hwi][d][k][s] = p;
+            if (MODE == 1) xv2[MODE == 1 ? hwi : 0][MODE == 1 ? d : 0][k][s] = p2;
+            if (s == 0) { xm[hwi][d][k] = cell | ((f & 2u) ? (1 << 30) : 0); xmb[hwi][d][k] = xbase[hwi][d]; }
+        }
+    };
     // coarse levels: the stencils of the item's first row, all levels in one round trip (then one more for x)
     {
         int c0[D], nb0[D];
@@ -177,7 +268,7 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
 #pragma unroll
         for (int d = G; d < D; ++d) {
             have[d] = c0[d] >= 0;
-            fb[d] = fz_block_base<MODE>(nb0[d], c0[d], direct[d]);
+            enter(d, nb0[d]);
             xs[d] = (have[d] && act && nb0[d] >= 0) ? x0[d] : 0.f;
             chg[d] &= ~1u;
         }
@@ -200,15 +291,20 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
             const int v = A.nbr32[(int64_t)(cj >= 0 ? cj : 0) * 32 + s];
             nbn[u][d] = cj >= 0 ? v : -1;
         }
+    // one pointer per level, advanced by U rows per trip: the U rows of a trip are loaded at immediate offsets.  Rows past the item's
+    // last one are read too (the array is padded by 320 rows) and never used: every use below is guarded by the row count.
+    const float* wp[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) wp[d] = A.rows_all + ((int64_t)d * A.rows_total + Ra) * 27 + sc;
     for (int rr = 0; rr < nmax; rr += U) {
         float w[U][D], xg[U][G > 0 ? G : 1];
         int nb[U][G > 0 ? G : 1];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int row = rr + u < nrows ? rr + u : lastrow;
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int d = 0; d < D; ++d) w[u][d] = FZ_ROW_LOAD(A.rows_all + ((int64_t)d * A.rows_total + R0 + row) * 27 + sc);
-        }
+            for (int d = 0; d < D; ++d) w[u][d] = FZ_ROW_LOAD(wp[d] + u * 27);
+#pragma unroll
+        for (int d = 0; d < D; ++d) wp[d] += U * 27;
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -229,14 +325,14 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const bool ok = rr + u < nrows && act;
+            // (MODE 0: lanes 27.. hold a copy of slot 26 and rows past the item's end hold whatever follows -- both harmless: x is 0 in
+            // those lanes, and nothing of a row past the end is accumulated)
 #pragma unroll
-            for (int d = 0; d < D; ++d) w[u][d] = ok ? w[u][d] : 0.f;
-#pragma unroll
-            for (int d = 0; d < G; ++d) xg[u][d] = (ok && nb[u][d] >= 0) ? xg[u][d] : 0.f;
+            for (int d = 0; d < G; ++d) xg[u][d] = (act && nb[u][d] >= 0) ? xg[u][d] : 0.f;
             if (MODE == 1) {
+                const bool ok = rr + u < nrows && act;
 #pragma unroll
-                for (int d = 0; d < D; ++d) nnz += w[u][d] != 0.f ? 1 : 0;
+                for (int d = 0; d < D; ++d) { w[u][d] = ok ? w[u][d] : 0.f; nnz += w[u][d] != 0.f ? 1 : 0; }
             }
         }
         // rows of the trip that cross a cell boundary of a level >= NG: the trip is cut there
@@ -251,14 +347,14 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
 #pragma unroll
                 for (int d = G; d < D; ++d)
                     if ((chg[d] >> (rr + from)) & 1u) {
-                        if (have[d]) { (direct[d] ? cellp + (int64_t)fb[d] * 32 : part + ((int64_t)fb[d] + item) * 32)[s] = P[d]; if (MODE == 1) part2[((int64_t)fb[d] + item) * 32 + s] = P2[d]; }
+                        if (have[d]) emit(d, __shfl(cells[d], (rr + from - 1) & 31, 32), P[d], P2[MODE == 1 ? d : 0]);
                         P[d] = 0.f;
                         if (MODE == 1) P2[d] = 0.f;
                         xs[d] = 0.f;
                         have[d] = (pos[d] >> (rr + from)) & 1u;
                         if (have[d]) {
                             const int nbv = A.nbr32[(int64_t)__shfl(cells[d], (rr + from) & 31, 32) * 32 + s];      // `from` differs between the halves: no scalar lane read here
-                            fb[d] = fz_block_base<MODE>(nbv, __shfl(cells[d], (rr + from) & 31, 32), direct[d]);
+                            enter(d, nbv);
                             if (MODE == 0 && act && nbv >= 0) xs[d] = x[nbv];
                         }
                     }
@@ -294,11 +390,11 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
                     if (d < G && in && ((chg[d] >> (rr + u)) & 1u)) {      // fine levels: the block leaves with its cell
-                        if (have[d]) { (direct[d] ? cellp + (int64_t)fb[d] * 32 : part + ((int64_t)fb[d] + item) * 32)[s] = P[d]; if (MODE == 1) part2[((int64_t)fb[d] + item) * 32 + s] = P2[d]; }
+                        if (have[d]) emit(d, half_lane_i(cells[d], (rr + u - 1) & 31, upper), P[d], P2[MODE == 1 ? d : 0]);
                         P[d] = 0.f;
                         if (MODE == 1) P2[d] = 0.f;
                         have[d] = (pos[d] >> (rr + u)) & 1u;
-                        if (have[d]) fb[d] = fz_block_base<MODE>(nb[u][d < G ? d : 0], half_lane_i(cells[d], (rr + u) & 31, upper), direct[d]);
+                        if (have[d]) enter(d, nb[u][d < G ? d : 0]);
                     }
                     if (in && have[d]) {
                         P[d] = fmaf(w[u][d], t[u], P[d]);
@@ -312,31 +408,81 @@ __global__ void __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float*
     }
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        if (have[d]) { (direct[d] ? cellp + (int64_t)fb[d] * 32 : part + ((int64_t)fb[d] + item) * 32)[s] = P[d]; if (MODE == 1) part2[((int64_t)fb[d] + item) * 32 + s] = P2[d]; }
+        if (have[d]) emit(d, __shfl(cells[d], lastrow, 32), P[d], P2[MODE == 1 ? d : 0]);
     if (MODE == 1 && A.nnz_counter) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o);
         if ((threadIdx.x & 63) == 0 && nnz) atomicAdd(A.nnz_counter, (unsigned long long)nnz);           // integer: order-free
     }
+    // ---- cells that cross item boundaries inside this workgroup: the item in which the cell ends (or the workgroup's last item)
+    // adds the pieces in item order.  A cell that lies inside the workgroup is final; one that reaches into other workgroups leaves
+    // one partial block per workgroup (k_fz_cellsum adds those).
+    // ---- cells that cross item boundaries inside this workgroup: the item in which the cell ends (or the workgroup's last item)
+    // adds the pieces in item order.  A cell that lies inside the workgroup is final; one that reaches into other workgroups leaves
+    // one partial block per workgroup (k_fz_cellsum adds those).  Everything is decided from the exchange in LDS: the cell of item
+    // h - 1 is the same cell <=> ids match; a cell began in the item that holds it as its LAST cell (entry 1).
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = xm[hwi][d][k];
+            if (e < 0) continue;
+            const int c = e & ~(1 << 30);
+            const bool ends = (e >> 30) & 1;
+            if (!(ends || hwi == FZ_HW - 1)) continue;
+            int h0 = hwi;
+            bool started = k == 1;
+            while (!started && h0 > 0) {
+                --h0;
+                started = (xm[h0][d][1] & ~(1 << 30)) == c && xm[h0][d][1] >= 0;
+            }
+            float acc = 0.f, acc2 = 0.f;
+            for (int h = h0; h <= hwi; ++h) {
+                const int kk = (h == h0 && started) ? 1 : 0;
+                acc += xv[h][d][kk][s];
+                if (MODE == 1) acc2 += xv2[MODE == 1 ? h : 0][MODE == 1 ? d : 0][kk][s];
+            }
+            if (started && ends) {
+                finish(d, c, acc, acc2);
+            } else {
+                const int base = xmb[hwi][d][k];
+                part[((int64_t)base + blockIdx.x) * 32 + s] = acc;
+                if (MODE == 1) part2[((int64_t)base + blockIdx.x) * 32 + s] = acc2;
+            }
+        }
+    // ---- the staged blocks leave slot-major: lane = cell, 27 stores of contiguous runs
+    __syncthreads();
+    {
+        const int t = threadIdx.x;
+        const bool l0 = t < CAP0, l1 = !l0 && t < CAP0 + CAP1;
+        if ((l0 || l1) && stf[t]) {
+            const float* src = l0 ? st0 + t * 27 : st1 + (t - CAP0) * 27;
+            const float* srcb = MODE == 1 ? (l0 ? st0b + t * 27 : st1b + (t - CAP0) * 27) : nullptr;
+            float* dst = ct + (l0 ? cw0 + t : cw1 + (t - CAP0));
+            float* dstb = MODE == 1 ? ct2 + (l0 ? cw0 + t : cw1 + (t - CAP0)) : nullptr;
+#pragma unroll
+            for (int q = 0; q < 27; ++q) {
+                dst[(int64_t)q * A.M] = src[q];
+                if (MODE == 1) dstb[(int64_t)q * A.M] = srcb[q];
+            }
+        }
+    }
 }
 
-// C[c][s] = sum of the partial blocks of cell c (one block per 32-row item the cell's rows touch: mostly one, hundreds for a
-// coarse cell), so that the gather below reads exactly one block per neighbour.  LIST: only the cells with more than one block
-// (A.multi) -- inside the operator the sweep writes single-block cells straight into C.  A half-wave takes FOUR cells at once
+// ct[s][c] = sum of the partial blocks of cell c (one per workgroup of the sweep its rows reach into: the cells of A.multi --
+// coarse cells, hundreds of blocks each; cells inside one workgroup never get here).  A half-wave takes FOUR cells at once
 // (lane = slot): the pass is latency-bound, the first two blocks of the four cells are requested together.  Fixed order.
-#define FZ_GI 4
-template <bool LIST>
-__global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __restrict__ part, float* __restrict__ cellp,
+__global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __restrict__ part, float* __restrict__ ct,
                                                    const int* __restrict__ done) {
     if (done && *done) return;
     const int s = threadIdx.x & 31;
-    if (LIST && (int)blockIdx.x < A.n_big) {
+    if ((int)blockIdx.x < A.n_big) {
         // a coarse cell with many blocks (A.multi[0 .. n_big)): the whole workgroup sums it -- half-wave h takes blocks h, h + 8, ...
         // (one serial chain over hundreds of blocks was the critical path of the pass), then the eight partial sums in order
         __shared__ float partial[8][32];
         const int cell = A.multi[blockIdx.x], h = threadIdx.x >> 5;
-        if (A.seg_done && A.unknown_seg && A.seg_done_count && *A.seg_done_count >= A.seg_gate &&
-            A.seg_done[(int64_t)A.unknown_seg[cell] * A.seg_stride] != 0) return;          // uniform over the workgroup
+        if (fz_gate_open(A) && A.seg_done[(int64_t)A.unknown_seg[cell] * A.seg_stride] != 0) return;          // uniform over the workgroup
         const int b0 = A.offsets[cell], n = A.offsets[cell + 1] - b0;
         const float* p = part + (int64_t)(b0 + h) * 32 + s;
         float acc = 0.f;
@@ -345,24 +491,21 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
         for (; b < n; b += 8, p += 256) acc += p[0];
         partial[h][s] = acc;
         __syncthreads();
-        if (h == 0) {
+        if (h == 0 && s < 27) {
             float t = partial[0][s];
 #pragma unroll
             for (int k = 1; k < 8; ++k) t += partial[k][s];
-            cellp[(int64_t)cell * 32 + s] = t;
+            ct[(int64_t)s * A.M + cell] = t;
         }
         return;
     }
-    const int first = LIST ? A.n_big : 0, ncell = (LIST ? A.n_multi : A.M) - first;
-    const int i0 = (((LIST ? (int)blockIdx.x - A.n_big : (int)blockIdx.x) * 256 + (int)threadIdx.x) >> 5) * FZ_GI;
+    const int first = A.n_big, ncell = A.n_multi - first;
+    const int i0 = ((((int)blockIdx.x - A.n_big) * 256 + (int)threadIdx.x) >> 5) * FZ_GI;
     if (i0 >= ncell) return;
-    if (fz_group_done(A, LIST ? A.multi + first : nullptr, i0, ncell - i0, s, (threadIdx.x & 32) != 0)) return;
+    if (fz_group_done(A, A.multi + first, i0, ncell - i0, s, (threadIdx.x & 32) != 0)) return;
     int cell[FZ_GI], b0[FZ_GI], n[FZ_GI];
 #pragma unroll
-    for (int k = 0; k < FZ_GI; ++k) {
-        const int i = first + (i0 + k < ncell ? i0 + k : ncell - 1);
-        cell[k] = LIST ? A.multi[i] : i;
-    }
+    for (int k = 0; k < FZ_GI; ++k) cell[k] = A.multi[first + (i0 + k < ncell ? i0 + k : ncell - 1)];
 #pragma unroll
     for (int k = 0; k < FZ_GI; ++k) {
         b0[k] = A.offsets[cell[k]];
@@ -381,50 +524,59 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
         int b = 2;
         for (; b + 4 <= n[k]; b += 4, p += 128) acc[k] += (p[0] + p[32]) + (p[64] + p[96]);
         for (; b < n[k]; ++b, p += 32) acc[k] += p[0];
-        if (i0 + k < ncell) cellp[(int64_t)cell[k] * 32 + s] = acc[k];
+        if (i0 + k < ncell && s < 27) ct[(int64_t)s * A.M + cell[k]] = acc[k];
     }
 }
 
-// y_j = (MODE 0: reg x_j, 1: 0, 2: reg) + sum over the 27 neighbour cells c of j:  C[c][26 - s']
-// A half-wave takes four consecutive unknowns, lane = neighbour slot; one transposing butterfly sums the four.  Workgroups are
-// dealt to the XCDs round-robin by the hardware: workgroup 8 i + k takes the i-th group of the k-th EIGHTH of the unknowns, so
-// that an XCD's L2 holds one contiguous (Morton-ordered) part of C instead of every XCD fetching all of it.
+// y_j = (MODE 0: reg x_j, 1: 0, 2: reg) + sum over the 27 neighbour cells c = nbrT[s'][j] of j:  ct[26 - s'][c]
+// One lane per unknown: the 27 table loads are coalesced, the 27 gathers of 64 consecutive unknowns hit a few neighbouring lines
+// each (consecutive unknowns have consecutive neighbours).  Fixed summation tree.  Workgroups are dealt to the XCDs round-robin by
+// the hardware: workgroup 8 i + k takes the i-th group of the k-th EIGHTH of the unknowns, so that an XCD's L2 holds one contiguous
+// (Morton-ordered) part of ct instead of every XCD fetching all of it.
 template <int MODE>
-__global__ void __launch_bounds__(256) k_fz_gather(FusedArgs A, int per_xcd, const float* __restrict__ cellp, const float* __restrict__ x,
+__global__ void __launch_bounds__(256) k_fz_gather(FusedArgs A, int per_xcd, const float* __restrict__ ct, const float* __restrict__ x,
                                                   float reg, float* __restrict__ y, const int* __restrict__ done) {
     if (done && *done) return;
     const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
-    const int local = (grp * 8 + (threadIdx.x >> 5)) * FZ_GI;        // first unknown of this half-wave inside its eighth
+    const int local = grp * 256 + threadIdx.x;
     if (local >= per_xcd) return;
-    const int j0 = xcd * per_xcd + local;
-    if (j0 >= A.M) return;
-    const int sp = threadIdx.x & 31;
-    if (fz_group_done(A, nullptr, j0, A.M - j0, sp, (threadIdx.x & 32) != 0)) return;
-    int c[FZ_GI];
+    const int j = xcd * per_xcd + local;
+    if (j >= A.M) return;
+    if (fz_gate_open(A) && A.seg_done[(int64_t)A.unknown_seg[j] * A.seg_stride] != 0) return;
+    int c[27];
 #pragma unroll
-    for (int k = 0; k < FZ_GI; ++k) c[k] = (sp < 27 && j0 + k < A.M) ? A.nbr32[(int64_t)(j0 + k) * 32 + sp] : -1;
-    float v[FZ_GI];
+    for (int k = 0; k < 27; ++k) c[k] = A.nbrT[(int64_t)k * A.M + j];
+    float v[27];
 #pragma unroll
-    for (int k = 0; k < FZ_GI; ++k) v[k] = c[k] >= 0 ? cellp[(int64_t)c[k] * 32 + (26 - sp)] : 0.f;
-    const float r = half_sum4(v[0], v[1], v[2], v[3], sp);           // lanes 8 k .. 8 k + 7 hold the total of unknown k
-    const int k = sp >> 3;
-    if ((sp & 7) == 0 && j0 + k < A.M) y[j0 + k] = r + (MODE == 0 ? reg * x[j0 + k] : (MODE == 2 ? reg : 0.f));
+    for (int k = 0; k < 27; ++k) v[k] = ct[(int64_t)(26 - k) * A.M + (c[k] >= 0 ? c[k] : 0)];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) v[k] = c[k] >= 0 ? v[k] : 0.f;
+    // fixed tree: 27 -> 9 -> 3 -> 1
+    float r9[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r9[k] = (v[3 * k] + v[3 * k + 1]) + v[3 * k + 2];
+    const float r = ((r9[0] + r9[1]) + r9[2]) + ((r9[3] + r9[4]) + r9[5]) + ((r9[6] + r9[7]) + r9[8]);
+    y[j] = r + (MODE == 0 ? reg * x[j] : (MODE == 2 ? reg : 0.f));
 }
 static void fz_gather_dims(int M, dim3& grid, int& per_xcd) {
-    per_xcd = ((M + 7) / 8 + 8 * FZ_GI - 1) / (8 * FZ_GI) * (8 * FZ_GI);        // whole workgroups (8 half-waves x FZ_GI unknowns)
-    grid = dim3((unsigned)(per_xcd / (8 * FZ_GI) * 8));
+    per_xcd = ((M + 7) / 8 + 255) / 256 * 256;                       // whole workgroups
+    grid = dim3((unsigned)(per_xcd / 256 * 8));
 }
 
 static size_t fz_align(size_t v) { return (v + 255) / 256 * 256; }
 
-struct FusedWork { float* part; float* part2; float* cellp; };   // [nblocks][32] partial blocks (x 2: the set-up pass makes two), [M][32] per-cell sums
+// workspace: [nblocks][32] partial blocks (x 2: the set-up pass makes two) + the set-up pass's second slot-major array [27][M]
+struct FusedWork { float* part; float* part2; float* ct; float* ct2; };
 static size_t fz_blocks_bytes(int64_t nblocks) { return fz_align((size_t)(nblocks > 0 ? nblocks : 1) * 32 * sizeof(float)); }
-extern "C" size_t nksr_fused_workspace_bytes(int64_t nblocks) { return 2 * fz_blocks_bytes(nblocks); }
+extern "C" size_t nksr_fused_workspace_bytes(int64_t nblocks, int32_t M) {
+    return 2 * fz_blocks_bytes(nblocks) + fz_align((size_t)(M > 0 ? M : 1) * 27 * sizeof(float));
+}
 static FusedWork fz_carve(const nksr_fused_op_t* op) {
     FusedWork w;
     w.part = (float*)op->workspace;
     w.part2 = (float*)((char*)op->workspace + fz_blocks_bytes(op->nblocks));
-    w.cellp = op->cell_sums;
+    w.ct2 = (float*)((char*)op->workspace + 2 * fz_blocks_bytes(op->nblocks));
+    w.ct = op->cell_sums;
     return w;
 }
 
@@ -432,7 +584,7 @@ extern "C" int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_to
                                        int32_t* counts_out, void* stream) {
     if (depth < 1 || depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", depth);
     if (M <= 0) return NKSR_OK;
-    if (rows_total < 0 || rows_total >= ((int64_t)1 << 31) - 64) return nksr_set_error(NKSR_ERR_CAPACITY, "too many kernel rows");
+    if (rows_total < 0 || rows_total >= ((int64_t)1 << 31) - FZ_WG_ROWS) return nksr_set_error(NKSR_ERR_CAPACITY, "too many kernel rows");
     if (!span_out || !counts_out || (rows_total > 0 && !row_cells)) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
     hipStream_t st = (hipStream_t)stream;
     NKSR_CHECK_HIP(hipMemsetAsync(span_out, 0xFF, (size_t)2 * M * sizeof(int32_t), st));
@@ -444,12 +596,14 @@ extern "C" int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_to
     return NKSR_OK;
 }
 
-extern "C" int nksr_fused_tables(const nksr_hier_t* h, const int32_t* offsets, const int32_t* span, int32_t* nbr32_out, void* stream) {
+extern "C" int nksr_fused_tables(const nksr_hier_t* h, const int32_t* offsets, const int32_t* span, int32_t* nbr32_out, int32_t* nbrT_out,
+                                 void* stream) {
     if (!h || h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad hierarchy");
     const int M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
     if (M <= 0) return NKSR_OK;
-    if (!offsets || !span || !nbr32_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
-    hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)M * 32, 256)), dim3(256), 0, (hipStream_t)stream, *h, M, offsets, span, nbr32_out);
+    if (!offsets || !span || !nbr32_out || !nbrT_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)M * 32, 256)), dim3(256), 0, (hipStream_t)stream, *h, M, offsets, span, span + M, nbr32_out);
+    hipLaunchKernelGGL(k_fz_nbrT, dim3(nksr_blocks(M, 64)), dim3(256), 0, (hipStream_t)stream, M, (const int32_t*)nbr32_out, nbrT_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -457,19 +611,19 @@ extern "C" int nksr_fused_tables(const nksr_hier_t* h, const int32_t* offsets, c
 static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
     if (!op) return nksr_set_error(NKSR_ERR_ARG, "operator is NULL");
     if (op->depth < 1 || op->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", op->depth);
-    if (op->M > 0 && (!op->rows_all || !op->row_cells || !op->nbr32 || !op->offsets || !op->workspace || !op->cell_sums ||
+    if (op->M > 0 && (!op->rows_all || !op->row_cells || !op->nbr32 || !op->nbrT || !op->offsets || !op->workspace || !op->cell_sums ||
                       (op->n_multi > 0 && !op->multi) || op->n_big < 0 || op->n_big > op->n_multi))
         return nksr_set_error(NKSR_ERR_ARG, "operator has NULL arrays");
-    if (op->rows_total < 0 || op->rows_total >= ((int64_t)1 << 31) - 64 || op->nblocks >= ((int64_t)1 << 31) - ((int64_t)1 << 26))
+    if (op->rows_total < 0 || op->rows_total >= ((int64_t)1 << 31) - FZ_WG_ROWS || op->nblocks >= ((int64_t)1 << 31) - ((int64_t)1 << 26))
         return nksr_set_error(NKSR_ERR_CAPACITY, "operator too large");
     memset(&A, 0, sizeof(A));
-    A.rows_all = op->rows_all; A.targets_all = op->targets_all; A.row_cells = op->row_cells; A.nbr32 = op->nbr32; A.offsets = op->offsets;
+    A.rows_all = op->rows_all; A.targets_all = op->targets_all; A.row_cells = op->row_cells; A.nbr32 = op->nbr32; A.nbrT = op->nbrT; A.offsets = op->offsets;
     A.multi = op->multi; A.n_multi = op->n_multi; A.n_big = op->n_big;
     A.M = op->M; A.depth = op->depth; A.rows_total = op->rows_total; A.nblocks = op->nblocks;
     A.nnz_counter = (unsigned long long*)op->nnz_counter;
     A.item_seg = op->item_seg; A.unknown_seg = op->unknown_seg;
     const int64_t items = (op->rows_total + FZ_RC - 1) / FZ_RC;
-    A.hw_total = (int)((items + 1) / 2 * 2);
+    A.hw_total = (int)items;
     return NKSR_OK;
 }
 
@@ -479,33 +633,37 @@ static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
 #define FZ_GATHER_LEVELS 1
 
 template <int MODE, int U, int NG>
-static void fz_sweep_v(const FusedArgs& A, const float* x, float* part, float* part2, float* cellp, const int* done, hipStream_t st) {
-    const dim3 grid(nksr_blocks((int64_t)A.hw_total * 32, FZ_BLOCK)), blk(FZ_BLOCK);
+static void fz_sweep_v(const FusedArgs& A, const float* x, const FusedWork& w, const int* done, hipStream_t st) {
+    const dim3 grid(nksr_blocks((int64_t)A.hw_total, FZ_HW)), blk(FZ_BLOCK);
     switch (A.depth) {
-        case 1: hipLaunchKernelGGL((k_fz_sweep<MODE, 1, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
-        case 2: hipLaunchKernelGGL((k_fz_sweep<MODE, 2, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
-        case 3: hipLaunchKernelGGL((k_fz_sweep<MODE, 3, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
-        case 4: hipLaunchKernelGGL((k_fz_sweep<MODE, 4, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
-        case 5: hipLaunchKernelGGL((k_fz_sweep<MODE, 5, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
-        default: hipLaunchKernelGGL((k_fz_sweep<MODE, 6, U, NG>), grid, blk, 0, st, A, x, part, part2, cellp, done); break;
+        case 1: hipLaunchKernelGGL((k_fz_sweep<MODE, 1, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 2: hipLaunchKernelGGL((k_fz_sweep<MODE, 2, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 3: hipLaunchKernelGGL((k_fz_sweep<MODE, 3, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 4: hipLaunchKernelGGL((k_fz_sweep<MODE, 4, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 5: hipLaunchKernelGGL((k_fz_sweep<MODE, 5, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        default: hipLaunchKernelGGL((k_fz_sweep<MODE, 6, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
     }
 }
 
 template <int MODE>
-static void fz_sweep(const FusedArgs& A, const float* x, float* part, float* part2, float* cellp, const int* done, hipStream_t st) {
+static void fz_sweep(const FusedArgs& A, const float* x, const FusedWork& w, const int* done, hipStream_t st) {
     if (A.hw_total <= 0) return;
-    fz_sweep_v<MODE, FZ_ROWS_PER_TRIP, FZ_GATHER_LEVELS>(A, x, part, part2, cellp, done, st);
+    fz_sweep_v<MODE, FZ_ROWS_PER_TRIP, FZ_GATHER_LEVELS>(A, x, w, done, st);
+}
+
+static void fz_cellsum(const FusedArgs& A, const float* part, float* ct, const int* done, hipStream_t st) {
+    if (A.n_multi > 0)
+        hipLaunchKernelGGL(k_fz_cellsum, dim3(A.n_big + nksr_blocks(((int64_t)(A.n_multi - A.n_big) + FZ_GI - 1) / FZ_GI * 32, 256)), dim3(256), 0, st, A,
+                           part, ct, done);
 }
 
 static int fz_apply(const FusedArgs& A, float reg, const FusedWork& w, const float* x, float* y, const int* done, hipStream_t st) {
     dim3 gg;
     int per_xcd;
     fz_gather_dims(A.M, gg, per_xcd);
-    fz_sweep<0>(A, x, w.part, nullptr, w.cellp, done, st);
-    if (A.n_multi > 0)
-        hipLaunchKernelGGL(k_fz_cellsum<true>, dim3(A.n_big + nksr_blocks(((int64_t)(A.n_multi - A.n_big) + FZ_GI - 1) / FZ_GI * 32, 256)), dim3(256), 0, st, A,
-                           (const float*)w.part, w.cellp, done);
-    hipLaunchKernelGGL((k_fz_gather<0>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.cellp, x, reg, y, done);
+    fz_sweep<0>(A, x, w, done, st);
+    fz_cellsum(A, w.part, w.ct, done, st);
+    hipLaunchKernelGGL((k_fz_gather<0>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.ct, x, reg, y, done);
     return NKSR_OK;
 }
 
@@ -524,7 +682,6 @@ extern "C" int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* 
     if (A.M <= 0) return NKSR_OK;
     const FusedWork w = fz_carve(op);
     hipStream_t st = (hipStream_t)stream;
-    const dim3 gm(nksr_blocks(((int64_t)A.M + FZ_GI - 1) / FZ_GI * 32, 256));
     dim3 gg;
     int per_xcd;
     fz_gather_dims(A.M, gg, per_xcd);
@@ -532,16 +689,17 @@ extern "C" int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* 
     const int* nod = nullptr;
     if (b_out && !A.targets_all) return nksr_set_error(NKSR_ERR_ARG, "targets_all is NULL");
     if (!b_out && !diag_out) return NKSR_OK;
-    // one sweep over the rows makes the blocks of both (and counts the stored entries)
+    // one sweep over the rows makes the per-cell sums of both (and counts the stored entries); cells without rows keep their zeros
     if (A.nnz_counter) (void)hipMemsetAsync(A.nnz_counter, 0, sizeof(unsigned long long), st);
-    fz_sweep<1>(A, nof, w.part, w.part2, nullptr, nod, st);
+    NKSR_CHECK_HIP(hipMemsetAsync(w.ct2, 0, (size_t)A.M * 27 * sizeof(float), st));
+    fz_sweep<1>(A, nof, w, nod, st);
     if (b_out) {
-        hipLaunchKernelGGL(k_fz_cellsum<false>, gm, dim3(256), 0, st, A, (const float*)w.part, w.cellp, nod);
-        hipLaunchKernelGGL((k_fz_gather<1>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.cellp, nof, reg, b_out, nod);
+        fz_cellsum(A, w.part, w.ct, nod, st);
+        hipLaunchKernelGGL((k_fz_gather<1>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.ct, nof, reg, b_out, nod);
     }
     if (diag_out) {
-        hipLaunchKernelGGL(k_fz_cellsum<false>, gm, dim3(256), 0, st, A, (const float*)w.part2, w.cellp, nod);
-        hipLaunchKernelGGL((k_fz_gather<2>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.cellp, nof, reg, diag_out, nod);
+        fz_cellsum(A, w.part2, w.ct2, nod, st);
+        hipLaunchKernelGGL((k_fz_gather<2>), gg, dim3(256), 0, st, A, per_xcd, (const float*)w.ct2, nof, reg, diag_out, nod);
     }
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
@@ -562,15 +720,16 @@ struct FusedOperator : PcgOperator {
         // Algorithmic minimum of the matrix-free operator: every STORED entry of G and Q once (4 bytes:
         // the value; stored = the non-zero slots, counted by the set-up pass), the row -> cell map (4 bytes per row and level: the
         // only per-row index), one 27-entry stencil per cell (the column information, 108 bytes) and x, y once.
-        // Physical: every dense slot once (zeros included), the row -> cell map, partial blocks written + read, one neighbour
-        // row per block (sweep), the per-cell sums written + read and one neighbour row per unknown (gather), x and y.
+        // Physical: every dense slot once (zeros included), the row -> cell map, one 128-byte neighbour row per cell (sweep), the
+        // slot-major per-cell sums written + read and the slot-major neighbour table (gather: 3 x 108 bytes per unknown), the
+        // partial blocks of the cells that span workgroups written + read, x and y (+ x again for reg x).
         // SURVEY.md section 8d's formula prices an index per entry and both products: 2 x 8 bytes per stored entry + 12 M + 4.
         const double slots = 27.0 * A.depth * (double)A.rows_total;
         unsigned long long nnz = 0;                                  // (only reached with nksr_pcg_profile on, after a stream sync)
         if (A.nnz_counter) (void)hipMemcpy(&nnz, A.nnz_counter, sizeof(nnz), hipMemcpyDeviceToHost);
         const double stored = nnz > 0 ? (double)nnz : slots;
         *alg = 4.0 * stored + 4.0 * A.depth * (double)A.rows_total + (108.0 + 8.0) * A.M + 4.0;
-        *phys = 4.0 * slots + 4.0 * A.depth * (double)A.rows_total + 3.0 * 128.0 * (double)A.nblocks + (3.0 * 128.0 + 8.0 + 12.0) * A.M;
+        *phys = 4.0 * slots + 4.0 * A.depth * (double)A.rows_total + 2.0 * 128.0 * (double)A.nblocks + (128.0 + 3.0 * 108.0 + 12.0) * A.M;
         *survey = 2.0 * 8.0 * stored + 12.0 * A.M + 4.0;
     }
 };

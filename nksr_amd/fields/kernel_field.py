@@ -387,18 +387,18 @@ class KernelField(BaseField):
             ncomp_site = torch.cat([torch.full((n,), sp[5], dtype=torch.int32, device=dev) for n, sp in zip(counts_s, specs)])
             first_row = ops.exclusive_sum_i32(torch.cat([ncomp_site[order], ncomp_site.new_zeros(1)]))       # [nsite + 1]
             if segments is not None:
-                # every segment's rows start on a work-item boundary (32 rows): the partial blocks of a cell -- and with them every
-                # summation order of the operator -- are then the same whether the segment is solved alone or with others.
-                # Pad rows have no cell (row_cells = -1) and zero values.
+                # every segment's rows start on a workgroup boundary of the sweep (256 rows): which cells meet in a workgroup, the partial
+                # blocks of the others -- and with them every summation order of the operator -- are then the same whether the
+                # segment is solved alone or with others.  Pad rows have no cell (row_cells = -1) and zero values.
                 sb = torch.searchsorted(ks_all, torch.cat([segments.key_lo, segments.key_hi[-1:]]))            # site bounds [nseg + 1]
                 sb[-1] = nsite
                 rb = first_row[sb].long()                                                                       # unpadded row bounds
                 rows_seg = rb[1:] - rb[:-1]
-                pad = (-rows_seg) % 32
+                pad = (-rows_seg) % 256
                 pad_before = torch.cumsum(pad, 0) - pad
                 first_row = first_row[:nsite] + pad_before[segments.of_keys(ks_all)].to(torch.int32)
                 ends = rb[1:] + pad_before                                                                      # first pad row of every segment
-                pad_rows = (ends[:, None] + torch.arange(31, device=dev)[None])[torch.arange(31, device=dev)[None] < pad[:, None]]
+                pad_rows = (ends[:, None] + torch.arange(255, device=dev)[None])[torch.arange(255, device=dev)[None] < pad[:, None]]
                 rows_total = rows_total + int(pad.sum().item())
                 # segment of every 32-row work item (the solve skips the items of converged segments)
                 item_start = (rb[:-1] + pad_before) // 32
@@ -409,7 +409,7 @@ class KernelField(BaseField):
             row_of_site[order] = first_row
             row_index = list(torch.split(row_of_site, counts_s))
         td = _tick('_', time.perf_counter())
-        pad = 64 * 27      # (the operator's loads are unconditional: the last wavefront reads up to 63 rows past the end)
+        pad = 320 * 27     # (the operator's loads are unconditional: the last workgroup reads up to 255 + 63 rows past the end)
         rows_all = torch.empty(L * rows_total * 27 + pad, dtype=torch.float32, device=dev)
         rows_all[L * rows_total * 27:].zero_()
         row_cells = torch.empty((L, rows_total), dtype=torch.int32, device=dev)
@@ -432,21 +432,23 @@ class KernelField(BaseField):
                 targets_all[(ri.long()[:, None] + torch.arange(ncomp, device=dev)[None]).reshape(-1)] = tgt.reshape(-1)
             keep += [xs, ri]
         td = _tick('op:kernel_rows', td)
-        # work items = runs of 32 rows; a cell owns one partial block per item its rows touch
+        # work items = runs of 32 rows, eight of them a workgroup of the sweep; a cell whose rows lie inside one workgroup is finished
+        # there, a cell that reaches into k > 1 workgroups owns k partial blocks (the coarse cells: ~1 % of all)
         span = torch.empty((2, M), dtype=torch.int32, device=dev)
         counts = torch.empty(M + 1, dtype=torch.int32, device=dev)
         call('nksr_fused_block_counts', L, M, rows_total, ptr(row_cells), ptr(span), ptr(counts), stream())
         offsets = ops.exclusive_sum_i32(counts)
         nbr32 = torch.empty((M, 32), dtype=torch.int32, device=dev)
-        call('nksr_fused_tables', C.byref(self._hier), ptr(offsets), ptr(span), ptr(nbr32), stream())
+        nbrT = torch.empty((27, M), dtype=torch.int32, device=dev)
+        call('nksr_fused_tables', C.byref(self._hier), ptr(offsets), ptr(span), ptr(nbr32), ptr(nbrT), stream())
         big = torch.nonzero(counts[:M] > 16).reshape(-1).to(torch.int32)          # coarse cells: a workgroup each in the per-cell sum
         multi = torch.cat([big, torch.nonzero((counts[:M] > 1) & (counts[:M] <= 16)).reshape(-1).to(torch.int32)])
         nblocks = int(offsets[M].item())
-        ws = torch.empty(int(_lib.lib.nksr_fused_workspace_bytes(nblocks)), dtype=torch.uint8, device=dev)
-        cell_sums = torch.zeros((M, 32), dtype=torch.float32, device=dev)
+        ws = torch.empty(int(_lib.lib.nksr_fused_workspace_bytes(nblocks, M)), dtype=torch.uint8, device=dev)
+        cell_sums = torch.zeros((27, M), dtype=torch.float32, device=dev)
         op = FusedOpT()
         op.depth, op.M, op.n_multi, op.n_big, op.rows_total, op.nblocks = L, M, int(multi.numel()), int(big.numel()), rows_total, nblocks
-        op.rows_all, op.targets_all, op.row_cells, op.nbr32 = ptr(rows_all), ptr(targets_all), ptr(row_cells), ptr(nbr32)
+        op.rows_all, op.targets_all, op.row_cells, op.nbr32, op.nbrT = ptr(rows_all), ptr(targets_all), ptr(row_cells), ptr(nbr32), ptr(nbrT)
         op.offsets, op.multi, op.workspace, op.cell_sums = ptr(offsets), (ptr(multi) if multi.numel() else None), ptr(ws), ptr(cell_sums)
         # SURVEY.md section 8d counts the operator's bytes per STORED entry; the dense-slot rows hold structural zeros (absent
         # neighbours, B-spline support ends): the set-up pass counts the non-zero slots on its way (read back on demand)
@@ -455,7 +457,7 @@ class KernelField(BaseField):
         if item_seg is not None:
             op.item_seg, op.unknown_seg = ptr(item_seg), ptr(segments.unknown_seg)
             keep += [item_seg, segments.unknown_seg]
-        keep += [nbr32, offsets, multi, ws, cell_sums, nnz_counter]
+        keep += [nbr32, nbrT, offsets, multi, ws, cell_sums, nnz_counter]
         td = _tick('op:tables', td)
         return {'op': op, 'nsets': len(specs), 'nblocks': nblocks, 'rows_total': rows_total, 'n_multi': int(multi.numel()),
                 'nnz_counter': nnz_counter, 'keep': keep, 'span': span, 'rows_all': rows_all}
