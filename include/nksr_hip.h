@@ -314,6 +314,7 @@ typedef struct {
     const int32_t* nbr32;      /* [M, 32]: [0..26] GLOBAL unknown index of every neighbour voxel or -1; [27] block base, [28] / [29] first / last row of
                                 * the cell (nksr_fused_tables) */
     const int32_t* nbrT;       /* [27, M]: the same neighbour indices SLOT-MAJOR (the second product's gather runs one lane per unknown) */
+    const int32_t* item_begin; /* [nksr_fused_item_entries(rows_total)] first row of every work item of the sweep (nksr_fused_block_counts) */
     const int32_t* offsets;    /* [M + 1] partial blocks of a cell = [offsets[j], offsets[j + 1])                             */
     const int32_t* multi;      /* [n_multi] the cells with partial blocks (cells whose rows span several 256-row workgroups of the sweep):
                                 * first the n_big cells with more than 16 blocks (one workgroup each in the per-cell sum), then the others */
@@ -322,17 +323,21 @@ typedef struct {
                                 * stored entries of G and Q (roofline accounting) */
     void* workspace;           /* nksr_fused_workspace_bytes(nblocks, M)                                                     */
     float* cell_sums;          /* [27, M] per-cell block sums, slot-major, ZERO-INITIALISED by the caller (cells without rows are never written) */
-    const int32_t* item_seg;   /* batched chunks (nksr_segments_t), both or neither: [ceil(rows_total / 32) + 1] segment of every 32-row work
-                                * item (a segment's rows are padded to whole 256-row workgroups) and                          */
+    const int32_t* item_seg;   /* batched chunks (nksr_segments_t), both or neither: [ceil(rows_total / 32) + 1] segment of every 32-row window
+                                * of the row list (a segment's rows are padded to a multiple of 256) and                      */
     const int32_t* unknown_seg;/* [M] segment of every unknown: the solve skips the rows / unknowns of segments that have converged */
 } nksr_fused_op_t;
-/* Work items are runs of 32 consecutive rows, eight of them (256 rows) a workgroup; a cell whose rows lie inside one workgroup is
- * finished by the sweep, a cell whose rows reach into k > 1 workgroups owns k partial blocks.
- * nksr_fused_block_counts: span_out [2, M] (first / last row of every cell, -1 = none), counts_out [M + 1] (0 or k; last entry 0) ->
- * exclusive scan = offsets -> nksr_fused_tables (nbr32_out [M, 32], nbrT_out [27, M]). */
-int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_total, const int32_t* row_cells, int32_t* span_out, int32_t* counts_out,
-                            void* stream);
-int nksr_fused_tables(const nksr_hier_t* h, const int32_t* offsets, const int32_t* span, int32_t* nbr32_out, int32_t* nbrT_out, void* stream);
+/* A UNIT is a maximal run of rows that lie in the same cell at every level (the rows of one level-0 cell); work item i of the sweep =
+ * the units that start in the 32-row window [32 i, 32 i + 32) = rows [item_begin[i], item_begin[i + 1]); eight items are a workgroup.
+ * A cell whose rows lie inside one workgroup is finished by the sweep, a cell whose rows reach into k > 1 workgroups owns k partial
+ * blocks.  rows_all / targets_all must be readable 320 rows past rows_total (unconditional loads).
+ * nksr_fused_block_counts: span_out [2, M] (first / last row of every cell, -1 = none), item_begin_out [nksr_fused_item_entries],
+ * counts_out [M + 1] (0 or k; last entry 0) -> exclusive scan = offsets -> nksr_fused_tables (nbr32_out [M, 32], nbrT_out [27, M]). */
+int64_t nksr_fused_item_entries(int64_t rows_total);
+int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_total, const int32_t* row_cells, int32_t* span_out, int32_t* item_begin_out,
+                            int32_t* counts_out, void* stream);
+int nksr_fused_tables(const nksr_hier_t* h, int64_t rows_total, const int32_t* item_begin, const int32_t* offsets, const int32_t* span,
+                      int32_t* nbr32_out, int32_t* nbrT_out, void* stream);
 size_t nksr_fused_workspace_bytes(int64_t nblocks, int32_t M);
 /* b = sum_s R_s^T t_s and diag = reg + sum_s diag(R_s^T R_s) (either may be NULL): one sweep over the rows serves both. */
 int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* b_out, float* diag_out, void* stream);

@@ -25,7 +25,7 @@ class HierT(C.Structure):
 
 class FusedOpT(C.Structure):
     _fields_ = [('depth', _i32), ('M', _i32), ('n_multi', _i32), ('n_big', _i32), ('rows_total', _i64), ('rows_all', _vp),
-                ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('nbrT', _vp), ('offsets', _vp), ('multi', _vp), ('nblocks', _i64),
+                ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('nbrT', _vp), ('item_begin', _vp), ('offsets', _vp), ('multi', _vp), ('nblocks', _i64),
                 ('nnz_counter', _vp), ('workspace', _vp), ('cell_sums', _vp), ('item_seg', _vp), ('unknown_seg', _vp)]
 
 
@@ -78,6 +78,8 @@ lib.nksr_assemble_split_bytes.restype = _sz
 lib.nksr_assemble_split_bytes.argtypes = [C.POINTER(HierT), _i64]
 lib.nksr_spmv_workspace_bytes.restype = _sz
 lib.nksr_spmv_workspace_bytes.argtypes = [_i64]
+lib.nksr_fused_item_entries.restype = _i64
+lib.nksr_fused_item_entries.argtypes = [_i64]
 lib.nksr_fused_workspace_bytes.restype = _sz
 lib.nksr_fused_workspace_bytes.argtypes = [_i64, _i32]
 lib.nksr_pcg_vector_workspace_bytes.restype = _sz
@@ -126,8 +128,8 @@ _PROTOS = {
     'nksr_pack_cols21': [_vp, _i64, _vp, _vp],
     'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _vp, _vp],
     'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(C.c_double), _vp],
-    'nksr_fused_block_counts': [_i32, _i32, _i64, _vp, _vp, _vp, _vp],
-    'nksr_fused_tables': [_P(HierT), _vp, _vp, _vp, _vp, _vp],
+    'nksr_fused_block_counts': [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
+    'nksr_fused_tables': [_P(HierT), _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_fused_rhs_diag': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(SegmentsT), _P(C.c_double), _vp],
@@ -166,7 +168,7 @@ for _name, _args in _PROTOS.items():
 
 EXPORTED = ['nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
             'nksr_assemble_split_bytes',
-            'nksr_fused_workspace_bytes', 'nksr_pcg_vector_workspace_bytes', 'nksr_pcg_vector_workspace_bytes_seg', 'nksr_pcg_profile_survey_bytes', 'nksr_bbox_work_floats'] + sorted(_PROTOS)
+            'nksr_fused_workspace_bytes', 'nksr_fused_item_entries', 'nksr_pcg_vector_workspace_bytes', 'nksr_pcg_vector_workspace_bytes_seg', 'nksr_pcg_profile_survey_bytes', 'nksr_bbox_work_floats'] + sorted(_PROTOS)
 
 
 def check(rc):

@@ -59,14 +59,41 @@ __global__ void k_fz_spans(int depth, int64_t rows_total, const int32_t* __restr
     if (r == rows_total - 1 || row_cells[lin + 1] != c) last[c] = (int32_t)r;
 }
 
-// partial blocks of a cell: one per workgroup (256 rows) its rows touch -- if that is more than one; a cell inside one workgroup
-// has none (the sweep finishes it)
-__global__ void k_fz_block_counts(int M, const int32_t* __restrict__ first, const int32_t* __restrict__ last, int32_t* __restrict__ counts) {
+// A UNIT = a maximal run of rows that lie in the same cell at every level (the rows of one level-0 cell, as a rule).  Item i of the
+// sweep = the units that start in the 32-row window [32 i, 32 i + 32): rows [item_begin[i], item_begin[i + 1]) -- variable length,
+// aligned to unit boundaries; an item is empty when a long unit covers its window.  Eight items are a workgroup.
+__global__ void k_fz_item_begin(int depth, int64_t rows_total, int nitems, int nentries, const int32_t* __restrict__ row_cells,
+                                int32_t* __restrict__ item_begin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nentries) return;
+    int64_t r = (int64_t)i * FZ_RC;
+    if (i >= nitems || r >= rows_total) { item_begin[i] = (int32_t)rows_total; return; }
+    while (r > 0 && r < rows_total) {
+        bool start = false;
+        for (int d = 0; d < depth; ++d) start = start || row_cells[(int64_t)d * rows_total + r] != row_cells[(int64_t)d * rows_total + r - 1];
+        if (start) break;
+        ++r;
+    }
+    item_begin[i] = (int32_t)r;
+}
+// workgroup of the sweep that processes row r: the last w with item_begin[8 w] <= r
+__device__ __forceinline__ int fz_wg_of(const int32_t* __restrict__ item_begin, int nwg, int r) {
+    int lo = 0, hi = nwg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (item_begin[mid * FZ_HW] <= r) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+// partial blocks of a cell: one per workgroup its rows reach into -- if that is more than one; a cell inside one workgroup has none
+// (the sweep finishes it)
+__global__ void k_fz_block_counts(int M, int nwg, const int32_t* __restrict__ item_begin, const int32_t* __restrict__ first,
+                                  const int32_t* __restrict__ last, int32_t* __restrict__ counts) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > M) return;
     int n = 0;
     if (j < M && first[j] >= 0) {
-        n = last[j] / FZ_WG_ROWS - first[j] / FZ_WG_ROWS + 1;
+        n = fz_wg_of(item_begin, nwg, last[j]) - fz_wg_of(item_begin, nwg, first[j]) + 1;
         if (n == 1) n = 0;
     }
     counts[j] = n;
@@ -80,8 +107,8 @@ __device__ __forceinline__ int fz_level(const nksr_hier_t& h, int j) {
 
 // nbr32[j][0..26]: global unknown index of the neighbour voxels or -1;  [27]: (first block of j) - (first workgroup of j), so that
 // the block of workgroup w is nbr32[j][27] + w;  [28] / [29]: first / last row of the cell (-1: none)
-__global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__ offsets, const int32_t* __restrict__ first,
-                            const int32_t* __restrict__ last, int32_t* __restrict__ nbr32) {
+__global__ void k_fz_tables(nksr_hier_t hier, int M, int nwg, const int32_t* __restrict__ item_begin, const int32_t* __restrict__ offsets,
+                            const int32_t* __restrict__ first, const int32_t* __restrict__ last, int32_t* __restrict__ nbr32) {
     const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lin >= (int64_t)M * 32) return;
     const int j = (int)(lin >> 5), s = (int)(lin & 31);
@@ -91,7 +118,7 @@ __global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__
         const int nb = hier.lv[d].nbr[(int64_t)c * 27 + s];
         v = nb >= 0 ? nb + hier.lv[d].offset : -1;
     } else if (s == 27) {
-        v = offsets[j] - (first[j] >= 0 ? first[j] / FZ_WG_ROWS : 0);
+        v = offsets[j] - (first[j] >= 0 ? fz_wg_of(item_begin, nwg, first[j]) : 0);
     } else if (s == 28) {
         v = first[j];
     } else if (s == 29) {
@@ -121,10 +148,11 @@ struct FusedArgs {               // uniform scalars and base pointers only
     const int32_t* row_cells;    // [depth][rows_total]
     const int32_t* nbr32;        // [M][32]
     const int32_t* nbrT;         // [27][M]
+    const int32_t* item_begin;   // [8 nwg + 1] first row of every item
     const int32_t* offsets;      // [M + 1] partial blocks of a cell
     const int32_t* multi;        // cells with partial blocks: the n_big cells with more than FZ_BIG blocks first
     int n_multi, n_big, M, depth;
-    int hw_total;                // half-waves = items, rounded up to whole workgroups
+    int hw_total;                // items (32-row windows of the row list)
     int64_t rows_total, nblocks;
     unsigned long long* nnz_counter;   // the set-up pass (MODE 1) adds the non-zero slots it sees (may be NULL)
     const int32_t* item_seg;     // [hw_total] segment of every 32-row item, [M] segment of every unknown (batched chunks; may be NULL)
@@ -162,18 +190,21 @@ __device__ __forceinline__ float half_lane_f(float v, int l, bool upper) { retur
 
 // MODE 0: the operator (t from x).  MODE 1: the set-up pass -- right-hand side (t = target) into ct / part, Jacobi diagonal
 // (P2 += rows^2) into ct2 / part2, and the count of non-zero slots, all in one sweep over the rows.
-// U rows per trip.  Levels < NG (the fine ones, where a cell holds a handful of rows) fetch the stencil of EVERY row (neighbour
-// row, then 27 x values: the loads of a trip go out together, nothing to decide); levels >= NG keep the stencil of their current
-// cell in registers and refresh it on the rare trip that crosses a cell boundary -- that trip is processed in two parts, before
-// and after the refresh.  Which rows change cell / have a cell at all is known up front as two 32-bit masks per level.
-template <int MODE, int D, int U, int NG>
-__global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 5 : 4))) __launch_bounds__(FZ_BLOCK) k_fz_sweep(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
+//
+// Round 4, second half -- the sweep walks UNITS, not rows.  A unit is a maximal run of rows that lie in the same cell at every level
+// (in practice: the rows of one level-0 cell, ~4 of them); an item = the units that START in a 32-row window (item_begin[]: variable
+// length, aligned to unit boundaries), one item per 32-lane half of a wavefront, lane = stencil slot.  Per trip a half-wave takes up to
+// U rows of its current unit: the stencil of the unit's level-0 cell is fetched once per UNIT (its neighbour row one unit ahead, so
+// that every load of a trip is independent), level-0 blocks are always complete when their unit ends (no exchange), and the coarser
+// levels change cell only BETWEEN units -- no trip is ever cut.  The row-streaming version spent ~600 instructions per 8 rows on
+// finding out which rows change cell at which level (rows x levels masks, half-lane selects, the cut loop); this one ~150.
+template <int MODE, int D, int U>
+__global__ void __launch_bounds__(FZ_BLOCK) k_fz_cells(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
                                                       float* __restrict__ part2, float* __restrict__ ct, float* __restrict__ ct2,
                                                       const int* __restrict__ done) {
     if (done && *done) return;
-    constexpr int G = NG < D ? NG : D;                               // levels that gather per row
-    // blocks of cells that cross an item boundary inside this workgroup: [item][level][0: the item's first cell, which began before
-    // it / 1: its last cell, which goes on after it] -- summed after the row loop (see below)
+    // blocks of coarse cells that cross an item boundary inside this workgroup: [item][level][0: the item's first cell, which began
+    // before it / 1: its last cell, which goes on after it] -- summed after the row loop (see below)
     __shared__ float xv[FZ_HW][D][2][32];
     __shared__ float xv2[MODE == 1 ? FZ_HW : 1][MODE == 1 ? D : 1][2][32];
     __shared__ int xm[FZ_HW][D][2];                                  // their cells (-1: no entry; bit 30: the cell ends in that item)
@@ -189,43 +220,45 @@ __global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 5 : 4))) __launch_bo
     __syncthreads();
     const int hwi = threadIdx.x >> 5;
     const int item = blockIdx.x * FZ_HW + hwi;
-    const int R0 = item * FZ_RC;                                    // (rows_total < 2^31 - 256: row numbers fit an int)
-    const int64_t left = A.rows_total - (int64_t)R0;
-    // (the rows of a segment whose conjugate gradients have finished are skipped: a workgroup lies inside ONE segment -- segments
-    // are padded to whole workgroups -- and a half-wave without rows just idles next to its partner)
-    const int nrows = (item >= A.hw_total || (MODE == 0 && left > 0 && fz_seg_done(A, A.item_seg, item))) ? 0
-                      : (left >= FZ_RC ? FZ_RC : (left > 0 ? (int)left : 0));
-    const int Ra = nrows > 0 ? R0 : 0;                               // (addresses of a half-wave without rows stay inside the arrays)
-    const int W0 = blockIdx.x * FZ_WG_ROWS;
-    // first cell of the staged levels with rows in this workgroup (uniform)
-    const int cw0 = __builtin_amdgcn_readfirstlane((int64_t)W0 < A.rows_total ? A.row_cells[W0] : -1);
-    const int cw1 = __builtin_amdgcn_readfirstlane((D > 1 && (int64_t)W0 < A.rows_total) ? A.row_cells[A.rows_total + W0] : -1);
     const int s = threadIdx.x & 31;
     const bool act = s < 27, upper = (threadIdx.x & 32) != 0;
     const int sh = upper ? 32 : 0;
+    const int sc = act ? s : 26;
+    const int Rb = A.item_begin[item];                               // (row numbers fit an int: rows_total < 2^31 - 512)
+    int Re = A.item_begin[item + 1];
+    // (the rows of a segment whose conjugate gradients have finished are skipped: a workgroup lies inside ONE segment -- segments
+    // are padded to whole workgroups)
+    if (MODE == 0 && Re > Rb && fz_seg_done(A, A.item_seg, Rb >> 5)) Re = Rb;
+    const int W0 = __builtin_amdgcn_readfirstlane(A.item_begin[blockIdx.x * FZ_HW]);
+    // first cell of the staged levels with rows in this workgroup (uniform)
+    const int cw0 = __builtin_amdgcn_readfirstlane((int64_t)W0 < A.rows_total ? A.row_cells[W0] : -1);
+    const int cw1 = __builtin_amdgcn_readfirstlane((D > 1 && (int64_t)W0 < A.rows_total) ? A.row_cells[A.rows_total + W0] : -1);
     if (s < 2 * D) xm[hwi][s >> 1][s & 1] = -1;
-    // the cells (and targets) of the item's rows, one row per lane: a single coalesced load each
+    // the cells of the item's first 32 rows, one row per lane (every unit of the item starts among them)
+    const int len32 = Re - Rb < 32 ? Re - Rb : 32;
     int cells[D];
-    unsigned chg[D], pos[D];         // bit l: row l lies in another cell than row l - 1 / lies in a cell at all
+    unsigned chg[D > 1 ? D : 2];     // levels >= 1, bit l: row l lies in another cell than row l - 1
+    unsigned um = 0;                 // bit l: a unit starts at row l
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        cells[d] = s < nrows ? A.row_cells[(int64_t)d * A.rows_total + R0 + s] : -1;
+        cells[d] = s < len32 ? A.row_cells[(int64_t)d * A.rows_total + Rb + s] : -1;
         const int before = __shfl_up(cells[d], 1, 32);
-        chg[d] = (unsigned)(__ballot(cells[d] != (s ? before : -1)) >> sh);
-        pos[d] = (unsigned)(__ballot(cells[d] >= 0) >> sh);
+        const unsigned m = (unsigned)(__ballot(s > 0 && s < len32 && cells[d] != before) >> sh);
+        if (d > 0) chg[d] = m;
+        um |= m;
     }
-    const float tg = (MODE == 1 && A.targets_all && s < nrows) ? A.targets_all[R0 + s] : 0.f;
-    // of the current cell of every level only two bits are kept: do its rows start / end inside this item (bits 2 d, 2 d + 1)
+    um |= 1u;
+    // of the current cell of every coarse level two bits are kept: do its rows start / end inside this item (bits 2 d, 2 d + 1)
     unsigned inside = 0;
     float P[D], P2[MODE == 1 ? D : 1], xs[D];
     bool have[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { P[d] = 0.f; P2[MODE == 1 ? d : 0] = 0.f; xs[d] = 0.f; have[d] = false; }
-    // nbv: the neighbour row of the cell that becomes current at level d (lanes 28 / 29: its first / last row)
+    // nbv: the neighbour row of the cell that becomes current at level d (lanes 27 / 28 / 29: its block base, first / last row)
     auto enter = [&](int d, int nbv) {
         const int first = __shfl(nbv, 28, 32), last = __shfl(nbv, 29, 32);
         if (s == 27) xbase[hwi][d] = nbv;
-        inside = (inside & ~(3u << (2 * d))) | ((first >= R0 ? 1u : 0u) << (2 * d)) | ((last < R0 + FZ_RC ? 2u : 0u) << (2 * d));
+        inside = (inside & ~(3u << (2 * d))) | ((first >= Rb ? 1u : 0u) << (2 * d)) | ((last < Re ? 2u : 0u) << (2 * d));
     };
     // the final block of a cell that lies inside this workgroup: staged (levels 0 and 1, while there is room) or written word by word
     auto finish = [&](int d, int cell, float p, float p2) {
@@ -241,8 +274,8 @@ __global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 5 : 4))) __launch_bo
             if (MODE == 1) ct2[(int64_t)s * A.M + cell] = p2;
         }
     };
-    // the running block of level d leaves (`cell`: its cell): complete (all rows of the cell lie in this item) -> final; otherwise ->
-    // the workgroup exchange
+    // the running block of coarse level d leaves (`cell`: its cell): complete (all rows of the cell lie in this item) -> final;
+    // otherwise -> the workgroup exchange
     auto emit = [&](int d, int cell, float p, float p2) {
         const unsigned f = (inside >> (2 * d)) & 3u;
         if (f == 3u) {
@@ -254,192 +287,158 @@ __global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 5 : 4))) __launch_bo
             if (s == 0) { xm[hwi][d][k] = cell | ((f & 2u) ? (1 << 30) : 0); xmb[hwi][d][k] = xbase[hwi][d]; }
         }
     };
-    // coarse levels: the stencils of the item's first row, all levels in one round trip (then one more for x)
+    // end row of the unit that starts at position p (of the item's first 32 rows)
+    auto unit_end = [&](int p) {
+        const unsigned after = um & ~((2u << p) - 1u);
+        return after ? Rb + (int)__builtin_ctz(after) : Re;
+    };
+    // ---- the first unit: its stencils at all levels (one round trip for the neighbour rows, one for x)
+    bool work = Rb < Re;
+    int pos = 0, r = Rb, uend = unit_end(0);
+    int c0 = __shfl(cells[0], 0, 32);
+    int line0;
     {
-        int c0[D], nb0[D];
+        int cd[D], nb0[D];
         float x0[D];
 #pragma unroll
-        for (int d = G; d < D; ++d) {
-            c0[d] = half_lane_i(cells[d], 0, upper);
-            nb0[d] = A.nbr32[(int64_t)(c0[d] >= 0 ? c0[d] : 0) * 32 + s];
+        for (int d = 0; d < D; ++d) {
+            cd[d] = __shfl(cells[d], 0, 32);
+            nb0[d] = A.nbr32[(int64_t)(cd[d] >= 0 ? cd[d] : 0) * 32 + s];
         }
 #pragma unroll
-        for (int d = G; d < D; ++d) x0[d] = MODE == 0 ? x[(act && nb0[d] >= 0) ? nb0[d] : 0] : 0.f;
+        for (int d = 1; d < D; ++d) x0[d] = MODE == 0 ? x[(act && nb0[d] >= 0) ? nb0[d] : 0] : 0.f;
+        line0 = nb0[0];
 #pragma unroll
-        for (int d = G; d < D; ++d) {
-            have[d] = c0[d] >= 0;
+        for (int d = 1; d < D; ++d) {
+            have[d] = work && cd[d] >= 0;
             enter(d, nb0[d]);
             xs[d] = (have[d] && act && nb0[d] >= 0) ? x0[d] : 0.f;
-            chg[d] &= ~1u;
         }
     }
-    const int nlo = __builtin_amdgcn_readlane(nrows, 0), nhi = __builtin_amdgcn_readlane(nrows, 32);
-    const int nmax = nlo > nhi ? nlo : nhi;
     int nnz = 0;                                                     // MODE 1: this lane's non-zero slots (stored entries of G and Q)
-    // the neighbour rows of the fine levels are requested one trip ahead: with them in hand all loads of a trip (kernel rows, x
-    // stencils, the next trip's neighbour rows) are independent -- one memory round trip per trip instead of two
-    // (all loads of the row loop are UNCONDITIONAL -- clamped addresses, results masked afterwards: a load under a branch makes
-    // the compiler lose count of the outstanding loads and wait for all of them)
-    const int sc = act ? s : 26;
-    const int lastrow = nrows > 0 ? nrows - 1 : 0;
-    int nbn[U][G > 0 ? G : 1];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int d = 0; d < G; ++d) {
-            const int cj = half_lane_i(cells[d], u, upper);
-            const int v = A.nbr32[(int64_t)(cj >= 0 ? cj : 0) * 32 + s];
-            nbn[u][d] = cj >= 0 ? v : -1;
-        }
-    // one pointer per level, advanced by U rows per trip: the U rows of a trip are loaded at immediate offsets.  Rows past the item's
-    // last one are read too (the array is padded by 320 rows) and never used: every use below is guarded by the row count.
+    // one pointer per level; the U rows of a trip are loaded at immediate offsets.  Rows past the unit's (or the item's) last one are
+    // read too (the array is padded by 320 rows) and never used: their t is 0
     const float* wp[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) wp[d] = A.rows_all + ((int64_t)d * A.rows_total + Ra) * 27 + sc;
-    for (int rr = 0; rr < nmax; rr += U) {
-        float w[U][D], xg[U][G > 0 ? G : 1];
-        int nb[U][G > 0 ? G : 1];
-#pragma unroll
+    for (int d = 0; d < D; ++d) wp[d] = A.rows_all + (int64_t)d * A.rows_total * 27 + sc;
+    while (__any(work)) {
+        // all loads of the trip: U rows x D levels, the x stencil of the unit's level-0 cell, the neighbour row of the NEXT unit's
+        // level-0 cell (all unconditional -- clamped addresses, results masked afterwards: a load under a branch makes the compiler
+        // lose count of the outstanding loads and wait for all of them)
+        float w[U][D];
+        #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int d = 0; d < D; ++d) w[u][d] = FZ_ROW_LOAD(wp[d] + u * 27);
+            for (int d = 0; d < D; ++d) w[u][d] = FZ_ROW_LOAD(wp[d] + ((int64_t)r + u) * 27);
+        const float xg = MODE == 0 ? x[(act && line0 >= 0) ? line0 : 0] : 0.f;
+        float tg[U];
+        if (MODE == 1) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) wp[d] += U * 27;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int d = 0; d < G; ++d) {
-                nb[u][d] = nbn[u][d];
-                xg[u][d] = MODE == 0 ? x[(act && nb[u][d] >= 0) ? nb[u][d] : 0] : 0.f;      // (lanes 27.. of a neighbour row are not x indices)
-            }
-        {
-            const int nr = rr + U < 32 ? rr + U : 0;                  // (the last trip's request is a harmless repeat)
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int d = 0; d < G; ++d) {
-                    const int cj = half_lane_i(cells[d], (nr + u) & 31, upper);
-                    const int v = A.nbr32[(int64_t)(cj >= 0 ? cj : 0) * 32 + s];
-                    nbn[u][d] = cj >= 0 ? v : -1;
-                }
+            for (int u = 0; u < U; ++u) tg[u] = A.targets_all ? A.targets_all[r + u] : 0.f;       // (targets_all is padded like the rows)
         }
+        const int npos = uend - Rb;                                   // the next unit starts here, if the item goes on
+        const int cn = __shfl(cells[0], npos & 31, 32);
+        const int line0n = A.nbr32[(int64_t)((uend < Re && cn >= 0) ? cn : 0) * 32 + s];
+        const int nt = work ? (uend - r < U ? uend - r : U) : 0;      // rows of this trip
+        const float x0 = (c0 >= 0 && act && line0 >= 0) ? xg : 0.f;
+        float t[U];
+        if (MODE == 0) {
+            float prod[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // (MODE 0: lanes 27.. hold a copy of slot 26 and rows past the item's end hold whatever follows -- both harmless: x is 0 in
-            // those lanes, and nothing of a row past the end is accumulated)
+            for (int u = 0; u < U; ++u) {
+                prod[u] = w[u][0] * x0;
 #pragma unroll
-            for (int d = 0; d < G; ++d) xg[u][d] = (act && nb[u][d] >= 0) ? xg[u][d] : 0.f;
-            if (MODE == 1) {
-                const bool ok = rr + u < nrows && act;
+                for (int d = 1; d < D; ++d) prod[u] = fmaf(w[u][d], xs[d], prod[u]);
+            }
+            const float rs = half_sum4(prod[0], prod[1], prod[2 % U], prod[3 % U], s);
+#pragma unroll
+            for (int u = 0; u < U; ++u) t[u] = u < nt ? half_lane_f(rs, 8 * u, upper) : 0.f;
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = u < nt && act;
+                t[u] = u < nt ? tg[u] : 0.f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) { w[u][d] = ok ? w[u][d] : 0.f; nnz += w[u][d] != 0.f ? 1 : 0; }
             }
         }
-        // rows of the trip that cross a cell boundary of a level >= NG: the trip is cut there
-        unsigned cut = 0;
 #pragma unroll
-        for (int d = G; d < D; ++d) cut |= chg[d] >> rr;
-        cut &= (1u << U) - 1u;
-        int from = 0;
-        while (true) {
-            // refresh the coarse stencils that change at row `from`
-            if ((cut >> from) & 1u) {
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int d = G; d < D; ++d)
-                    if ((chg[d] >> (rr + from)) & 1u) {
-                        if (have[d]) emit(d, __shfl(cells[d], (rr + from - 1) & 31, 32), P[d], P2[MODE == 1 ? d : 0]);
+            for (int d = 0; d < D; ++d) {
+                P[d] = fmaf(w[u][d], t[u], P[d]);
+                if (MODE == 1) P2[d] = fmaf(w[u][d], w[u][d], P2[d]);
+            }
+        r += nt;
+        if (work && r >= uend) {
+            // the unit is done: its level-0 block is final
+            if (c0 >= 0) finish(0, c0, P[0], P2[0]);
+            P[0] = 0.f;
+            if (MODE == 1) P2[0] = 0.f;
+            work = uend < Re;
+            if (work) {
+                pos = npos;
+                c0 = cn;
+                line0 = line0n;
+                uend = unit_end(pos);
+                // coarse levels whose cell changes with this unit: the finished block leaves, the new stencil is fetched (rare: a
+                // level-1 cell holds ~8 units)
+#pragma unroll
+                for (int d = 1; d < D; ++d)
+                    if ((chg[d] >> pos) & 1u) {
+                        const int before = __shfl(cells[d], (pos + 31) & 31, 32);
+                        if (have[d]) emit(d, before, P[d], P2[MODE == 1 ? d : 0]);
                         P[d] = 0.f;
                         if (MODE == 1) P2[d] = 0.f;
                         xs[d] = 0.f;
-                        have[d] = (pos[d] >> (rr + from)) & 1u;
+                        const int cd = __shfl(cells[d], pos, 32);
+                        have[d] = cd >= 0;
                         if (have[d]) {
-                            const int nbv = A.nbr32[(int64_t)__shfl(cells[d], (rr + from) & 31, 32) * 32 + s];      // `from` differs between the halves: no scalar lane read here
+                            const int nbv = A.nbr32[(int64_t)cd * 32 + s];
                             enter(d, nbv);
                             if (MODE == 0 && act && nbv >= 0) xs[d] = x[nbv];
                         }
                     }
-                cut &= ~(1u << from);
             }
-            const int to = cut ? __builtin_ctz(cut) : U;             // rows [from, to) see the same coarse cells
-            float t[U];
-            if (MODE == 0) {
-                float prod[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    prod[u] = 0.f;
-                    const bool in = u >= from && u < to;
-#pragma unroll
-                    for (int d = 0; d < D; ++d) prod[u] = fmaf(in ? w[u][d] : 0.f, d < G ? xg[u][d < G ? d : 0] : xs[d], prod[u]);
-                }
-                if (U == 4) {
-                    const float r = half_sum4(prod[0], prod[1], prod[2 % U], prod[3 % U], s);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) t[u] = half_lane_f(r, 8 * u, upper);
-                } else {
-                    const float r = half_sum2(prod[0], prod[1], s);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) t[u] = half_lane_f(r, 16 * u, upper);
-                }
-            } else if (MODE == 1) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) t[u] = half_lane_f(tg, (rr + u) & 31, upper);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool in = u >= from && u < to && rr + u < nrows;
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    if (d < G && in && ((chg[d] >> (rr + u)) & 1u)) {      // fine levels: the block leaves with its cell
-                        if (have[d]) emit(d, half_lane_i(cells[d], (rr + u - 1) & 31, upper), P[d], P2[MODE == 1 ? d : 0]);
-                        P[d] = 0.f;
-                        if (MODE == 1) P2[d] = 0.f;
-                        have[d] = (pos[d] >> (rr + u)) & 1u;
-                        if (have[d]) enter(d, nb[u][d < G ? d : 0]);
-                    }
-                    if (in && have[d]) {
-                        P[d] = fmaf(w[u][d], t[u], P[d]);
-                        if (MODE == 1) P2[d] = fmaf(w[u][d], w[u][d], P2[d]);
-                    }
-                }
-            }
-            if (to >= U) break;
-            from = to;
         }
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-        if (have[d]) emit(d, __shfl(cells[d], lastrow, 32), P[d], P2[MODE == 1 ? d : 0]);
+    for (int d = 1; d < D; ++d)
+        if (have[d]) emit(d, __shfl(cells[d], pos, 32), P[d], P2[MODE == 1 ? d : 0]);
     if (MODE == 1 && A.nnz_counter) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o);
         if ((threadIdx.x & 63) == 0 && nnz) atomicAdd(A.nnz_counter, (unsigned long long)nnz);           // integer: order-free
     }
-    // ---- cells that cross item boundaries inside this workgroup: the item in which the cell ends (or the workgroup's last item)
+    // ---- coarse cells that cross item boundaries inside this workgroup: the LAST item of the workgroup that holds a piece of the cell
     // adds the pieces in item order.  A cell that lies inside the workgroup is final; one that reaches into other workgroups leaves
-    // one partial block per workgroup (k_fz_cellsum adds those).
-    // ---- cells that cross item boundaries inside this workgroup: the item in which the cell ends (or the workgroup's last item)
-    // adds the pieces in item order.  A cell that lies inside the workgroup is final; one that reaches into other workgroups leaves
-    // one partial block per workgroup (k_fz_cellsum adds those).  Everything is decided from the exchange in LDS: the cell of item
-    // h - 1 is the same cell <=> ids match; a cell began in the item that holds it as its LAST cell (entry 1).
+    // one partial block per workgroup (k_fz_cellsum adds those).  Everything is decided from the exchange in LDS: an item holds a
+    // piece of cell c <=> one of its two entries names c; a cell began in the item that holds it as its LAST cell (entry 1); items
+    // may be empty (a long unit covers their window).
     __syncthreads();
 #pragma unroll
-    for (int d = 0; d < D; ++d)
+    for (int d = 1; d < D; ++d)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int e = xm[hwi][d][k];
             if (e < 0) continue;
             const int c = e & ~(1 << 30);
             const bool ends = (e >> 30) & 1;
-            if (!(ends || hwi == FZ_HW - 1)) continue;
+            bool later = false;
+            if (!ends)
+                for (int h = hwi + 1; h < FZ_HW; ++h) later = later || (xm[h][d][0] >= 0 && (xm[h][d][0] & ~(1 << 30)) == c);
+            if (later) continue;
             int h0 = hwi;
             bool started = k == 1;
             while (!started && h0 > 0) {
                 --h0;
-                started = (xm[h0][d][1] & ~(1 << 30)) == c && xm[h0][d][1] >= 0;
+                started = xm[h0][d][1] >= 0 && (xm[h0][d][1] & ~(1 << 30)) == c;
             }
             float acc = 0.f, acc2 = 0.f;
             for (int h = h0; h <= hwi; ++h) {
                 const int kk = (h == h0 && started) ? 1 : 0;
+                const int eh = h == hwi ? e : xm[h][d][kk];
+                if (eh < 0 || (eh & ~(1 << 30)) != c) continue;       // (an empty item in between)
                 acc += xv[h][d][kk][s];
                 if (MODE == 1) acc2 += xv2[MODE == 1 ? h : 0][MODE == 1 ? d : 0][kk][s];
             }
@@ -580,29 +579,36 @@ static FusedWork fz_carve(const nksr_fused_op_t* op) {
     return w;
 }
 
+static int fz_items(int64_t rows_total) { return (int)((rows_total + FZ_RC - 1) / FZ_RC); }
+static int fz_nwg(int64_t rows_total) { return (fz_items(rows_total) + FZ_HW - 1) / FZ_HW; }
+extern "C" int64_t nksr_fused_item_entries(int64_t rows_total) { return (int64_t)fz_nwg(rows_total) * FZ_HW + 1; }
+
 extern "C" int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_total, const int32_t* row_cells, int32_t* span_out,
-                                       int32_t* counts_out, void* stream) {
+                                       int32_t* item_begin_out, int32_t* counts_out, void* stream) {
     if (depth < 1 || depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", depth);
     if (M <= 0) return NKSR_OK;
-    if (rows_total < 0 || rows_total >= ((int64_t)1 << 31) - FZ_WG_ROWS) return nksr_set_error(NKSR_ERR_CAPACITY, "too many kernel rows");
-    if (!span_out || !counts_out || (rows_total > 0 && !row_cells)) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    if (rows_total < 0 || rows_total >= ((int64_t)1 << 31) - 2 * FZ_WG_ROWS) return nksr_set_error(NKSR_ERR_CAPACITY, "too many kernel rows");
+    if (!span_out || !counts_out || !item_begin_out || (rows_total > 0 && !row_cells)) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
     hipStream_t st = (hipStream_t)stream;
     NKSR_CHECK_HIP(hipMemsetAsync(span_out, 0xFF, (size_t)2 * M * sizeof(int32_t), st));
+    const int nent = (int)nksr_fused_item_entries(rows_total);
+    hipLaunchKernelGGL(k_fz_item_begin, dim3(nksr_blocks(nent, 256)), dim3(256), 0, st, depth, rows_total, fz_items(rows_total), nent, row_cells, item_begin_out);
     if (rows_total > 0)
         hipLaunchKernelGGL(k_fz_spans, dim3(nksr_blocks(rows_total * depth, 256)), dim3(256), 0, st, depth, rows_total, row_cells, span_out, span_out + M);
-    hipLaunchKernelGGL(k_fz_block_counts, dim3(nksr_blocks((int64_t)M + 1, 256)), dim3(256), 0, st, M, (const int32_t*)span_out,
-                       (const int32_t*)(span_out + M), counts_out);
+    hipLaunchKernelGGL(k_fz_block_counts, dim3(nksr_blocks((int64_t)M + 1, 256)), dim3(256), 0, st, M, fz_nwg(rows_total) > 0 ? fz_nwg(rows_total) : 1,
+                       (const int32_t*)item_begin_out, (const int32_t*)span_out, (const int32_t*)(span_out + M), counts_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
 
-extern "C" int nksr_fused_tables(const nksr_hier_t* h, const int32_t* offsets, const int32_t* span, int32_t* nbr32_out, int32_t* nbrT_out,
-                                 void* stream) {
+extern "C" int nksr_fused_tables(const nksr_hier_t* h, int64_t rows_total, const int32_t* item_begin, const int32_t* offsets, const int32_t* span,
+                                 int32_t* nbr32_out, int32_t* nbrT_out, void* stream) {
     if (!h || h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad hierarchy");
     const int M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
     if (M <= 0) return NKSR_OK;
-    if (!offsets || !span || !nbr32_out || !nbrT_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
-    hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)M * 32, 256)), dim3(256), 0, (hipStream_t)stream, *h, M, offsets, span, span + M, nbr32_out);
+    if (!offsets || !span || !nbr32_out || !nbrT_out || !item_begin) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)M * 32, 256)), dim3(256), 0, (hipStream_t)stream, *h, M, fz_nwg(rows_total) > 0 ? fz_nwg(rows_total) : 1,
+                       item_begin, offsets, span, span + M, nbr32_out);
     hipLaunchKernelGGL(k_fz_nbrT, dim3(nksr_blocks(M, 64)), dim3(256), 0, (hipStream_t)stream, M, (const int32_t*)nbr32_out, nbrT_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
@@ -611,44 +617,37 @@ extern "C" int nksr_fused_tables(const nksr_hier_t* h, const int32_t* offsets, c
 static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
     if (!op) return nksr_set_error(NKSR_ERR_ARG, "operator is NULL");
     if (op->depth < 1 || op->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", op->depth);
-    if (op->M > 0 && (!op->rows_all || !op->row_cells || !op->nbr32 || !op->nbrT || !op->offsets || !op->workspace || !op->cell_sums ||
+    if (op->M > 0 && (!op->rows_all || !op->row_cells || !op->nbr32 || !op->nbrT || !op->item_begin || !op->offsets || !op->workspace || !op->cell_sums ||
                       (op->n_multi > 0 && !op->multi) || op->n_big < 0 || op->n_big > op->n_multi))
         return nksr_set_error(NKSR_ERR_ARG, "operator has NULL arrays");
-    if (op->rows_total < 0 || op->rows_total >= ((int64_t)1 << 31) - FZ_WG_ROWS || op->nblocks >= ((int64_t)1 << 31) - ((int64_t)1 << 26))
+    if (op->rows_total < 0 || op->rows_total >= ((int64_t)1 << 31) - 2 * FZ_WG_ROWS || op->nblocks >= ((int64_t)1 << 31) - ((int64_t)1 << 26))
         return nksr_set_error(NKSR_ERR_CAPACITY, "operator too large");
     memset(&A, 0, sizeof(A));
-    A.rows_all = op->rows_all; A.targets_all = op->targets_all; A.row_cells = op->row_cells; A.nbr32 = op->nbr32; A.nbrT = op->nbrT; A.offsets = op->offsets;
+    A.rows_all = op->rows_all; A.targets_all = op->targets_all; A.row_cells = op->row_cells; A.nbr32 = op->nbr32; A.nbrT = op->nbrT; A.item_begin = op->item_begin; A.offsets = op->offsets;
     A.multi = op->multi; A.n_multi = op->n_multi; A.n_big = op->n_big;
     A.M = op->M; A.depth = op->depth; A.rows_total = op->rows_total; A.nblocks = op->nblocks;
     A.nnz_counter = (unsigned long long*)op->nnz_counter;
     A.item_seg = op->item_seg; A.unknown_seg = op->unknown_seg;
-    const int64_t items = (op->rows_total + FZ_RC - 1) / FZ_RC;
-    A.hw_total = (int)items;
+    A.hw_total = fz_items(op->rows_total);
     return NKSR_OK;
 }
 
-// rows per trip / per-row-gather levels.  Measured on the bench workload: (4, 1) 587 us per application,
-// (2, 1) 600, (4, 2) 649, (2, 2) 647; the tree_depth-5 chunks of configs[4] rank the same way.
+// rows per trip
 #define FZ_ROWS_PER_TRIP 4
-#define FZ_GATHER_LEVELS 1
-
-template <int MODE, int U, int NG>
-static void fz_sweep_v(const FusedArgs& A, const float* x, const FusedWork& w, const int* done, hipStream_t st) {
-    const dim3 grid(nksr_blocks((int64_t)A.hw_total, FZ_HW)), blk(FZ_BLOCK);
-    switch (A.depth) {
-        case 1: hipLaunchKernelGGL((k_fz_sweep<MODE, 1, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 2: hipLaunchKernelGGL((k_fz_sweep<MODE, 2, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 3: hipLaunchKernelGGL((k_fz_sweep<MODE, 3, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 4: hipLaunchKernelGGL((k_fz_sweep<MODE, 4, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 5: hipLaunchKernelGGL((k_fz_sweep<MODE, 5, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        default: hipLaunchKernelGGL((k_fz_sweep<MODE, 6, U, NG>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-    }
-}
 
 template <int MODE>
 static void fz_sweep(const FusedArgs& A, const float* x, const FusedWork& w, const int* done, hipStream_t st) {
     if (A.hw_total <= 0) return;
-    fz_sweep_v<MODE, FZ_ROWS_PER_TRIP, FZ_GATHER_LEVELS>(A, x, w, done, st);
+    constexpr int U = FZ_ROWS_PER_TRIP;
+    const dim3 grid(nksr_blocks((int64_t)A.hw_total, FZ_HW)), blk(FZ_BLOCK);
+    switch (A.depth) {
+        case 1: hipLaunchKernelGGL((k_fz_cells<MODE, 1, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 2: hipLaunchKernelGGL((k_fz_cells<MODE, 2, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 3: hipLaunchKernelGGL((k_fz_cells<MODE, 3, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 4: hipLaunchKernelGGL((k_fz_cells<MODE, 4, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 5: hipLaunchKernelGGL((k_fz_cells<MODE, 5, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        default: hipLaunchKernelGGL((k_fz_cells<MODE, 6, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+    }
 }
 
 static void fz_cellsum(const FusedArgs& A, const float* part, float* ct, const int* done, hipStream_t st) {

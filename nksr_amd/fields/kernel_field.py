@@ -413,7 +413,7 @@ class KernelField(BaseField):
         rows_all = torch.empty(L * rows_total * 27 + pad, dtype=torch.float32, device=dev)
         rows_all[L * rows_total * 27:].zero_()
         row_cells = torch.empty((L, rows_total), dtype=torch.int32, device=dev)
-        targets_all = torch.zeros(rows_total, dtype=torch.float32, device=dev)
+        targets_all = torch.zeros(rows_total + 320, dtype=torch.float32, device=dev)[:rows_total]      # (readable past the end, like the rows)
         if pad_rows is not None and pad_rows.numel():
             row_cells[:, pad_rows] = -1
             rows_all[:L * rows_total * 27].view(L, rows_total, 27)[:, pad_rows] = 0.0
@@ -436,11 +436,12 @@ class KernelField(BaseField):
         # there, a cell that reaches into k > 1 workgroups owns k partial blocks (the coarse cells: ~1 % of all)
         span = torch.empty((2, M), dtype=torch.int32, device=dev)
         counts = torch.empty(M + 1, dtype=torch.int32, device=dev)
-        call('nksr_fused_block_counts', L, M, rows_total, ptr(row_cells), ptr(span), ptr(counts), stream())
+        item_begin = torch.empty(int(_lib.lib.nksr_fused_item_entries(rows_total)), dtype=torch.int32, device=dev)
+        call('nksr_fused_block_counts', L, M, rows_total, ptr(row_cells), ptr(span), ptr(item_begin), ptr(counts), stream())
         offsets = ops.exclusive_sum_i32(counts)
         nbr32 = torch.empty((M, 32), dtype=torch.int32, device=dev)
         nbrT = torch.empty((27, M), dtype=torch.int32, device=dev)
-        call('nksr_fused_tables', C.byref(self._hier), ptr(offsets), ptr(span), ptr(nbr32), ptr(nbrT), stream())
+        call('nksr_fused_tables', C.byref(self._hier), rows_total, ptr(item_begin), ptr(offsets), ptr(span), ptr(nbr32), ptr(nbrT), stream())
         big = torch.nonzero(counts[:M] > 16).reshape(-1).to(torch.int32)          # coarse cells: a workgroup each in the per-cell sum
         multi = torch.cat([big, torch.nonzero((counts[:M] > 1) & (counts[:M] <= 16)).reshape(-1).to(torch.int32)])
         nblocks = int(offsets[M].item())
@@ -449,6 +450,7 @@ class KernelField(BaseField):
         op = FusedOpT()
         op.depth, op.M, op.n_multi, op.n_big, op.rows_total, op.nblocks = L, M, int(multi.numel()), int(big.numel()), rows_total, nblocks
         op.rows_all, op.targets_all, op.row_cells, op.nbr32, op.nbrT = ptr(rows_all), ptr(targets_all), ptr(row_cells), ptr(nbr32), ptr(nbrT)
+        op.item_begin = ptr(item_begin)
         op.offsets, op.multi, op.workspace, op.cell_sums = ptr(offsets), (ptr(multi) if multi.numel() else None), ptr(ws), ptr(cell_sums)
         # SURVEY.md section 8d counts the operator's bytes per STORED entry; the dense-slot rows hold structural zeros (absent
         # neighbours, B-spline support ends): the set-up pass counts the non-zero slots on its way (read back on demand)
@@ -457,7 +459,7 @@ class KernelField(BaseField):
         if item_seg is not None:
             op.item_seg, op.unknown_seg = ptr(item_seg), ptr(segments.unknown_seg)
             keep += [item_seg, segments.unknown_seg]
-        keep += [nbr32, nbrT, offsets, multi, ws, cell_sums, nnz_counter]
+        keep += [nbr32, nbrT, item_begin, offsets, multi, ws, cell_sums, nnz_counter]
         td = _tick('op:tables', td)
         return {'op': op, 'nsets': len(specs), 'nblocks': nblocks, 'rows_total': rows_total, 'n_multi': int(multi.numel()),
                 'nnz_counter': nnz_counter, 'keep': keep, 'span': span, 'rows_all': rows_all}

@@ -27,7 +27,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.LevelT) == 80
     assert ctypes.sizeof(_lib.HierT) == 16 + 6 * 80
     assert ctypes.sizeof(_lib.SiteSetT) == 32 + 2 * 6 * 8 + 16
-    assert ctypes.sizeof(_lib.FusedOpT) == 16 + 8 + 7 * 8 + 8 + 5 * 8
+    assert ctypes.sizeof(_lib.FusedOpT) == 16 + 8 + 8 * 8 + 8 + 5 * 8
     assert ctypes.sizeof(_lib.CoarsePrecondT) == 16 + 8 + 14 * 8
     assert ctypes.sizeof(_lib.SegmentsT) == 8 + 3 * 8
     assert _lib.lib.nksr_version() >= 100
@@ -122,8 +122,8 @@ def test_c_abi_argument_errors_without_a_gpu():
     h = _lib.HierT()
     h.depth = 4
     assert lib.nksr_kernel_rows(C.byref(h), null, C.c_int64(5), C.c_int(0), C.c_float(1.0), null, C.c_int64(0), null, null, null, null, null) != 0 and 'NULL' in err()
-    assert lib.nksr_fused_block_counts(C.c_int32(9), C.c_int32(10), C.c_int64(5), null, null, null, null) != 0 and 'depth' in err()
-    assert lib.nksr_fused_block_counts(C.c_int32(4), C.c_int32(10), C.c_int64(5), null, null, null, null) != 0 and 'NULL' in err()
+    assert lib.nksr_fused_block_counts(C.c_int32(9), C.c_int32(10), C.c_int64(5), null, null, null, null, null) != 0 and 'depth' in err()
+    assert lib.nksr_fused_block_counts(C.c_int32(4), C.c_int32(10), C.c_int64(5), null, null, null, null, null) != 0 and 'NULL' in err()
     op = _lib.FusedOpT()
     op.depth, op.M = 4, 10
     assert lib.nksr_fused_apply(C.byref(op), C.c_float(1.0), null, null, null) != 0 and 'NULL' in err()
@@ -133,7 +133,7 @@ def test_c_abi_argument_errors_without_a_gpu():
     hh = _lib.HierT()
     hh.depth = 4
     hh.lv[3].n = 5
-    assert lib.nksr_fused_tables(C.byref(hh), null, null, null, null, null) != 0 and 'NULL' in err()
+    assert lib.nksr_fused_tables(C.byref(hh), C.c_int64(0), null, null, null, null, null, null) != 0 and 'NULL' in err()
     assert lib.nksr_coarse_lambda_max(null, null, null, null, C.c_int32(5), C.c_int(8), null, null, None, C.c_int32(0), null) != 0 and 'NULL' in err()
     one = (C.c_float * 8)()
     assert lib.nksr_sdf_from_points(one, one, null, null, null, null, null, C.c_int32(0), C.c_float(1.0), C.c_float(1.0), one, C.c_int64(1), C.c_int(0),
