@@ -30,7 +30,7 @@
 #define FZ_BLOCK 256
 #define FZ_HW (FZ_BLOCK / 32)              // items (half-waves) of a workgroup
 #define FZ_WG_ROWS (FZ_RC * FZ_HW)         // 256 consecutive rows per workgroup
-#define FZ_STAGE0 128                      // level-0 / level-1 cells of a workgroup whose final blocks are staged in LDS (a workgroup holds
+#define FZ_STAGE0 96                       // level-0 / level-1 cells of a workgroup whose final blocks are staged in LDS (a workgroup holds
 #define FZ_STAGE1 32                       // ~64 / ~8 of them at four rows per level-0 cell; more than fit are written word by word)
 
 // Round 4 -- where the blocks go.  A cell's block P[c][27] is final as soon as all rows of the cell have been seen.  Rounds 2-3
@@ -199,7 +199,7 @@ __device__ __forceinline__ float half_lane_f(float v, int l, bool upper) { retur
 // levels change cell only BETWEEN units -- no trip is ever cut.  The row-streaming version spent ~600 instructions per 8 rows on
 // finding out which rows change cell at which level (rows x levels masks, half-lane selects, the cut loop); this one ~150.
 template <int MODE, int D, int U>
-__global__ void __launch_bounds__(FZ_BLOCK) k_fz_cells(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
+__global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 6 : 5))) __launch_bounds__(FZ_BLOCK) k_fz_cells(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
                                                       float* __restrict__ part2, float* __restrict__ ct, float* __restrict__ ct2,
                                                       const int* __restrict__ done) {
     if (done && *done) return;

@@ -9,14 +9,14 @@ import os
 import subprocess
 import sys
 
-KERNELS = ('k_fz_sweep', 'k_fz_cellsum', 'k_fz_gather')
+KERNELS = ('k_fz_cells', 'k_fz_cellsum', 'k_fz_gather')
 
 
 def _match(k, name):
     """operator instantiations only (MODE 0), mangled or demangled kernel names"""
     if k not in name:
         return False
-    if k in ('k_fz_sweep', 'k_fz_gather'):
+    if k in ('k_fz_cells', 'k_fz_gather'):
         return (k + 'ILi0') in name or (k + '<0') in name
     return True
 
@@ -54,7 +54,8 @@ def main():
     points = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
     fv, fd, desc = run_pass('FETCH_SIZE', points, 'ffetch')
     wv, wd, _ = run_pass('WRITE_SIZE', points, 'fwrite')
-    rec = {'probe': 'python -m nksr_amd.tools.fused_probe %d 10' % points, 'system': desc,
+    from nksr_amd import build
+    rec = {'probe': 'python -m nksr_amd.tools.fused_probe %d 10' % points, 'system': desc, 'kernel_source_hash': build.kernel_hash('fused'),
            'correction': 'KiB units; gfx950 FETCH_SIZE counts the 128-B requests of a coalesced stream at 64 B: doubled; WRITE_SIZE uncorrected',
            'kernels': {}}
     tot = 0.0
@@ -72,7 +73,8 @@ def main():
     m = re.search(r'M=(\d+) rows=(\d+) partial blocks=(\d+)', desc)
     if m:      # same formula as csrc/fused.hip FusedOperator::bytes (depth 4 on the probe workload)
         M, rows, blocks = int(m.group(1)), int(m.group(2)), int(m.group(3))
-        rec['physical_bytes_per_application'] = 4 * 27 * 4 * rows + 4 * 4 * rows + 3 * 128 * blocks + 404 * M
+        rec['physical_bytes_per_application'] = 4 * 27 * 4 * rows + 4 * 4 * rows + 2 * 128 * blocks + (128 + 3 * 108 + 12) * M
+        rec['algorithmic_note'] = 'algorithmic minimum (DESIGN.md section 3.5): 4 B per stored entry + 4 B per row and level + 116 B per unknown'
     json.dump(rec, open(out, 'w'), indent=1)
     print(json.dumps(rec))
 

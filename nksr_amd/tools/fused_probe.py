@@ -44,7 +44,7 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     slots = 27 * f.svh.depth * op['rows_total']
-    phys = 4 * slots + 4 * f.svh.depth * op['rows_total'] + 3 * 128 * op['nblocks'] + 404 * M      # csrc/fused.hip FusedOperator::bytes
+    phys = 4 * slots + 4 * f.svh.depth * op['rows_total'] + 2 * 128 * op['nblocks'] + (128 + 3 * 108 + 12) * M      # csrc/fused.hip FusedOperator::bytes
     nnz = int(torch.count_nonzero(op['keep'][0]).item())
     alg = 16.0 * nnz + 12 * M + 4
     print('fused apply: %.1f us  physical %.3f GB -> %.2f TB/s (%.1f%% of 8 TB/s);  SURVEY 8d figure (16 B x %d non-zero slots of %d) %.3f GB -> %.2f TB/s'
