@@ -70,7 +70,8 @@ int nksr_splat_keys(const float* xyz, int64_t n, float inv_w0, int level, int mo
  * index), mode 1 -> 27 keys per cell at the same level. */
 int nksr_cell_footprint_keys(const int64_t* cell_keys, int64_t nc, int level, int mode, int64_t* keys_out, void* stream);
 /* Axis-aligned bounding box of a cloud (the host side of detail_level / chunk_size needs it: NKSR-USAGE.md:129-137):
- * out6 = (min x, y, z, max x, y, z), exact; work: nksr_bbox_work_floats() floats of scratch. */
+ * out6 = (min x, y, z, max x, y, z), exact; out6[0] = NaN when any coordinate is NaN / infinite (the readback of the box is the
+ * finiteness check of the input); work: nksr_bbox_work_floats() floats of scratch. */
 int nksr_bbox(const float* xyz, int64_t n, float* work, float* out6, void* stream);
 int64_t nksr_bbox_work_floats(void);
 /* The same key streams (xyz != NULL: nksr_splat_keys; cell_keys != NULL: nksr_cell_footprint_keys; exactly one of them) with the
@@ -331,7 +332,7 @@ typedef struct {
  * the units that start in the 32-row window [32 i, 32 i + 32) = rows [item_begin[i], item_begin[i + 1]); eight items are a workgroup.
  * A cell whose rows lie inside one workgroup is finished by the sweep, a cell whose rows reach into k > 1 workgroups owns k partial
  * blocks.  rows_all / targets_all must be readable 320 rows past rows_total (unconditional loads).
- * nksr_fused_block_counts: span_out [2, M] (first / last row of every cell, -1 = none), item_begin_out [nksr_fused_item_entries],
+ * nksr_fused_block_counts: span_out [3, M] (first / last row of every cell, -1 = none; first workgroup), item_begin_out [nksr_fused_item_entries],
  * counts_out [M + 1] (0 or k; last entry 0) -> exclusive scan = offsets -> nksr_fused_tables (nbr32_out [M, 32], nbrT_out [27, M]). */
 int64_t nksr_fused_item_entries(int64_t rows_total);
 int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_total, const int32_t* row_cells, int32_t* span_out, int32_t* item_begin_out,

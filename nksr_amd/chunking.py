@@ -631,13 +631,15 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     active = D.active() and sim is None            # a process group takes part (world > 1, or forced at world 1: NKSR_DIST_FORCE)
     collective = sharded_input and active
     from .density import bbox_center
-    if xyz.shape[0] and (not bool(torch.isfinite(xyz).all())):
-        raise RuntimeError('non-finite coordinates in the input')
+    if xyz.shape[0]:
+        lo_t, hi_t, _ = bbox_center(xyz)
+        if not abs(float(lo_t[0])) < float('inf'):         # (nksr_bbox: NaN when any coordinate is NaN / infinite)
+            raise RuntimeError('non-finite coordinates in the input')
     if chunk_bounds is not None:
         lo, hi = [float(v) for v in chunk_bounds[0]], [float(v) for v in chunk_bounds[1]]
     else:
         if xyz.shape[0]:
-            lo_t, hi_t, _ = bbox_center(xyz)
+            pass
         else:
             lo_t = torch.full((3,), float('inf'), device=dev)
             hi_t = -lo_t
@@ -727,8 +729,7 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
         for c in small:
             npts[c] = 0
     jobs = [c for c in jobs if npts[c] >= MIN_CHUNK_POINTS]
-    if bx.shape[0] and not bool(torch.isfinite(bn).all()):
-        raise RuntimeError('non-finite normals in the input')
+    # (non-finite normals: caught by the box readback every batch starts with, Reconstructor._key_bits)
     # sub-batches of whole chunks (memory: ~2 KB per point at tree_depth 5), chunks of a batch in slot order
     jobs.sort(key=lambda c: frame.key_range(c)[0])
     budget = int(getattr(rec, 'chunk_batch_points', 0) or (1 << 25))

@@ -88,13 +88,18 @@ __device__ __forceinline__ int fz_wg_of(const int32_t* __restrict__ item_begin, 
 // partial blocks of a cell: one per workgroup its rows reach into -- if that is more than one; a cell inside one workgroup has none
 // (the sweep finishes it)
 __global__ void k_fz_block_counts(int M, int nwg, const int32_t* __restrict__ item_begin, const int32_t* __restrict__ first,
-                                  const int32_t* __restrict__ last, int32_t* __restrict__ counts) {
+                                  const int32_t* __restrict__ last, int32_t* __restrict__ wgfirst, int32_t* __restrict__ counts) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > M) return;
     int n = 0;
-    if (j < M && first[j] >= 0) {
-        n = fz_wg_of(item_begin, nwg, last[j]) - fz_wg_of(item_begin, nwg, first[j]) + 1;
-        if (n == 1) n = 0;
+    if (j < M) {
+        int w0 = 0;
+        if (first[j] >= 0) {
+            w0 = fz_wg_of(item_begin, nwg, first[j]);
+            n = fz_wg_of(item_begin, nwg, last[j]) - w0 + 1;
+            if (n == 1) n = 0;
+        }
+        wgfirst[j] = w0;
     }
     counts[j] = n;
 }
@@ -107,8 +112,8 @@ __device__ __forceinline__ int fz_level(const nksr_hier_t& h, int j) {
 
 // nbr32[j][0..26]: global unknown index of the neighbour voxels or -1;  [27]: (first block of j) - (first workgroup of j), so that
 // the block of workgroup w is nbr32[j][27] + w;  [28] / [29]: first / last row of the cell (-1: none)
-__global__ void k_fz_tables(nksr_hier_t hier, int M, int nwg, const int32_t* __restrict__ item_begin, const int32_t* __restrict__ offsets,
-                            const int32_t* __restrict__ first, const int32_t* __restrict__ last, int32_t* __restrict__ nbr32) {
+__global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__ offsets, const int32_t* __restrict__ first,
+                            const int32_t* __restrict__ last, const int32_t* __restrict__ wgfirst, int32_t* __restrict__ nbr32) {
     const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lin >= (int64_t)M * 32) return;
     const int j = (int)(lin >> 5), s = (int)(lin & 31);
@@ -118,7 +123,7 @@ __global__ void k_fz_tables(nksr_hier_t hier, int M, int nwg, const int32_t* __r
         const int nb = hier.lv[d].nbr[(int64_t)c * 27 + s];
         v = nb >= 0 ? nb + hier.lv[d].offset : -1;
     } else if (s == 27) {
-        v = offsets[j] - (first[j] >= 0 ? fz_wg_of(item_begin, nwg, first[j]) : 0);
+        v = offsets[j] - wgfirst[j];
     } else if (s == 28) {
         v = first[j];
     } else if (s == 29) {
@@ -596,7 +601,7 @@ extern "C" int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_to
     if (rows_total > 0)
         hipLaunchKernelGGL(k_fz_spans, dim3(nksr_blocks(rows_total * depth, 256)), dim3(256), 0, st, depth, rows_total, row_cells, span_out, span_out + M);
     hipLaunchKernelGGL(k_fz_block_counts, dim3(nksr_blocks((int64_t)M + 1, 256)), dim3(256), 0, st, M, fz_nwg(rows_total) > 0 ? fz_nwg(rows_total) : 1,
-                       (const int32_t*)item_begin_out, (const int32_t*)span_out, (const int32_t*)(span_out + M), counts_out);
+                       (const int32_t*)item_begin_out, (const int32_t*)span_out, (const int32_t*)(span_out + M), span_out + 2 * (int64_t)M, counts_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -607,8 +612,8 @@ extern "C" int nksr_fused_tables(const nksr_hier_t* h, int64_t rows_total, const
     const int M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
     if (M <= 0) return NKSR_OK;
     if (!offsets || !span || !nbr32_out || !nbrT_out || !item_begin) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
-    hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)M * 32, 256)), dim3(256), 0, (hipStream_t)stream, *h, M, fz_nwg(rows_total) > 0 ? fz_nwg(rows_total) : 1,
-                       item_begin, offsets, span, span + M, nbr32_out);
+    hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)M * 32, 256)), dim3(256), 0, (hipStream_t)stream, *h, M, offsets, span, span + M,
+                       span + 2 * (int64_t)M, nbr32_out);
     hipLaunchKernelGGL(k_fz_nbrT, dim3(nksr_blocks(M, 64)), dim3(256), 0, (hipStream_t)stream, M, (const int32_t*)nbr32_out, nbrT_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;

@@ -244,7 +244,8 @@ __global__ void k_cell_footprint_keys(const int64_t* __restrict__ cell_keys, int
     }
 }
 
-// ---- bounding box of a cloud: exact min / max per axis (two fixed-order stages; NaNs are skipped, callers validate) ----------
+// ---- bounding box of a cloud: exact min / max per axis (two fixed-order stages).  A non-finite coordinate anywhere turns out6[0]
+// into NaN: the one readback of the box is also the "is the input finite" check (torch.isfinite(...).all() was a pass + a sync each) --
 #define BB_BLOCKS 1024
 __device__ __forceinline__ void bb_wave(float (&lo)[3], float (&hi)[3]) {
 #pragma unroll
@@ -255,15 +256,19 @@ __device__ __forceinline__ void bb_wave(float (&lo)[3], float (&hi)[3]) {
 __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ xyz, int64_t n, const float* __restrict__ part_in, float* __restrict__ out) {
     __shared__ float sm[4][6];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool bad = false;
     if (part_in) {       // second stage: BB_BLOCKS partial boxes
-        for (int i = threadIdx.x; i < BB_BLOCKS; i += 256)
+        for (int i = threadIdx.x; i < BB_BLOCKS; i += 256) {
+            bad = bad || part_in[i * 6] != part_in[i * 6];
 #pragma unroll
             for (int a = 0; a < 3; ++a) { lo[a] = fminf(lo[a], part_in[i * 6 + a]); hi[a] = fmaxf(hi[a], part_in[i * 6 + 3 + a]); }
+        }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)BB_BLOCKS * 256)
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { const float v = xyz[i * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+            for (int a = 0; a < 3; ++a) { const float v = xyz[i * 3 + a]; bad = bad || !(fabsf(v) <= 3.402823466e38f); lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
     }
+    bad = __syncthreads_or(bad ? 1 : 0) != 0;
     bb_wave(lo, hi);
     if ((threadIdx.x & 63) == 0)
 #pragma unroll
@@ -273,7 +278,7 @@ __global__ void __launch_bounds__(256) k_bbox(const float* __restrict__ xyz, int
         const int a = threadIdx.x;
         float v = sm[0][a];
         for (int w = 1; w < 4; ++w) v = a < 3 ? fminf(v, sm[w][a]) : fmaxf(v, sm[w][a]);
-        out[(part_in ? 0 : (int64_t)blockIdx.x * 6) + a] = v;
+        out[(part_in ? 0 : (int64_t)blockIdx.x * 6) + a] = (bad && a == 0) ? NAN : v;
     }
 }
 // out6 = (min x, y, z, max x, y, z);  work: BB_BLOCKS * 6 floats

@@ -2,6 +2,12 @@
 // operations (rocPRIM through the hipCUB front-end); every domain kernel is hand-written.
 #include "common.h"
 #include <hipcub/hipcub.hpp>
+#include <rocprim/rocprim.hpp>
+
+// rocPRIM sorts up to 2^20 items by merge sort (block sort + log2(n / 1024) merge passes of two launches each: ~17 launches of 6-7 us
+// for the 10^5-key streams of the coarser hierarchy levels and the mesh keys); with the bit range of a cloud's Morton keys (one
+// onesweep pass per 8 varying bits) the onesweep path is fewer launches and less time from ~16 k items on.
+using nksr_sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 16384>;
 #include <stdarg.h>
 
 thread_local char g_nksr_err[512] = "";
@@ -20,7 +26,7 @@ extern "C" int nksr_version(void) { return 100; }
 extern "C" int nksr_sort_keys_u64(void* tmp, size_t* tmp_bytes, const uint64_t* in, uint64_t* out, int64_t n,
                                   int begin_bit, int end_bit, void* stream) {
     if (!tmp_bytes) return nksr_set_error(NKSR_ERR_ARG, "tmp_bytes is NULL");
-    NKSR_CHECK_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, *tmp_bytes, in, out, n, begin_bit, end_bit, (hipStream_t)stream));
+    NKSR_CHECK_HIP(rocprim::radix_sort_keys<nksr_sort_config>(tmp, *tmp_bytes, in, out, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, (hipStream_t)stream));
     return NKSR_OK;
 }
 
@@ -28,8 +34,8 @@ extern "C" int nksr_sort_pairs_u64_u32(void* tmp, size_t* tmp_bytes, const uint6
                                        const uint32_t* vin, uint32_t* vout, int64_t n, int begin_bit, int end_bit,
                                        void* stream) {
     if (!tmp_bytes) return nksr_set_error(NKSR_ERR_ARG, "tmp_bytes is NULL");
-    NKSR_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, *tmp_bytes, kin, kout, vin, vout, n, begin_bit, end_bit,
-                                                      (hipStream_t)stream));
+    NKSR_CHECK_HIP(rocprim::radix_sort_pairs<nksr_sort_config>(tmp, *tmp_bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit,
+                                                               (hipStream_t)stream));
     return NKSR_OK;
 }
 

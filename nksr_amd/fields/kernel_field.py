@@ -172,7 +172,7 @@ class KernelField(BaseField):
         keys = torch.empty(n, dtype=torch.int64, device=self.device)
         call('nksr_point_keys', ptr(xyz), n, self.svh.inv_w0, ptr(keys), stream())
         idx = torch.arange(n, dtype=torch.int32, device=self.device)
-        ks, perm = ops.sort_pairs(keys, idx)
+        ks, perm = ops.sort_pairs(keys, idx, level=0)
         return ks, perm.long()
 
     def _site_ranges(self, site_keys):
@@ -382,7 +382,7 @@ class KernelField(BaseField):
         if len(specs) == 1 and segments is None:
             row_index = [torch.arange(counts_s[0], dtype=torch.int32, device=dev) * specs[0][5]]
         else:
-            ks_all, order = ops.sort_pairs(torch.cat([sp[1] for sp in specs]), torch.arange(nsite, dtype=torch.int32, device=dev))
+            ks_all, order = ops.sort_pairs(torch.cat([sp[1] for sp in specs]), torch.arange(nsite, dtype=torch.int32, device=dev), level=0)
             order = order.long()
             ncomp_site = torch.cat([torch.full((n,), sp[5], dtype=torch.int32, device=dev) for n, sp in zip(counts_s, specs)])
             first_row = ops.exclusive_sum_i32(torch.cat([ncomp_site[order], ncomp_site.new_zeros(1)]))       # [nsite + 1]
@@ -434,7 +434,7 @@ class KernelField(BaseField):
         td = _tick('op:kernel_rows', td)
         # work items = runs of 32 rows, eight of them a workgroup of the sweep; a cell whose rows lie inside one workgroup is finished
         # there, a cell that reaches into k > 1 workgroups owns k partial blocks (the coarse cells: ~1 % of all)
-        span = torch.empty((2, M), dtype=torch.int32, device=dev)
+        span = torch.empty((3, M), dtype=torch.int32, device=dev)          # first / last row of every cell, first workgroup
         counts = torch.empty(M + 1, dtype=torch.int32, device=dev)
         item_begin = torch.empty(int(_lib.lib.nksr_fused_item_entries(rows_total)), dtype=torch.int32, device=dev)
         call('nksr_fused_block_counts', L, M, rows_total, ptr(row_cells), ptr(span), ptr(item_begin), ptr(counts), stream())

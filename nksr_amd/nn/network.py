@@ -86,7 +86,7 @@ def sort_cloud(xyz, feat, inv_w0):
     n = xyz.shape[0]
     keys = torch.empty(n, dtype=torch.int64, device=xyz.device)
     call('nksr_point_keys', ptr(xyz), n, inv_w0, ptr(keys), stream())
-    ks, perm = ops.sort_pairs(keys, torch.arange(n, dtype=torch.int32, device=xyz.device))
+    ks, perm = ops.sort_pairs(keys, torch.arange(n, dtype=torch.int32, device=xyz.device), level=0)
     perm = perm.long()
     return ks, xyz[perm].contiguous(), (feat[perm].contiguous() if feat is not None else None)
 

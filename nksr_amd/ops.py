@@ -12,27 +12,68 @@ def _bits(n):
     return b
 
 
-def varying_bits(keys):
+class KeyBits:
+    """Bit range of the Morton keys of one cloud, from its bounding box -- known on the host after the ONE readback a reconstruction
+    starts with, so no sort has to look at its keys first (round 3: ``int((keys ^ keys[:1]).max())`` before every large sort, a
+    reduction + a host sync each).  lo / hi: level-0 cell coordinates of the box (inclusive).  The keys of level d are Morton codes of
+    (cell >> d) + 2^(20 - d); everything a hierarchy level, a site list or a footprint stream of this cloud
+    holds lies within two cells of the box at its level, and all integers between two bounds share their common binary prefix."""
+
+    def __init__(self, lo, hi):
+        self.lo, self.hi = [int(v) for v in lo], [int(v) for v in hi]
+
+    def bits(self, level=0):
+        b = 0
+        for a in range(3):
+            bias = 1 << (20 - level)
+            lo, hi = (self.lo[a] >> level) - 2 + bias, (self.hi[a] >> level) + 2 + bias
+            b = max(b, (lo ^ hi).bit_length())
+        return max(1, min(63, 3 * b))
+
+
+_key_hint = None
+
+
+class key_hint:
+    """``with ops.key_hint(KeyBits(lo, hi)):`` -- sorts of Morton keys that name their ``level`` take their bit range from the box."""
+
+    def __init__(self, kb):
+        self.kb = kb
+
+    def __enter__(self):
+        global _key_hint
+        self.prev, _key_hint = _key_hint, self.kb
+        return self.kb
+
+    def __exit__(self, *exc):
+        global _key_hint
+        _key_hint = self.prev
+
+
+def varying_bits(keys, level=None):
     """Number of low bits that differ anywhere in ``keys``: Morton keys of one cloud share their high bits
     (always when the cloud lies in one octant of the biased lattice), and every 8 constant bits save one
-    radix pass.  Small inputs are not worth the host round trip."""
+    radix pass.  With a key_hint in force and a ``level`` given, the answer comes from the cloud's box (no device work);
+    otherwise small inputs are not worth the host round trip and large ones are looked at."""
+    if level is not None and _key_hint is not None:
+        return _key_hint.bits(level)
     if keys.numel() < (1 << 17):
         return 63
     return max(1, int((keys ^ keys[:1]).max()).bit_length())
 
 
-def sort_keys(keys, end_bit=None):
-    """Ascending radix sort of non-negative int64 keys."""
+def sort_keys(keys, end_bit=None, level=None):
+    """Ascending radix sort of non-negative int64 keys (``level``: they are Morton keys of that hierarchy level, see key_hint)."""
     n = keys.numel()
     out = torch.empty_like(keys)
     if n:
         if end_bit is None:
-            end_bit = varying_bits(keys)
+            end_bit = varying_bits(keys, level)
         with_tmp('nksr_sort_keys_u64', keys.device, ptr(keys), ptr(out), n, 0, int(end_bit), stream())
     return out
 
 
-def sort_pairs(keys, vals32, end_bit=None, pad=0):
+def sort_pairs(keys, vals32, end_bit=None, pad=0, level=None):
     """Sort (int64 key, 32-bit payload) pairs by key.  ``pad`` extra (zeroed) elements are kept
     behind the returned views so that 16-byte loads may run past the end."""
     n = keys.numel()
@@ -40,7 +81,7 @@ def sort_pairs(keys, vals32, end_bit=None, pad=0):
     vo = torch.zeros(n + pad, dtype=vals32.dtype, device=vals32.device)[:n] if pad else torch.empty_like(vals32)
     if n:
         if end_bit is None:
-            end_bit = varying_bits(keys)
+            end_bit = varying_bits(keys, level)
         with_tmp('nksr_sort_pairs_u64_u32', keys.device, ptr(keys), ptr(ko), ptr(vals32), ptr(vo), n, 0, int(end_bit), stream())
     return ko, vo
 
@@ -56,12 +97,12 @@ def unique_sorted(keys_sorted):
     return out[:int(cnt.item())].clone()
 
 
-def sort_unique(keys, maybe_sorted=False):
+def sort_unique(keys, maybe_sorted=False, level=None):
     """``maybe_sorted``: the stream is expected to be strictly ascending already (keys derived in order from a sorted
     parent list): one comparison pass + host sync instead of the radix sort and the unique pass when it is."""
     if maybe_sorted and keys.numel() > 1 and bool((keys[1:] > keys[:-1]).all()):
         return keys
-    return unique_sorted(sort_keys(keys))
+    return unique_sorted(sort_keys(keys, level=level))
 
 
 def dedup_keys(keys):
@@ -124,8 +165,10 @@ class HashTable:
             cap *= 2
         dev = keys_sorted_unique.device
         self.cap = cap
-        self.hkeys = torch.full((cap,), -1, dtype=torch.int64, device=dev)
-        self.hvals = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+        # keys and values in ONE buffer cleared by ONE fill (-1 = all bytes 0xFF in both)
+        buf = torch.full((cap * 12,), 255, dtype=torch.uint8, device=dev)
+        self.hkeys = buf[:cap * 8].view(torch.int64)
+        self.hvals = buf[cap * 8:].view(torch.int32)
         if n:
             call('nksr_hash_build', ptr(keys_sorted_unique), n, ptr(self.hkeys), ptr(self.hvals), cap, stream())
 

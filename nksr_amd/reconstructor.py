@@ -49,6 +49,32 @@ class Reconstructor:
         """``chunks`` = (ids, key_lo, key_hi, frame): the cloud is a batch of chunks in the exploded frame (nksr_amd/chunking.py) -- one
         hierarchy, one network pass, ONE block-diagonal solve whose diagonal blocks (segments) are the chunks; every chunk keeps
         the solver weights of its own point / normal-site counts (models/nksr_net.py:103-111)."""
+        from . import ops
+        with ops.key_hint(self._key_bits(xyz, normal)):
+            return self._reconstruct_hinted(xyz, normal, approx_kernel_grad, solver_max_iter, solver_tol, fused_mode, chunks)
+
+    def _key_bits(self, xyz, normal):
+        """ONE readback before anything is built: the boxes of the cloud and of its normals (nksr_bbox; a non-finite value anywhere
+        comes back as NaN) = the input check, the lattice range check and the bit range of every Morton key sort that follows."""
+        from . import ops
+        from .density import bbox_center
+        from .svh import inv_w0_f32
+        lo, hi, _ = bbox_center(xyz)
+        nlo, _, _ = bbox_center(normal)
+        v = torch.cat([lo, hi, nlo[:1]]).tolist()
+        if not all(abs(c) < float('inf') for c in v[:6]):        # (NaN compares false)
+            raise RuntimeError('non-finite coordinates in the input')
+        if not abs(v[6]) < float('inf'):
+            raise RuntimeError('non-finite normals in the input')
+        inv = inv_w0_f32(self.hparams.voxel_size)
+        amax = max(abs(c) for c in v[:6])
+        if not (amax * inv < (1 << 20) - 8):
+            raise RuntimeError('coordinates out of range: |x| / voxel_size must stay below 2^20 (got %g); '
+                               'recentre the cloud or use a larger voxel_size' % (amax * inv))
+        import math
+        return ops.KeyBits([math.floor(c * inv) - 1 for c in v[:3]], [math.floor(c * inv) + 1 for c in v[3:6]])
+
+    def _reconstruct_hinted(self, xyz, normal, approx_kernel_grad, solver_max_iter, solver_tol, fused_mode, chunks=None):
         hp = self.hparams
         t = {}
         tic = time.perf_counter()
@@ -133,9 +159,7 @@ class Reconstructor:
                                'preprocess_fn=nksr.get_estimate_normal_preprocess_fn(...)')
         if xyz.shape[0] < 8:
             raise RuntimeError('need at least 8 points to reconstruct (got %d)' % xyz.shape[0])
-        if not bool(torch.isfinite(xyz).all()) or not bool(torch.isfinite(normal).all()):
-            raise RuntimeError('non-finite coordinates / normals in the input')
-        scale = self._global_scale(xyz, detail_level, voxel_size)
+        scale = self._global_scale(xyz, detail_level, voxel_size)          # (non-finite input is caught by the box readback of _key_bits)
         xs = (xyz * scale).contiguous() if scale != 1.0 else xyz.contiguous()
         field = self._reconstruct_single(xs, normal.to(torch.float32).contiguous(), approx_kernel_grad, solver_max_iter,
                                          solver_tol, fused_mode)

@@ -93,7 +93,7 @@ class SparseFeatureHierarchy:
         if xyz.dtype != torch.float32 or xyz.dim() != 2 or xyz.shape[1] != 3:
             raise RuntimeError('xyz must be a float32 [N,3] tensor')
         _lib.require_gpu(xyz.device)
-        if xyz.shape[0]:
+        if xyz.shape[0] and ops._key_hint is None:        # (under a key_hint the caller has checked the cloud's box already)
             amax = float(xyz.abs().max())
             if not (amax * self.inv_w0 < (1 << 20) - 8):     # also catches NaN / inf
                 raise RuntimeError('coordinates out of range: |x| / voxel_size must stay below 2^20 (got %g); '
@@ -107,7 +107,7 @@ class SparseFeatureHierarchy:
         for d in range(self.depth):
             raw = torch.empty(n * per, dtype=torch.int64, device=self.device)
             call('nksr_splat_keys', ptr(xyz), n, self.inv_w0, d, mode, ptr(raw), stream())
-            keys = ops.sort_unique(raw)
+            keys = ops.sort_unique(raw, level=d)
             self._levels[d] = SparseGrid(keys, d, self.voxel_size)
         return self
 
@@ -134,9 +134,9 @@ class SparseFeatureHierarchy:
         per = 8 if mode == 0 else 27
         raw = torch.empty(cells.numel() * per, dtype=torch.int64, device=self.device)
         if raw.numel() >= _DEDUP_MIN:
-            return ops.sort_unique(self._dedup(None, cells, cells.numel(), level, mode, raw))
+            return ops.sort_unique(self._dedup(None, cells, cells.numel(), level, mode, raw), level=level + (1 if mode == 0 else 0))
         call('nksr_cell_footprint_keys', ptr(cells), cells.numel(), level, mode, ptr(raw), stream())
-        return ops.sort_unique(raw)
+        return ops.sort_unique(raw, level=level + (1 if mode == 0 else 0))
 
     def _dedup(self, xyz, cells, n, level, mode, raw):
         """Large key streams: duplicates of neighbouring (Morton-ordered) elements are dropped in LDS before the sort
@@ -157,7 +157,7 @@ class SparseFeatureHierarchy:
             raw = self._dedup(xyz_sorted, None, n, 0, 0, raw)
         else:
             call('nksr_splat_keys', ptr(xyz_sorted), n, self.inv_w0, 0, 0, ptr(raw), stream())
-        self._levels[0] = SparseGrid(ops.sort_unique(raw), 0, self.voxel_size)
+        self._levels[0] = SparseGrid(ops.sort_unique(raw, level=0), 0, self.voxel_size)
         if cells is None and self.depth > 1:
             cells = self.cells_with_points(point_keys_sorted, self.depth - 1)
         for d in range(1, self.depth):
