@@ -548,7 +548,9 @@ class KernelField(BaseField):
             # bytes, no tails), and every PCG iteration saved is a sweep over all kernel rows (configs[4], one GPU, ratio 40:
             # 8 / 10 / 12 steps -> 11.19 / 10.91 / 10.72 iterations per chunk, 390.7 / 392.5 / 395.7 ms per step: flat);
             # small blocks are bound by the number of launches, not by bytes: they keep eight
-            if 'steps' not in cfg and n >= 100000:
+            # (chunk mode always takes ten: the count must not depend on how many chunks share the batch -- a chunk's iterates are
+            # the same bits alone and among 63 others, tests/test_gpu_full_size.py)
+            if 'steps' not in cfg and (segments is not None or n >= 100000):
                 pc.steps = 10
                 info['steps'] = 10
             pc.format, pc.row_seg, pc.work = 1, ptr(row_seg_new), ptr(work)

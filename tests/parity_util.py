@@ -45,16 +45,16 @@ def check_alpha(name, alpha_hip, ofl, tol):
     a relative RESIDUAL of ``tol`` agree in alpha only to cond(A) x tol, while the field they define agrees to ~tol.
     What is checked, therefore: (1) the HIP alpha solves the ORACLE's system to 10 x tol (fp64 residual with the oracle's
     own matrix and right-hand side) -- the conditioning-free statement of "same solution"; (2) alpha itself within
-    ALPHA_TOL of the oracle's (measured worst case 4.2e-4 of max|alpha| on MI355X in round 2).  The 1e-4 contract on
-    alpha of SURVEY.md section 8c is asserted where it is meaningful: after a FIXED number of iterations
-    (tests/test_gpu_parity.py::test_pcg_matches_oracle_and_scipy) and on the field values (every test here)."""
+    ALPHA_TOL = 1e-4 of the oracle's, the contract of SURVEY.md section 8c (round 2 needed 2e-3: 4.2e-4 measured; since the
+    fp32 rounding fixes of round 3 the worst case over all cases is 4.2e-5).  The same 1e-4 holds after a FIXED number of
+    iterations (tests/test_gpu_parity.py::test_pcg_matches_oracle_and_scipy) and on the field values (every test here)."""
     a = np.asarray(alpha_hip, np.float64)
     A, b = ofl['A'].astype(np.float64), ofl['b'].astype(np.float64)
     check(name + ':residual_in_oracle_system', np.linalg.norm(b - A @ a) / np.linalg.norm(b), 10.0 * tol)
     check(name + ':alpha_rel', np.abs(a - ofl['alpha']).max() / np.abs(ofl['alpha']).max(), ALPHA_TOL)
 
 
-ALPHA_TOL = 2e-3
+ALPHA_TOL = 1e-4      # SURVEY.md section 8c / BASELINE.md section 2.1 (measured on MI355X: <= 4.2e-5 over all cases, profiles/r03_parity_report.txt)
 
 
 def _rows_view(a):

@@ -252,3 +252,124 @@ def test_mesh_is_watertight_and_on_the_data(big, mise_iter):
     fv = fld.evaluate_f(mesh.v).value
     assert float(fv.abs().max()) < 0.5
     assert bool(torch.isfinite(mesh.v).all())
+
+
+# ---- BASELINE.json configs[4] at its full size: the 64-chunk batch of bench.py -------------------------------------------------------
+def _bench():
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec_ = importlib.util.spec_from_file_location('bench_mod_fs', os.path.join(root, 'bench.py'))
+    m = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(m)
+    return m
+
+
+def test_bench_scale_batch_is_its_solo_chunks_bit_for_bit_and_its_operator_rows_match_the_oracle():
+    """The scene bench.py times (10 M points, 8 x 8 tiles, tree_depth 5, all 64 chunks of the rank as ONE block-diagonal solve):
+      * every chunk solved ALONE (chunk_batch_points = 1: 64 batches of one) gives the voxel keys, the iteration count and the
+        coefficients of its segment of the 64-chunk batch BIT FOR BIT -- the reference solves its chunks one after the other
+        (examples/recons_by_chunk.py:26-29); batching them must not change a single bit;
+      * one chunk of the batch against the oracle: its voxel keys at all five levels exactly, and rows of y = A x of ~1 000 sampled
+        unknowns of that chunk -- x random over the WHOLE batch, so a leak between the diagonal blocks would show -- against the
+        oracle evaluating all constraint rows in their support, bound 3e-6 (|A| |x|)_i as at the configs[2] size."""
+    import parity_util as pu
+    import scipy.sparse as sp
+    import nksr_amd
+    from nksr_amd import configs
+    from oracle import hierarchy as ohier, kernel as okern, spec
+    b = _bench()
+    dev = torch.device('cuda:0')
+    rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', tree_depth=5))
+    rec.keep_solve_inputs = True
+    hp = rec.hparams
+    L = hp.tree_depth
+    xyz, nrm, scale, owner, bounds, n_scene, _ = b.terrain_setup(rec, dev, 10_000_000, 0, 1)
+    assert n_scene == 10_000_000
+    kw = dict(detail_level=None, chunk_size=b.TILE * scale, sharded_input=True, chunk_owner=owner, chunk_bounds=bounds)
+    fld = rec.reconstruct(xyz, nrm, **kw)
+    assert len(fld.parts) == 1 and len(fld.parts[0].ids) == 64
+    part = fld.parts[0]
+    bf = part.field
+    inp = bf._solve_inputs
+    seg = inp['segments']
+    info = bf.solve_info['segment_info'].cpu().numpy()
+    lo, hi = seg.lo.cpu().numpy(), seg.hi.cpu().numpy()            # [64, L] unknown ranges of every chunk
+    off = bf.svh.offsets
+    batch = {}
+    for i, c in enumerate(part.ids):
+        batch[c] = ([bf.svh.level(d).keys[lo[i, d] - off[d]:hi[i, d] - off[d]].clone() for d in range(L)],
+                    torch.cat([bf.alpha[lo[i, d]:hi[i, d]] for d in range(L)]).clone(), int(info[i, 0]))
+    assert max(v[2] for v in batch.values()) <= 40 and float(info[:, 1].max()) <= 1e-5
+
+    # ---- one chunk of the batch against the oracle
+    i = 27
+    c = part.ids[i]
+    pk = inp['pos_sorted_keys']
+    p0, p1 = [int(v) for v in torch.searchsorted(pk, torch.stack([seg.key_lo[i], seg.key_hi[i]])).tolist()]
+    xs = inp['pos_xyz'][p0:p1].cpu().numpy()
+    H0, _ = spec.half_index(xs, hp.voxel_size)
+    pk0 = spec.morton_key(H0 >> 1, 0)
+    assert np.array_equal(pk0, pk[p0:p1].cpu().numpy())
+    first = np.concatenate([[True], pk0[1:] != pk0[:-1]])
+    oh = ohier.Hierarchy(hp.voxel_size, L).build_point_neighborhood(xs[first])
+    for d in range(L):
+        assert np.array_equal(batch[c][0][d].cpu().numpy(), oh.levels[d].keys), 'chunk %d level %d voxel keys' % (c, d)
+    Mc = oh.num_unknowns
+    feats = [bf._feat[d][lo[i, d] - off[d]:hi[i, d] - off[d]].cpu().numpy() for d in range(L)]
+    interps = []
+    for d in range(L):
+        m = rec.network.interpolators[d]
+        interps.append(okern.Interpolator(*[getattr(m, k).detach().cpu().numpy() for k in ('W1', 'b1', 'W2', 'b2', 'W3', 'b3')]))
+    psis = [okern.voxel_psi(feats[d], interps[d]) for d in range(L)]
+    assert hp.adaptive_depth == 1
+    q0, q1 = int(lo[i, 0]), int(hi[i, 0])                          # normal sites = the chunk's finest voxel centres
+    nxyz = inp['normal_xyz'][q0:q1].cpu().numpy()
+    nk0 = oh.levels[0].keys
+    rs = np.random.RandomState(0)
+    U, psel, qsel = [], [], []
+    for d, cnt in {0: 700, 1: 200, 2: 60, 3: 10, 4: 3}.items():
+        lv = oh.levels[d]
+        j = np.sort(rs.choice(lv.n, min(cnt, lv.n), replace=False))
+        U.append(j + oh.offsets[d])
+        cells = (lv.ijk[j][:, None, :] + spec.NBR_OFFSETS[None]).reshape(-1, 3)
+        ck = np.unique(spec.morton_key(cells, d))
+        for keys_d, out in ((pk0 >> (3 * d), psel), (nk0 >> (3 * d), qsel)):
+            out.append(_ranges(np.searchsorted(keys_d, ck, 'left'), np.searchsorted(keys_d, ck, 'right')))
+    U = np.concatenate(U)
+    psel, qsel = np.unique(np.concatenate(psel)), np.unique(np.concatenate(qsel))
+    gc, gv, _ = okern.kernel_rows(oh, feats, interps, psis, xs[psel], False, False)
+    qc, _, qd = okern.kernel_rows(oh, feats, interps, psis, nxyz[qsel], True, False)
+    G = okern.rows_to_csr(gc, gv, Mc).astype(np.float64)
+    Q = sp.vstack([okern.rows_to_csr(qc, qd[:, a], Mc) for a in range(3)]).tocsr().astype(np.float64)
+    # the chunk's own solver weights (models/nksr_net.py:103-111): the batch carries sqrt(weight) per site
+    wp, wn = float(inp['pos_weight'][p0]) ** 2, float(inp['normal_weight'][q0]) ** 2
+    assert abs(wp - hp.solver.pos_weight / (p1 - p0)) <= 1e-6 * wp and abs(wn - hp.solver.normal_weight / (q1 - q0) * hp.voxel_size ** 2) <= 1e-6 * wn
+    M = bf.svh.num_unknowns
+    xb = torch.randn(M, device=dev)
+    # chunk-local -> batch unknown index (level-major inside the chunk, level-major inside the batch)
+    glob = np.concatenate([np.arange(lo[i, d], hi[i, d]) for d in range(L)])
+    x64 = xb.cpu().numpy()[glob].astype(np.float64)
+    y = wp * (G.T @ (G @ x64)) + wn * (Q.T @ (Q @ x64)) + x64
+    mag = wp * (abs(G).T @ (abs(G) @ np.abs(x64))) + wn * (abs(Q).T @ (abs(Q) @ np.abs(x64))) + np.abs(x64)
+    op = bf.fused_operator(inp['pos_xyz'], inp['normal_xyz'], inp['normal_value'], inp['pos_weight'], inp['normal_weight'],
+                           inp['pos_sorted_keys'], inp['normal_sorted_keys'], segments=seg)
+    yf = bf.fused_apply(op, xb, 1.0).cpu().numpy()[glob].astype(np.float64)
+    del op
+    pu.report('bench_scale:operator_rows', chunk=c, unknowns=int(U.size), pos_sites=int(psel.size), normal_sites=int(qsel.size), batch_M=M)
+    pu.check('bench_scale:fused_apply_rows', (np.abs(yf[U] - y[U]) / mag[U]).max(), 3e-6)
+
+    # ---- every chunk alone
+    del fld, part, bf, inp, seg
+    torch.cuda.empty_cache()
+    rec.keep_solve_inputs = False
+    rec.chunk_batch_points = 1
+    solo = rec.reconstruct(xyz, nrm, **kw)
+    assert len(solo.parts) == 64 and all(len(p.ids) == 1 for p in solo.parts)
+    for p in solo.parts:
+        c = p.ids[0]
+        keys_b, alpha_b, it_b = batch[c]
+        for d in range(L):
+            assert torch.equal(p.field.svh.level(d).keys, keys_b[d]), 'chunk %d level %d: voxel keys differ between batch and solo' % (c, d)
+        assert p.field.solve_info['iters'] == it_b, 'chunk %d: %d iterations alone, %d in the batch' % (c, p.field.solve_info['iters'], it_b)
+        assert torch.equal(p.field.alpha, alpha_b), 'chunk %d: coefficients differ between batch and solo' % c

@@ -487,7 +487,7 @@ def test_solve_is_differentiable_wrt_features_and_interpolators(approx, fused):
         return
     # (2) approx mode (rows continuous in theta): central differences of the ORACLE's loss along random directions
     eps = 2e-3
-    for trial in range(2):            # directions in feature space
+    for trial in range(1):            # a direction in feature space (two oracle solves each: the slowest part of the GPU suite on a slow host)
         v = [rs.randn(*f.shape).astype(np.float32) for f in feats]
         fd = (oracle_loss([f + np.float32(eps) * d for f, d in zip(feats, v)], ointerps) -
               oracle_loss([f - np.float32(eps) * d for f, d in zip(feats, v)], ointerps)) / (2 * eps)
@@ -495,7 +495,7 @@ def test_solve_is_differentiable_wrt_features_and_interpolators(approx, fused):
         pu.report('autograd_theta[approx=%s]:d_features[%d]:values' % (approx, trial), analytic=float(an), finite_difference=float(fd), loss=float(base))
         pu.check('autograd_theta[approx=%s]:d_features[%d]' % (approx, trial), abs(an - fd) / max(abs(fd), 1e-12), 6e-2)
     P0 = [p.detach().cpu().numpy() for p in params]
-    for trial in range(2):            # directions in weight space
+    for trial in range(1):            # a direction in weight space
         v = [rs.randn(*p.shape).astype(np.float32) for p in P0]
 
         def interps(sign):
