@@ -27,6 +27,7 @@ given either the same full cloud or -- ``sharded_input=True`` -- only the points
 collective on the solve path, one all_gather of the chunk HALOS before meshing, one point-to-point gather of the
 mesh pieces to rank 0 after it.
 """
+import contextlib
 import ctypes as C
 import math
 import weakref
@@ -42,6 +43,30 @@ from .fields.kernel_field import KernelField, Segments
 from .fields.mask_fields import LayerField, NeuralField
 from .normals import TooFewPoints as ChunkTooSmall      # a normal-estimating preprocess_fn on a chunk with fewer points than k: chunk skipped
 from .svh import SparseFeatureHierarchy
+
+
+@contextlib.contextmanager
+def borrowed(obj, device):
+    """A PARKED field (its tensors live on ``chunk_tmp_device`` / were moved by ``to_('cpu')``: NKSR-USAGE.md:150-167) made usable on
+    ``device`` for the duration of the block: ``to_()`` replaces the object's tensors by copies on ``device``; on exit the references
+    to the parked tensors are put back and the copies die.  Nothing travels back -- evaluation and meshing do not change a field.
+    ``obj``: a KernelField (with its hierarchy and mask) or a SparseFeatureHierarchy."""
+    device = torch.device(device)
+    if obj.device == device or (obj.device.type == device.type == 'cuda'):
+        yield obj
+        return
+    objs = [obj]
+    for o in (getattr(obj, 'svh', None), getattr(obj, 'mask_field', None), getattr(getattr(obj, 'mask_field', None), 'svh', None)):
+        if o is not None and all(o is not q for q in objs):
+            objs.append(o)
+    saved = [(o, dict(o.__dict__)) for o in objs]
+    try:
+        obj.to_(device)
+        yield obj
+    finally:
+        for o, d in saved:
+            o.__dict__.clear()
+            o.__dict__.update(d)
 
 
 def chunk_grid(lo, hi, chunk_size):
@@ -377,7 +402,8 @@ class ChunkUnionMask(BaseField):
             s = torch.nonzero(pl == pi).reshape(-1) if pl is not None else None
             qq, xx = (q, xq) if s is None else (q[s], xq[s].contiguous())
             if qq.numel():
-                kq = part.field.mask_field.evaluate_mask(xx)
+                with borrowed(part.field, m.home) as pf:
+                    kq = pf.mask_field.evaluate_mask(xx)
                 keep[qq[kq]] = True          # a query may appear once per chunk: "any chunk keeps it"
         return keep
 
@@ -424,8 +450,9 @@ class MultiChunkField(BaseField):
                 g = p.field.svh.level(d)
                 if g.num_voxels == 0:
                     continue
-                seg = torch.bucketize(g.keys, kr >> (3 * d), right=True) - 1
-                ijk = (g.ijk - (sc_all[seg] >> d)).contiguous()
+                gk, gi = g.keys.to(device), g.ijk.to(device)              # (a parked part: its finest keys visit the GPU for this)
+                seg = torch.bucketize(gk, kr >> (3 * d), right=True) - 1
+                ijk = (gi - (sc_all[seg] >> d)).contiguous()
                 k = torch.empty(ijk.shape[0], dtype=torch.int64, device=device)
                 call('nksr_encode_keys', ptr(ijk), ijk.shape[0], d, ptr(k), stream())
                 keys[d].append(k)
@@ -438,6 +465,7 @@ class MultiChunkField(BaseField):
             self.mask_field = ChunkUnionMask(self)
         self.solve_info = {}
         self.fields = _ChunkViews(self.parts, self.part_of, interpolators)
+        self.home = torch.device(device)           # where evaluation and meshing run, wherever the parts are parked
 
     def chunk_infos(self):
         """[{'chunk', 'M', 'iters', 'rel_residual'}] of the chunks solved here (one host read per part)."""
@@ -485,8 +513,10 @@ class MultiChunkField(BaseField):
         m = xq.shape[0]
         if m == 0:                                 # no chunk weighs at any query: f = 0
             return EvaluationResult(f_out, g_out)
+        # (a part parked on chunk_tmp_device / by to_('cpu') is borrowed for its evaluation: out-of-core, one part resident at a time)
         if len(self.parts) == 1:                   # one evaluation call per part for ALL pairs
-            res = self.parts[0].field._evaluate_f_model(xq, grad, max_points)
+            with borrowed(self.parts[0].field, self.home) as pf:
+                res = pf._evaluate_f_model(xq, grad, max_points)
             f, gr = res.value.contiguous(), (res.gradient.contiguous() if grad else None)
         else:
             f = torch.empty(m, dtype=torch.float32, device=xyz.device)
@@ -495,7 +525,8 @@ class MultiChunkField(BaseField):
             for pi, part in enumerate(self.parts):
                 s = torch.nonzero(pl == pi).reshape(-1)
                 if s.numel():
-                    res = part.field._evaluate_f_model(xq[s].contiguous(), grad, max_points)
+                    with borrowed(part.field, self.home) as pf:
+                        res = pf._evaluate_f_model(xq[s].contiguous(), grad, max_points)
                     f[s] = res.value
                     if grad:
                         gr[s] = res.gradient
@@ -577,10 +608,21 @@ class MultiChunkField(BaseField):
                                world_size, self.frame, self.interpolators, self.svh.device, adaptive_depth=self.meshing_depth)
 
     def to_(self, device):
+        """``to_('cpu')`` parks the parts and the union grid on the host (NKSR-USAGE.md:163: "Put everything onto CPU"); evaluation
+        and ``extract_dual_mesh`` keep running on the GPU the field was made on, borrowing one part at a time (out-of-core meshing:
+        peak HBM = one part + the union grid + the lattice, not the scene).  The chunk tables (a few KB) stay where they are."""
         for p in self.parts:
             p.field.to_(device)
         self.svh.to_(device)
         return self
+
+    def evaluate_f(self, xyz, grad=False):
+        return super().evaluate_f(xyz.to(self.home), grad)
+
+    @torch.no_grad()
+    def extract_dual_mesh(self, mise_iter=0, grid_upsample=1, max_points=-1):
+        with borrowed(self.svh, self.home):
+            return super().extract_dual_mesh(mise_iter=mise_iter, grid_upsample=grid_upsample, max_points=max_points)
 
 
 # ---- the batched solve ------------------------------------------------------------------------------------------------------
@@ -780,12 +822,20 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
         def band_of(c):
             return exchange_band(cores[c], frame.chunk3(c), grid, ov, hp.voxel_size)
         local = {c: p.pack_chunk(c, band_of(c)) for p in parts for c in p.ids}
-        payload = D.exchange_payloads(local)
-        solved = sorted(payload)
-        # a rank only evaluates the blend inside its own cores (+ the halo ring it evaluates): it needs exactly the
-        # chunks whose weight support (core +- ov) reaches there -- its spatial neighbours, not all N
+        # a rank only evaluates the blend inside its own cores (+ the halo ring it evaluates): it needs exactly the chunks whose
+        # weight support (core +- ov) reaches there -- its spatial neighbours, not all N.  Who needs what is geometry (cores, owners,
+        # which cores hold points): every rank computes the same table, so a halo is SENT only to the ranks that need it
+        # (all_to_all with per-pair sizes; a chunk its owner skipped is simply not sent)
+        nonempty = [c for c in range(nchunk) if counts[c] > 0]
+        dest_of = {}
+        for r in range(ws):
+            owned_r = [c for c in nonempty if owner[c] == r]
+            for c in needed_chunks(cores, ov + 2.5 * hp.voxel_size, grid, owned_r, nonempty):
+                if owner[c] != r:
+                    dest_of.setdefault(c, []).append(r)
+        payload = D.exchange_payloads_to(local, dest_of)
         mine = set(local)
-        need = [c for c in needed_chunks(cores, ov + 2.5 * hp.voxel_size, grid, [c for c in solved if owner[c] == rank], solved) if c not in mine]
+        need = sorted(c for c in payload if c not in mine)
         if need:
             remote = fields_from_payloads([(frame.key_range(c)[0], payload[c][0], payload[c][1]) for c in need], hp.voxel_size, interps, dev)
             remote.meshing_depth = int(hp.adaptive_depth)
@@ -793,10 +843,8 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
                 remote.set_mask_field(LayerField(remote.svh, hp.adaptive_depth))
             parts.append(ChunkPart(remote, sorted(need, key=lambda c: frame.key_range(c)[0]), frame, solved=False))
         timing['t_exchange'] = _now(rec) - t_x          # halo exchange: pack, size + byte collectives, the remote field's tables
-    else:
-        for p in parts:
-            if p.field.device != dev:
-                p.field.to_(dev)          # meshing runs on the GPU: bring the parked batches back
+    # (batches parked on chunk_tmp_device stay there: the blend borrows one part at a time -- borrowed() -- so meshing a scene
+    # whose chunks do not fit the GPU together works as the reference's small-memory recipe says, NKSR-USAGE.md:150-167)
     return MultiChunkField(parts, cores, ov, lo, chunk_size, grid, owner, rank, ws, frame, interps, dev, distributed=active,
                            adaptive_depth=int(hp.adaptive_depth))
 

@@ -5,9 +5,10 @@ The solve of a chunk is independent of every other chunk (the reference runs chu
 on one device, examples/recons_by_chunk.py:26-29), so chunks are sharded over ranks with NO
 collective on the solve path.  Exactly one exchange step precedes meshing -- every rank needs the
 solved fields that overlap the cells it meshes -- and one gather step follows it:
-  * exchange_payloads: ONE all_gather of sizes (the only host sync) + ONE all_gather of a padded byte buffer
-    holding every chunk halo of the rank (a couple of MB: latency-, not bandwidth-bound; on the fully
-    connected xGMI mesh an all_gather is direct peer copies, no ring bottleneck)
+  * exchange_payloads_to: ONE all_to_all_single of sizes (the only host sync) + ONE all_to_all_single of a byte buffer with
+    per-pair split sizes: a rank receives the halos of the chunks whose blend weight reaches its cells -- its spatial
+    neighbours' -- and nothing else (round 3: an all_gather gave every halo to every rank); on the fully connected xGMI
+    mesh these are direct peer copies, no ring
   * gather_meshes: one size collective, then point-to-point transfers to rank 0 only (the other ranks
     receive nothing); rank 0 merges seam vertices by their canonical (lattice key, axis) identity.
 Everything here works on CPU tensors too, so the protocol is covered by world_size-2 gloo tests.
@@ -127,6 +128,38 @@ def all_gather_tensors(tensors):
     return res
 
 
+def all_to_all_tensors(send):
+    """``send[r]`` = the list of k 1-D tensors this rank has for rank r (same k and dtypes for every pair; any lengths, empty
+    allowed).  Returns ``recv[r]`` = the k tensors rank r had for this rank.  Two collectives: ONE all_to_all_single of the k
+    lengths per pair (the only host sync) + ONE all_to_all_single of a packed byte buffer with per-pair split sizes -- on the fully
+    connected xGMI mesh RCCL runs that as direct peer copies, and a rank only receives what was addressed to it (the all_gather
+    of round 3 delivered every halo to every rank)."""
+    import torch.distributed as dist
+    rank, ws = world()
+    if not active():
+        return [list(send[0])]
+    k = len(send[0])
+    src_dev = send[0][0].device
+    dev = _comm_device(send[0][0])
+    dtypes = [t.dtype for t in send[0]]
+    packed = [_pack_bytes([t.to(dev) for t in send[r]])[0] for r in range(ws)]
+    n_out = torch.tensor([[t.numel() for t in send[r]] for r in range(ws)], dtype=torch.int64, device=dev).reshape(-1)
+    n_in = torch.empty(ws * k, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(n_in, n_out)
+    sizes = n_in.view(ws, k).tolist()                         # one host sync for the whole exchange
+    es = [torch.empty(0, dtype=dt).element_size() for dt in dtypes]
+    in_bytes = [sum(n * e + ((-(n * e)) % 8) for n, e in zip(row, es)) for row in sizes]
+    out_bytes = [int(p.numel()) for p in packed]
+    inp = torch.cat(packed) if sum(out_bytes) else torch.zeros(0, dtype=torch.uint8, device=dev)
+    out = torch.empty(sum(in_bytes), dtype=torch.uint8, device=dev)
+    dist.all_to_all_single(out, inp, output_split_sizes=in_bytes, input_split_sizes=out_bytes)
+    recv, o = [], 0
+    for r in range(ws):
+        recv.append([t.to(src_dev) for t in _unpack_bytes(out[o:o + in_bytes[r]], dtypes, sizes[r])])
+        o += in_bytes[r]
+    return recv
+
+
 def all_gather_variable(t):
     """all_gather of 1-D tensors whose lengths differ per rank.  Returns the list of per-rank tensors (on t's device)."""
     return [r[0] for r in all_gather_tensors([t])]
@@ -156,15 +189,53 @@ def gather_tensors(tensors, dst=0):
         return None
     bufs = [buf if r == dst else torch.empty(nbytes[r], dtype=torch.uint8, device=dev) for r in range(ws)]
     ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(ws) if r != dst and nbytes[r]]
+    import os
+    if ws == 1 and os.environ.get('NKSR_DIST_FORCE', '') == '1' and nbytes[dst]:
+        # single-rank group forced through the backend (tests/test_gpu_rccl1.py): the destination's own piece takes the point-to-point
+        # transport too -- a send to self inside one group call -- so that batch_isend_irecv has run under RCCL before an 8-GPU run
+        bufs[dst] = torch.empty_like(buf)
+        ops = [dist.P2POp(dist.isend, buf, dst), dist.P2POp(dist.irecv, bufs[dst], dst)]
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
     return [[t.to(src_dev) for t in _unpack_bytes(bufs[r], [m[0] for m in meta], sizes[r])] for r in range(ws)]
 
 
+def exchange_payloads_to(local, dest_of):
+    """Neighbour-only halo exchange: ``local`` = {chunk_id: (int64 tensor, float32 tensor)} of the chunks this rank solved,
+    ``dest_of[chunk]`` = the ranks whose cells that chunk's blend weight reaches (chunking.needed_chunks; the owner excluded).
+    Every rank receives exactly the payloads addressed to it: returns {chunk_id: (ints, floats)} = own chunks + received ones.
+    One size collective + one byte collective (all_to_all_tensors); every rank takes part, with or without chunks."""
+    rank, ws = world()
+    if not active():
+        return dict(local)
+    ids = sorted(local)
+    dev = local[ids[0]][0].device if ids else _default_device()
+    send = []
+    for r in range(ws):
+        mine = [c for c in ids if r != rank and r in dest_of.get(c, ())]
+        if ws == 1:
+            mine = ids                                              # (forced single-rank group: everything goes through the backend once)
+        head = torch.tensor([v for c in mine for v in (c, local[c][0].numel(), local[c][1].numel())], dtype=torch.int64, device=dev)
+        ib = torch.cat([local[c][0].reshape(-1) for c in mine]) if mine else torch.zeros(0, dtype=torch.int64, device=dev)
+        fb = torch.cat([local[c][1].reshape(-1) for c in mine]) if mine else torch.zeros(0, dtype=torch.float32, device=dev)
+        send.append([head, ib, fb])
+    out = dict(local)
+    for h, ib, fb in all_to_all_tensors(send):
+        io = fo = 0
+        hl = h.tolist()
+        for k in range(0, len(hl), 3):
+            c, ni, nf = hl[k], hl[k + 1], hl[k + 2]
+            out[c] = (ib[io:io + ni], fb[fo:fo + nf])
+            io += ni
+            fo += nf
+    return out
+
+
 def exchange_payloads(local, expected_ids=None):
     """``local``: {chunk_id: (int64 tensor, float32 tensor)} for the chunks this rank owns.
-    Returns the same dict for ALL chunks on every rank (one size collective + one byte collective)."""
+    Returns the same dict for ALL chunks on every rank (one size collective + one byte collective): the everyone-gets-everything
+    variant (save / load of whole scenes, tests); the meshing path uses exchange_payloads_to."""
     rank, ws = world()
     if not active():
         return dict(local)

@@ -38,6 +38,24 @@ def _worker(rank, world, port, q):
             g = torch.Generator().manual_seed(c)
             assert torch.equal(got[c][0], torch.randint(0, 1 << 40, (100 + 7 * c,), generator=g, dtype=torch.int64))
             assert torch.equal(got[c][1], torch.randn(33 * (c + 1), generator=g))
+        # --- neighbour-only exchange: a payload goes to the ranks named for it and to nobody else (odd chunks -> the other rank)
+        other = 1 - rank
+        dest_of = {c: [1 - owner[c]] for c in range(5) if c % 2 == 1}
+        got2 = D.exchange_payloads_to(local, dest_of)
+        want = sorted(set(local) | {c for c in range(5) if owner[c] == other and c % 2 == 1})
+        assert sorted(got2) == want, (sorted(got2), want)
+        for c in want:
+            g = torch.Generator().manual_seed(c)
+            assert torch.equal(got2[c][0], torch.randint(0, 1 << 40, (100 + 7 * c,), generator=g, dtype=torch.int64))
+            assert torch.equal(got2[c][1], torch.randn(33 * (c + 1), generator=g))
+        # nothing addressed to anybody: the collectives still complete, everybody keeps its own
+        assert sorted(D.exchange_payloads_to(local, {})) == sorted(local)
+        # the raw all_to_all: ragged lists incl. empty ones, three dtypes
+        send = [[torch.arange(3 * r + rank, dtype=torch.int64), torch.full((r,), float(rank)), torch.zeros(2 * rank, dtype=torch.uint8)] for r in range(world)]
+        recv = D.all_to_all_tensors(send)
+        for r in range(world):
+            assert torch.equal(recv[r][0], torch.arange(3 * rank + r, dtype=torch.int64)) and recv[r][1].tolist() == [float(r)] * rank
+            assert recv[r][2].numel() == 2 * r and recv[r][2].dtype == torch.uint8
         # --- mesh gather + seam merge: two quads sharing an edge, one per rank
         if rank == 0:
             v = torch.tensor([[0., 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])

@@ -234,3 +234,53 @@ def test_fields_die_with_their_last_reference():
             assert probe() is None, 'the field is kept alive by a reference cycle'
     finally:
         gc.enable()
+
+
+def test_small_memory_recipe_meshes_a_parked_field_out_of_core():
+    """The reference's small-memory recipe, verbatim (NKSR-USAGE.md:150-167): ``chunk_tmp_device = cpu`` -> reconstruct in chunk mode
+    -> ``field.to_("cpu")``, ``network.to("cpu")`` -> ``field.extract_dual_mesh(mise_iter=1)``.  Here the parked field is meshed OUT OF
+    CORE on the GPU it was made on: the blend borrows one batch of chunks at a time (chunking.borrowed), nothing is evaluated on the
+    host.  The mesh and the field equal the resident run's bit for bit; the peak device memory of the extraction stays below 1.5 x
+    what reconstructing ONE batch takes; the parked tensors are still parked afterwards."""
+    import nksr_amd
+    dev = torch.device('cuda:0')
+    xyz, nrm = _wide_scene()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ext = float(xyz[:, 0].max() - xyz[:, 0].min())
+    cs = ext / 4 + 1e-3
+    rec = nksr_amd.Reconstructor(dev)
+    rec.chunk_batch_points = 90000                      # a few chunks per batch
+    res = rec.reconstruct(t(xyz), t(nrm), detail_level=None, chunk_size=cs)
+    assert len(res.parts) > 1
+    m0 = res.extract_dual_mesh(mise_iter=1)
+    q = t(xyz[::37].copy())
+    f0 = res.evaluate_f(q, grad=True)
+    del res
+    reconstructor = nksr_amd.Reconstructor(dev)
+    reconstructor.chunk_batch_points = 90000
+    reconstructor.chunk_tmp_device = torch.device('cpu')
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    field = reconstructor.reconstruct(t(xyz), t(nrm), detail_level=None, chunk_size=cs)
+    peak_solve = torch.cuda.max_memory_allocated(dev) - base
+    assert all(p.field.device.type == 'cpu' for p in field.parts)          # solved batches were parked as they came
+    # Put everything onto CPU.
+    field.to_('cpu')
+    reconstructor.network.to('cpu')
+    assert field.svh.device.type == 'cpu'
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    mesh = field.extract_dual_mesh(mise_iter=1)
+    peak_mesh = torch.cuda.max_memory_allocated(dev) - base
+    assert mesh.v.is_cuda and torch.equal(mesh.v, m0.v) and torch.equal(mesh.f, m0.f)
+    assert peak_mesh <= 1.5 * peak_solve, (peak_mesh, peak_solve)
+    assert all(p.field.device.type == 'cpu' and not p.field.alpha.is_cuda for p in field.parts) and field.svh.device.type == 'cpu'
+    f1 = field.evaluate_f(q.cpu(), grad=True)           # queries may come from the host too
+    assert torch.equal(f1.value, f0.value) and torch.equal(f1.gradient, f0.gradient)
+    field.to_(dev)                                       # and back: resident again, same mesh
+    m2 = field.extract_dual_mesh(mise_iter=1)
+    assert all(p.field.device.type == 'cuda' for p in field.parts) and torch.equal(m2.v, m0.v) and torch.equal(m2.f, m0.f)

@@ -3,8 +3,9 @@ NKSR_DIST_FORCE=1, which makes every collective helper of nksr_amd/dist.py run t
 short-circuiting at world size 1 (the first time RCCL touches these buffers must not be the driver's
 8-GPU run).  Exercised: all_reduce (bounding box, per-core counts), all_gather_into_tensor on int64 size vectors and on the
 uint8 payload buffer of the chunk-halo exchange, the mesh gather -- and the distributed chunk pipeline end to end with
-sharded input, which must reproduce the plain single-process mesh bit for bit.  Point-to-point transfers need a second
-rank: covered by the gloo tests (tests/test_dist_cpu.py, tests/test_gpu_dist2.py)."""
+sharded input, which must reproduce the plain single-process mesh bit for bit.  Round 4: the neighbour-only halo exchange
+(all_to_all_single with per-pair split sizes) and the mesh gather's point-to-point transport (batch_isend_irecv, as a send to
+self) run here under RCCL too; with a second rank they are covered by the gloo tests (tests/test_dist_cpu.py, tests/test_gpu_dist2.py)."""
 import os
 import socket
 
@@ -71,6 +72,14 @@ def _worker(port, q):
         assert len(got) == 1 and all(torch.equal(a, b) and a.dtype == b.dtype for a, b in zip(got[0], parts))
         pay = D.exchange_payloads({3: (parts[0], parts[1]), 9: (parts[0][:5].contiguous(), parts[1][:0].contiguous())}, [3, 9])
         assert torch.equal(pay[3][0], parts[0]) and torch.equal(pay[3][1], parts[1]) and pay[9][1].numel() == 0
+        # the neighbour-only exchange (all_to_all_single with per-pair split sizes) and the mesh gather's point-to-point transport
+        # (batch_isend_irecv: a send to self inside one group call under the forced single-rank group)
+        pay2 = D.exchange_payloads_to({3: (parts[0], parts[1]), 9: (parts[0][:5].contiguous(), parts[1][:0].contiguous())}, {3: [0]})
+        assert sorted(pay2) == [3, 9] and torch.equal(pay2[3][0], parts[0]) and torch.equal(pay2[3][1], parts[1]) and pay2[9][0].numel() == 5
+        rv = D.all_to_all_tensors([[parts[0], parts[1], parts[2]]])
+        assert len(rv) == 1 and all(torch.equal(a, b) for a, b in zip(rv[0], parts[:3]))
+        gt = D.gather_tensors([parts[0], parts[1], parts[2], parts[3]])
+        assert len(gt) == 1 and all(torch.equal(a, b) and a.dtype == b.dtype for a, b in zip(gt[0], parts))
         # the distributed chunk pipeline through RCCL: sharded input (bbox / count all_reduce), halo exchange, mesh gather
         lo, hi = xyz.min(0), xyz.max(0)
         fld = rec.reconstruct(t(xyz), t(nrm), detail_level=None, chunk_size=8.1, sharded_input=True)
