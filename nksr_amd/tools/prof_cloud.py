@@ -1,6 +1,6 @@
 """configs[2] step (1M-point cloud, detail_level=1.0, reconstruct + extract_dual_mesh(mise_iter=1)) by itself: wall time per step,
 stage times, and -- with --host -- a cProfile of the host side (where the launch train is made).
-python -m nksr_amd.tools.prof_cloud [points] [steps] [--host]"""
+python -m nksr_amd.tools.prof_cloud [points] [steps] [--host] [--non-fused]"""
 import sys
 import time
 
@@ -20,7 +20,7 @@ def main():
     rec = nksr_amd.Reconstructor(dev)
 
     def step():
-        f = rec.reconstruct(xyz, nrm, detail_level=1.0)
+        f = rec.reconstruct(xyz, nrm, detail_level=1.0, fused_mode='--non-fused' not in sys.argv)
         return f.extract_dual_mesh(mise_iter=1)
     step()
     torch.cuda.synchronize()

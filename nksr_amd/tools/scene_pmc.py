@@ -22,7 +22,7 @@ GROUPS = [
     ['TA_ADDR_STALLED_BY_TC_CYCLES_sum', 'TA_DATA_STALLED_BY_TC_CYCLES_sum', 'TCP_TCP_TA_DATA_STALL_CYCLES_sum', 'TD_TD_BUSY_sum'],
 ]
 LAST_BENCH_LINE = None
-KERNELS = ['k_cell_blocks', 'k_fz_sweep', 'k_cheb16_step', 'k_kernel_rows', 'k_sparse_conv3', 'k_splat_mean32', 'k_splat_trilinear',
+KERNELS = ['k_cell_blocks', 'k_fz_cells', 'k_cheb16_step', 'k_kernel_rows', 'k_sparse_conv3', 'k_splat_mean32', 'k_splat_trilinear',
            'k_fz_gather', 'k_fz_cellsum', 'k_evaluate_f', 'k_build_nbr', 'k_row_count', 'k_row_fill']
 
 
@@ -65,7 +65,7 @@ def run_pass(counters, flags, tag):
 
 def main():
     out = sys.argv[1]
-    flags = sys.argv[2:] or ['--scene', 'terrain', '--steps', '1', '--warmup', '0', '--no-cpu-baseline']
+    flags = sys.argv[2:] or ['--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-cloud', '--no-small-inputs']
     rec = {'command': 'bench.py ' + ' '.join(flags), 'kernels': {}}
     for gi, g in enumerate(GROUPS):
         res = run_pass(g, flags, 'g%d' % gi)
@@ -87,7 +87,7 @@ def main():
         if e.get('TCC_HIT_sum') is not None and e.get('TCC_MISS_sum') is not None and e['TCC_HIT_sum'] + e['TCC_MISS_sum'] > 0:
             e['l2_hit'] = e['TCC_HIT_sum'] / (e['TCC_HIT_sum'] + e['TCC_MISS_sum'])
     # the operator application with every chunk still iterating = the longest dispatch of each of its three kernels
-    op = [k for k in rec['kernels'] if k.startswith(('k_fz_sweep<0', 'k_fz_cellsum<true', 'k_fz_gather<0'))]
+    op = [k for k in rec['kernels'] if k.startswith(('k_fz_cells<0', 'k_fz_cellsILi0', 'k_fz_cellsum', 'k_fz_gather<0', 'k_fz_gatherILi0'))]
     if len(op) == 3 and all('fetch_bytes' in rec['kernels'][k] and 'write_bytes' in rec['kernels'][k] for k in op):
         rec['operator_application'] = {k: {'fetch_bytes': rec['kernels'][k]['fetch_bytes'], 'write_bytes': rec['kernels'][k]['write_bytes'],
                                            'us': rec['kernels'][k].get('us_pass2')} for k in op}
@@ -98,6 +98,8 @@ def main():
                 rec['algorithmic_bytes_per_application'] = json.loads(LAST_BENCH_LINE)['roofline']['bytes_per_launch']
             except Exception:
                 pass
+        from nksr_amd import build
+        rec['kernel_source_hash'] = build.kernel_hash('fused')
         rec['correction'] = 'KiB units; gfx950 FETCH_SIZE counts the 128-B requests of a coalesced stream at 64 B: doubled; WRITE_SIZE uncorrected'
     json.dump(rec, open(out, 'w'), indent=1, sort_keys=True)
     for k in sorted(rec['kernels'], key=lambda k: -rec['kernels'][k].get('us_pass0', 0)):

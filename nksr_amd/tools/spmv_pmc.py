@@ -52,7 +52,9 @@ def main():
     fetch_kb, write_kb = sum(fv) / len(fv), sum(wv) / len(wv)
     hbm = 2.0 * fetch_kb * 1024.0 + write_kb * 1024.0
     alg = 8 * nnz + 12 * M + 4
+    from nksr_amd import build
     rec = {
+        'kernel_source_hash': build.kernel_hash('spmv'),
         'kernel': 'k_spmv<0> (tools/spmv_probe.py, bench matrix: M=%d nnz=%d)' % (M, nnz),
         'command': 'rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python -m nksr_amd.tools.spmv_probe %d 0  '
                    '(second pass: --pmc WRITE_SIZE); driver: python -m nksr_amd.tools.spmv_pmc' % points,
