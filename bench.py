@@ -113,7 +113,7 @@ def roofline_record(ms, launches, alg, phys, survey, fused=False):
     rate = lambda b: (b / avg_s if avg_s > 0 else 0.0)
     traffic, src, note = ((load_traffic_fused(p) if fused else load_traffic(a)) if launches else (None, None, None))
     rec = {'bound': 'hbm',
-           'kernel': ('k_fz_sweep + k_fz_gather (+ k_fz_cellsum) (matrix-free normal-equation operator inside the PCG loop, fused_mode=True)' if fused else
+           'kernel': ('k_fz_cells + k_fz_gather (+ k_fz_cellsum) (matrix-free normal-equation operator inside the PCG loop, fused_mode=True)' if fused else
                       'k_spmv<3,0> + k_spmv_fixup (packed-column CSR SpMV inside the PCG loop, fused_mode=False)'),
            'achieved': rate(a) / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': rate(a) / HBM_PEAK,
            'achieved_physical': rate(p) / 1e9, 'frac_physical': rate(p) / HBM_PEAK,

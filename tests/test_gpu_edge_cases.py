@@ -145,7 +145,7 @@ def test_bench_contract_line():
         assert k in r, k
     assert (r['traffic'] is None) == (r['traffic_source'] is None) and r['launches_timed'] > 0
     # a roofline fraction is a fraction: algorithmic minimum <= what the layout moves <= what the HBM could stream
-    assert d['config']['fused_mode'] is True and 'k_fz_sweep' in r['kernel'] and 0 < r['frac'] < r['frac_physical'] <= 1.0
+    assert d['config']['fused_mode'] is True and 'k_fz_cells' in r['kernel'] and 0 < r['frac'] < r['frac_physical'] <= 1.0
     c2 = d['cloud_1m']                 # configs[2]: one field, the operator roofline + the assembled solve's CSR SpMV roofline
     assert 'configs[2]' in c2['config']['workload'] and c2['value'] > 0
     rc = c2['roofline']
