@@ -292,6 +292,65 @@ class ChunkPart:
         return _pack(f.svh, f.kdim, f.approx_kernel_grad, f._feat, f.alpha, [f.mask_field.features[d] for d in range(nu)],
                      f.mask_field.level_set if nu else 0.0, self.ranges()[c], band, self.frame.shift(c))
 
+    def pack_halos(self, bands):
+        """``{c: (ints, flts)}`` for every chunk of the part -- exactly what ``pack_chunk(c, bands[c])`` returns, made for all chunks at
+        once: one mask and one compaction per LEVEL instead of one per chunk and level (8 chunks x 5 levels of small launches and
+        host syncs were 11 ms of a rank's 80 ms at 8 ranks, tools/prof_rank_tail.py)."""
+        f = self.field
+        svh, dev, depth = f.svh, f.svh.device, f.svh.depth
+        nu = _udf_levels(f)
+        ids, nc = self.ids, len(self.ids)
+        if nc == 0:
+            return {}
+        kr = [self.frame.key_range(c) for c in ids]
+        klo = torch.tensor([k[0] for k in kr], dtype=torch.int64, device=dev)
+        shift = torch.from_numpy(np.stack([np.asarray(self.frame.shift(c), np.float32) for c in ids])).to(dev)      # [nc, 3]
+        # band table: up to two intervals per axis (the faces shared with the chunk before / after); none = an empty interval
+        blo = np.full((nc, 3, 2), np.inf)
+        bhi = np.full((nc, 3, 2), -np.inf)
+        for i, c in enumerate(ids):
+            used = [0, 0, 0]
+            for a, lo_, hi_ in bands[c]:
+                blo[i, a, used[a]], bhi[i, a, used[a]] = lo_, hi_
+                used[a] += 1
+        off = svh.offsets
+        sel, cnt = [], []
+        for d in range(depth):
+            g = svh.level(d)
+            if g.num_voxels == 0:
+                sel.append(torch.zeros(0, dtype=torch.long, device=dev))
+                cnt.append(torch.zeros(nc, dtype=torch.long, device=dev))
+                continue
+            w = g.voxel_size
+            seg = torch.bucketize(g.keys, klo >> (3 * d), right=True) - 1
+            # (thresholds in double, compared in fp32, as pack_field does with Python scalars)
+            tlo = torch.from_numpy((blo - 2.5 * w).astype(np.float32)).to(dev)
+            thi = torch.from_numpy((bhi + 2.5 * w).astype(np.float32)).to(dev)
+            m = torch.zeros(g.num_voxels, dtype=torch.bool, device=dev)
+            for a in range(3):
+                ca = (g.ijk[:, a].to(torch.float32) + 0.5) * w - shift[seg, a]
+                for k in range(2):
+                    m |= (ca >= tlo[seg, a, k]) & (ca <= thi[seg, a, k])
+            idx = torch.nonzero(m).reshape(-1)
+            sel.append(idx)
+            cnt.append(torch.bincount(seg[idx], minlength=nc))
+        counts = torch.stack(cnt, 1).tolist()                                   # [nc][depth]   (one host read)
+        keys = [svh.level(d).keys[sel[d]] for d in range(depth)]
+        feats = [f._feat[d][sel[d]] for d in range(depth)]
+        alphas = [f.alpha[sel[d] + off[d]] for d in range(depth)]
+        udf = [f.mask_field.features[d][sel[d]] for d in range(nu)]
+        heads = torch.tensor([[depth, f.kdim, int(f.approx_kernel_grad), nu] + counts[i] for i in range(nc)], dtype=torch.int64, device=dev)
+        tail = [torch.tensor([f.mask_field.level_set], dtype=torch.float32, device=dev)] if nu else []
+        out, o = {}, [0] * depth
+        for i, c in enumerate(ids):
+            sl = [slice(o[d], o[d] + counts[i][d]) for d in range(depth)]
+            ints = torch.cat([heads[i]] + [keys[d][sl[d]] for d in range(depth)])
+            parts = [feats[d][sl[d]].reshape(-1) for d in range(depth)] + [alphas[d][sl[d]] for d in range(depth)]
+            parts += [udf[d][sl[d]].reshape(-1) for d in range(nu)] + tail
+            out[c] = (ints, torch.cat(parts))
+            o = [o[d] + counts[i][d] for d in range(depth)]
+        return out
+
     def chunk_view(self, c, interpolators):
         """Chunk c as a KernelField of its own (exploded frame): tests, save_field, simulated ranks."""
         ints, flts = self.pack_chunk(c)
@@ -316,10 +375,16 @@ def chunk_grid_struct(origin, grid, chunk_size, sel_band, w_band, device, shift=
     on the host: lo_sel/hi_sel = core -+ sel_band (membership of the solve), lo_w/hi_w = core -+ w_band (blend ramps)."""
     G = ChunkGridT()
     keep = []
+    # candidate window of a point: its home chunk +- reach.  floor + 1, not ceil: the kernel finds the home chunk with x * (1 / chunk_size),
+    # the host bounds with origin + j * chunk_size -- at an exact chunk boundary the two may differ by one
     reach = 1
     for b in (sel_band, w_band):
         if b is not None:
-            reach = max(reach, int(math.ceil(b / chunk_size)))
+            reach = max(reach, int(math.floor(b / chunk_size)) + 1)
+    if reach > 4:
+        raise RuntimeError('chunk_size %g is too small for this hierarchy: a chunk is solved on its core + a band of %g (overlap + 1.5 coarsest '
+                           'voxels), which must stay below 4 chunk sizes -- use chunk_size >= %g' % (chunk_size, max(b for b in (sel_band, w_band) if b is not None),
+                                                                                              max(b for b in (sel_band, w_band) if b is not None) / 3.9))
     for a in range(3):
         G.grid[a] = int(grid[a])
         G.origin[a] = float(origin[a])
@@ -660,8 +725,10 @@ def select_chunk_points(xyz, lo, grid, chunk_size, band, wanted):
 
 
 def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, approx_kernel_grad, solver_max_iter,
-                         solver_tol, fused_mode, preprocess_fn, sim=None, sharded_input=False, chunk_owner=None, chunk_bounds=None):
-    """``sim=(rank, world_size)`` runs one simulated rank without a process group (tests).
+                         solver_tol, fused_mode, preprocess_fn, sim=None, sharded_input=False, chunk_owner=None, chunk_bounds=None, sim_exchange=None):
+    """``sim=(rank, world_size)`` runs one simulated rank without a process group (tests); with ``sim_exchange(local, dest_of) ->
+    payload`` the simulated rank goes through the halo exchange step too, the callable standing in for the collectives
+    (tools/prof_rank_tail.py: everything a rank of N does after its solve, timed on one GPU).
     ``sharded_input``: every rank passes only ITS part of the cloud -- at least the points inside core +- band of the
     chunks it owns ("each rank receives only its chunks' points (+overlap)").  The chunk grid then
     comes from ``chunk_bounds`` = (lo[3], hi[3]) or from an all_reduce of the local bounding boxes, the per-core point
@@ -816,12 +883,14 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     rec.timing = timing
     interps = rec.network.interpolators
     t_x = _now(rec)
-    if active:
+    if active or (sim is not None and sim_exchange is not None):
         # the exchange carries the halo of every chunk (the voxels other ranks can touch), not the whole field; which
         # chunks were actually solved travels with it (a sparse chunk may have been skipped by its owner)
         def band_of(c):
             return exchange_band(cores[c], frame.chunk3(c), grid, ov, hp.voxel_size)
-        local = {c: p.pack_chunk(c, band_of(c)) for p in parts for c in p.ids}
+        local = {}
+        for p in parts:
+            local.update(p.pack_halos({c: band_of(c) for c in p.ids}))
         # a rank only evaluates the blend inside its own cores (+ the halo ring it evaluates): it needs exactly the chunks whose
         # weight support (core +- ov) reaches there -- its spatial neighbours, not all N.  Who needs what is geometry (cores, owners,
         # which cores hold points): every rank computes the same table, so a halo is SENT only to the ranks that need it
@@ -833,7 +902,7 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
             for c in needed_chunks(cores, ov + 2.5 * hp.voxel_size, grid, owned_r, nonempty):
                 if owner[c] != r:
                     dest_of.setdefault(c, []).append(r)
-        payload = D.exchange_payloads_to(local, dest_of)
+        payload = D.exchange_payloads_to(local, dest_of) if active else sim_exchange(local, dest_of)
         mine = set(local)
         need = sorted(c for c in payload if c not in mine)
         if need:

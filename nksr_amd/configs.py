@@ -38,6 +38,10 @@ _DEFAULT = {
     'interpolator': {'n_hidden': 2, 'hidden_dim': 16},
     'solver': {'pos_weight': 10000.0, 'normal_weight': 10000.0},
     'seed': 0, 'interpolator_init_scale': 0.0, 'head_init_scale': 0.0,
+    # [ASSUMPTION] (the layer that makes feat.normal_features is in the absent wheel): the normal targets are the
+    # splatted input normals divided by max(|nv|, normal_min_length * sum w, normal_min_weight) -- unit length unless the normals of a
+    # voxel's points cancel or the voxel is barely touched.  0 / 0 = plain unit normalisation nv / |nv|.
+    'normal_min_length': 1e-2, 'normal_min_weight': 1e-3,
 }
 
 _PRESETS = {

@@ -97,7 +97,7 @@ static int chunk_check(const nksr_chunk_grid_t* G, int mode) {
         if (G->grid[a] > 1 && (mode == 0 ? (!G->lo_sel[a] || !G->hi_sel[a]) : (!G->lo_w[a] || !G->hi_w[a])))
             return nksr_set_error(NKSR_ERR_ARG, "chunk grid: bounds of a split axis are NULL");
     }
-    if (G->reach < 1 || G->reach > 4) return nksr_set_error(NKSR_ERR_ARG, "chunk grid: reach must be 1..4");
+    if (G->reach < 1 || G->reach > 4) return nksr_set_error(NKSR_ERR_ARG, "chunk grid: reach (candidate window of a point: home chunk +- reach, floor(band / chunk_size) + 1) must be 1..4, got %d", G->reach);
     if (mode == 1 && !G->shift) return nksr_set_error(NKSR_ERR_ARG, "chunk grid: shift is NULL");
     return NKSR_OK;
 }

@@ -227,6 +227,10 @@ __global__ void __launch_bounds__(64 * KW_WAVES) k_knn_pca_wave(KnnGrid g, int64
     __shared__ float cd[KW_WAVES][KW_CAP];
     __shared__ int32_t ci[KW_WAVES][KW_CAP];
     __shared__ double amb[KW_WAVES][16];
+    // 64.5 KB of static LDS per workgroup: written for the 160 KB per CU of gfx950 (two workgroups = eight wavefronts per CU); a
+    // 64 KB-LDS part (gfx942 / gfx90a) would need KW_WAVES 2
+    static_assert(sizeof(float) * KW_WAVES * KW_CAP + sizeof(int32_t) * KW_WAVES * KW_CAP + sizeof(double) * KW_WAVES * 16 <= 80 * 1024,
+                  "k_knn_pca_wave: two workgroups must fit the 160 KB LDS of a gfx950 CU");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * KW_WAVES + wave;
     if (i >= n) return;

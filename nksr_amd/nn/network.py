@@ -278,7 +278,9 @@ class StructureUNet(nn.Module):
                 # unit length -- unless the splatted normals cancel (|sum w n| < 1e-2 sum w: both sides of a thin sheet in one voxel)
                 # or the voxel is barely touched (sum w < 1e-3: a point on the edge of its stencil weighs 0 or 1e-8 depending on
                 # rounding): that vector is noise; it stays short instead of becoming an arbitrary unit target
-                den = torch.maximum(nv.norm(dim=1), NORMAL_MIN_LENGTH * ws).clamp_min(NORMAL_MIN_WEIGHT)
+                nml = float(getattr(hp, 'normal_min_length', NORMAL_MIN_LENGTH))
+                nmw = float(getattr(hp, 'normal_min_weight', NORMAL_MIN_WEIGHT))
+                den = torch.maximum(nv.norm(dim=1), nml * ws).clamp_min(max(nmw, 1e-30))      # (0 / 0: plain unit normalisation)
                 feat.normal_features[d] = nv / den[:, None]
         return feat, dec_svh, dec_svh
 

@@ -132,6 +132,35 @@ def test_simulated_two_ranks_equal_one_rank(scene):
     assert np.array_equal(fm, f1)                                                  # index-exact topology
 
 
+def test_batched_halo_pack_equals_the_per_chunk_pack_bit_for_bit():
+    """ChunkPart.pack_halos (all chunks of a rank at once: one mask + one compaction per level) against pack_chunk(c, band) chunk by
+    chunk -- the payloads of the halo exchange, integers and floats bit for bit; with and without the UDF mask features."""
+    import nksr_amd
+    from nksr_amd import chunking
+    dev = torch.device('cuda:0')
+    xyz, nrm = _wide_scene()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ext = float(xyz[:, 0].max() - xyz[:, 0].min())
+    for cfg in ('ks', 'carla'):
+        rec = nksr_amd.Reconstructor(dev, config=cfg)
+        fld = chunking.reconstruct_by_chunk(rec, t(xyz), t(nrm), None, ext / 3 + 1e-3, 0.05, False, 2000, 1e-5, True, None)
+        npart = 0
+        for p in fld.parts:
+            bands = {}
+            for c in p.ids:
+                c3 = (c // (fld.grid[1] * fld.grid[2]), (c // fld.grid[2]) % fld.grid[1], c % fld.grid[2])
+                bands[c] = chunking.exchange_band(fld.cores[c], c3, fld.grid, fld.ov, rec.hparams.voxel_size)
+            got = p.pack_halos(bands)
+            assert sorted(got) == sorted(p.ids)
+            for c in p.ids:
+                ints, flts = p.pack_chunk(c, bands[c])
+                assert torch.equal(got[c][0], ints)
+                assert torch.equal(got[c][1].view(torch.int32), flts.view(torch.int32))
+                assert ints.numel() < p.pack_chunk(c)[0].numel()           # a halo, not the whole chunk
+                npart += 1
+        assert npart >= 3
+
+
 def test_a_chunk_does_not_depend_on_its_batch_mates():
     """All chunks of a rank are solved as ONE block-diagonal system (one hierarchy, one network pass, one PCG with per-chunk
     scalars).  Reconstructor.chunk_batch_points cuts the chunks into several such batches: every chunk must come out bit
