@@ -69,6 +69,50 @@ def borrowed(obj, device):
             o.__dict__.update(d)
 
 
+def spill_to_disk(field, directory):
+    """A field PARKED on the host (``to_('cpu')``) moved on to DISK: every tensor of the field, its hierarchy and its mask is replaced
+    by a file-backed copy (``torch.from_file(..., shared=True)``, one file per tensor under ``directory``, unlinked at once: the
+    mapping keeps the blocks until the tensor dies, nothing is left behind).  The host then holds reclaimable page cache instead of
+    anonymous memory, and ``borrowed()`` pages a part in when evaluation / meshing visits it -- the out-of-core flow of
+    NKSR-USAGE.md:150-167 for scenes whose solved chunks exceed host memory too.  Returns the bytes written."""
+    import os
+    import uuid
+    os.makedirs(directory, exist_ok=True)
+    total = 0
+    seen = set()
+
+    def move(t):
+        nonlocal total
+        if not torch.is_tensor(t) or t.device.type != 'cpu' or t.numel() == 0 or t.dtype == torch.bool:
+            return t
+        path = os.path.join(directory, 'nksr_spill_%s.bin' % uuid.uuid4().hex)
+        flat = torch.from_file(path, shared=True, size=t.numel(), dtype=t.dtype)
+        flat.copy_(t.reshape(-1))
+        os.unlink(path)
+        total += t.numel() * t.element_size()
+        return flat.view(t.shape)
+
+    def walk(o):
+        if o is None or id(o) in seen or not hasattr(o, '__dict__'):
+            return
+        seen.add(id(o))
+        for k, v in list(o.__dict__.items()):
+            if torch.is_tensor(v):
+                o.__dict__[k] = move(v)
+            elif isinstance(v, (list, tuple)) and v and all(torch.is_tensor(x) or x is None for x in v):
+                o.__dict__[k] = type(v)(move(x) for x in v)
+            elif isinstance(v, (list, tuple)):
+                for x in v:
+                    if type(x).__module__.startswith('nksr_amd'):
+                        walk(x)
+            elif type(v).__module__.startswith('nksr_amd') and not isinstance(v, type):
+                walk(v)
+    if field.device.type != 'cpu':
+        raise RuntimeError('spill_to_disk: park the field on the host first (field.to_("cpu"))')
+    walk(field)
+    return total
+
+
 def chunk_grid(lo, hi, chunk_size):
     n = [max(1, int(math.ceil((hi[a] - lo[a]) / chunk_size - 1e-9))) for a in range(3)]
     return n
@@ -879,6 +923,8 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
             timing[k] = timing.get(k, 0.0) + v
         if rec.chunk_tmp_device != dev and not active and sim is None and len(batches) > 1:
             fld.to_(rec.chunk_tmp_device)  # reference semantics: park solved chunks elsewhere (only useful when there are several batches)
+            if getattr(rec, 'chunk_spill_dir', None) and torch.device(rec.chunk_tmp_device).type == 'cpu':
+                timing['spilled_bytes'] = timing.get('spilled_bytes', 0) + spill_to_disk(fld, rec.chunk_spill_dir)
         parts.append(ChunkPart(fld, ids, frame))
     rec.timing = timing
     interps = rec.network.interpolators

@@ -30,6 +30,8 @@ class Reconstructor:
         # chunk mode: ALL chunks of a rank are solved as one block-diagonal system (nksr_amd/chunking.py); chunk_batch_points caps the
         # points (band included) of one such batch -- ~2 KB of HBM per point at tree_depth 5 -- None = 2^25.  Results do not depend on it.
         self.chunk_batch_points = None
+        self.chunk_spill_dir = None      # chunk mode, batches parked on a CPU chunk_tmp_device: a directory -> the parked batches live in unlinked files there
+        #                                  (chunking.spill_to_disk: out-of-core beyond host memory; not part of the reference surface)
         self.coarse_precond = None  # matrix-free solve: None = automatic (coarse-level block preconditioner for 5+ levels), False = Jacobi only,
         #                             or {'first_level', 'steps', 'ratio'} (fields/kernel_field.py _coarse_precond)
         self.keep_solve_inputs = False   # parity tests: the field keeps the site sets / weights of its solve (field._solve_inputs)

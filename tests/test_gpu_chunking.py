@@ -313,3 +313,33 @@ def test_small_memory_recipe_meshes_a_parked_field_out_of_core():
     field.to_(dev)                                       # and back: resident again, same mesh
     m2 = field.extract_dual_mesh(mise_iter=1)
     assert all(p.field.device.type == 'cuda' for p in field.parts) and torch.equal(m2.v, m0.v) and torch.equal(m2.f, m0.f)
+
+
+def test_parked_batches_spill_to_disk_and_mesh_bit_identically(tmp_path):
+    """``Reconstructor.chunk_spill_dir``: batches parked on a CPU ``chunk_tmp_device`` are moved on into unlinked files
+    (chunking.spill_to_disk: file-backed tensors, SURVEY.md section 8f-3 "enables chunk spill to disk") -- the out-of-core flow of
+    NKSR-USAGE.md:150-167 for scenes whose solved chunks exceed host memory.  Mesh and field equal the resident run's bit for bit,
+    every parked tensor is file-backed, nothing stays behind in the directory."""
+    import os
+    import nksr_amd
+    dev = torch.device('cuda:0')
+    xyz, nrm = _wide_scene()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ext = float(xyz[:, 0].max() - xyz[:, 0].min())
+    cs = ext / 4 + 1e-3
+    rec = nksr_amd.Reconstructor(dev)
+    rec.chunk_batch_points = 90000
+    m0 = rec.reconstruct(t(xyz), t(nrm), detail_level=None, chunk_size=cs).extract_dual_mesh(mise_iter=1)
+    rec = nksr_amd.Reconstructor(dev)
+    rec.chunk_batch_points = 90000
+    rec.chunk_tmp_device = torch.device('cpu')
+    rec.chunk_spill_dir = str(tmp_path / 'spill')
+    field = rec.reconstruct(t(xyz), t(nrm), detail_level=None, chunk_size=cs)
+    assert len(field.parts) > 1 and rec.timing.get('spilled_bytes', 0) > 1_000_000
+    assert os.path.isdir(rec.chunk_spill_dir) and os.listdir(rec.chunk_spill_dir) == []          # unlinked mappings: nothing left behind
+    for p in field.parts:
+        assert p.field.device.type == 'cpu'
+        for tns in [p.field.alpha] + list(p.field._feat) + [p.field.svh.level(0).keys, p.field.svh.level(0).nbr, p.field.svh.level(0).hash.hkeys]:
+            assert tns.device.type == 'cpu' and (tns.numel() == 0 or tns.untyped_storage().filename is not None)
+    mesh = field.extract_dual_mesh(mise_iter=1)
+    assert torch.equal(mesh.v, m0.v) and torch.equal(mesh.f, m0.f)
