@@ -429,6 +429,10 @@ int nksr_cell_corner_keys(const int64_t* cell_keys, int64_t ncell, int64_t* corn
 int nksr_lattice_positions(const int64_t* vkeys, int64_t n, float h, float half_w0, float* xyz_out, void* stream);
 /* sorted-key lower-bound lookup (exact match required; -1 otherwise) */
 int nksr_sorted_lookup(const int64_t* sorted, int64_t n, const int64_t* q, int64_t nq, int32_t* idx_out, void* stream);
+/* rank of every element of the ASCENDING list q in the ascending list `sorted`: rank_out[i] = #{ sorted < q[i] } (upper == 0) or
+ * #{ sorted <= q[i] } (upper != 0) -- the merge of two sorted site lists without sorting them again (KernelField.solve: the shared
+ * Morton-ordered row list of the position and the normal sites, models/nksr_net.py:105-112).  n < 2^31. */
+int nksr_rank_sorted(const int64_t* sorted, int64_t n, const int64_t* q, int64_t nq, int upper, int32_t* rank_out, void* stream);
 /* per cell: 8-bit sign configuration (bit c set iff f[corner c] > 0) and triangle count */
 int nksr_cell_config(const int32_t* corner_idx, const float* f, int64_t ncell, int32_t* config, int32_t* ntri, void* stream);
 /* flags[i]=1 where the cell's corners do not share a sign (MISE candidates) */

@@ -108,6 +108,7 @@ _PROTOS = {
     'nksr_build_nbr': [_vp, _i32, C.c_int, _vp, _vp, _i32, _vp, _vp],
     'nksr_site_ranges': [_vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp],
     'nksr_sorted_lookup': [_vp, _i64, _vp, _i64, _vp, _vp],
+    'nksr_rank_sorted': [_vp, _i64, _vp, _i64, C.c_int, _vp, _vp],
     'nksr_splat_trilinear': [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp],
     'nksr_point_mlp': [_vp, _vp, _i64, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_splat_mean': [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp],

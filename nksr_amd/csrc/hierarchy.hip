@@ -114,6 +114,29 @@ __global__ void k_sorted_lookup(const int64_t* __restrict__ sorted, int64_t n, c
     out[i] = (pos < n && sorted[pos] == v) ? (int32_t)pos : -1;
 }
 
+// rank of every element of the ASCENDING list q in the ascending list `sorted`: out[i] = #{ sorted < q[i] } (upper == 0) or
+// #{ sorted <= q[i] } (upper != 0).  The ranks of a block's first and last query bound the window of `sorted` all its queries fall
+// into (q is ascending): two full bisections per 256 queries, then ~8 steps inside a window the whole block shares -- a bisection
+// per query from scratch is 25 dependent, uncoalesced loads (torch.searchsorted on 2e7 keys: ~10 ms; this: < 1 ms).
+__device__ __forceinline__ int64_t bound_i64(const int64_t* __restrict__ a, int64_t lo, int64_t hi, int64_t v, bool upper) {
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t x = a[mid];
+        if (upper ? (x <= v) : (x < v)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__global__ void __launch_bounds__(256) k_rank_sorted(const int64_t* __restrict__ sorted, int64_t n, const int64_t* __restrict__ q, int64_t nq,
+                                                     int upper, int32_t* __restrict__ out) {
+    __shared__ int64_t win[2];
+    const int64_t i0 = (int64_t)blockIdx.x * 256, i = i0 + threadIdx.x;
+    const int64_t last = (i0 + 255 < nq ? i0 + 255 : nq - 1);
+    if (threadIdx.x == 0) win[0] = bound_i64(sorted, 0, n, q[i0], upper != 0);
+    if (threadIdx.x == 64) win[1] = bound_i64(sorted, 0, n, q[last], upper != 0);
+    __syncthreads();
+    if (i < nq) out[i] = (int32_t)bound_i64(sorted, win[0], win[1], q[i], upper != 0);
+}
+
 #define LAUNCH1D(kern, n, stream, ...)                                                              \
     do {                                                                                            \
         if ((n) > 0) {                                                                              \
@@ -162,6 +185,13 @@ extern "C" int nksr_build_nbr(const int32_t* ijk, int32_t n, int level, const in
 extern "C" int nksr_site_ranges(const int64_t* site_keys, int64_t ns, const int64_t* vox_keys, int32_t n, int level,
                                 int32_t* start_out, int32_t* end_out, void* stream) {
     LAUNCH1D(k_site_ranges, n, stream, site_keys, ns, vox_keys, n, 3 * level, start_out, end_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_rank_sorted(const int64_t* sorted, int64_t n, const int64_t* q, int64_t nq, int upper, int32_t* rank_out, void* stream) {
+    if (nq <= 0) return NKSR_OK;
+    if (n < 0 || n >= ((int64_t)1 << 31) || !q || !rank_out || (n > 0 && !sorted)) return nksr_set_error(NKSR_ERR_ARG, "rank_sorted: bad arguments");
+    hipLaunchKernelGGL(k_rank_sorted, dim3(nksr_blocks(nq, 256)), dim3(256), 0, (hipStream_t)stream, sorted, n, q, nq, upper, rank_out);
+    NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
 extern "C" int nksr_sorted_lookup(const int64_t* sorted, int64_t n, const int64_t* q, int64_t nq, int32_t* idx_out,

@@ -381,6 +381,34 @@ class KernelField(BaseField):
         pad_rows = item_seg = None
         if len(specs) == 1 and segments is None:
             row_index = [torch.arange(counts_s[0], dtype=torch.int32, device=dev) * specs[0][5]]
+        elif len(specs) == 2 and os.environ.get('NKSR_ROW_ORDER', 'merge') != 'sort':
+            # Both site lists are sorted already: the merged (stable: set 0 first on equal keys) order is a MERGE, and all it is needed
+            # for is every site's first row = its own sites before it + the other set's sites before it -- two rank passes
+            # (nksr_rank_sorted) instead of a 63-bit radix sort of the concatenated keys, a scan and a scatter
+            (xa, ka, _, _, _, ca), (xb, kb, _, _, _, cb) = specs
+            na, nb = counts_s
+            ra = torch.empty(na, dtype=torch.int32, device=dev)
+            rb_ = torch.empty(nb, dtype=torch.int32, device=dev)
+            call('nksr_rank_sorted', ptr(kb), nb, ptr(ka), na, 0, ptr(ra), stream())          # sites of set 1 with a smaller key
+            call('nksr_rank_sorted', ptr(ka), na, ptr(kb), nb, 1, ptr(rb_), stream())         # sites of set 0 with a smaller or equal key
+            fa = torch.arange(na, dtype=torch.int32, device=dev) * ca + ra * cb
+            fb = torch.arange(nb, dtype=torch.int32, device=dev) * cb + rb_ * ca
+            if segments is not None:
+                klo = segments.key_lo
+                rb = (torch.searchsorted(ka, klo) * ca + torch.searchsorted(kb, klo) * cb).long()
+                rb = torch.cat([rb, rb.new_tensor([rows_total])])                                               # unpadded row bounds
+                rows_seg = rb[1:] - rb[:-1]
+                pad = (-rows_seg) % 256
+                pad_before = torch.cumsum(pad, 0) - pad
+                pb32 = pad_before.to(torch.int32)
+                fa = fa + pb32[segments.of_keys(ka)]
+                fb = fb + pb32[segments.of_keys(kb)]
+                ends = rb[1:] + pad_before
+                pad_rows = (ends[:, None] + torch.arange(255, device=dev)[None])[torch.arange(255, device=dev)[None] < pad[:, None]]
+                rows_total = rows_total + int(pad.sum().item())
+                item_start = (rb[:-1] + pad_before) // 32
+                item_seg = (torch.bucketize(torch.arange(rows_total // 32 + 2, device=dev), item_start, right=True) - 1).clamp_(0, segments.nseg - 1).to(torch.int32)
+            row_index = [fa, fb]
         else:
             ks_all, order = ops.sort_pairs(torch.cat([sp[1] for sp in specs]), torch.arange(nsite, dtype=torch.int32, device=dev), level=0)
             order = order.long()

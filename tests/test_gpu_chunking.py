@@ -161,6 +161,26 @@ def test_batched_halo_pack_equals_the_per_chunk_pack_bit_for_bit():
         assert npart >= 3
 
 
+def test_batched_row_order_by_rank_passes_equals_the_sorted_merge(monkeypatch):
+    """The batched chunk solve (segments padded to whole workgroups of the sweep) with the row order from rank passes against the
+    sorted merge: alpha of every part and the mesh bit for bit."""
+    import nksr_amd
+    dev = torch.device('cuda:0')
+    xyz, nrm = _wide_scene()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ext = float(xyz[:, 0].max() - xyz[:, 0].min())
+    out = {}
+    for mode in ('merge', 'sort'):
+        monkeypatch.setenv('NKSR_ROW_ORDER', mode)
+        rec = nksr_amd.Reconstructor(dev)
+        fld = rec.reconstruct(t(xyz), t(nrm), detail_level=None, chunk_size=ext / 3 + 1e-3)
+        m = fld.extract_dual_mesh(mise_iter=1)
+        out[mode] = ([p.field.alpha.clone() for p in fld.parts], m.v, m.f)
+    assert len(out['merge'][0]) == len(out['sort'][0]) >= 1
+    assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(out['merge'][0], out['sort'][0]))
+    assert torch.equal(out['merge'][1], out['sort'][1]) and torch.equal(out['merge'][2], out['sort'][2])
+
+
 def test_a_chunk_does_not_depend_on_its_batch_mates():
     """All chunks of a rank are solved as ONE block-diagonal system (one hierarchy, one network pass, one PCG with per-chunk
     scalars).  Reconstructor.chunk_batch_points cuts the chunks into several such batches: every chunk must come out bit

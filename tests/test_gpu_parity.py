@@ -249,6 +249,35 @@ def test_fused_operator_matches_the_assembled_matrix(approx):
     pu.check('fused:field_vs_csr', float((f_fused - f_csr).abs().max() / f_csr.abs().max()), 1e-4)
 
 
+def test_row_order_by_rank_passes_equals_the_sorted_merge(monkeypatch):
+    """The shared Morton-ordered row list of the two site sets: first rows from two rank passes over the already sorted key lists
+    (nksr_rank_sorted) against the radix sort of the concatenated keys + scan + scatter -- rows, row cells and targets bit for bit;
+    the primitive itself against torch.searchsorted, both bounds, with runs of equal keys."""
+    from nksr_amd.fields import KernelField
+    from nksr_amd._lib import call, ptr, stream
+    rs = np.random.RandomState(3)
+    a = torch.from_numpy(np.sort(rs.randint(0, 5000, 20000)).astype(np.int64)).to(_dev())
+    b = torch.from_numpy(np.sort(rs.randint(0, 5000, 7000)).astype(np.int64)).to(_dev())
+    for upper in (0, 1):
+        out = torch.empty(b.numel(), dtype=torch.int32, device=_dev())
+        call('nksr_rank_sorted', ptr(a), a.numel(), ptr(b), b.numel(), upper, ptr(out), stream())
+        assert torch.equal(out.long(), torch.searchsorted(a, b, right=bool(upper)))
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=3000)
+    fld = KernelField(svh, net.interpolators, [torch.from_numpy(f) for f in feats])
+    t = lambda x: torch.from_numpy(x).to(_dev())
+    nxyz = np.concatenate([oh.levels[0].centers(), oh.levels[1].centers()])
+    nval = np.random.RandomState(5).randn(len(nxyz), 3).astype(np.float32)
+    out = {}
+    for mode in ('merge', 'sort'):
+        monkeypatch.setenv('NKSR_ROW_ORDER', mode)
+        op = fld.fused_operator(t(xyz), t(nxyz), t(nval), 1e4 / len(xyz), 1e2 / len(nxyz))
+        n = op['op'].depth * op['rows_total'] * 27
+        out[mode] = (op['rows_all'][:n].clone(), op['keep'][2].clone(), op['keep'][1].clone(), op['rows_total'])
+    assert out['merge'][3] == out['sort'][3]
+    assert torch.equal(out['merge'][1], out['sort'][1]) and torch.equal(out['merge'][2], out['sort'][2])
+    assert torch.equal(out['merge'][0].view(torch.int32), out['sort'][0].view(torch.int32))
+
+
 @pytest.mark.parametrize('fused', [False, True])
 def test_solve_is_differentiable_wrt_the_normal_targets(fused):
     """SURVEY.md section 8(f)-4, the part that is built: under autograd, solve*() makes alpha a differentiable function of
