@@ -155,6 +155,22 @@ int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int appr
 int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx, int active_only,
                     float* f_out, float* grad_out, void* stream);
 
+/* ---- backward of the kernel rows w.r.t. theta = (basis features, interpolator weights): the training path, models/nksr_net.py:
+ *      105-112 (loss -> solve_non_fused / evaluate_f -> network).  With per-row factors g_r[s] = a_r lam[col] + b_r alpha[col] the
+ *      kernels ADD  dS/dtheta,  S = sum_r sum_s row_scale R_r[s] g_r[s]  (R = the rows of nksr_kernel_rows: value rows, or
+ *      gradient rows with / without the d(phi)/dx term) to the caller's zero-initialised arrays.  coef_a / coef_b: [n] (value rows) or
+ *      [n, 3] (gradient rows), either may be NULL (= 0; coef_a needs lam).  Floating-point atomics: reproducible to rounding. */
+typedef struct {
+    float* gfeat[NKSR_MAX_DEPTH]; /* [n_d, kdim] += through the trilinear stencil of the sites                                    */
+    float* gpsi[NKSR_MAX_DEPTH];  /* [n_d, kdim] += dS/dpsi_j of the neighbour voxels (finish with nksr_voxel_psi_vjp)           */
+    float* gmlp[NKSR_MAX_DEPTH];  /* packed interpolator weights of the level (W1 b1 W2 b2 W3 b3) +=                             */
+} nksr_theta_grad_t;
+int nksr_kernel_rows_vjp(const nksr_hier_t* h, const float* xyz, int64_t n, int grad_rows, int approx, float row_scale, const float* coef_a,
+                         const float* coef_b, const float* alpha, const float* lam, const nksr_theta_grad_t* out, void* stream);
+/* psi_j = f_j + MLP(f_j) (nksr_voxel_psi) backwards: gfeat_j += (d psi_j / d f_j)^T gpsi_j, gmlp += the weight cotangents */
+int nksr_voxel_psi_vjp(const float* feat, int32_t n, int kdim, int hidden, const float* mlp, const float* gpsi, float* gfeat, float* gmlp,
+                       void* stream);
+
 /* ---- normal-equation assembly (KernelField.solve_non_fused, models/nksr_net.py:105-112) */
 typedef struct {
     int64_t n;                 /* sites                                                */

@@ -23,6 +23,10 @@ class HierT(C.Structure):
     _fields_ = [('depth', _i32), ('kdim', _i32), ('hidden', _i32), ('inv_w0', _f32), ('lv', LevelT * MAX_DEPTH)]
 
 
+class ThetaGradT(C.Structure):
+    _fields_ = [('gfeat', _vp * MAX_DEPTH), ('gpsi', _vp * MAX_DEPTH), ('gmlp', _vp * MAX_DEPTH)]
+
+
 class FusedOpT(C.Structure):
     _fields_ = [('depth', _i32), ('M', _i32), ('n_multi', _i32), ('n_big', _i32), ('rows_total', _i64), ('rows_all', _vp),
                 ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('nbrT', _vp), ('item_begin', _vp), ('offsets', _vp), ('multi', _vp), ('nblocks', _i64),
@@ -121,6 +125,8 @@ _PROTOS = {
     'nksr_voxel_psi': [_vp, _i32, C.c_int, C.c_int, _vp, _vp, _vp],
     'nksr_kernel_rows': [_P(HierT), _vp, _i64, C.c_int, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     'nksr_evaluate_f': [_P(HierT), _vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp, _vp],
+    'nksr_kernel_rows_vjp': [_P(HierT), _vp, _i64, C.c_int, C.c_int, _f32, _vp, _vp, _vp, _vp, _P(ThetaGradT), _vp],
+    'nksr_voxel_psi_vjp': [_vp, _i32, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
     'nksr_assemble_count': [_P(HierT), _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_assemble': [_P(HierT), _P(SiteSetT), C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp],
     'nksr_place_mirrors': [_vp, _vp, _i64, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _vp],

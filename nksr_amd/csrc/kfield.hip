@@ -423,3 +423,262 @@ extern "C" int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const f
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
+
+// ---- vector-Jacobian products of the kernel rows w.r.t. the basis features and the interpolator weights ---------------------------
+// Training path only (models/nksr_net.py:105-112: the loss back-propagates through solve_non_fused / evaluate_f into the network's
+// basis features and into the interpolators): with per-row factors  g_r[s] = a_r lambda[col] + b_r alpha[col]  this computes
+//     dS/dtheta,  S = sum_r sum_s R'_r[s] g_r[s],   R' = row_scale * (dense-slot kernel rows of nksr_kernel_rows)
+// -- the theta term of the implicit-function backward of the solve (a = t' - u, b = -v) and of evaluate_f (a = 0, b = dL/df),
+// fields/kernel_field.py _SolveFunction / _EvaluateFunction.  One thread per (site, level), as the rows themselves are made: the
+// forward of the row is recomputed (cell, trilinear stencil, interpolator with its forward-mode tangents, psi gathers), then
+//   * dS/dpsi_j for the 27 neighbours            -> gpsi   (the voxel's own feature through the interpolator: k_psi_vjp)
+//   * reverse mode through phi = t + MLP(t) and, for exact-gradient rows, through J = Jt + W3 D2 W2 D1 W1 Jt (the ReLU masks D
+//     are the constants they are almost everywhere) -> weight cotangents (LDS accumulators, one global add per weight and
+//     workgroup) and dS/dt, dS/dJt
+//   * the transpose of the trilinear stencil     -> gfeat.
+// Accumulation is by floating-point atomics (hardware global_atomic_add_f32 / ds_add_f32): gradients are reproducible to fp32
+// rounding of a sum, not bit for bit -- unlike every kernel of the solve-time path.
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+__device__ __forceinline__ void vjp_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+template <int K, int H, bool JAC>
+__device__ __forceinline__ void mlp_residual_vjp(const MlpView<K, H>& m, float* __restrict__ gw, const float t[K], const float Jt[JAC ? K : 1][3],
+                                                 const float gphi[K], const float gJ[JAC ? K : 1][3], float gt[K], float gJt[JAC ? K : 1][3]) {
+    float* gW1 = gw;
+    float* gb1 = gW1 + H * K;
+    float* gW2 = gb1 + H;
+    float* gb2 = gW2 + H * H;
+    float* gW3 = gb2 + H;
+    float* gb3 = gW3 + K * H;
+    float h1[H], d1[JAC ? H : 1][3], gh1[H], gd1[JAC ? H : 1][3];
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float a = m.b1[h];
+        float da[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float w = m.W1[h * K + k];
+            a = fmaf(w, t[k], a);
+            if (JAC) { da[0] = fmaf(w, Jt[k][0], da[0]); da[1] = fmaf(w, Jt[k][1], da[1]); da[2] = fmaf(w, Jt[k][2], da[2]); }
+        }
+        const bool on = a > 0.f;
+        h1[h] = on ? a : 0.f;
+        gh1[h] = 0.f;
+        if (JAC) {
+            d1[h][0] = on ? da[0] : 0.f; d1[h][1] = on ? da[1] : 0.f; d1[h][2] = on ? da[2] : 0.f;
+            gd1[h][0] = gd1[h][1] = gd1[h][2] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        gt[k] = gphi[k];                                      // the residual skip
+        if (JAC) { gJt[k][0] = gJ[k][0]; gJt[k][1] = gJ[k][1]; gJt[k][2] = gJ[k][2]; }
+        if (gphi[k] != 0.f) atomicAdd(gb3 + k, gphi[k]);
+    }
+#pragma unroll 1
+    for (int g = 0; g < H; ++g) {
+        float a = m.b2[g];
+        float da[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float w = m.W2[g * H + h];
+            a = fmaf(w, h1[h], a);
+            if (JAC) { da[0] = fmaf(w, d1[h][0], da[0]); da[1] = fmaf(w, d1[h][1], da[1]); da[2] = fmaf(w, d1[h][2], da[2]); }
+        }
+        if (!(a > 0.f)) continue;                             // unit off: h2 = d2 = 0 and nothing flows back through it
+        float gh2 = 0.f, ge[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float w = m.W3[k * H + g];
+            gh2 = fmaf(w, gphi[k], gh2);
+            float gw3 = gphi[k] * a;
+            if (JAC) {
+                ge[0] = fmaf(w, gJ[k][0], ge[0]); ge[1] = fmaf(w, gJ[k][1], ge[1]); ge[2] = fmaf(w, gJ[k][2], ge[2]);
+                gw3 += gJ[k][0] * da[0] + gJ[k][1] * da[1] + gJ[k][2] * da[2];
+            }
+            atomicAdd(gW3 + k * H + g, gw3);
+        }
+        atomicAdd(gb2 + g, gh2);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float w = m.W2[g * H + h];
+            float gw2 = gh2 * h1[h];
+            gh1[h] = fmaf(w, gh2, gh1[h]);
+            if (JAC) {
+                gw2 += ge[0] * d1[h][0] + ge[1] * d1[h][1] + ge[2] * d1[h][2];
+                gd1[h][0] = fmaf(w, ge[0], gd1[h][0]); gd1[h][1] = fmaf(w, ge[1], gd1[h][1]); gd1[h][2] = fmaf(w, ge[2], gd1[h][2]);
+            }
+            atomicAdd(gW2 + g * H + h, gw2);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        if (!(h1[h] > 0.f)) continue;                         // (a1 > 0  <=>  h1 > 0)
+        const float ga = gh1[h];
+        atomicAdd(gb1 + h, ga);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float w = m.W1[h * K + k];
+            float gw1 = ga * t[k];
+            gt[k] = fmaf(w, ga, gt[k]);
+            if (JAC) {
+                gw1 += gd1[h][0] * Jt[k][0] + gd1[h][1] * Jt[k][1] + gd1[h][2] * Jt[k][2];
+                gJt[k][0] = fmaf(w, gd1[h][0], gJt[k][0]); gJt[k][1] = fmaf(w, gd1[h][1], gJt[k][1]); gJt[k][2] = fmaf(w, gd1[h][2], gJt[k][2]);
+            }
+            atomicAdd(gW1 + h * K + k, gw1);
+        }
+    }
+}
+
+struct VjpOut { float* gfeat[NKSR_MAX_DEPTH]; float* gpsi[NKSR_MAX_DEPTH]; float* gmlp[NKSR_MAX_DEPTH]; };
+
+template <int K, int H, bool GRAD, bool JAC>
+__global__ void __launch_bounds__(64) k_rows_vjp(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float sw, const float* __restrict__ ca,
+                                                 const float* __restrict__ cb, const float* __restrict__ alpha, const float* __restrict__ lam, VjpOut out) {
+    const int d = blockIdx.y;
+    const nksr_level_t& lv = hier.lv[d];
+    __shared__ float w[MlpView<K, H>::SIZE];
+    __shared__ float gw[MlpView<K, H>::SIZE];
+    for (int i = threadIdx.x; i < MlpView<K, H>::SIZE; i += 64) { w[i] = lv.mlp[i]; gw[i] = 0.f; }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i < n && lv.n > 0) {
+        const float x[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+        SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
+        if (sc.cell >= 0) {
+            const float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
+            float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
+            trilerp_feat<K, JAC>(lv, d, sc, inv_w, t, Jt);
+            MlpView<K, H> m(w);
+            mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
+            float bw[3][3], bd[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
+            int nb[27];
+            load_nbr_row(lv.nbr + (int64_t)sc.cell * 27, nb);
+            float fa[GRAD ? 3 : 1], fb[GRAD ? 3 : 1];
+#pragma unroll
+            for (int a = 0; a < (GRAD ? 3 : 1); ++a) {
+                fa[a] = ca ? ca[i * (GRAD ? 3 : 1) + a] : 0.f;
+                fb[a] = cb ? cb[i * (GRAD ? 3 : 1) + a] : 0.f;
+            }
+            float gphi[K], gJ[JAC ? K : 1][3];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { gphi[k] = 0.f; if (JAC) gJ[k][0] = gJ[k][1] = gJ[k][2] = 0.f; }
+#pragma unroll 1
+            for (int s = 0; s < 27; ++s) {
+                const int j = nb[s];
+                if (j < 0) continue;
+                const int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
+                const float bx = sel3(bw[0], ox), by = sel3(bw[1], oy), bz = sel3(bw[2], oz);
+                const float B = bx * by * bz;
+                const float al = alpha[lv.offset + j], la = lam ? lam[lv.offset + j] : 0.f;
+                float cphi, cJ[3] = {0.f, 0.f, 0.f};
+                if (!GRAD) {
+                    cphi = (fa[0] * la + fb[0] * al) * sw * B;
+                } else {
+                    const float g0 = (fa[0] * la + fb[0] * al) * sw, g1 = (fa[1] * la + fb[1] * al) * sw, g2 = (fa[2] * la + fb[2] * al) * sw;
+                    cphi = g0 * (sel3(bd[0], ox) * by * bz * inv_w) + g1 * (bx * sel3(bd[1], oy) * bz * inv_w) + g2 * (bx * by * sel3(bd[2], oz) * inv_w);
+                    if (JAC) { cJ[0] = g0 * B; cJ[1] = g1 * B; cJ[2] = g2 * B; }
+                }
+                const float* ps = lv.psi + (int64_t)j * K;
+                float* gp = out.gpsi[d] + (int64_t)j * K;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float pk = ps[k];
+                    gphi[k] = fmaf(cphi, pk, gphi[k]);
+                    float gps = cphi * phi[k];
+                    if (JAC) {
+                        gJ[k][0] = fmaf(cJ[0], pk, gJ[k][0]); gJ[k][1] = fmaf(cJ[1], pk, gJ[k][1]); gJ[k][2] = fmaf(cJ[2], pk, gJ[k][2]);
+                        gps += cJ[0] * J[k][0] + cJ[1] * J[k][1] + cJ[2] * J[k][2];
+                    }
+                    if (gps != 0.f) vjp_add(gp + k, gps);
+                }
+            }
+            float gt[K], gJt[JAC ? K : 1][3];
+            mlp_residual_vjp<K, H, JAC>(m, gw, t, Jt, gphi, gJ, gt, gJt);
+            // transpose of the trilinear stencil (the same eight corners and weights as trilerp_feat)
+            float v[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = sc.u[a] + 0.5f - (float)sc.hb[a];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int cx = c >> 2, cy = (c >> 1) & 1, cz = c & 1;
+                const int s = (sc.hb[0] + cx) * 9 + (sc.hb[1] + cy) * 3 + (sc.hb[2] + cz);
+                const int j = nb[s];
+                if (j < 0) continue;
+                const float wx = cx ? v[0] : 1.f - v[0], wy = cy ? v[1] : 1.f - v[1], wz = cz ? v[2] : 1.f - v[2];
+                const float wt = wx * wy * wz;
+                const float gx = (cx ? 1.f : -1.f) * wy * wz * inv_w, gy = wx * (cy ? 1.f : -1.f) * wz * inv_w, gz = wx * wy * (cz ? 1.f : -1.f) * inv_w;
+                float* gf = out.gfeat[d] + (int64_t)j * K;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    float g = wt * gt[k];
+                    if (JAC) g += gx * gJt[k][0] + gy * gJt[k][1] + gz * gJt[k][2];
+                    if (g != 0.f) vjp_add(gf + k, g);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < MlpView<K, H>::SIZE; q += 64)
+        if (gw[q] != 0.f) vjp_add(out.gmlp[d] + q, gw[q]);
+}
+
+// psi_j = f_j + MLP(f_j): gfeat_j += d psi_j / d f_j ^T gpsi_j, weight cotangents as above (one thread per voxel)
+template <int K, int H>
+__global__ void __launch_bounds__(64) k_psi_vjp(const float* __restrict__ feat, int n, const float* __restrict__ mlp, const float* __restrict__ gpsi,
+                                                float* __restrict__ gfeat, float* __restrict__ gmlp) {
+    __shared__ float w[MlpView<K, H>::SIZE];
+    __shared__ float gw[MlpView<K, H>::SIZE];
+    for (int i = threadIdx.x; i < MlpView<K, H>::SIZE; i += 64) { w[i] = mlp[i]; gw[i] = 0.f; }
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) {
+        float t[K], g[K], gt[K];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { t[k] = feat[(int64_t)i * K + k]; g[k] = gpsi[(int64_t)i * K + k]; any = any || g[k] != 0.f; }
+        if (any) {
+            MlpView<K, H> m(w);
+            mlp_residual_vjp<K, H, false>(m, gw, t, nullptr, g, nullptr, gt, nullptr);
+#pragma unroll
+            for (int k = 0; k < K; ++k) gfeat[(int64_t)i * K + k] += gt[k];          // (this voxel's entry: no other thread of this launch touches it)
+        }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < MlpView<K, H>::SIZE; q += 64)
+        if (gw[q] != 0.f) vjp_add(gmlp + q, gw[q]);
+}
+
+extern "C" int nksr_kernel_rows_vjp(const nksr_hier_t* h, const float* xyz, int64_t n, int grad_rows, int approx, float row_scale, const float* coef_a,
+                                    const float* coef_b, const float* alpha, const float* lam, const nksr_theta_grad_t* out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (!h || !xyz || !alpha || !out || (!coef_a && !coef_b)) return nksr_set_error(NKSR_ERR_ARG, "rows vjp: NULL arrays");
+    if (coef_a && !lam) return nksr_set_error(NKSR_ERR_ARG, "rows vjp: coef_a needs lam");
+    if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
+    VjpOut o;
+    for (int d = 0; d < NKSR_MAX_DEPTH; ++d) {
+        o.gfeat[d] = out->gfeat[d]; o.gpsi[d] = out->gpsi[d]; o.gmlp[d] = out->gmlp[d];
+        if (d < h->depth && h->lv[d].n > 0 && (!o.gfeat[d] || !o.gpsi[d] || !o.gmlp[d])) return nksr_set_error(NKSR_ERR_ARG, "rows vjp: NULL output of level %d", d);
+    }
+    dim3 grid(nksr_blocks(n, 64), h->depth), block(64);
+    DISPATCH_KH(h->kdim, h->hidden, {
+        if (!grad_rows) hipLaunchKernelGGL((k_rows_vjp<K, H, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, coef_a, coef_b, alpha, lam, o);
+        else if (approx) hipLaunchKernelGGL((k_rows_vjp<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, coef_a, coef_b, alpha, lam, o);
+        else hipLaunchKernelGGL((k_rows_vjp<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, coef_a, coef_b, alpha, lam, o);
+    })
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+extern "C" int nksr_voxel_psi_vjp(const float* feat, int32_t n, int kdim, int hidden, const float* mlp, const float* gpsi, float* gfeat, float* gmlp,
+                                  void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (!feat || !mlp || !gpsi || !gfeat || !gmlp) return nksr_set_error(NKSR_ERR_ARG, "psi vjp: NULL arrays");
+    DISPATCH_KH(kdim, hidden, {
+        hipLaunchKernelGGL((k_psi_vjp<K, H>), dim3(nksr_blocks(n, 64)), dim3(64), 0, (hipStream_t)stream, feat, n, mlp, gpsi, gfeat, gmlp);
+    })
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}

@@ -740,6 +740,8 @@ class KernelField(BaseField):
         theta = self._theta()
         if not theta:
             return []
+        if os.environ.get('NKSR_THETA_VJP', 'hip') != 'torch' and all(not torch.is_tensor(sw) for _, _, sw, _ in sets):
+            return self._theta_vjp_hip(sets, alpha, lam)
         with torch.enable_grad():
             S = torch.zeros((), dtype=torch.float32, device=self.device)
             for xyz, grad_rows, sw, coeff in sets:
@@ -763,6 +765,57 @@ class KernelField(BaseField):
                 S = S + (R * g).sum()
             grads = torch.autograd.grad(S, theta, allow_unused=True)
         return [gr if gr is not None else torch.zeros_like(t) for gr, t in zip(grads, theta)]
+
+    def _theta_vjp_hip(self, sets, alpha, lam=None):
+        """The same sum as _theta_vjp in HIP (csrc/kfield.hip: nksr_kernel_rows_vjp + nksr_voxel_psi_vjp): the per-row factors
+        from two field evaluations with the rows' support (u = R' alpha, v = R' lambda are f / grad f at the sites), then one
+        thread per (site, level) recomputes its row's forward and pushes the cotangents into the basis features (trilinear
+        stencil), the neighbours' psi and the interpolator weights; psi_j = f_j + MLP(f_j) is taken back per voxel.  Returns
+        the gradients in the order of ``_theta()``.  (kernel_rows_torch.py stays the reference the tests differentiate.)"""
+        from .._lib import ThetaGradT
+        dev, L, K = self.device, self.svh.depth, self.kdim
+        al = alpha.detach().to(dev, torch.float32).contiguous()
+        lm = lam.detach().to(dev, torch.float32).contiguous() if lam is not None else None
+        gfeat = [torch.zeros_like(self._feat[d]) for d in range(L)]
+        gpsi = [torch.zeros_like(self._feat[d]) for d in range(L)]
+        gmlp = [torch.zeros_like(self._mlp[d]) for d in range(L)]
+        tg = ThetaGradT()
+        for d in range(L):
+            tg.gfeat[d] = ptr(gfeat[d]) if gfeat[d].numel() else None
+            tg.gpsi[d] = ptr(gpsi[d]) if gpsi[d].numel() else None
+            tg.gmlp[d] = ptr(gmlp[d])
+        with torch.no_grad():
+            for xyz, grad_rows, sw, coeff in sets:
+                if xyz is None or xyz.shape[0] == 0:
+                    continue
+                xs = xyz.detach().to(dev, torch.float32).contiguous()
+                ra = self._evaluate_raw(al, xs, bool(grad_rows), active_only=True)
+                u = (ra.gradient if grad_rows else ra.value) * float(sw)
+                v = None
+                if lm is not None:
+                    rl = self._evaluate_raw(lm, xs, bool(grad_rows), active_only=True)
+                    v = (rl.gradient if grad_rows else rl.value) * float(sw)
+                a, b = coeff(u, v)
+                ca = a.to(dev, torch.float32).contiguous() if (a is not None and lm is not None) else None
+                cb = b.to(dev, torch.float32).contiguous() if b is not None else None
+                if ca is None and cb is None:
+                    continue
+                call('nksr_kernel_rows_vjp', C.byref(self._hier), ptr(xs), xs.shape[0], int(bool(grad_rows)), int(self.approx_kernel_grad), float(sw),
+                     ptr(ca), ptr(cb), ptr(al), ptr(lm) if ca is not None else None, C.byref(tg), stream())
+            for d in range(L):
+                n_d = self._feat[d].shape[0]
+                if n_d:
+                    call('nksr_voxel_psi_vjp', ptr(self._feat[d]), n_d, K, self.hidden, ptr(self._mlp[d]), ptr(gpsi[d]), ptr(gfeat[d]), ptr(gmlp[d]), stream())
+        out = [gfeat[d].to(f.device, f.dtype) for d, f in enumerate(self._feat_in) if torch.is_tensor(f) and f.requires_grad]
+        H = self.hidden
+        sizes = [H * K, H, H * H, H, K * H, K]
+        for d, m in enumerate(self._interps_in):
+            if isinstance(m, torch.nn.Module):
+                parts = dict(zip(('W1', 'b1', 'W2', 'b2', 'W3', 'b3'), torch.split(gmlp[d], sizes)))
+                for name, q in m.named_parameters():
+                    if q.requires_grad:
+                        out.append(parts[name].reshape(q.shape).to(q.device, q.dtype))
+        return out
 
     def solve(self, pos_xyz, normal_xyz, normal_value, pos_weight, normal_weight, reg_weight=1.0, fused_mode=True,
               pos_sorted_keys=None, normal_sorted_keys=None, segments=None):

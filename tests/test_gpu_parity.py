@@ -536,6 +536,45 @@ def test_solve_is_differentiable_wrt_features_and_interpolators(approx, fused):
         pu.check('autograd_theta[approx=%s]:d_weights[%d]' % (approx, trial), abs(an - fd) / max(abs(fd), 1e-12), 6e-2)
 
 
+@pytest.mark.parametrize('K,H', [(4, 16), (16, 32)])
+@pytest.mark.parametrize('approx', [False, True])
+def test_hip_theta_vjp_matches_autograd_through_the_torch_rows(K, H, approx, monkeypatch):
+    """The theta term of the solve's / evaluate_f's backward as HIP kernels (nksr_kernel_rows_vjp + nksr_voxel_psi_vjp: one thread
+    per (site, level) recomputes its row and pushes the cotangents into the basis features, the neighbours' psi and the
+    interpolator weights) against torch autograd through fields/kernel_rows_torch.py, the differentiable statement of the same
+    rows: value rows and gradient rows (exact and approx_kernel_grad), with and without the lambda term, both (kernel_dim,
+    hidden) pairs of the presets.  Relative L2 error per parameter group; the HIP path must not touch the torch rows."""
+    from nksr_amd.fields import KernelField, kernel_rows_torch as krt
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=1500, K=K, H=H, init_scale=0.3)
+    net.to(_dev())
+    t = lambda a: torch.from_numpy(a).to(_dev())
+    tf = [t(f).requires_grad_(True) for f in feats]
+    fld = KernelField(svh, net.interpolators, tf, approx_kernel_grad=approx)
+    rs = np.random.RandomState(11)
+    M = svh.num_unknowns
+    alpha, lam = t(rs.randn(M).astype(np.float32)), t(rs.randn(M).astype(np.float32))
+    q = t((xyz[:400] + rs.randn(400, 3).astype(np.float32) * np.float32(0.03)).astype(np.float32))       # some queries leave the finest level
+    nx = t(oh.levels[0].centers()[:500].astype(np.float32))
+    tn = t(rs.randn(500, 3).astype(np.float32))
+    g1, g3 = t(rs.randn(400).astype(np.float32)), t(rs.randn(400, 3).astype(np.float32))
+    cases = {'solve': ([(q, False, 0.7, lambda u, v: (-u, -v)), (nx, True, 1.3, lambda u, v: (tn - u, -v))], lam),
+             'evaluate': ([(q, False, 1.0, lambda u, v: (None, g1)), (q, True, 1.0, lambda u, v: (None, g3))], None)}
+    for name, (sets, lm) in cases.items():
+        monkeypatch.setenv('NKSR_THETA_VJP', 'torch')
+        ref = fld._theta_vjp(sets, alpha, lm)
+        monkeypatch.setenv('NKSR_THETA_VJP', 'hip')
+        with monkeypatch.context() as mp:
+            mp.setattr(krt, 'rows', lambda *a, **k: (_ for _ in ()).throw(AssertionError('the HIP path went through the torch rows')))
+            got = fld._theta_vjp(sets, alpha, lm)
+        assert len(got) == len(ref) == len(tf) + 6 * len(net.interpolators)
+        for grp, lo, hi in (('features', 0, len(tf)), ('weights', len(tf), len(ref))):
+            num = sum(float(((a.double() - b.double()) ** 2).sum()) for a, b in zip(got[lo:hi], ref[lo:hi])) ** 0.5
+            den = sum(float((b.double() ** 2).sum()) for b in ref[lo:hi]) ** 0.5
+            assert den > 0
+            pu.check('theta_vjp_hip[K=%d,H=%d,approx=%s]:%s:%s_rel_l2' % (K, H, approx, name, grp), num / den, 2e-5)
+        assert all(a.shape == b.shape and torch.isfinite(a).all() for a, b in zip(got, ref))
+
+
 def test_pcg_matches_oracle_and_scipy():
     import scipy.sparse as sp
     import scipy.sparse.linalg as sla
