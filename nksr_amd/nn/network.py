@@ -187,12 +187,19 @@ class PointEncoder(nn.Module):
             enc.keys, enc.xyz, enc.feat = sorted_keys, xyz.contiguous(), feat.to(torch.float32).contiguous()
         else:
             enc.keys, enc.xyz, enc.feat = sort_cloud(xyz.contiguous(), feat.to(torch.float32).contiguous(), svh.inv_w0)
+        if self.training and torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            from .backward import EncoderFunction          # training: the voxel features carry a graph into the encoder's parameters
+            enc.voxel_feat = EncoderFunction.apply(self, enc, svh, depth, self.W1, self.b1, self.W2, self.b2)
+        else:
+            enc.voxel_feat = self._forward_hip(enc, svh, depth)
+        return enc
+
+    def _forward_hip(self, enc, svh, depth):
         n = enc.xyz.shape[0]
-        g = torch.empty((n, self.channels), dtype=torch.float32, device=xyz.device)
+        g = torch.empty((n, self.channels), dtype=torch.float32, device=enc.xyz.device)
         call('nksr_point_mlp', ptr(enc.xyz), ptr(enc.feat), n, svh.inv_w0, self.channels, ptr(self.W1.detach().contiguous()),
              ptr(self.b1.detach().contiguous()), ptr(self.W2.detach().contiguous()), ptr(self.b2.detach().contiguous()), ptr(g), stream())
-        enc.voxel_feat = splat_mean(svh.level(depth), depth, svh.inv_w0, enc.keys, enc.xyz, g)
-        return enc
+        return splat_mean(svh.level(depth), depth, svh.inv_w0, enc.keys, enc.xyz, g)
 
 
 class StructureUNet(nn.Module):
@@ -209,20 +216,45 @@ class StructureUNet(nn.Module):
         self.udf_heads = nn.ModuleList([Head(C_, 8, hs, generator) for _ in range(D)])
 
     def forward(self, enc, enc_svh, adaptive_depth=1, gt_decoder_svh=None):
+        if self.training and torch.is_grad_enabled() and (enc.voxel_feat.requires_grad or any(q.requires_grad for q in self.parameters())):
+            # training (models/nksr_net.py:74-78 under autograd): same HIP forward, its outputs tied to the reverse sweep of nn/backward.py
+            from .backward import UNetFunction
+            tape = {}
+            outs = UNetFunction.apply(self, enc, enc_svh, adaptive_depth, gt_decoder_svh, tape, enc.voxel_feat,
+                                      *[q for _, q in self.named_parameters()])
+            feat, dec_svh = tape['feat'], tape['dec_svh']
+            for (kind, d), o in zip(tape['layout'], outs):
+                if kind == 'structure':
+                    feat.structure_features[d] = o
+                else:
+                    getattr(feat, kind + '_features')[d] = o
+            return feat, dec_svh, dec_svh
+        return self._forward_impl(enc, enc_svh, adaptive_depth, gt_decoder_svh, None)
+
+    def _forward_impl(self, enc, enc_svh, adaptive_depth, gt_decoder_svh, tape):
+        """``tape`` (dict or None): what the reverse sweep (nn/backward.py) needs from this forward."""
         hp = self.hparams
         D = enc_svh.depth
         dev = enc_svh.device
         K = int(hp.kernel_dim)
+        vf = enc.voxel_feat.detach()
+        if tape is not None:
+            tape.update(x=None, pool=[vf] + [None] * (D - 1), enc_nbr=[enc_svh.level(d).nbr for d in range(D)], ranges=[None] * D,
+                        dec=[None] * D, normal=[None] * D, trunk=None)
         # ---- down path on the encoder hierarchy ----------------------------------------------------
         x = [None] * D
         g = enc_svh.level(0)
-        x[0] = self.down[0](enc.voxel_feat, g.nbr)
+        x[0] = self.down[0](vf, g.nbr)
         for d in range(1, D):
             g, gc = enc_svh.level(d), enc_svh.level(d - 1)
             st, en = site_ranges(gc.keys, g, 1)      # children = contiguous Morton range one level down
             p = torch.empty((g.num_voxels, x[d - 1].shape[1]), dtype=torch.float32, device=dev)
             call('nksr_pool_children', ptr(x[d - 1]), ptr(st), ptr(en), g.num_voxels, p.shape[1], ptr(p), stream())
             x[d] = self.down[d](p, g.nbr)
+            if tape is not None:
+                tape['pool'][d], tape['ranges'][d] = p, (st, en)
+        if tape is not None:
+            tape['x'] = x
         # ---- candidate decoder structure ------------------------------------------------------------
         cand = gt_decoder_svh if gt_decoder_svh is not None else \
             SparseFeatureHierarchy(enc_svh.voxel_size, D, dev).build_point_neighborhood_sorted(enc.keys, getattr(enc, 'cells', None))
@@ -239,13 +271,16 @@ class StructureUNet(nn.Module):
                     keys = keys[ok].contiguous()
                     gc = SparseGrid(keys, d, enc_svh.voxel_size)
                     par = dec_levels[d + 1].hash.query((keys >> 3).contiguous())
-            t = gather_rows(x[d], enc_svh.level(d).hash.query(keys))
+            je = enc_svh.level(d).hash.query(keys)
+            t = gather_rows(x[d], je)
             if d < D - 1:
                 t = gather_rows(y_up, par, add=t)
             y = self.up[d](t, gc.nbr)
             s = self.structure_heads[d](y)
             status = s.argmax(1)
             exist = status != 0
+            if tape is not None:
+                tape['dec'][d] = dict(je=je, par=par if d < D - 1 else None, t=t, nbr=gc.nbr, y_pre=y, exist=None if bool(exist.all()) else exist)
             if not bool(exist.all()):          # prune "not-exist" voxels (needs a re-indexed grid)
                 y, s, status = y[exist].contiguous(), s[exist].contiguous(), status[exist]
                 gc = SparseGrid(keys[exist].contiguous(), d, enc_svh.voxel_size)
@@ -280,8 +315,13 @@ class StructureUNet(nn.Module):
                 # rounding): that vector is noise; it stays short instead of becoming an arbitrary unit target
                 nml = float(getattr(hp, 'normal_min_length', NORMAL_MIN_LENGTH))
                 nmw = float(getattr(hp, 'normal_min_weight', NORMAL_MIN_WEIGHT))
-                den = torch.maximum(nv.norm(dim=1), nml * ws).clamp_min(max(nmw, 1e-30))      # (0 / 0: plain unit normalisation)
+                nn_ = nv.norm(dim=1)
+                den = torch.maximum(nn_, nml * ws).clamp_min(max(nmw, 1e-30))      # (0 / 0: plain unit normalisation)
                 feat.normal_features[d] = nv / den[:, None]
+                if tape is not None:
+                    tape['normal'][d] = (nv, den, nn_ >= den)
+        if tape is not None:
+            tape['trunk'] = feat.trunk_features
         return feat, dec_svh, dec_svh
 
 
