@@ -117,6 +117,11 @@ int nksr_splat_mean(const float* xyz_sorted, const float* feat_sorted, int C, co
  * (+ residual)),  W [27, C, C] */
 int nksr_sparse_conv3(const float* in, const int32_t* nbr, int32_t n, int C, const float* W, const float* bias,
                       const float* residual, int relu, float* out, void* stream);
+/* Weight gradient of nksr_sparse_conv3 (training path, network.unet under autograd, models/nksr_net.py:74-78):
+ * partial[chunk][s][ci][co] = sum over the chunk's voxels i of in[nbr[i][s]][ci] * gz[i][co]  (gz = output gradient through the
+ * activation); nksr_conv3_wgrad_chunks(n) chunks, the caller adds them up (fixed order: deterministic). */
+int64_t nksr_conv3_wgrad_chunks(int32_t n);
+int nksr_conv3_wgrad(const float* in, const int32_t* nbr, int32_t n, int C, const float* gz, float* partial, void* stream);
 /* mean over the children (contiguous Morton range start/end in the finer level) of every voxel */
 int nksr_pool_children(const float* child_feat, const int32_t* start, const int32_t* end, int32_t n_parent, int C,
                        float* out, void* stream);

@@ -86,6 +86,8 @@ lib.nksr_fused_item_entries.restype = _i64
 lib.nksr_fused_item_entries.argtypes = [_i64]
 lib.nksr_fused_workspace_bytes.restype = _sz
 lib.nksr_fused_workspace_bytes.argtypes = [_i64, _i32]
+lib.nksr_conv3_wgrad_chunks.restype = _i64
+lib.nksr_conv3_wgrad_chunks.argtypes = [_i32]
 lib.nksr_pcg_vector_workspace_bytes.restype = _sz
 lib.nksr_pcg_vector_workspace_bytes.argtypes = [_i32]
 lib.nksr_pcg_profile_survey_bytes.restype = C.c_double
@@ -118,6 +120,7 @@ _PROTOS = {
     'nksr_splat_mean': [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp],
     'nksr_sparse_conv3': [_vp, _vp, _i32, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp],
     'nksr_pool_children': [_vp, _vp, _vp, _i32, C.c_int, _vp, _vp],
+    'nksr_conv3_wgrad': [_vp, _vp, _i32, C.c_int, _vp, _vp, _vp],
     'nksr_gather_rows': [_vp, _vp, _i64, C.c_int, _vp, _vp, _vp],
     'nksr_linear': [_vp, _i64, C.c_int, _vp, _vp, C.c_int, _vp, _vp],
     'nksr_splat_plane': [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp],
@@ -173,7 +176,7 @@ for _name, _args in _PROTOS.items():
     _fn.argtypes = _args
     _fn.restype = C.c_int
 
-EXPORTED = ['nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
+EXPORTED = ['nksr_conv3_wgrad_chunks', 'nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
             'nksr_assemble_split_bytes',
             'nksr_fused_workspace_bytes', 'nksr_fused_item_entries', 'nksr_pcg_vector_workspace_bytes', 'nksr_pcg_vector_workspace_bytes_seg', 'nksr_pcg_profile_survey_bytes', 'nksr_bbox_work_floats'] + sorted(_PROTOS)
 

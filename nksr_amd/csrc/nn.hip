@@ -271,6 +271,50 @@ __global__ void __launch_bounds__(256) k_sparse_conv3(const float* __restrict__ 
     }
 }
 
+// ---- weight gradient of the convolution (training path, nn/backward.py) -------------------------------------------------------------
+// gW[s][ci][co] = sum_i in[nbr[i][s]][ci] * gz[i][co]: per tap a [32 x n] x [n x 32] product, the reduction runs over the voxels.  One
+// wavefront per (chunk of CW_CHUNK voxels, tap): v_mfma_f32_32x32x2_f32 takes TWO voxels per instruction -- lane l supplies
+// A[ci = l & 31][k = l >> 5] = the gathered input row of voxel k of the pair and B[k][co = l & 31] = its output-gradient row, both
+// coalesced 128-byte reads.  Every wavefront writes its own 32 x 32 partial (no atomics: deterministic); the host adds the chunks.
+#define CW_CHUNK 2048
+__global__ void __launch_bounds__(64) k_conv3_wgrad(const float* __restrict__ in, const int32_t* __restrict__ nbr, int n, const float* __restrict__ gz,
+                                                    float* __restrict__ partial) {
+    const int chunk = blockIdx.x, s = blockIdx.y, lane = threadIdx.x;
+    const int ci = lane & 31, k = lane >> 5;
+    const int i0 = chunk * CW_CHUNK, i1 = (i0 + CW_CHUNK < n) ? i0 + CW_CHUNK : n;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = i0; i < i1; i += 8) {                   // four pairs per trip: their loads go out together
+        float a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int v = i + 2 * q + k;
+            const bool live = v < i1;
+            const int j = live ? nbr[(int64_t)v * 27 + s] : -1;
+            a[q] = j >= 0 ? in[(int64_t)j * NN_C + ci] : 0.f;
+            b[q] = live ? gz[(int64_t)v * NN_C + ci] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+    }
+    float* out = partial + ((int64_t)chunk * 27 + s) * NN_C * NN_C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * k;
+        out[row * NN_C + ci] = acc[r];
+    }
+}
+extern "C" int64_t nksr_conv3_wgrad_chunks(int32_t n) { return n > 0 ? (int64_t)nksr_blocks(n, CW_CHUNK) : 0; }
+extern "C" int nksr_conv3_wgrad(const float* in, const int32_t* nbr, int32_t n, int C, const float* gz, float* partial, void* stream) {
+    if (C != NN_C) return nksr_set_error(NKSR_ERR_ARG, "unet.f_maps must be %d", NN_C);
+    if (n <= 0) return NKSR_OK;
+    if (!in || !nbr || !gz || !partial) return nksr_set_error(NKSR_ERR_ARG, "conv3 wgrad: NULL arrays");
+    hipLaunchKernelGGL(k_conv3_wgrad, dim3(nksr_blocks(n, CW_CHUNK), 27), dim3(64), 0, (hipStream_t)stream, in, nbr, n, gz, partial);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
 // ---- mean over the children of every coarse voxel (children are a contiguous Morton range) ------------------
 __global__ void k_pool_children(const float* __restrict__ child_feat, const int32_t* __restrict__ start,
                                 const int32_t* __restrict__ end, int n_parent, int C, float* __restrict__ out) {

@@ -5,8 +5,8 @@ nn/network.py; here its reverse sweep, wrapped as two ``torch.autograd.Function`
 
   * sparse convolution, data gradient: the SAME fp32-MFMA kernel (csrc/nn.hip k_sparse_conv3) with the taps mirrored and the
     weight tiles transposed -- the neighbour relation of a grid is symmetric (nbr[i][s] = j  <=>  nbr[j][26 - s] = i);
-  * sparse convolution, weight gradient, and the linear heads: plain library GEMMs (rocBLAS through torch.matmul) over the
-    gathered taps;
+  * sparse convolution, weight gradient: csrc/nn.hip k_conv3_wgrad (fp32 MFMA over pairs of voxels, deterministic per-chunk
+    partials); the linear heads: plain library GEMMs (rocBLAS through torch.matmul);
   * pooling / gathers / splats: the transposes of their index maps (index_add over the tables the forward recorded); the
     trilinear splat of the encoder is transposed through the points' eight-corner tables (hash queries);
   * ReLU masks and the normal target's normalisation: element-wise.
@@ -29,16 +29,17 @@ def conv3_dgrad(gz, nbr, weight):
     return out
 
 
-def conv3_wgrad(x, nbr, gz, block=1 << 16):
-    """d(weight)[s] = sum_i in[nbr[i][s]]^T gz[i]  -- 27 GEMMs over the gathered taps (rocBLAS), in blocks of voxels."""
+def conv3_wgrad(x, nbr, gz):
+    """d(weight)[s] = sum_i in[nbr[i][s]]^T gz[i]: csrc/nn.hip k_conv3_wgrad (fp32 MFMA, two voxels per instruction, one wavefront per
+    (chunk of voxels, tap), per-chunk partials added here in chunk order)."""
+    from .._lib import lib
     n, C = x.shape
-    xp = torch.cat([x, x.new_zeros(1, C)])
-    gw = x.new_zeros(27, C, gz.shape[1])
-    for s0 in range(0, n, block):
-        idx = nbr[s0:s0 + block].long()
-        idx = torch.where(idx >= 0, idx, torch.full_like(idx, n))
-        gw += torch.einsum('nsc,nd->scd', xp[idx], gz[s0:s0 + block])
-    return gw
+    if n == 0:
+        return x.new_zeros(27, C, C)
+    nch = int(lib.nksr_conv3_wgrad_chunks(n))
+    part = torch.empty((nch, 27, C, C), dtype=torch.float32, device=x.device)
+    call('nksr_conv3_wgrad', ptr(x.contiguous()), ptr(nbr), n, C, ptr(gz.contiguous()), ptr(part), stream())
+    return part.sum(0)
 
 
 def conv3_backward(x_in, nbr, weight, out_post, g_out):
