@@ -261,9 +261,18 @@ def pack_field(f, band=None, shift=None):
                  f.mask_field.level_set if nu else 0.0, [(0, svh.num_voxels(d)) for d in range(svh.depth)], band, shift)
 
 
-def _parse_payload(ints, flts):
-    depth, kdim, approx, nu = int(ints[0]), int(ints[1]), bool(int(ints[2])), int(ints[3])
-    ns = [int(v) for v in ints[4:4 + depth]]
+def _payload_heads(ints_list):
+    """The headers (4 + at most 6 level counts) of several payloads in ONE host read."""
+    if not ints_list:
+        return []
+    return torch.stack([torch.nn.functional.pad(i[:10], (0, 10 - min(10, int(i.numel())))) for i in ints_list]).tolist()
+
+
+def _parse_payload(ints, flts, head=None):
+    if head is None:
+        head = _payload_heads([ints])[0]            # (was one host read per header entry)
+    depth, kdim, approx, nu = int(head[0]), int(head[1]), bool(int(head[2])), int(head[3])
+    ns = [int(v) for v in head[4:4 + depth]]
     off = 4 + depth
     keys = []
     for n in ns:
@@ -289,7 +298,9 @@ def _parse_payload(ints, flts):
 def fields_from_payloads(payloads, voxel_size, interpolators, device):
     """ONE KernelField from the payloads of several chunks -- [(key_lo of the chunk's slot, ints, flts), ...]; the slots are
     disjoint key ranges, so concatenating the chunks in slot order gives every level in canonical (ascending key) order."""
-    ps = [_parse_payload(i.to(device), f.to(device)) for _, i, f in sorted(payloads, key=lambda p: p[0])]
+    payloads = [(k, i.to(device), f.to(device)) for k, i, f in sorted(payloads, key=lambda p: p[0])]
+    heads = _payload_heads([i for _, i, _ in payloads])
+    ps = [_parse_payload(i, f, h) for (_, i, f), h in zip(payloads, heads)]
     depth, kdim, approx, nu = ps[0]['depth'], ps[0]['kdim'], ps[0]['approx'], max(p['nu'] for p in ps)
     keys = [torch.cat([p['keys'][d] for p in ps]).contiguous() for d in range(depth)]
     svh = SparseFeatureHierarchy(voxel_size, depth, device).build_from_keys(keys, sorted_unique=True)
