@@ -440,10 +440,19 @@ extern "C" int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const f
 // rounding of a sum, not bit for bit -- unlike every kernel of the solve-time path.
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 __device__ __forceinline__ void vjp_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+// weight cotangents: the 64 lanes of the (single-wavefront) workgroup add into ONE LDS word -- a butterfly sum and one plain add by
+// lane 0 instead of 64 serialised LDS atomics (k_psi_vjp: 416 -> 90 us per 6 000 voxels, k_rows_vjp 850 -> 530).  Every lane must arrive (no divergence around
+// the call): lanes without work carry zeros.
+__device__ __forceinline__ void wave_acc(float* lds, float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) *lds += v;
+}
 
 template <int K, int H, bool JAC>
 __device__ __forceinline__ void mlp_residual_vjp(const MlpView<K, H>& m, float* __restrict__ gw, const float t[K], const float Jt[JAC ? K : 1][3],
                                                  const float gphi[K], const float gJ[JAC ? K : 1][3], float gt[K], float gJt[JAC ? K : 1][3]) {
+    // (called by ALL lanes of the wavefront, converged: the weight cotangents are summed over the lanes, wave_acc)
     float* gW1 = gw;
     float* gb1 = gW1 + H * K;
     float* gW2 = gb1 + H;
@@ -473,7 +482,7 @@ __device__ __forceinline__ void mlp_residual_vjp(const MlpView<K, H>& m, float* 
     for (int k = 0; k < K; ++k) {
         gt[k] = gphi[k];                                      // the residual skip
         if (JAC) { gJt[k][0] = gJ[k][0]; gJt[k][1] = gJ[k][1]; gJt[k][2] = gJ[k][2]; }
-        if (gphi[k] != 0.f) atomicAdd(gb3 + k, gphi[k]);
+        wave_acc(gb3 + k, gphi[k]);
     }
 #pragma unroll 1
     for (int g = 0; g < H; ++g) {
@@ -485,20 +494,23 @@ __device__ __forceinline__ void mlp_residual_vjp(const MlpView<K, H>& m, float* 
             a = fmaf(w, h1[h], a);
             if (JAC) { da[0] = fmaf(w, d1[h][0], da[0]); da[1] = fmaf(w, d1[h][1], da[1]); da[2] = fmaf(w, d1[h][2], da[2]); }
         }
-        if (!(a > 0.f)) continue;                             // unit off: h2 = d2 = 0 and nothing flows back through it
+        const float on = a > 0.f ? 1.f : 0.f;                 // unit off: h2 = d2 = 0 and nothing flows back through it
+        const float h2 = on * a;
         float gh2 = 0.f, ge[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float w = m.W3[k * H + g];
             gh2 = fmaf(w, gphi[k], gh2);
-            float gw3 = gphi[k] * a;
+            float gw3 = gphi[k] * h2;
             if (JAC) {
                 ge[0] = fmaf(w, gJ[k][0], ge[0]); ge[1] = fmaf(w, gJ[k][1], ge[1]); ge[2] = fmaf(w, gJ[k][2], ge[2]);
-                gw3 += gJ[k][0] * da[0] + gJ[k][1] * da[1] + gJ[k][2] * da[2];
+                gw3 += on * (gJ[k][0] * da[0] + gJ[k][1] * da[1] + gJ[k][2] * da[2]);
             }
-            atomicAdd(gW3 + k * H + g, gw3);
+            wave_acc(gW3 + k * H + g, gw3);
         }
-        atomicAdd(gb2 + g, gh2);
+        gh2 *= on;
+        if (JAC) { ge[0] *= on; ge[1] *= on; ge[2] *= on; }
+        wave_acc(gb2 + g, gh2);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             const float w = m.W2[g * H + h];
@@ -508,24 +520,26 @@ __device__ __forceinline__ void mlp_residual_vjp(const MlpView<K, H>& m, float* 
                 gw2 += ge[0] * d1[h][0] + ge[1] * d1[h][1] + ge[2] * d1[h][2];
                 gd1[h][0] = fmaf(w, ge[0], gd1[h][0]); gd1[h][1] = fmaf(w, ge[1], gd1[h][1]); gd1[h][2] = fmaf(w, ge[2], gd1[h][2]);
             }
-            atomicAdd(gW2 + g * H + h, gw2);
+            wave_acc(gW2 + g * H + h, gw2);
         }
     }
 #pragma unroll
     for (int h = 0; h < H; ++h) {
-        if (!(h1[h] > 0.f)) continue;                         // (a1 > 0  <=>  h1 > 0)
-        const float ga = gh1[h];
-        atomicAdd(gb1 + h, ga);
+        const float on = h1[h] > 0.f ? 1.f : 0.f;             // (a1 > 0  <=>  h1 > 0)
+        const float ga = on * gh1[h];
+        float ge[3] = {0.f, 0.f, 0.f};
+        if (JAC) { ge[0] = on * gd1[h][0]; ge[1] = on * gd1[h][1]; ge[2] = on * gd1[h][2]; }
+        wave_acc(gb1 + h, ga);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const float w = m.W1[h * K + k];
             float gw1 = ga * t[k];
             gt[k] = fmaf(w, ga, gt[k]);
             if (JAC) {
-                gw1 += gd1[h][0] * Jt[k][0] + gd1[h][1] * Jt[k][1] + gd1[h][2] * Jt[k][2];
-                gJt[k][0] = fmaf(w, gd1[h][0], gJt[k][0]); gJt[k][1] = fmaf(w, gd1[h][1], gJt[k][1]); gJt[k][2] = fmaf(w, gd1[h][2], gJt[k][2]);
+                gw1 += ge[0] * Jt[k][0] + ge[1] * Jt[k][1] + ge[2] * Jt[k][2];
+                gJt[k][0] = fmaf(w, ge[0], gJt[k][0]); gJt[k][1] = fmaf(w, ge[1], gJt[k][1]); gJt[k][2] = fmaf(w, ge[2], gJt[k][2]);
             }
-            atomicAdd(gW1 + h * K + k, gw1);
+            wave_acc(gW1 + h * K + k, gw1);
         }
     }
 }
@@ -542,81 +556,87 @@ __global__ void __launch_bounds__(64) k_rows_vjp(nksr_hier_t hier, const float* 
     for (int i = threadIdx.x; i < MlpView<K, H>::SIZE; i += 64) { w[i] = lv.mlp[i]; gw[i] = 0.f; }
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    MlpView<K, H> m(w);
+    const float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
+    // a lane without a row (past the end, or its site lies in no active cell of this level) carries zeros through the weight part
+    bool valid = false;
+    SiteCell sc;
+    int nb[27];
+    float t[K], Jt[JAC ? K : 1][3], gphi[K], gJ[JAC ? K : 1][3];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t[k] = 0.f; gphi[k] = 0.f; if (JAC) { Jt[k][0] = Jt[k][1] = Jt[k][2] = 0.f; gJ[k][0] = gJ[k][1] = gJ[k][2] = 0.f; } }
     if (i < n && lv.n > 0) {
         const float x[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
-        SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
-        if (sc.cell >= 0) {
-            const float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
-            float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
-            trilerp_feat<K, JAC>(lv, d, sc, inv_w, t, Jt);
-            MlpView<K, H> m(w);
-            mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
-            float bw[3][3], bd[3][3];
+        sc = locate_site(lv, d, hier.inv_w0, x);
+        valid = sc.cell >= 0;
+    }
+    if (valid) {
+        float phi[K], J[JAC ? K : 1][3];
+        trilerp_feat<K, JAC>(lv, d, sc, inv_w, t, Jt);
+        mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
+        float bw[3][3], bd[3][3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
-            int nb[27];
-            load_nbr_row(lv.nbr + (int64_t)sc.cell * 27, nb);
-            float fa[GRAD ? 3 : 1], fb[GRAD ? 3 : 1];
+        for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
+        load_nbr_row(lv.nbr + (int64_t)sc.cell * 27, nb);
+        float fa[GRAD ? 3 : 1], fb[GRAD ? 3 : 1];
 #pragma unroll
-            for (int a = 0; a < (GRAD ? 3 : 1); ++a) {
-                fa[a] = ca ? ca[i * (GRAD ? 3 : 1) + a] : 0.f;
-                fb[a] = cb ? cb[i * (GRAD ? 3 : 1) + a] : 0.f;
-            }
-            float gphi[K], gJ[JAC ? K : 1][3];
-#pragma unroll
-            for (int k = 0; k < K; ++k) { gphi[k] = 0.f; if (JAC) gJ[k][0] = gJ[k][1] = gJ[k][2] = 0.f; }
+        for (int a = 0; a < (GRAD ? 3 : 1); ++a) {
+            fa[a] = ca ? ca[i * (GRAD ? 3 : 1) + a] : 0.f;
+            fb[a] = cb ? cb[i * (GRAD ? 3 : 1) + a] : 0.f;
+        }
 #pragma unroll 1
-            for (int s = 0; s < 27; ++s) {
-                const int j = nb[s];
-                if (j < 0) continue;
-                const int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
-                const float bx = sel3(bw[0], ox), by = sel3(bw[1], oy), bz = sel3(bw[2], oz);
-                const float B = bx * by * bz;
-                const float al = alpha[lv.offset + j], la = lam ? lam[lv.offset + j] : 0.f;
-                float cphi, cJ[3] = {0.f, 0.f, 0.f};
-                if (!GRAD) {
-                    cphi = (fa[0] * la + fb[0] * al) * sw * B;
-                } else {
-                    const float g0 = (fa[0] * la + fb[0] * al) * sw, g1 = (fa[1] * la + fb[1] * al) * sw, g2 = (fa[2] * la + fb[2] * al) * sw;
-                    cphi = g0 * (sel3(bd[0], ox) * by * bz * inv_w) + g1 * (bx * sel3(bd[1], oy) * bz * inv_w) + g2 * (bx * by * sel3(bd[2], oz) * inv_w);
-                    if (JAC) { cJ[0] = g0 * B; cJ[1] = g1 * B; cJ[2] = g2 * B; }
-                }
-                const float* ps = lv.psi + (int64_t)j * K;
-                float* gp = out.gpsi[d] + (int64_t)j * K;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    const float pk = ps[k];
-                    gphi[k] = fmaf(cphi, pk, gphi[k]);
-                    float gps = cphi * phi[k];
-                    if (JAC) {
-                        gJ[k][0] = fmaf(cJ[0], pk, gJ[k][0]); gJ[k][1] = fmaf(cJ[1], pk, gJ[k][1]); gJ[k][2] = fmaf(cJ[2], pk, gJ[k][2]);
-                        gps += cJ[0] * J[k][0] + cJ[1] * J[k][1] + cJ[2] * J[k][2];
-                    }
-                    if (gps != 0.f) vjp_add(gp + k, gps);
-                }
+        for (int s = 0; s < 27; ++s) {
+            const int j = nb[s];
+            if (j < 0) continue;
+            const int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
+            const float bx = sel3(bw[0], ox), by = sel3(bw[1], oy), bz = sel3(bw[2], oz);
+            const float B = bx * by * bz;
+            const float al = alpha[lv.offset + j], la = lam ? lam[lv.offset + j] : 0.f;
+            float cphi, cJ[3] = {0.f, 0.f, 0.f};
+            if (!GRAD) {
+                cphi = (fa[0] * la + fb[0] * al) * sw * B;
+            } else {
+                const float g0 = (fa[0] * la + fb[0] * al) * sw, g1 = (fa[1] * la + fb[1] * al) * sw, g2 = (fa[2] * la + fb[2] * al) * sw;
+                cphi = g0 * (sel3(bd[0], ox) * by * bz * inv_w) + g1 * (bx * sel3(bd[1], oy) * bz * inv_w) + g2 * (bx * by * sel3(bd[2], oz) * inv_w);
+                if (JAC) { cJ[0] = g0 * B; cJ[1] = g1 * B; cJ[2] = g2 * B; }
             }
-            float gt[K], gJt[JAC ? K : 1][3];
-            mlp_residual_vjp<K, H, JAC>(m, gw, t, Jt, gphi, gJ, gt, gJt);
-            // transpose of the trilinear stencil (the same eight corners and weights as trilerp_feat)
-            float v[3];
+            const float* ps = lv.psi + (int64_t)j * K;
+            float* gp = out.gpsi[d] + (int64_t)j * K;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) v[a] = sc.u[a] + 0.5f - (float)sc.hb[a];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int cx = c >> 2, cy = (c >> 1) & 1, cz = c & 1;
-                const int s = (sc.hb[0] + cx) * 9 + (sc.hb[1] + cy) * 3 + (sc.hb[2] + cz);
-                const int j = nb[s];
-                if (j < 0) continue;
-                const float wx = cx ? v[0] : 1.f - v[0], wy = cy ? v[1] : 1.f - v[1], wz = cz ? v[2] : 1.f - v[2];
-                const float wt = wx * wy * wz;
-                const float gx = (cx ? 1.f : -1.f) * wy * wz * inv_w, gy = wx * (cy ? 1.f : -1.f) * wz * inv_w, gz = wx * wy * (cz ? 1.f : -1.f) * inv_w;
-                float* gf = out.gfeat[d] + (int64_t)j * K;
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    float g = wt * gt[k];
-                    if (JAC) g += gx * gJt[k][0] + gy * gJt[k][1] + gz * gJt[k][2];
-                    if (g != 0.f) vjp_add(gf + k, g);
+            for (int k = 0; k < K; ++k) {
+                const float pk = ps[k];
+                gphi[k] = fmaf(cphi, pk, gphi[k]);
+                float gps = cphi * phi[k];
+                if (JAC) {
+                    gJ[k][0] = fmaf(cJ[0], pk, gJ[k][0]); gJ[k][1] = fmaf(cJ[1], pk, gJ[k][1]); gJ[k][2] = fmaf(cJ[2], pk, gJ[k][2]);
+                    gps += cJ[0] * J[k][0] + cJ[1] * J[k][1] + cJ[2] * J[k][2];
                 }
+                if (gps != 0.f) vjp_add(gp + k, gps);
+            }
+        }
+    }
+    float gt[K], gJt[JAC ? K : 1][3];
+    mlp_residual_vjp<K, H, JAC>(m, gw, t, Jt, gphi, gJ, gt, gJt);           // all 64 lanes, converged
+    if (valid) {
+        // transpose of the trilinear stencil (the same eight corners and weights as trilerp_feat)
+        float v[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) v[a] = sc.u[a] + 0.5f - (float)sc.hb[a];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int cx = c >> 2, cy = (c >> 1) & 1, cz = c & 1;
+            const int s = (sc.hb[0] + cx) * 9 + (sc.hb[1] + cy) * 3 + (sc.hb[2] + cz);
+            const int j = nb[s];
+            if (j < 0) continue;
+            const float wx = cx ? v[0] : 1.f - v[0], wy = cy ? v[1] : 1.f - v[1], wz = cz ? v[2] : 1.f - v[2];
+            const float wt = wx * wy * wz;
+            const float gx = (cx ? 1.f : -1.f) * wy * wz * inv_w, gy = wx * (cy ? 1.f : -1.f) * wz * inv_w, gz = wx * wy * (cz ? 1.f : -1.f) * inv_w;
+            float* gf = out.gfeat[d] + (int64_t)j * K;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float g = wt * gt[k];
+                if (JAC) g += gx * gJt[k][0] + gy * gJt[k][1] + gz * gJt[k][2];
+                if (g != 0.f) vjp_add(gf + k, g);
             }
         }
     }
@@ -634,17 +654,14 @@ __global__ void __launch_bounds__(64) k_psi_vjp(const float* __restrict__ feat, 
     for (int i = threadIdx.x; i < MlpView<K, H>::SIZE; i += 64) { w[i] = mlp[i]; gw[i] = 0.f; }
     __syncthreads();
     const int i = blockIdx.x * 64 + threadIdx.x;
+    float t[K], g[K], gt[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t[k] = i < n ? feat[(int64_t)i * K + k] : 0.f; g[k] = i < n ? gpsi[(int64_t)i * K + k] : 0.f; }
+    MlpView<K, H> m(w);
+    mlp_residual_vjp<K, H, false>(m, gw, t, nullptr, g, nullptr, gt, nullptr);          // all 64 lanes, converged
     if (i < n) {
-        float t[K], g[K], gt[K];
-        bool any = false;
 #pragma unroll
-        for (int k = 0; k < K; ++k) { t[k] = feat[(int64_t)i * K + k]; g[k] = gpsi[(int64_t)i * K + k]; any = any || g[k] != 0.f; }
-        if (any) {
-            MlpView<K, H> m(w);
-            mlp_residual_vjp<K, H, false>(m, gw, t, nullptr, g, nullptr, gt, nullptr);
-#pragma unroll
-            for (int k = 0; k < K; ++k) gfeat[(int64_t)i * K + k] += gt[k];          // (this voxel's entry: no other thread of this launch touches it)
-        }
+        for (int k = 0; k < K; ++k) gfeat[(int64_t)i * K + k] += gt[k];          // (this voxel's entry: no other thread of this launch touches it)
     }
     __syncthreads();
     for (int q = threadIdx.x; q < MlpView<K, H>::SIZE; q += 64)
