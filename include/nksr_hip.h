@@ -415,6 +415,34 @@ int nksr_knn_pca_normals(const float* xyz_sorted, int64_t n, const int32_t* star
                          int max_ring, float* normal_out, float* radius2_out, int32_t* valid_out,
                          int32_t* todo_work /* [n] ints: one wavefront per query (candidates through LDS); NULL: one thread per query */,
                          void* stream);
+/* An octree over ONE Morton-sorted cloud (ext.sdfgen, reference ext/common/kdtree_cuda.cu: the role of its kd-tree): level l has cells
+ * of size cell * 2^l, its cell keys are the level-0 keys >> 3 l (sorted unique); start / end = the point range of every cell, hkeys /
+ * hvals / hcap the key -> cell hash of the level, and for l > 0 child [n_l + 1] / cmask [n_l] = the range of a cell's children on level
+ * l - 1 and their occupied octants (nksr_knn_pyramid_level builds start / end / child / cmask of a level from the level below).
+ * nksr_sdf_from_points_pyramid / nksr_knn_mean_dist_pyramid = nksr_sdf_from_points / nksr_knn_mean_dist for nb_points <= 32 over
+ * EVERY scale in one launch: a query climbs to the first level with a point within one cell of it and takes its k nearest there
+ * (kept sorted in registers; cells nearest first, descended with box pruning down to cells of <= leaf points), climbing on only when
+ * fewer than k lie within max_ring rings; valid = 0: not even the coarsest level holds k points in reach. */
+#define NKSR_KNN_LEVELS 12
+typedef struct {
+    const float* xyz_sorted;
+    const int32_t* start[NKSR_KNN_LEVELS];
+    const int32_t* end[NKSR_KNN_LEVELS];
+    const int32_t* child[NKSR_KNN_LEVELS];
+    const uint8_t* cmask[NKSR_KNN_LEVELS];
+    const int64_t* hkeys[NKSR_KNN_LEVELS];
+    const int32_t* hvals[NKSR_KNN_LEVELS];
+    int32_t hcap[NKSR_KNN_LEVELS];
+    int32_t levels, leaf;
+    float cell, inv_cell;
+} nksr_knn_pyramid_t;
+int nksr_knn_pyramid_level(const int64_t* child_keys, int32_t n_child, const int32_t* child_start, const int32_t* child_end,
+                           const int64_t* keys, int32_t n, int32_t* child_out, uint8_t* cmask_out, int32_t* start_out, int32_t* end_out,
+                           void* stream);
+int nksr_sdf_from_points_pyramid(const nksr_knn_pyramid_t* pyramid, const float* normal_sorted, const float* ref_std_sorted, const float* query,
+                                 int64_t nq, int k, int max_ring, float stdv, int imls, float* sdf_out, float* grad_out, int32_t* valid_out,
+                                 void* stream);
+int nksr_knn_mean_dist_pyramid(const nksr_knn_pyramid_t* pyramid, int64_t n, int k, int max_ring, float* out, int32_t* valid_out, void* stream);
 /* Signed distance of arbitrary queries to an oriented cloud from their k = nb_points nearest reference points: the training
  * ground truth ext.sdfgen.sdf_from_points(queries, ref_xyz, ref_normal, nb_points, stdv, compute_grad, imls, adaptive_knn)
  * (ext/sdfgen/sdf_from_points.cu:32-235; models/loss.py:85, dataset/av_gt_geometry.py:72).  imls = 0: nearest-neighbour magnitude

@@ -27,6 +27,15 @@ class ThetaGradT(C.Structure):
     _fields_ = [('gfeat', _vp * MAX_DEPTH), ('gpsi', _vp * MAX_DEPTH), ('gmlp', _vp * MAX_DEPTH)]
 
 
+KNN_LEVELS = 12
+
+
+class KnnPyramidT(C.Structure):
+    _fields_ = [('xyz_sorted', _vp), ('start', _vp * KNN_LEVELS), ('end', _vp * KNN_LEVELS), ('child', _vp * KNN_LEVELS),
+                ('cmask', _vp * KNN_LEVELS), ('hkeys', _vp * KNN_LEVELS), ('hvals', _vp * KNN_LEVELS), ('hcap', _i32 * KNN_LEVELS),
+                ('levels', _i32), ('leaf', _i32), ('cell', _f32), ('inv_cell', _f32)]
+
+
 class FusedOpT(C.Structure):
     _fields_ = [('depth', _i32), ('M', _i32), ('n_multi', _i32), ('n_big', _i32), ('rows_total', _i64), ('rows_all', _vp),
                 ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('nbrT', _vp), ('item_begin', _vp), ('offsets', _vp), ('multi', _vp), ('nblocks', _i64),
@@ -157,6 +166,9 @@ _PROTOS = {
     'nksr_nearest_index': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, _vp, _vp],
     'nksr_sdf_from_points': [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp],
     'nksr_knn_mean_dist': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp],
+    'nksr_knn_pyramid_level': [_vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+    'nksr_sdf_from_points_pyramid': [_P(KnnPyramidT), _vp, _vp, _vp, _i64, C.c_int, C.c_int, _f32, C.c_int, _vp, _vp, _vp, _vp],
+    'nksr_knn_mean_dist_pyramid': [_P(KnnPyramidT), _i64, C.c_int, C.c_int, _vp, _vp, _vp],
     'nksr_base_cell_flags': [_vp, _i32, _vp, _vp],
     'nksr_base_cell_keys': [_vp, _vp, _i64, C.c_int, _vp, _vp],
     'nksr_level_cell_keys': [_vp, _vp, _i64, C.c_int, C.c_int, _vp, _vp],

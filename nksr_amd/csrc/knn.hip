@@ -542,6 +542,392 @@ __global__ void __launch_bounds__(128) k_knn_mean_dist(KnnGrid g, int64_t n, int
     valid[i] = 1;
 }
 
+// ---- the same two operations with ONE scan per ring: the k nearest candidates kept in registers -------------------------------------
+// The bisection above scans the candidate block ~35 times per query (ring search + 32 bit-steps + the visits).  For k <= 32 a
+// thread keeps the k smallest (distance, index) pairs sorted in registers and inserts every candidate once (an unrolled
+// compare-and-shift over KMAX slots; a candidate AT the k-th distance does not displace one seen earlier), ring after ring
+// (only the new shell of cells is scanned) until the k-th distance lies inside the scanned block.  Measured against the
+// REFERENCE'S OWN extension on the same MI355X (tests/sdfgen_vs_ref.py): before, 44 ms against the reference's 3.0 ms at 4 000
+// reference points / 1 000 queries and 2.7 s against 20 ms at 1 M / 1 M.
+template <int KMAX>
+struct TopK {
+    // The k candidates live in the LAST k slots (ascending); the KMAX - k slots before them hold a sentinel below every distance and
+    // are never displaced.  The k-th candidate is therefore always slot KMAX - 1, a fixed register: indexed by k it was a select
+    // chain that the compiler turned into an indexed load from a scratch copy of the arrays, written back after every scanned cell.
+    float d2[KMAX];
+    int idx[KMAX];
+    bool any;
+    __device__ __forceinline__ void init(int k) {
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) { d2[j] = j < KMAX - k ? -1.f : 3.4e38f; idx[j] = -1; }
+        any = false;
+    }
+    __device__ __forceinline__ void insert(float d, int id) {
+        if (!(d < d2[KMAX - 1])) return;
+        any = true;
+#pragma unroll
+        for (int j = KMAX - 1; j >= 1; --j) {
+            const bool shift = d < d2[j - 1];
+            const bool here = !shift && d < d2[j];
+            d2[j] = shift ? d2[j - 1] : (here ? d : d2[j]);
+            idx[j] = shift ? idx[j - 1] : (here ? id : idx[j]);
+        }
+        if (d < d2[0]) { d2[0] = d; idx[0] = id; }
+    }
+    __device__ __forceinline__ float kth() const { return d2[KMAX - 1]; }               // 3.4e38 while fewer than k were seen
+    __device__ __forceinline__ bool full() const { return d2[KMAX - 1] < 3.4e38f; }
+};
+// candidates [s, e) of the sorted cloud, four at a time: the twelve coordinate loads of a group are in flight together (one at a time,
+// a cell of 30 points was 30 memory latencies end to end -- the insertion needs each distance before the next)
+template <int KMAX>
+__device__ __forceinline__ void knn_scan(const float* __restrict__ xyz, int s, int e, const float q[3], TopK<KMAX>& top) {
+    int kk = s;
+    for (; kk + 4 <= e; kk += 4) {
+        float p[12];
+#pragma unroll
+        for (int t = 0; t < 12; ++t) p[t] = xyz[kk * 3 + t];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) top.insert(knn_d2(p[3 * t] - q[0], p[3 * t + 1] - q[1], p[3 * t + 2] - q[2]), kk + t);
+    }
+    for (; kk < e; ++kk) top.insert(knn_d2(xyz[kk * 3] - q[0], xyz[kk * 3 + 1] - q[1], xyz[kk * 3 + 2] - q[2]), kk);
+}
+// The search itself, for ONE grid scale.  Cells are handed to `visit(cx, cy, cz)` in this order: the 27 cells around q's cell c
+// NEAREST FIRST (by the distance of their box from q -- separable, one squared gap per axis and side; q's own cell has gap 0 and
+// comes first), stopping at the first cell farther than the current k-th candidate: a query next to the surface looks at 3-5 cells
+// instead of 27.  Then, only while the k-th candidate lies outside the scanned block, the shells R = 2 .. max_ring, every cell whose
+// BOX is farther than the k-th candidate skipped without a look-up (the gap is shortened by 2 % of a cell against the fp32
+// rounding of the box bounds c * cell at large coordinates).  Returns 1: the k nearest are in `top`; 0: fewer than k inside
+// max_ring rings; -1: NOTHING within one cell (q is far from the cloud on this scale).
+template <int KMAX, class Visit>
+__device__ __forceinline__ int knn_rings(float cellsz, const float q[3], const int c[3], int k, int max_ring, bool coarser_exists,
+                                         TopK<KMAX>& top, Visit&& visit) {
+    top.init(k);
+    const float slack = 0.02f * cellsz;
+    float gs[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float lo = (float)c[a] * cellsz;
+        const float em = fmaxf(q[a] - lo - slack, 0.f), ep = fmaxf(lo + cellsz - q[a] - slack, 0.f);
+        gs[a][0] = em * em; gs[a][1] = 0.f; gs[a][2] = ep * ep;
+    }
+    unsigned visited = 0u;
+    int R = 1, dx = 0, dy = 0, dz = 0;
+    for (;;) {
+        int ox, oy, oz;
+        if (R == 1) {
+            float best = 3.4e38f;
+            int bi = -1;
+#pragma unroll
+            for (int j = 0; j < 27; ++j) {
+                const float gj = gs[0][j / 9] + gs[1][(j / 3) % 3] + gs[2][j % 3];
+                if (!((visited >> j) & 1u) && gj < best) { best = gj; bi = j; }
+            }
+            if (bi < 0 || best > top.kth()) {
+                if (top.kth() <= cellsz * cellsz) return 1;
+                if (!top.any) return -1;
+                // fewer than k candidates so far: nothing prunes the wider shells (98, 218, 386 look-ups) -- a coarser scale, if there
+                // is one, reaches the same points in 27
+                if (max_ring < 2 || (coarser_exists && !top.full())) return 0;
+                R = 2; dx = dy = dz = -2;
+                continue;
+            }
+            visited |= 1u << bi;
+            ox = bi / 9 - 1; oy = (bi / 3) % 3 - 1; oz = bi % 3 - 1;
+        } else {
+            if (dx > R) {                                   // shell R done: the ball of radius R * cell around q lies inside the block
+                const float rr = (float)R * cellsz;
+                if (top.kth() <= rr * rr) return 1;
+                if (++R > max_ring || (coarser_exists && !top.full())) return 0;
+                dx = dy = dz = -R;
+                continue;
+            }
+            ox = dx; oy = dy; oz = dz;
+            const bool inner = abs(dx) < R && abs(dy) < R;  // (inside the shell only its two z faces are new)
+            dz += inner ? 2 * R : 1;
+            if (dz > R) { dz = -R; if (++dy > R) { dy = -R; ++dx; } }
+            float gap2 = 0.f;
+            const int cc[3] = {c[0] + ox, c[1] + oy, c[2] + oz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float lo = (float)cc[a] * cellsz, hi = lo + cellsz;
+                const float e = fmaxf(fmaxf(lo - q[a], q[a] - hi) - slack, 0.f);
+                gap2 = fmaf(e, e, gap2);
+            }
+            if (gap2 > top.kth()) continue;
+        }
+        visit(c[0] + ox, c[1] + oy, c[2] + oz);
+    }
+}
+// one grid: the k nearest reference points of q; false: fewer than k inside max_ring rings
+template <int KMAX>
+__device__ __forceinline__ bool knn_topk(const KnnGrid& g, const float q[3], int k, int max_ring, TopK<KMAX>& top) {
+    int c[3];
+    cell_of(g, q, c);
+    return knn_rings<KMAX>(g.cell, q, c, k, max_ring, false, top, [&](int cx, int cy, int cz) {
+        const int ci = hash_find(g.hkeys, g.hvals, g.hcap, morton_biased(cx, cy, cz, NKSR_BIAS0));
+        if (ci < 0) return;
+        knn_scan<KMAX>(g.xyz, g.start[ci], g.end[ci], q, top);
+    }) == 1;
+}
+
+// the two estimators over the k nearest neighbours in `top` (nearest first)
+template <int KMAX>
+__device__ __forceinline__ void sdf_estimate(const float* __restrict__ xyz, const float* __restrict__ nrm, const float* __restrict__ ref_std, const float q[3],
+                                             const TopK<KMAX>& top, int k, float stdv, int imls, int64_t i, float* __restrict__ sdf,
+                                             float* __restrict__ grad) {
+    float out = 0.f, gr[3] = {0.f, 0.f, 0.f};
+    if (imls) {
+        const float inv_s2 = 1.f / (stdv * stdv);
+        float emin = 0.f, wsum = 0.f, acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            if (j < KMAX - k) continue;
+            if (j == KMAX - k) emin = top.d2[j] * inv_s2;                       // the nearest neighbour
+            const int kk = top.idx[j];
+            const float ex = q[0] - xyz[kk * 3], ey = q[1] - xyz[kk * 3 + 1], ez = q[2] - xyz[kk * 3 + 2];
+            const float nx = nrm[kk * 3], ny = nrm[kk * 3 + 1], nz = nrm[kk * 3 + 2];
+            const float w = expf(-top.d2[j] * inv_s2 + emin);
+            wsum += w;
+            acc += (nx * ex + ny * ey + nz * ez) * w;
+            gr[0] += nx * w; gr[1] += ny * w; gr[2] += nz * w;
+        }
+        out = acc / wsum;
+        gr[0] /= wsum; gr[1] /= wsum; gr[2] /= wsum;
+    } else {
+        int npos = 0;
+        float sd = 0.f, g0[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            if (j < KMAX - k) continue;
+            const int kk = top.idx[j];
+            const float ex = q[0] - xyz[kk * 3], ey = q[1] - xyz[kk * 3 + 1], ez = q[2] - xyz[kk * 3 + 2];
+            const float nx = nrm[kk * 3], ny = nrm[kk * 3 + 1], nz = nrm[kk * 3 + 2];
+            const float d = nx * ex + ny * ey + nz * ez;
+            npos += d > 0.f;
+            if (j == KMAX - k) {                      // the nearest neighbour sets the magnitude
+                const float len = sqrtf(top.d2[j]);
+                if (len < stdv * (ref_std ? ref_std[kk] : 1.f)) {
+                    sd = fabsf(d);
+                    const float sg = d > 0.f ? 1.f : -1.f;
+                    g0[0] = sg * nx; g0[1] = sg * ny; g0[2] = sg * nz;
+                } else {
+                    sd = len;
+                    g0[0] = ex / len; g0[1] = ey / len; g0[2] = ez / len;
+                }
+            }
+        }
+        const float sg = npos <= k / 2 ? -1.f : 1.f;
+        out = sg * sd;
+        gr[0] = sg * g0[0]; gr[1] = sg * g0[1]; gr[2] = sg * g0[2];
+    }
+    sdf[i] = out;
+    if (grad) { grad[i * 3] = gr[0]; grad[i * 3 + 1] = gr[1]; grad[i * 3 + 2] = gr[2]; }
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(128) k_sdf_topk(KnnGrid g, const float* __restrict__ nrm, const float* __restrict__ ref_std,
+                                                  const float* __restrict__ query, int64_t nq, int k, int max_ring, float stdv, int imls,
+                                                  float* __restrict__ sdf, float* __restrict__ grad, int32_t* __restrict__ valid) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float q[3] = {query[i * 3], query[i * 3 + 1], query[i * 3 + 2]};
+    TopK<KMAX> top;
+    if (!knn_topk<KMAX>(g, q, k, max_ring, top)) { valid[i] = 0; return; }
+    valid[i] = 1;
+    sdf_estimate<KMAX>(g.xyz, nrm, ref_std, q, top, k, stdv, imls, i, sdf, grad);
+}
+
+// ---- every scale in one launch: an octree over the same Morton-sorted points ---------------------------------------------------------
+// Level l has cells of size cell * 2^l; its cell keys are the level-0 keys >> 3 l, so a level-l cell is a contiguous range of the
+// sorted points AND of the level-(l-1) cells (its <= 8 children, in octant order: child[l][i] .. child[l][i + 1], cmask[l][i] = the
+// occupied octants).  A query climbs to the first level with anything within one cell of it (27 look-ups per level -- a far query
+// leaves the fine levels at once), and searches THAT scale with knn_rings; a cell there is not scanned but DESCENDED: children
+// nearest octant first, every child whose box lies farther than the current k-th candidate cut off, points scanned only in
+// cells of <= leaf points.  A query at distance d from the cloud therefore costs ~log(d / cell) box tests plus the few leaves that
+// face it -- on the single coarse grid of the host's round loop (x4 cell per round, 16x points per cell) it scanned whole cells
+// of thousands of points, 14 ms for the last 16 000 queries of 1 M.  The descent keeps one (node, cursor) pair per level in LDS --
+// and so does the table of per-level pointers: indexed by a per-lane level IN THE KERNEL ARGUMENTS it was a vector load from the
+// kernarg segment (host-visible, uncached) at every step, 1.7 ms for 4 000 queries that now take a fraction of it.
+struct KnnPyramid {
+    const int32_t* start[NKSR_KNN_LEVELS];
+    const int32_t* end[NKSR_KNN_LEVELS];
+    const int32_t* child[NKSR_KNN_LEVELS];
+    const uint8_t* cmask[NKSR_KNN_LEVELS];
+    const int64_t* hkeys[NKSR_KNN_LEVELS];
+    const int32_t* hvals[NKSR_KNN_LEVELS];
+    int hcap[NKSR_KNN_LEVELS];
+    int levels, leaf;
+    const float* xyz;
+    float cell, inv_cell;
+};
+#define KNN_PYR_BLOCK 128
+template <int KMAX>
+__device__ __forceinline__ bool knn_topk_pyramid(const KnnPyramid& P, const float q[3], int k, int max_ring, TopK<KMAX>& top, int* node,
+                                                 unsigned char* cursor) {
+    int c0[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float p;
+        c0[a] = half_index(q[a], P.inv_cell, p) >> 1;
+    }
+    // the finest level with anything in the 27 cells around q: "occupied" is monotone in the level (the block of level l + 1 covers
+    // the block of level l), so after level 0 it is bisected -- a far query pays ~4 probes, most of them ended by an early hit
+    auto occupied = [&](int l) {
+        const int bias = NKSR_BIAS0 >> l;
+        for (int j = 0; j < 27; ++j)
+            if (hash_find(P.hkeys[l], P.hvals[l], P.hcap[l],
+                          morton_biased((c0[0] >> l) + j / 9 - 1, (c0[1] >> l) + (j / 3) % 3 - 1, (c0[2] >> l) + j % 3 - 1, bias)) >= 0)
+                return true;
+        return false;
+    };
+    int first = 0;
+    if (P.levels > 1 && !occupied(0)) {
+        int lo = 0;
+        first = P.levels - 1;
+        while (first - lo > 1) {
+            const int mid = (lo + first) >> 1;
+            if (occupied(mid)) first = mid; else lo = mid;
+        }
+    }
+    for (int l = first; l < P.levels; ++l) {
+        const float cell_l = P.cell * (float)(1 << l);
+        const int c[3] = {c0[0] >> l, c0[1] >> l, c0[2] >> l};
+        const int rc = knn_rings<KMAX>(cell_l, q, c, k, max_ring, l + 1 < P.levels, top, [&](int cx, int cy, int cz) {
+            int ci = hash_find(P.hkeys[l], P.hvals[l], P.hcap[l], morton_biased(cx, cy, cz, NKSR_BIAS0 >> l));
+            if (ci < 0) return;
+            int lvl = l;
+            bool enter = true;
+            for (;;) {
+                if (enter) {
+                    const int s = P.start[lvl][ci], e = P.end[lvl][ci];
+                    if (lvl == 0 || e - s <= P.leaf) {
+                        knn_scan<KMAX>(P.xyz, s, e, q, top);
+                        if (lvl == l) return;
+                        ++lvl; cx >>= 1; cy >>= 1; cz >>= 1;               // back to the parent
+                    } else {
+                        node[lvl * KNN_PYR_BLOCK] = ci;
+                        cursor[lvl * KNN_PYR_BLOCK] = 0;
+                    }
+                    enter = false;
+                    continue;
+                }
+                // the next child of node[lvl] (cell (cx, cy, cz) of level lvl) worth a visit
+                const int nd = node[lvl * KNN_PYR_BLOCK];
+                int t = cursor[lvl * KNN_PYR_BLOCK];
+                const unsigned mask = P.cmask[lvl][nd];
+                const float cl = P.cell * (float)(1 << lvl), ch = 0.5f * cl, slack = 0.02f * ch;
+                const unsigned qo = (q[0] >= ((float)cx + 0.5f) * cl ? 1u : 0u) | (q[1] >= ((float)cy + 0.5f) * cl ? 2u : 0u) |
+                                    (q[2] >= ((float)cz + 0.5f) * cl ? 4u : 0u);
+                bool found = false;
+                while (t < 8) {
+                    const unsigned o = ((0x76534210u >> (4 * t)) & 7u) ^ qo;      // octants by the number of axes they differ from q's in
+                    ++t;
+                    if (!((mask >> o) & 1u)) continue;
+                    const int x = 2 * cx + (int)(o & 1u), y = 2 * cy + (int)((o >> 1) & 1u), z = 2 * cz + (int)(o >> 2);
+                    const float lo[3] = {(float)x * ch, (float)y * ch, (float)z * ch};
+                    float gap2 = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const float e = fmaxf(fmaxf(lo[a] - q[a], q[a] - (lo[a] + ch)) - slack, 0.f);
+                        gap2 = fmaf(e, e, gap2);
+                    }
+                    if (gap2 > top.kth()) continue;
+                    ci = P.child[lvl][nd] + __popc(mask & ((1u << o) - 1u));
+                    cx = x; cy = y; cz = z;
+                    found = true;
+                    break;
+                }
+                if (found) {
+                    cursor[lvl * KNN_PYR_BLOCK] = (unsigned char)t;
+                    --lvl;
+                    enter = true;
+                } else {
+                    if (lvl == l) return;
+                    ++lvl; cx >>= 1; cy >>= 1; cz >>= 1;
+                }
+            }
+        });
+        if (rc == 1) return true;
+    }
+    return false;
+}
+template <int KMAX>
+__global__ void __launch_bounds__(KNN_PYR_BLOCK) k_sdf_pyramid(KnnPyramid Parg, const float* __restrict__ nrm, const float* __restrict__ ref_std,
+                                                               const float* __restrict__ query, int64_t nq, int k, int max_ring, float stdv,
+                                                               int imls, float* __restrict__ sdf, float* __restrict__ grad,
+                                                               int32_t* __restrict__ valid) {
+    __shared__ int s_node[NKSR_KNN_LEVELS][KNN_PYR_BLOCK];
+    __shared__ unsigned char s_cursor[NKSR_KNN_LEVELS][KNN_PYR_BLOCK];
+    __shared__ KnnPyramid P;
+    if (threadIdx.x == 0) P = Parg;
+    __syncthreads();
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float q[3] = {query[i * 3], query[i * 3 + 1], query[i * 3 + 2]};
+    TopK<KMAX> top;
+    if (!knn_topk_pyramid<KMAX>(P, q, k, max_ring, top, &s_node[0][threadIdx.x], &s_cursor[0][threadIdx.x])) { valid[i] = 0; return; }
+    valid[i] = 1;
+    sdf_estimate<KMAX>(P.xyz, nrm, ref_std, q, top, k, stdv, imls, i, sdf, grad);
+}
+template <int KMAX>
+__global__ void __launch_bounds__(KNN_PYR_BLOCK) k_knn_mean_dist_pyramid(KnnPyramid Parg, int64_t n, int k, int max_ring, float* __restrict__ out,
+                                                                         int32_t* __restrict__ valid) {
+    __shared__ int s_node[NKSR_KNN_LEVELS][KNN_PYR_BLOCK];
+    __shared__ unsigned char s_cursor[NKSR_KNN_LEVELS][KNN_PYR_BLOCK];
+    __shared__ KnnPyramid P;
+    if (threadIdx.x == 0) P = Parg;
+    __syncthreads();
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float q[3] = {P.xyz[i * 3], P.xyz[i * 3 + 1], P.xyz[i * 3 + 2]};
+    TopK<KMAX> top;
+    if (!knn_topk_pyramid<KMAX>(P, q, k, max_ring, top, &s_node[0][threadIdx.x], &s_cursor[0][threadIdx.x])) { valid[i] = 0; out[i] = 0.f; return; }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+        if (j >= KMAX - k) s += sqrtf(top.d2[j]);
+    out[i] = s / (float)k;
+    valid[i] = 1;
+}
+// one level of the octree from the one below: thread p owns parent cell p (keys = sorted unique child keys >> 3)
+__global__ void __launch_bounds__(256) k_pyramid_level(const int64_t* __restrict__ ckeys, int32_t nc, const int32_t* __restrict__ cstart,
+                                                       const int32_t* __restrict__ cend, const int64_t* __restrict__ pkeys, int32_t np,
+                                                       int32_t* __restrict__ child, uint8_t* __restrict__ cmask, int32_t* __restrict__ pstart,
+                                                       int32_t* __restrict__ pend) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= np) return;
+    const int64_t key = pkeys[p];
+    int lo = 0, hi = nc;                                    // first child: lower bound of key << 3
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((ckeys[mid] >> 3) < key) lo = mid + 1; else hi = mid;
+    }
+    unsigned m = 0u;
+    int j = lo;
+    for (; j < nc && (ckeys[j] >> 3) == key; ++j) m |= 1u << (unsigned)(ckeys[j] & 7);
+    child[p] = lo;
+    if (p == np - 1) child[np] = nc;
+    cmask[p] = (uint8_t)m;
+    pstart[p] = cstart[lo];
+    pend[p] = cend[j - 1];
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(128) k_knn_mean_dist_topk(KnnGrid g, int64_t n, int k, int max_ring, float* __restrict__ out,
+                                                            int32_t* __restrict__ valid) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float q[3] = {g.xyz[i * 3], g.xyz[i * 3 + 1], g.xyz[i * 3 + 2]};
+    TopK<KMAX> top;
+    if (!knn_topk<KMAX>(g, q, k, max_ring, top)) { valid[i] = 0; out[i] = 0.f; return; }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+        if (j >= KMAX - k) s += sqrtf(top.d2[j]);
+    out[i] = s / (float)k;
+    valid[i] = 1;
+}
+
 static KnnGrid make_grid(const float* xyz_sorted, const int32_t* start, const int32_t* end, const int64_t* hkeys,
                          const int32_t* hvals, int hcap, float cell, float inv_cell) {
     KnnGrid g;
@@ -590,8 +976,69 @@ extern "C" int nksr_sdf_from_points(const float* xyz_sorted, const float* normal
     if (!(stdv > 0.f)) return nksr_set_error(NKSR_ERR_ARG, "stdv must be > 0");
     if (!xyz_sorted || !normal_sorted || !query || !sdf_out || !valid_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
     KnnGrid g = make_grid(xyz_sorted, start, end, hkeys, hvals, hcap, cell, inv_cell);
-    hipLaunchKernelGGL(k_sdf_from_points, dim3(nksr_blocks(nq, 128)), dim3(128), 0, (hipStream_t)stream, g, normal_sorted, ref_std_sorted, query,
-                       nq, k, max_ring, stdv, imls, sdf_out, grad_out, valid_out);
+    const dim3 gr(nksr_blocks(nq, 128)), bl(128);
+#define SDF_TOPK(KM) hipLaunchKernelGGL((k_sdf_topk<KM>), gr, bl, 0, (hipStream_t)stream, g, normal_sorted, ref_std_sorted, query, nq, k, max_ring, stdv, imls, sdf_out, grad_out, valid_out)
+    if (k <= 8) SDF_TOPK(8);
+    else if (k <= 16) SDF_TOPK(16);
+    else if (k <= 32) SDF_TOPK(32);
+    else                                   // more neighbours than fit the register list: the bisection kernel
+        hipLaunchKernelGGL(k_sdf_from_points, gr, bl, 0, (hipStream_t)stream, g, normal_sorted, ref_std_sorted, query,
+                           nq, k, max_ring, stdv, imls, sdf_out, grad_out, valid_out);
+#undef SDF_TOPK
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+static int make_pyramid(KnnPyramid& P, const nksr_knn_pyramid_t* p) {
+    if (!p || p->levels < 1 || p->levels > NKSR_KNN_LEVELS || !p->xyz_sorted) return nksr_set_error(NKSR_ERR_ARG, "kNN pyramid: 1..%d levels", NKSR_KNN_LEVELS);
+    memset(&P, 0, sizeof(P));
+    for (int l = 0; l < p->levels; ++l) {
+        if (!p->start[l] || !p->end[l] || !p->hkeys[l] || !p->hvals[l] || p->hcap[l] < 8 || (l > 0 && (!p->child[l] || !p->cmask[l])))
+            return nksr_set_error(NKSR_ERR_ARG, "kNN pyramid: level %d incomplete", l);
+        P.start[l] = p->start[l]; P.end[l] = p->end[l]; P.child[l] = p->child[l]; P.cmask[l] = p->cmask[l];
+        P.hkeys[l] = p->hkeys[l]; P.hvals[l] = p->hvals[l]; P.hcap[l] = p->hcap[l];
+    }
+    P.levels = p->levels; P.leaf = p->leaf > 0 ? p->leaf : 48; P.xyz = p->xyz_sorted; P.cell = p->cell; P.inv_cell = p->inv_cell;
+    return NKSR_OK;
+}
+extern "C" int nksr_knn_pyramid_level(const int64_t* child_keys, int32_t n_child, const int32_t* child_start, const int32_t* child_end,
+                                      const int64_t* keys, int32_t n, int32_t* child_out, uint8_t* cmask_out, int32_t* start_out,
+                                      int32_t* end_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (!child_keys || !child_start || !child_end || !keys || !child_out || !cmask_out || !start_out || !end_out || n_child < n)
+        return nksr_set_error(NKSR_ERR_ARG, "kNN pyramid level: NULL arrays or more parents than children");
+    hipLaunchKernelGGL(k_pyramid_level, dim3(nksr_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, child_keys, n_child, child_start, child_end,
+                       keys, n, child_out, cmask_out, start_out, end_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+extern "C" int nksr_sdf_from_points_pyramid(const nksr_knn_pyramid_t* pyramid, const float* normal_sorted, const float* ref_std_sorted, const float* query,
+                                            int64_t nq, int k, int max_ring, float stdv, int imls, float* sdf_out, float* grad_out,
+                                            int32_t* valid_out, void* stream) {
+    if (nq <= 0) return NKSR_OK;
+    if (k < 1 || k > 32) return nksr_set_error(NKSR_ERR_ARG, "pyramid search: 1 <= nb_points <= 32 (got %d)", k);
+    if (!(stdv > 0.f)) return nksr_set_error(NKSR_ERR_ARG, "stdv must be > 0");
+    if (!normal_sorted || !query || !sdf_out || !valid_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    KnnPyramid P;
+    if (int rc = make_pyramid(P, pyramid)) return rc;
+    const dim3 gr(nksr_blocks(nq, 128)), bl(128);
+#define SDF_PYR(KM) hipLaunchKernelGGL((k_sdf_pyramid<KM>), gr, bl, 0, (hipStream_t)stream, P, normal_sorted, ref_std_sorted, query, nq, k, max_ring, stdv, imls, sdf_out, grad_out, valid_out)
+    if (k <= 8) SDF_PYR(8);
+    else if (k <= 16) SDF_PYR(16);
+    else SDF_PYR(32);
+#undef SDF_PYR
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+extern "C" int nksr_knn_mean_dist_pyramid(const nksr_knn_pyramid_t* pyramid, int64_t n, int k, int max_ring, float* out, int32_t* valid_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (k < 1 || k > 32) return nksr_set_error(NKSR_ERR_ARG, "pyramid search: 1 <= k <= 32 (got %d)", k);
+    KnnPyramid P;
+    if (int rc = make_pyramid(P, pyramid)) return rc;
+    const dim3 gr(nksr_blocks(n, 128)), bl(128);
+    if (k <= 8) hipLaunchKernelGGL((k_knn_mean_dist_pyramid<8>), gr, bl, 0, (hipStream_t)stream, P, n, k, max_ring, out, valid_out);
+    else if (k <= 16) hipLaunchKernelGGL((k_knn_mean_dist_pyramid<16>), gr, bl, 0, (hipStream_t)stream, P, n, k, max_ring, out, valid_out);
+    else hipLaunchKernelGGL((k_knn_mean_dist_pyramid<32>), gr, bl, 0, (hipStream_t)stream, P, n, k, max_ring, out, valid_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
@@ -602,7 +1049,11 @@ extern "C" int nksr_knn_mean_dist(const float* xyz_sorted, int64_t n, const int3
     if (n <= 0) return NKSR_OK;
     if (k < 1) return nksr_set_error(NKSR_ERR_ARG, "k must be >= 1");
     KnnGrid g = make_grid(xyz_sorted, start, end, hkeys, hvals, hcap, cell, inv_cell);
-    hipLaunchKernelGGL(k_knn_mean_dist, dim3(nksr_blocks(n, 128)), dim3(128), 0, (hipStream_t)stream, g, n, k, max_ring, out, valid_out);
+    const dim3 gr(nksr_blocks(n, 128)), bl(128);
+    if (k <= 8) hipLaunchKernelGGL((k_knn_mean_dist_topk<8>), gr, bl, 0, (hipStream_t)stream, g, n, k, max_ring, out, valid_out);
+    else if (k <= 16) hipLaunchKernelGGL((k_knn_mean_dist_topk<16>), gr, bl, 0, (hipStream_t)stream, g, n, k, max_ring, out, valid_out);
+    else if (k <= 32) hipLaunchKernelGGL((k_knn_mean_dist_topk<32>), gr, bl, 0, (hipStream_t)stream, g, n, k, max_ring, out, valid_out);
+    else hipLaunchKernelGGL(k_knn_mean_dist, gr, bl, 0, (hipStream_t)stream, g, n, k, max_ring, out, valid_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }

@@ -30,6 +30,7 @@ class PointGrid:
         ks, perm = ops.sort_pairs(keys, torch.arange(n, dtype=torch.int32, device=dev))
         self.perm = perm.long()
         self.xyz = xyz[self.perm].contiguous()
+        self.keys_sorted = ks
         self.grid = SparseGrid(ops.unique_sorted(ks), 0, cell)
         self.start = torch.empty(self.grid.num_voxels, dtype=torch.int32, device=dev)
         self.end = torch.empty(self.grid.num_voxels, dtype=torch.int32, device=dev)
@@ -48,6 +49,46 @@ class PointGrid:
         return out
 
 
+class PointPyramid:
+    """Octree over a ``PointGrid``: level l = cells of size cell * 2^l (keys = the grid's keys >> 3 l), each with its point range, the
+    range of its children on the level below and their octant mask, and a key hash (csrc/knn.hip ``KnnPyramid``).  Built upward from
+    the grid until a level has <= ``top_cells`` cells (one kernel + one hash per level; the level sizes come back to the host).
+    Eight, not one: keys are biased coordinates, so the cells either side of a coordinate plane through the origin never merge."""
+
+    def __init__(self, pg, leaf=0, top_cells=8):
+        from ._lib import KNN_LEVELS, KnnPyramidT
+        dev = pg.xyz.device
+        self.pg = pg
+        keys, start, end = pg.grid.keys, pg.start, pg.end
+        self.keep = [keys, start, end]
+        t = KnnPyramidT()
+        t.xyz_sorted = ptr(pg.xyz)
+        t.cell, t.inv_cell, t.leaf = pg.cell, pg.inv_cell, int(leaf)
+        h = pg.grid.hash
+        lvl = 0
+        while True:
+            t.start[lvl], t.end[lvl], t.hkeys[lvl], t.hvals[lvl], t.hcap[lvl] = ptr(start), ptr(end), ptr(h.hkeys), ptr(h.hvals), h.cap
+            lvl += 1
+            nc = keys.numel()
+            if lvl == KNN_LEVELS or nc <= top_cells:
+                break
+            up = ops.unique_sorted(keys >> 3)
+            n = up.numel()
+            child = torch.empty(n + 1, dtype=torch.int32, device=dev)
+            cmask = torch.empty(n, dtype=torch.uint8, device=dev)
+            s2 = torch.empty(n, dtype=torch.int32, device=dev)
+            e2 = torch.empty(n, dtype=torch.int32, device=dev)
+            call('nksr_knn_pyramid_level', ptr(keys), nc, ptr(start), ptr(end), ptr(up), n, ptr(child), ptr(cmask), ptr(s2), ptr(e2), stream())
+            h = ops.HashTable(up)
+            t.child[lvl], t.cmask[lvl] = ptr(child), ptr(cmask)
+            self.keep += [up, child, cmask, s2, e2, h]
+            keys, start, end = up, s2, e2
+        t.levels = lvl
+        self.levels = lvl
+        self.top_cell = pg.cell * (1 << (lvl - 1))
+        self.struct = t
+
+
 def choose_cell_size(xyz, k):
     """Cell size such that a ball of one cell radius holds ~2k surface samples: density from the
     occupied-voxel count at one probe resolution (points on a surface: count ~ area / cell^2)."""
@@ -55,7 +96,10 @@ def choose_cell_size(xyz, k):
     n = xyz.shape[0]
     lo, hi, center = bbox_center(xyz)
     ext = float((hi - lo).max())
-    probe = max(ext / 256.0, 1e-6)
+    # the probe voxels must hold several samples each or their count saturates at n and the density comes out as 1 / probe^2 whatever
+    # the cloud (4 000 points at ext / 256: one point per cell, every kNN query ran to its outermost ring): a surface of area ~ ext^2
+    # sampled n times has ~4 samples per voxel of size 4 ext / sqrt(n); from 1 M points on that is finer than ext / 256 and nothing changes
+    probe = max(ext / 256.0, 4.0 * ext / math.sqrt(max(n, 1)), 1e-6)
     occ = max(occupied_voxels((xyz - lo[None]).contiguous(), probe), 1)
     area = occ * probe * probe                      # ~ surface area
     rho = n / max(area, 1e-20)

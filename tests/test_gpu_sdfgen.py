@@ -90,6 +90,34 @@ def test_sdf_from_points_matches_the_reference_binary(case):
         assert (gd[~bad] <= 1e-4).mean() >= 0.998, name
 
 
+@pytest.mark.parametrize('k', [8, 20])
+def test_octree_search_equals_the_single_grid_rounds_and_hands_on_what_it_cannot_reach(k, monkeypatch):
+    """The default search (every scale in one launch, csrc/knn.hip k_sdf_pyramid) against the single-grid rounds it replaced and
+    against exact kNN -- with queries at every distance: in the band, across the bounding box, and 100 cloud diameters away
+    (beyond the coarsest level: those come back unanswered and take the rounds)."""
+    from oracle import sdfgen as osdf
+    import ext
+    dev = torch.device('cuda:0')
+    xyz, nrm = _cloud(30000, seed=3)
+    rs = np.random.RandomState(5)
+    q = np.concatenate([_queries(xyz, nrm, 20000, seed=4), rs.uniform(-6, 6, (500, 3)), rs.uniform(-100, 100, (60, 3))]).astype(np.float32)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    kw = dict(nb_points=k, stdv=0.05, compute_grad=True)
+    for imls in (False, True):
+        monkeypatch.setenv('NKSR_SDFGEN_SEARCH', 'rounds')
+        a = ext.sdfgen.sdf_from_points(t(q), t(xyz), t(nrm), imls=imls, **kw)
+        monkeypatch.delenv('NKSR_SDFGEN_SEARCH')
+        b = ext.sdfgen.sdf_from_points(t(q), t(xyz), t(nrm), imls=imls, **kw)
+        ref_s, _ = osdf.sdf_from_points(q, xyz, nrm, k, 0.05, compute_grad=True, imls=imls)
+        sa, sb = a[0].cpu().numpy(), b[0].cpu().numpy()
+        tol = 1e-5 + 1e-5 * np.abs(ref_s)
+        pu.report('sdfgen octree[k=%d,%s]' % (k, 'imls' if imls else 'vote'), vs_rounds=float(np.abs(sa - sb).max()),
+                  differ_from_exact_knn=int((np.abs(sb - ref_s) > tol).sum()), queries=len(q))
+        assert (np.abs(sa - sb) > tol).mean() <= 1e-3
+        assert (np.abs(sb - ref_s) > tol).mean() <= 2e-3
+        assert ((a[1] - b[1]).abs().amax(1).cpu().numpy() > 1e-4).mean() <= 2e-3
+
+
 def test_sdf_from_points_argument_errors():
     import ext
     dev = torch.device('cuda:0')
