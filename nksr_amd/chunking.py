@@ -952,13 +952,7 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
         # weight support (core +- ov) reaches there -- its spatial neighbours, not all N.  Who needs what is geometry (cores, owners,
         # which cores hold points): every rank computes the same table, so a halo is SENT only to the ranks that need it
         # (all_to_all with per-pair sizes; a chunk its owner skipped is simply not sent)
-        nonempty = [c for c in range(nchunk) if counts[c] > 0]
-        dest_of = {}
-        for r in range(ws):
-            owned_r = [c for c in nonempty if owner[c] == r]
-            for c in needed_chunks(cores, ov + 2.5 * hp.voxel_size, grid, owned_r, nonempty):
-                if owner[c] != r:
-                    dest_of.setdefault(c, []).append(r)
+        dest_of = halo_destinations(cores, ov + 2.5 * hp.voxel_size, grid, owner, counts, ws)
         payload = D.exchange_payloads_to(local, dest_of) if active else sim_exchange(local, dest_of)
         mine = set(local)
         need = sorted(c for c in payload if c not in mine)
@@ -980,6 +974,19 @@ def _now(rec):
     if getattr(rec, 'sync_timing', False):
         torch.cuda.current_stream().synchronize()
     return time.perf_counter()
+
+
+def halo_destinations(cores, margin, grid, owner, counts, world_size):
+    """{chunk: [ranks that need its halo and do not own it]} -- pure geometry (cores, owners, which chunks hold points), so every
+    rank computes the same table and a halo is sent only where it is read."""
+    nonempty = [c for c in range(len(owner)) if counts[c] > 0]
+    dest_of = {}
+    for r in range(world_size):
+        owned_r = [c for c in nonempty if owner[c] == r]
+        for c in needed_chunks(cores, margin, grid, owned_r, nonempty):
+            if owner[c] != r:
+                dest_of.setdefault(c, []).append(r)
+    return dest_of
 
 
 def needed_chunks(cores, margin, grid, owned, candidates):

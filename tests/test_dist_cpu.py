@@ -1,5 +1,5 @@
-"""world_size-2 gloo tests (CPU) of the multi-rank protocol: chunk partition, payload exchange,
-mesh gather + seam merge (nksr_amd/dist.py).  The HIP kernels are not involved -- the GPU side of
+"""gloo tests (CPU) of the multi-rank protocol -- world size 2, and 4 / 8 ranks on the bench's 8 x 8 chunk layout: chunk partition,
+payload exchange, mesh gather + seam merge (nksr_amd/dist.py).  The HIP kernels are not involved -- the GPU side of
 the chunked path is covered by tests/test_gpu_chunking.py."""
 import os
 import socket
@@ -115,3 +115,98 @@ def test_partition_is_balanced_and_deterministic():
     assert needed_chunks(cores, 0.9, [6, 1, 1], [0, 5], list(range(6))) == [0, 1, 4, 5]
     assert D.merge_meshes([(torch.zeros((0, 3)), torch.zeros((0, 3), dtype=torch.int64), torch.zeros(0, dtype=torch.int64),
                             torch.zeros(0, dtype=torch.int8))])[0].shape[0] == 0
+
+
+# ---- the layout of the multi-GPU bench (8 x 8 tiles, Morton-cut partition) at 4 and 8 ranks ------------------------------------------
+def _tile_layout(world):
+    from nksr_amd import dist as D
+    grid = [8, 8, 1]
+    rs = np.random.RandomState(7)
+    counts = [int(v) for v in rs.randint(100_000, 220_000, 64)]
+    counts[5] = counts[40] = 0                                           # two tiles without points: never solved, never sent
+    cores = {c: ([125.0 * (c // 8), 125.0 * (c % 8), 0.0], [125.0 * (c // 8) + 125.0, 125.0 * (c % 8) + 125.0, 30.0]) for c in range(64)}
+    owner = D.partition_chunks(64, world, counts, grid)
+    return grid, counts, cores, owner
+
+
+def _payload_of(c):
+    g = torch.Generator().manual_seed(1000 + c)
+    return (torch.randint(0, 1 << 40, (50 + 3 * c,), generator=g, dtype=torch.int64), torch.randn(20 + c, generator=g))
+
+
+def _tile_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nksr_amd import dist as D
+    from nksr_amd.chunking import halo_destinations, needed_chunks
+    try:
+        grid, counts, cores, owner = _tile_layout(world)
+        margin = 12.5 + 2.5 * 0.1
+        mine = [c for c in range(64) if owner[c] == rank and counts[c] > 0]
+        local = {c: _payload_of(c) for c in mine}
+        dest_of = halo_destinations(cores, margin, grid, owner, counts, world)
+        got = D.exchange_payloads_to(local, dest_of)
+        # exactly the chunks whose blend support reaches this rank's cores: its own + their spatial neighbours on other ranks
+        nonempty = [c for c in range(64) if counts[c] > 0]
+        want = needed_chunks(cores, margin, grid, mine, nonempty)
+        assert sorted(got) == want, (rank, sorted(got), want)
+        for c in want:
+            a, b = _payload_of(c)
+            assert torch.equal(got[c][0], a) and torch.equal(got[c][1], b), (rank, c)
+        # a rank never receives more than its 8-neighbourhood ring: far fewer than all 64 halos
+        assert len(want) - len(mine) <= 64 - len(mine) and (world == 2 or len(want) < 48)
+        # mesh gather: a strip of quads, one per rank, each sharing an edge with the next rank's
+        v = torch.tensor([[rank, 0., 0], [rank + 1, 0, 0], [rank + 1, 1, 0], [rank, 1, 0]], dtype=torch.float32)
+        key = torch.tensor([2 * rank, 2 * rank + 2, 2 * rank + 3, 2 * rank + 1])
+        f = torch.tensor([[0, 1, 2], [0, 2, 3]])
+        mv, mf = D.gather_meshes(v, f, key, torch.zeros(4, dtype=torch.int8))
+        if rank == 0:
+            assert mv.shape[0] == 2 * world + 2 and mf.shape[0] == 2 * world, (mv.shape, mf.shape)
+            mfn = mf.numpy()
+            e = np.sort(np.concatenate([mfn[:, [0, 1]], mfn[:, [1, 2]], mfn[:, [2, 0]]]), 1)
+            _, cnt = np.unique(e, axis=0, return_counts=True)
+            assert (cnt == 2).sum() == world + (world - 1)          # one diagonal per quad + every stitched seam
+        q.put((rank, 'ok'))
+    except Exception as e:
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world(target, world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(r, 'ok') for r in range(world)], res
+
+
+def test_bench_tile_layout_at_four_and_eight_ranks_gloo():
+    """The 8 x 8 tiles of the multi-GPU bench cut for 4 and 8 ranks: every rank gets exactly the halos its cores read (its spatial
+    neighbours on other ranks), intact, and nothing else; the strip of per-rank meshes is stitched at every seam."""
+    for world in (4, 8):
+        _run_world(_tile_worker, world)
+
+
+def test_halo_destinations_are_symmetric_neighbours_only():
+    from nksr_amd.chunking import halo_destinations
+    for world in (2, 4, 8):
+        grid, counts, cores, owner = _tile_layout(world)
+        assert sorted(set(owner)) == list(range(world))
+        load = [sum(counts[c] for c in range(64) if owner[c] == r) for r in range(world)]
+        assert max(load) <= 1.25 * min(load), load                     # Morton cut: balanced to within a tile
+        dest = halo_destinations(cores, 12.75, grid, owner, counts, world)
+        assert 5 not in dest and 40 not in dest                         # empty tiles are never sent
+        for c, ranks in dest.items():
+            assert owner[c] not in ranks and len(set(ranks)) == len(ranks)
+            for r in ranks:                                             # r owns a tile adjacent (incl. diagonally) to c
+                assert any(counts[o] > 0 and owner[o] == r and abs(o // 8 - c // 8) <= 1 and abs(o % 8 - c % 8) <= 1 for o in range(64)), (c, r)
+        sent = sum(len(v) for v in dest.values())
+        assert sent < 62 * (world - 1) * 0.75                           # far fewer than every halo to every other rank
