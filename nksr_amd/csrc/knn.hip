@@ -4,10 +4,12 @@
 //                      examples/recons_waymo_cpu.py:21-41)
 //   k_nearest_index    nearest input point of every query -- fields.PCNNField colour lookup
 //                      (examples/recons_colored_mesh.py:28)
-//   k_sdf_from_points  signed distance of arbitrary queries to an oriented cloud from their k nearest reference points -- the
+//   k_sdf_pyramid      signed distance of arbitrary queries to an oriented cloud from their k nearest reference points -- the
 //                      training ground truth ext.sdfgen.sdf_from_points (ext/sdfgen/sdf_from_points.cu:32-140 on top of the
 //                      kd-tree of ext/common/kdtree_cuda.cu; call sites models/loss.py:85, dataset/av_gt_geometry.py:72):
-//                      sign vote or IMLS; k_knn_mean_dist = its adaptive_knn radius
+//                      sign vote or IMLS; k_knn_mean_dist_pyramid = its adaptive_knn radius.  k <= 32:
+//                      candidates sorted in registers, an octree over the grid searched in one launch (second half of this file);
+//                      k_sdf_from_points / k_knn_mean_dist = the same on ONE grid by bisection (any k; what the host falls back to)
 // The cloud is Morton-sorted by a uniform grid (cell size chosen by the host so that a 3^3 block
 // holds a few times k points); cells are contiguous point ranges found through the voxel hash.
 // EXACT selection without a per-thread heap: the k-th smallest squared distance is found by a
@@ -17,7 +19,8 @@
 // neighbour SET is the one an fp64 kd-tree search returns (an fp32-only rule swaps near-equidistant
 // neighbours against it: normals off by ~1e-3 at a few points, measured in round 2).  The covariance
 // is then accumulated in fp64 over that set.  One thread per query, queries in Morton order
-// (neighbouring lanes scan the same cells).
+// (neighbouring lanes scan the same cells).  (The normals keep the bisection: their queries ARE the cloud -- always near -- and
+// the fp64 tie rule needs the candidates AT the k-th distance, which a fixed-size list does not hold.)
 #include "common.h"
 
 struct KnnGrid {
@@ -547,8 +550,9 @@ __global__ void __launch_bounds__(128) k_knn_mean_dist(KnnGrid g, int64_t n, int
 // thread keeps the k smallest (distance, index) pairs sorted in registers and inserts every candidate once (an unrolled
 // compare-and-shift over KMAX slots; a candidate AT the k-th distance does not displace one seen earlier), ring after ring
 // (only the new shell of cells is scanned) until the k-th distance lies inside the scanned block.  Measured against the
-// REFERENCE'S OWN extension on the same MI355X (tests/sdfgen_vs_ref.py): before, 44 ms against the reference's 3.0 ms at 4 000
-// reference points / 1 000 queries and 2.7 s against 20 ms at 1 M / 1 M.
+// REFERENCE'S OWN extension on the same MI355X (tests/sdfgen_vs_ref.py, profiles/r04_sdfgen_vs_reference.md): with the bisection
+// 44 ms against the reference's 3.0 ms at 4 000 reference points / 1 000 queries and 2.7 s against 20 ms at 1 M / 1 M; with
+// everything below 1.0 ms and 13.8 ms.
 template <int KMAX>
 struct TopK {
     // The k candidates live in the LAST k slots (ascending); the KMAX - k slots before them hold a sentinel below every distance and
