@@ -506,6 +506,34 @@ int nksr_mc_emit(const int32_t* corner_idx, const int32_t* config, const int32_t
 int nksr_mc_vertices(const int64_t* edge_keys, int64_t nedge, const int64_t* vkeys, const int64_t* vhash_keys, const int32_t* vhash_vals,
                      int32_t vhash_cap, const float* vpos, const float* f, float h, float* verts_out, void* stream);
 
+/* ---- marching cubes on the ADAPTIVE dual graph: cells as large as their hierarchy level (field.extract_dual_mesh with
+ * LayerField(dec_svh, adaptive_depth), reference models/nksr_net.py:132,214,284; specification: oracle/dual_adaptive.py) ----------
+ * A primal cell is (lam, C): size 2^lam fine units, minimum corner C * 2^lam; its key = Morton(C + 2^20).  The cells of all sizes
+ * form ONE table, smallest first, each size sorted by key (id = offset[l] + rank); nksr_cell_table_t names the per-size key hashes
+ * (nksr_hash_build). */
+#define NKSR_CELL_SIZES 12
+typedef struct {
+    int32_t nlev;
+    int32_t lam[NKSR_CELL_SIZES];
+    int32_t offset[NKSR_CELL_SIZES];
+    int32_t hcap[NKSR_CELL_SIZES];
+    const int64_t* hkeys[NKSR_CELL_SIZES];
+    const int32_t* hvals[NKSR_CELL_SIZES];
+} nksr_cell_table_t;
+/* keys of k - 1 for the eight corners k of every cell of ONE size (fine coordinates): out has 8 keys per cell */
+int nksr_adaptive_corner_keys(const int64_t* cell_keys, int64_t ncell, int lam, int64_t* corner_keys_out, void* stream);
+/* the dual cell of every corner: cidx_out [ncorner, 8] = id of the cell that contains the fine voxel (k - 1) + o, o = (c >> 2, (c >> 1) & 1,
+ * c & 1), or -1 (the smallest size is asked first) */
+int nksr_adaptive_dual_cells(const int64_t* corner_keys, int64_t ncorner, const nksr_cell_table_t* table, int32_t* cidx_out, void* stream);
+/* cell centres: fl(fl(C 2^lam * u) + 2^lam * (u / 2)) per axis (the lattice positions of nksr_lattice_positions in the uniform case) */
+int nksr_adaptive_positions(const int64_t* cell_keys, const int32_t* cell_lam, int64_t ncell, float u, float* xyz_out, void* stream);
+/* triangle emission: vertex names (A << 33) | (axis << 31) | B -- the cells the cube edge joins, A on the low side -- [ntri_total, 3] */
+int nksr_mc_emit_pairs(const int32_t* corner_idx, const int32_t* config, const int32_t* tri_offset, int64_t ncell, int64_t* pair_keys,
+                       void* stream);
+/* mesh vertices from unique vertex names: pA + t (pB - pA), t = fA / (fA - fB), pB - pA exact from the integer coordinates */
+int nksr_pair_vertices(const int64_t* pair_keys, int64_t npair, const int64_t* cell_keys, const int32_t* cell_lam, const float* cell_pos,
+                       const float* f, float u, float* verts_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,14 @@ class KnnPyramidT(C.Structure):
                 ('levels', _i32), ('leaf', _i32), ('cell', _f32), ('inv_cell', _f32)]
 
 
+CELL_SIZES = 12
+
+
+class CellTableT(C.Structure):
+    _fields_ = [('nlev', _i32), ('lam', _i32 * CELL_SIZES), ('offset', _i32 * CELL_SIZES), ('hcap', _i32 * CELL_SIZES),
+                ('hkeys', _vp * CELL_SIZES), ('hvals', _vp * CELL_SIZES)]
+
+
 class FusedOpT(C.Structure):
     _fields_ = [('depth', _i32), ('M', _i32), ('n_multi', _i32), ('n_big', _i32), ('rows_total', _i64), ('rows_all', _vp),
                 ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('nbrT', _vp), ('item_begin', _vp), ('offsets', _vp), ('multi', _vp), ('nblocks', _i64),
@@ -182,6 +190,11 @@ _PROTOS = {
     'nksr_cell_children': [_vp, _vp, _i64, _vp, _vp],
     'nksr_mc_emit': [_vp, _vp, _vp, _i64, _vp, _vp],
     'nksr_mc_vertices': [_vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _f32, _vp, _vp],
+    'nksr_adaptive_corner_keys': [_vp, _i64, C.c_int, _vp, _vp],
+    'nksr_adaptive_dual_cells': [_vp, _i64, _P(CellTableT), _vp, _vp],
+    'nksr_adaptive_positions': [_vp, _vp, _i64, _f32, _vp, _vp],
+    'nksr_mc_emit_pairs': [_vp, _vp, _vp, _i64, _vp, _vp],
+    'nksr_pair_vertices': [_vp, _i64, _vp, _vp, _vp, _vp, _f32, _vp, _vp],
 }
 for _name, _args in _PROTOS.items():
     _fn = getattr(lib, _name)

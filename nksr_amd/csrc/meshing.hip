@@ -303,3 +303,115 @@ extern "C" int nksr_mise_constrain(const int64_t* vkeys_fine, int64_t nv, float*
     LAUNCH1D(k_mise_constrain, nv, stream, vkeys_fine, nv, f_fine, chash_keys, chash_vals, chash_cap, f_coarse, ahash_keys, ahash_vals, ahash_cap);
     return NKSR_OK;
 }
+
+// ---- marching cubes on the ADAPTIVE dual graph (specification: oracle/dual_adaptive.py) ------------------------------------------------
+// One hexahedron per octree corner k, its corners the cells around k; a cell that fills several octants (k on a face or an edge of
+// a larger cell) makes the hexahedron degenerate, which the 256-case table handles: equal values on a collapsed edge never cut it.
+// All integer work; positions with the two roundings of k_lattice_positions (contraction is off in this file).
+__global__ void k_adaptive_corner_keys(const int64_t* __restrict__ cell_keys, int64_t ncell, int lam, int64_t* __restrict__ out) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncell * 8) return;
+    int x, y, z;
+    morton_decode_biased(cell_keys[t >> 3], NKSR_BIAS0, x, y, z);
+    const int c = (int)(t & 7), s = 1 << lam;
+    out[t] = morton_biased((x + (c >> 2)) * s - 1, (y + ((c >> 1) & 1)) * s - 1, (z + (c & 1)) * s - 1, NKSR_BIAS0);
+}
+
+__global__ void k_adaptive_dual_cells(const int64_t* __restrict__ corner_keys, int64_t ncorner, nksr_cell_table_t T,
+                                      int32_t* __restrict__ cidx) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncorner * 8) return;
+    int x, y, z;
+    morton_decode_biased(corner_keys[t >> 3], NKSR_BIAS0, x, y, z);
+    const int c = (int)(t & 7);
+    x += c >> 2; y += (c >> 1) & 1; z += c & 1;
+    int id = -1;
+    for (int l = 0; l < T.nlev; ++l) {                    // (l is uniform: the table is read through scalar loads)
+        if (id >= 0) continue;
+        const int sh = T.lam[l];
+        const int j = hash_find(T.hkeys[l], T.hvals[l], T.hcap[l], morton_biased(x >> sh, y >> sh, z >> sh, NKSR_BIAS0));
+        if (j >= 0) id = T.offset[l] + j;
+    }
+    cidx[t] = id;
+}
+
+__global__ void k_adaptive_positions(const int64_t* __restrict__ cell_keys, const int32_t* __restrict__ cell_lam, int64_t n, float u,
+                                     float* __restrict__ xyz) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int x, y, z;
+    morton_decode_biased(cell_keys[i], NKSR_BIAS0, x, y, z);
+    const int s = 1 << cell_lam[i];
+    const float half = (float)s * (0.5f * u);             // exact: powers of two times u
+    const float px = (float)(x * s) * u, py = (float)(y * s) * u, pz = (float)(z * s) * u;
+    xyz[i * 3] = px + half;
+    xyz[i * 3 + 1] = py + half;
+    xyz[i * 3 + 2] = pz + half;
+}
+
+__global__ void k_mc_emit_pairs(const int32_t* __restrict__ corner_idx, const int32_t* __restrict__ config,
+                                const int32_t* __restrict__ tri_offset, int64_t ncell, int64_t* __restrict__ pair_keys) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncell) return;
+    const int cfg = config[i];
+    const int nt = MC_NTRI[cfg];
+    int64_t o = (int64_t)tri_offset[i] * 3;
+    for (int t = 0; t < nt * 3; ++t) {
+        const int e = MC_TRI[cfg][t];
+        const int lo = MC_EDGE_LO[e], axis = MC_EDGE_AXIS[e];
+        const int64_t a = corner_idx[i * 8 + lo], b = corner_idx[i * 8 + (lo | (4 >> axis))];
+        pair_keys[o + t] = (a << 33) | ((int64_t)axis << 31) | b;
+    }
+}
+
+__global__ void k_pair_vertices(const int64_t* __restrict__ pair_keys, int64_t npair, const int64_t* __restrict__ cell_keys,
+                                const int32_t* __restrict__ cell_lam, const float* __restrict__ cell_pos, const float* __restrict__ f,
+                                float u, float* __restrict__ verts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npair) return;
+    const int64_t k = pair_keys[i];
+    const int64_t a = k >> 33, b = k & 0x7FFFFFFFll;
+    int ca[3], cb[3];
+    morton_decode_biased(cell_keys[a], NKSR_BIAS0, ca[0], ca[1], ca[2]);
+    morton_decode_biased(cell_keys[b], NKSR_BIAS0, cb[0], cb[1], cb[2]);
+    const int sa = 1 << cell_lam[a], sb = 1 << cell_lam[b];
+    const float fa = f[a], fb = f[b];
+    const float t = fa / (fa - fb);
+    const float hu = 0.5f * u;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        const int d2 = 2 * (cb[x] * sb - ca[x] * sa) + (sb - sa);          // doubled centre difference in fine units: exact
+        const float d = (float)d2 * hu;
+        const float td = t * d;                                            // (rounded product, then rounded sum)
+        verts[i * 3 + x] = cell_pos[a * 3 + x] + td;
+    }
+}
+
+extern "C" int nksr_adaptive_corner_keys(const int64_t* cell_keys, int64_t ncell, int lam, int64_t* corner_keys_out, void* stream) {
+    if (lam < 0 || lam > 20) return nksr_set_error(NKSR_ERR_ARG, "cell size exponent out of range");
+    LAUNCH1D(k_adaptive_corner_keys, ncell * 8, stream, cell_keys, ncell, lam, corner_keys_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_adaptive_dual_cells(const int64_t* corner_keys, int64_t ncorner, const nksr_cell_table_t* table, int32_t* cidx_out,
+                                        void* stream) {
+    if (!table || table->nlev < 1 || table->nlev > NKSR_CELL_SIZES) return nksr_set_error(NKSR_ERR_ARG, "cell table: 1..%d sizes", NKSR_CELL_SIZES);
+    for (int l = 0; l < table->nlev; ++l)
+        if (!table->hkeys[l] || !table->hvals[l] || table->hcap[l] < 8 || table->lam[l] < 0 || table->lam[l] > 20)
+            return nksr_set_error(NKSR_ERR_ARG, "cell table: size %d incomplete", l);
+    LAUNCH1D(k_adaptive_dual_cells, ncorner * 8, stream, corner_keys, ncorner, *table, cidx_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_adaptive_positions(const int64_t* cell_keys, const int32_t* cell_lam, int64_t ncell, float u, float* xyz_out, void* stream) {
+    LAUNCH1D(k_adaptive_positions, ncell, stream, cell_keys, cell_lam, ncell, u, xyz_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_mc_emit_pairs(const int32_t* corner_idx, const int32_t* config, const int32_t* tri_offset, int64_t ncell,
+                                  int64_t* pair_keys, void* stream) {
+    LAUNCH1D(k_mc_emit_pairs, ncell, stream, corner_idx, config, tri_offset, ncell, pair_keys);
+    return NKSR_OK;
+}
+extern "C" int nksr_pair_vertices(const int64_t* pair_keys, int64_t npair, const int64_t* cell_keys, const int32_t* cell_lam,
+                                  const float* cell_pos, const float* f, float u, float* verts_out, void* stream) {
+    LAUNCH1D(k_pair_vertices, npair, stream, pair_keys, npair, cell_keys, cell_lam, cell_pos, f, u, verts_out);
+    return NKSR_OK;
+}

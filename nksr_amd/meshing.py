@@ -29,6 +29,11 @@ def _cell_vertices(cell_keys_raw):
 
 
 def extract_dual_mesh(field, mise_iter=0, grid_upsample=1, max_points=-1):
+    # field.dual_graph = 'adaptive': cells as large as the hierarchy level that carries them (the reference's dual graph of the
+    # flattened levels); 'lattice' (default): one uniform lattice over the adaptive support.  Chunked / distributed fields mesh
+    # on the lattice either way: their seams are stitched by lattice vertex keys.
+    if getattr(field, 'dual_graph', 'lattice') == 'adaptive' and not hasattr(field, 'finalize_mesh') and not hasattr(field, 'base_cell_mask'):
+        return _extract_adaptive(field, mise_iter, grid_upsample, max_points)
     res = _extract(field, mise_iter, grid_upsample, max_points)
     if hasattr(field, 'finalize_mesh'):       # distributed fields gather + stitch the pieces (collective)
         res = field.finalize_mesh(res)
@@ -141,22 +146,221 @@ def _extract(field, mise_iter, grid_upsample, max_points):
     # canonical identity of every mesh vertex: (lattice key of the lower end point, axis)
     ev = torch.div(uek, 3, rounding_mode='floor')
     edge_vkey, edge_axis = vkeys[ev], (uek - ev * 3).to(torch.int8)
-    keep_v = field.mask_vertices(verts)
-    if keep_v is not None and not bool(keep_v.all()):
-        keep_f = keep_v[faces.long()].all(1)
-        faces = faces[keep_f]
+    verts, faces, (edge_vkey, edge_axis) = _trim(field, verts, faces, (edge_vkey, edge_axis), masked=True)
+    res = _result(field, verts, faces)
+    res.edge_vkey, res.edge_axis, res.lattice_h = edge_vkey, edge_axis, h
+    return res
+
+
+def _trim(field, verts, faces, per_vertex=(), masked=True, drop_unused=False):
+    """Mask trim (triangles with a vertex outside the mask field go) and removal of the vertices no triangle uses."""
+    dev = verts.device
+    ne = verts.shape[0]
+    keep_v = field.mask_vertices(verts) if masked else None
+    trimmed = keep_v is not None and not bool(keep_v.all())
+    if trimmed:
+        faces = faces[keep_v[faces.long()].all(1)]
+    if trimmed or drop_unused:
         used = torch.zeros(ne, dtype=torch.int32, device=dev)
         used[faces.reshape(-1).long()] = 1
         remap = ops.exclusive_sum_i32(used)
-        vsel = ops.compact(used)
-        verts = verts[vsel.long()]
-        edge_vkey, edge_axis = edge_vkey[vsel.long()], edge_axis[vsel.long()]
+        vsel = ops.compact(used).long()
+        verts = verts[vsel]
+        per_vertex = tuple(a[vsel] for a in per_vertex)
         faces = remap[faces.long()]
+    return verts, faces, per_vertex
 
+
+def _result(field, verts, faces):
     v_world = verts / field.scale if field.scale != 1.0 else verts
     colors = None
     if field.texture_field is not None:
         colors = field.texture_field.evaluate_color(v_world)
-    res = MeshingResult(v_world, faces.long(), colors)
-    res.edge_vkey, res.edge_axis, res.lattice_h = edge_vkey, edge_axis, h
+    return MeshingResult(v_world, faces.long(), colors)
+
+
+# ---- marching cubes on the adaptive dual graph (specification: oracle/dual_adaptive.py) ------------------------------------------------
+def _leaf_coordinates(svh, adaptive):
+    """Per level d < adaptive: integer coordinates [m_d, 3] of the octree's leaves -- level-0 voxels, voxels without children, and
+    the children a refined voxel does not have ("virtual": empty space next to a refined region still carries a sample)."""
+    dev = svh.device
+    out = [[] for _ in range(adaptive)]
+    for d in range(adaptive):
+        g = svh.level(d)
+        if g.num_voxels == 0:
+            continue
+        if d == 0:
+            out[0].append(g.ijk)
+            continue
+        child = svh.level(d - 1)
+        internal = torch.zeros(g.num_voxels, dtype=torch.bool, device=dev)
+        if child.num_voxels:
+            pi = g.hash.query((child.keys >> 3).contiguous())             # the key of a parent is its child's without the low octant
+            internal[pi[pi >= 0].long()] = True
+        out[d].append(g.ijk[~internal])
+        ik = g.keys[internal]
+        if ik.numel():
+            ck = ((ik[:, None] << 3) | torch.arange(8, dtype=torch.int64, device=dev)[None]).reshape(-1).contiguous()
+            vk = ck[child.hash.query(ck) < 0].contiguous()
+            if vk.numel():
+                vijk = torch.empty((vk.numel(), 3), dtype=torch.int32, device=dev)
+                call('nksr_decode_keys', ptr(vk), vk.numel(), d - 1, ptr(vijk), stream())
+                out[d - 1].append(vijk)
+    return [torch.cat(o) if o else torch.zeros((0, 3), dtype=torch.int32, device=dev) for o in out]
+
+
+class _CellTable:
+    """The primal cells of all sizes as one table, smallest first, each size sorted by key: id = offset + rank (csrc/meshing.hip
+    nksr_cell_table_t).  ``f`` rides along (NaN = not evaluated yet)."""
+
+    def __init__(self, keys_by_lam, f_by_lam, dev):
+        from ._lib import CELL_SIZES, CellTableT
+        self.lams = sorted(l for l in keys_by_lam if keys_by_lam[l].numel())
+        if len(self.lams) > CELL_SIZES:
+            raise RuntimeError('adaptive dual graph: more than %d cell sizes' % CELL_SIZES)
+        self.keys, self.hashes, self.offset = {}, {}, {}
+        t = CellTableT()
+        n, fs, ks, ls = 0, [], [], []
+        for i, l in enumerate(self.lams):
+            k, f = keys_by_lam[l], f_by_lam[l]
+            ko, order = ops.sort_pairs(k.contiguous(), torch.arange(k.numel(), dtype=torch.int32, device=dev))
+            self.keys[l], self.hashes[l], self.offset[l] = ko, ops.HashTable(ko), n
+            t.lam[i], t.offset[i], t.hcap[i], t.hkeys[i], t.hvals[i] = l, n, self.hashes[l].cap, ptr(self.hashes[l].hkeys), ptr(self.hashes[l].hvals)
+            fs.append(f[order.long()])
+            ks.append(ko)
+            ls.append(torch.full((ko.numel(),), l, dtype=torch.int32, device=dev))
+            n += ko.numel()
+        t.nlev = len(self.lams)
+        self.struct, self.n = t, n
+        if n >= (1 << 30):
+            raise RuntimeError('adaptive dual graph: %d cells (vertex names hold 30-bit cell ids)' % n)
+        self.key = torch.cat(ks) if ks else torch.zeros(0, dtype=torch.int64, device=dev)
+        self.lam = torch.cat(ls) if ls else torch.zeros(0, dtype=torch.int32, device=dev)
+        self.f = torch.cat(fs) if fs else torch.zeros(0, dtype=torch.float32, device=dev)
+
+
+def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=None):
+    """``level_ijk`` (tests): the voxel coordinates per level instead of the field's hierarchy."""
+    svh = field.svh
+    dev = svh.device
+    w0 = svh.voxel_size
+    U, M = int(grid_upsample), int(mise_iter)
+    if U < 1 or U > 8 or M < 0:
+        raise RuntimeError('grid_upsample must be in [1, 8] and mise_iter >= 0')
+    empty = MeshingResult(torch.zeros((0, 3), dtype=torch.float32, device=dev), torch.zeros((0, 3), dtype=torch.int64, device=dev))
+    batch = max_points if (max_points is not None and max_points > 0) else (1 << 22)
+    if level_ijk is None:
+        adaptive = max(1, min(int(getattr(field, 'meshing_depth', 1)), svh.depth))
+        leaf = _leaf_coordinates(svh, adaptive)
+    else:
+        leaf = _leaf_coordinates(_LevelsOnly(level_ijk, w0, dev), len(level_ijk))
+    if not any(c.numel() for c in leaf):
+        return empty
+    reach = max(((int(c.abs().max()) + 2) << d) for d, c in enumerate(leaf) if c.numel()) * U * (1 << M) + 2
+    if reach >= (1 << 20):
+        raise RuntimeError('mesh lattice out of range: |ijk| * grid_upsample * 2^mise_iter = %d >= 2^20; recentre the cloud '
+                           '(or lower mise_iter / grid_upsample)' % reach)
+    u = w0 / U / (1 << M)
+    sub = torch.tensor([[a, b, c] for a in range(U) for b in range(U) for c in range(U)], dtype=torch.int32, device=dev)
+    keys_by, f_by = {}, {}
+    for d, c in enumerate(leaf):
+        if not c.numel():
+            continue
+        cc = (c[:, None, :] * U + sub[None]).reshape(-1, 3).contiguous()
+        k = torch.empty(cc.shape[0], dtype=torch.int64, device=dev)
+        call('nksr_encode_keys', ptr(cc), cc.shape[0], -1, ptr(k), stream())
+        keys_by[d + M] = ops.sort_unique(k)
+        f_by[d + M] = torch.full((keys_by[d + M].numel(),), float('nan'), dtype=torch.float32, device=dev)
+    for m in range(M + 1):
+        tab = _CellTable(keys_by, f_by, dev)
+        pos = torch.empty((tab.n, 3), dtype=torch.float32, device=dev)
+        call('nksr_adaptive_positions', ptr(tab.key), ptr(tab.lam), tab.n, float(u), ptr(pos), stream())
+        new = torch.isnan(tab.f)
+        f = tab.f
+        if bool(new.all()):
+            f = field._evaluate_f_model(pos, False, max_points=batch).value.contiguous()
+        elif bool(new.any()):
+            sel = torch.nonzero(new).flatten()
+            f = f.clone()
+            f[sel] = field._evaluate_f_model(pos[sel].contiguous(), False, max_points=batch).value
+        # dual cells: the corners of all cells, sorted by the key of k - 1; the eight cells around each
+        ck = []
+        for l in tab.lams:
+            o = torch.empty(tab.keys[l].numel() * 8, dtype=torch.int64, device=dev)
+            call('nksr_adaptive_corner_keys', ptr(tab.keys[l]), tab.keys[l].numel(), l, ptr(o), stream())
+            ck.append(o)
+        ckeys = ops.sort_unique(torch.cat(ck))
+        nk = ckeys.numel()
+        cidx = torch.empty((nk, 8), dtype=torch.int32, device=dev)
+        call('nksr_adaptive_dual_cells', ptr(ckeys), nk, tab.struct, ptr(cidx), stream())
+        whole = ops.compact((cidx >= 0).all(1).to(torch.int32).contiguous())
+        cidx = cidx[whole.long()].contiguous()
+        nc = cidx.shape[0]
+        if nc == 0:
+            return empty
+        config = torch.empty(nc, dtype=torch.int32, device=dev)
+        ntri = torch.empty(nc + 1, dtype=torch.int32, device=dev)
+        ntri[nc] = 0
+        call('nksr_cell_config', ptr(cidx), ptr(f), nc, ptr(config), ptr(ntri), stream())
+        if m < M:   # MISE: every cell around a sign-changing dual cell is split into 8; the rest keep their values
+            act = torch.empty(nc, dtype=torch.int32, device=dev)
+            call('nksr_cell_active_flags', ptr(config), nc, ptr(act), stream())
+            asel = ops.compact(act)
+            if asel.numel() == 0:
+                return empty
+            split = torch.zeros(tab.n, dtype=torch.bool, device=dev)
+            split[cidx[asel.long()].reshape(-1).long()] = True
+            split &= tab.lam > 0
+            keys_by, f_by = {}, {}
+            for l in tab.lams:
+                lo, n_l = tab.offset[l], tab.keys[l].numel()
+                sp = split[lo:lo + n_l]
+                keep = ~sp
+                if bool(keep.any()):
+                    keys_by.setdefault(l, []).append(tab.keys[l][keep])
+                    f_by.setdefault(l, []).append(f[lo:lo + n_l][keep])
+                ssel = ops.compact(sp.to(torch.int32).contiguous())
+                if ssel.numel():
+                    ch = torch.empty(ssel.numel() * 8, dtype=torch.int64, device=dev)
+                    call('nksr_cell_children', ptr(tab.keys[l]), ptr(ssel), ssel.numel(), ptr(ch), stream())
+                    keys_by.setdefault(l - 1, []).append(ch)
+                    f_by.setdefault(l - 1, []).append(torch.full((ch.numel(),), float('nan'), dtype=torch.float32, device=dev))
+            keys_by = {l: torch.cat(v) for l, v in keys_by.items()}
+            f_by = {l: torch.cat(v) for l, v in f_by.items()}
+    tri_off = ops.exclusive_sum_i32(ntri)
+    T = int(tri_off[nc].item())
+    if T == 0:
+        return empty
+    names = torch.empty(T * 3, dtype=torch.int64, device=dev)
+    call('nksr_mc_emit_pairs', ptr(cidx), ptr(config), ptr(tri_off), nc, ptr(names), stream())
+    names = names.view(T, 3)
+    good = (names[:, 0] != names[:, 1]) & (names[:, 1] != names[:, 2]) & (names[:, 0] != names[:, 2])     # collapsed edges of degenerate cells
+    names = names[good].contiguous().reshape(-1)
+    if names.numel() == 0:
+        return empty
+    uek = ops.sort_unique(names)
+    faces = ops.HashTable(uek).query(names).view(-1, 3)
+    ne = uek.numel()
+    verts = torch.empty((ne, 3), dtype=torch.float32, device=dev)
+    call('nksr_pair_vertices', ptr(uek), ne, ptr(tab.key), ptr(tab.lam), ptr(pos), ptr(f), float(u), ptr(verts), stream())
+    verts, faces, (uek,) = _trim(field, verts, faces, (uek,), masked=True)
+    res = _result(field, verts, faces)
+    res.vertex_name, res.cell_key, res.cell_lam, res.cell_f, res.fine_unit = uek, tab.key, tab.lam, f, u
     return res
+
+
+class _LevelsOnly:
+    """Voxel coordinates per level dressed as the part of a hierarchy _leaf_coordinates reads (tests: mixed-level patterns)."""
+
+    def __init__(self, level_ijk, voxel_size, dev):
+        from .svh import SparseGrid
+        self.device, self.voxel_size, self.depth = dev, voxel_size, len(level_ijk)
+        self._levels = []
+        for d, ijk in enumerate(level_ijk):
+            ijk = torch.as_tensor(ijk, dtype=torch.int32, device=dev).reshape(-1, 3).contiguous()
+            k = torch.empty(ijk.shape[0], dtype=torch.int64, device=dev)
+            call('nksr_encode_keys', ptr(ijk), ijk.shape[0], d, ptr(k), stream())
+            self._levels.append(SparseGrid(ops.sort_unique(k), d, voxel_size))
+
+    def level(self, d):
+        return self._levels[d]
