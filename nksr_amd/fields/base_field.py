@@ -33,6 +33,7 @@ class BaseField:
         self.mask_field = None
         self.texture_field = None
         self.meshing_depth = 1     # levels whose dual cells are meshed (Reconstructor sets hparams.adaptive_depth)
+        self.dual_graph = 'lattice'     # or 'adaptive': marching cubes on the dual graph of the flattened levels (meshing._extract_adaptive)
 
     @property
     def device(self):
