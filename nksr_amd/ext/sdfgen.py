@@ -10,7 +10,8 @@ octree is stacked on it (``normals.PointPyramid``: the same sorted points, cells
 candidates sorted in registers while it descends the cells around it with box pruning, and evaluates the estimator from them -- no
 index lists, no second pass.  What is left (queries farther from the cloud than 4 cells of the coarsest level; nb_points > 32,
 which bisects for the k-th distance instead) goes through single grids 4x coarser per round, so every query gets an answer like
-with a kd-tree.  ``NKSR_SDFGEN_SEARCH=rounds`` keeps everything on that path (the measurements of tests/sdfgen_vs_ref.py).
+with a kd-tree.  Measurement knobs (tests/sdfgen_vs_ref.py --variants): ``NKSR_SDFGEN_SEARCH=rounds`` keeps everything on that path,
+``NKSR_SDFGEN_LEAF`` / ``NKSR_SDFGEN_RINGS`` set the octree's scan threshold (48) and the rings searched per level (4).
 """
 import os
 
