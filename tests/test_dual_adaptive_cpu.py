@@ -146,3 +146,30 @@ def test_three_levels_and_virtual_children():
         v, t = da.extract(w0, [l0, l1, l2], f, mise_iter=m)
         _closed_and_oriented(t)
         assert _euler(v, t) == 2
+
+
+def test_on_a_solved_field_with_two_adaptive_levels_the_mesh_is_a_closed_sphere():
+    """A real hierarchy and a real field (oracle pipeline, adaptive_depth 2, samples sparser than the finest voxels -- the case of
+    tests/test_gpu_parity.py::test_adaptive_depth_meshing_covers_what_the_finest_level_leaves_open): the level-0 voxels alone
+    leave holes, the adaptive dual graph over levels 0 and 1 (childless level-1 voxels + the virtual children of the refined ones)
+    closes them, with as many triangles as the lattice mesher where everything ends up at level-0 resolution."""
+    from oracle import pipeline
+    n = 700
+    k = np.arange(n) + 0.5
+    phi, z = np.pi * (1 + 5 ** 0.5) * k, 1 - 2 * k / n
+    nrm = np.stack([np.cos(phi) * np.sqrt(1 - z * z), np.sin(phi) * np.sqrt(1 - z * z), z], 1).astype(np.float32)
+    xyz = (nrm * np.float32(0.45 * 2.5)).astype(np.float32)
+    fld = pipeline.reconstruct(xyz, nrm, adaptive_depth=2, tol=1e-6)
+    ev = lambda p: pipeline.evaluate(fld, p)[0]
+    lv = [L.ijk for L in fld['hier'].levels[:2]]
+    leaf = da.leaves(lv)
+    assert len(leaf[0]) > len(lv[0]) and 0 < len(leaf[1]) < len(lv[1])          # virtual children; some level-1 voxels are leaves
+    v0, t0 = da.extract(fld['voxel_size'], lv[:1], ev)
+    e = np.sort(_edges(t0), 1)
+    assert (np.unique(e, axis=0, return_counts=True)[1] == 1).sum() > 0          # level 0 alone: holes
+    for m in (0, 1):
+        v, t = da.extract(fld['voxel_size'], lv, ev, mise_iter=m)
+        _closed_and_oriented(t)
+        assert _euler(v, t) == 2
+        if m == 0:
+            assert len(t) == len(pipeline.extract_dual_mesh(fld, mise_iter=0)[1])
