@@ -104,10 +104,15 @@ def evaluate(fld, xyz, grad=False):
                             fld['approx_kernel_grad'])
 
 
-def extract_dual_mesh(fld, mise_iter=0, grid_upsample=1, info=None):
+def extract_dual_mesh(fld, mise_iter=0, grid_upsample=1, info=None, dual_graph='lattice'):
+    """dual_graph = 'adaptive': cells as large as their level (oracle/dual_adaptive.py) instead of one uniform lattice."""
     mask_fn = None
     if fld.get('udf_feats') is not None:      # NeuralField mask, level set 2 * voxel_size (models/nksr_net.py:130)
         from . import network as onet
         mask_fn = lambda p: onet.udf_decode(fld['hier'], fld['udf_feats'], p) < np.float32(fld.get('udf_level_set', 2 * fld['voxel_size']))
+    if dual_graph == 'adaptive':
+        from . import dual_adaptive
+        return dual_adaptive.extract(fld['voxel_size'], [L.ijk for L in fld['hier'].levels[:fld.get('adaptive_depth', 1)]],
+                                     lambda p: evaluate(fld, p)[0], mise_iter, grid_upsample, mask_fn=mask_fn, info=info)
     return meshing.extract(fld['voxel_size'], fld['hier'].levels[0], lambda p: evaluate(fld, p)[0], mise_iter, grid_upsample,
                            mask_fn=mask_fn, info=info, coarser=fld['hier'].levels[1:fld.get('adaptive_depth', 1)])

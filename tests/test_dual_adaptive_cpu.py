@@ -173,3 +173,4 @@ def test_on_a_solved_field_with_two_adaptive_levels_the_mesh_is_a_closed_sphere(
         assert _euler(v, t) == 2
         if m == 0:
             assert len(t) == len(pipeline.extract_dual_mesh(fld, mise_iter=0)[1])
+            assert np.array_equal(t, pipeline.extract_dual_mesh(fld, mise_iter=0, dual_graph='adaptive')[1])
