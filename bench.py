@@ -328,6 +328,7 @@ def main():
                'pcg_iters_per_chunk': float(np.mean([i['iters'] for i in infos])) if infos else 0,
                'pcg_iters_max_chunk': int(max([i['iters'] for i in infos])) if infos else 0,
                'pcg_iters_min_chunk': int(min([i['iters'] for i in infos])) if infos else 0,
+               'jacobi_fallbacks': int(sum(int(getattr(p.field, 'solve_info', {}).get('jacobi_fallbacks', 0) or 0) for p in field.parts if p.solved)),
                'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]),
                'parallelism': 'none' if world == 1 else 'chunks sharded over %d ranks (Morton-contiguous), sharded input, no collective in the solve, '
                                                         'one halo exchange, mesh gather + stitch on rank 0' % world}

@@ -52,7 +52,11 @@ def borrowed(obj, device):
     to the parked tensors are put back and the copies die.  Nothing travels back -- evaluation and meshing do not change a field.
     ``obj``: a KernelField (with its hierarchy and mask) or a SparseFeatureHierarchy."""
     device = torch.device(device)
-    if obj.device == device or (obj.device.type == device.type == 'cuda'):
+
+    def _norm(d):      # 'cuda' names the CURRENT device: compare full (type, index) pairs -- a field parked on another GPU is NOT resident
+        d = torch.device(d)
+        return (d.type, d.index if d.index is not None else (torch.cuda.current_device() if d.type == 'cuda' and torch.cuda.is_available() else 0))
+    if _norm(obj.device) == _norm(device):
         yield obj
         return
     objs = [obj]
@@ -712,10 +716,13 @@ class MultiChunkField(BaseField):
         if self.world_size == 1 and not self.distributed:
             return res
         import time
-        torch.cuda.current_stream().synchronize()
+        on_gpu = res.v.is_cuda and torch.cuda.is_available()      # (the gather also runs under gloo with CPU tensors: tests/test_dist_cpu.py)
+        if on_gpu:
+            torch.cuda.current_stream().synchronize()
         t0 = time.perf_counter()
         v, f = D.gather_meshes(res.v, res.f, res.edge_vkey, res.edge_axis)
-        torch.cuda.current_stream().synchronize()
+        if on_gpu:
+            torch.cuda.current_stream().synchronize()
         self.last_gather_s = time.perf_counter() - t0      # mesh gather (point-to-point to rank 0) + seam merge
         res.v, res.f = v, f
         res.c = self.texture_field.evaluate_color(v) if self.texture_field is not None else None
@@ -797,7 +804,7 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     from .density import bbox_center
     if xyz.shape[0]:
         lo_t, hi_t, _ = bbox_center(xyz)
-        if not abs(float(lo_t[0])) < float('inf'):         # (nksr_bbox: NaN when any coordinate is NaN / infinite)
+        if not bool(torch.isfinite(torch.cat([lo_t.reshape(-1), hi_t.reshape(-1)])).all()):   # (nksr_bbox: NaN in lo[0] when any coordinate is NaN / infinite; the CPU branch: the extrema themselves)
             raise RuntimeError('non-finite coordinates in the input')
     if chunk_bounds is not None:
         lo, hi = [float(v) for v in chunk_bounds[0]], [float(v) for v in chunk_bounds[1]]

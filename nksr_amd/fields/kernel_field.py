@@ -663,6 +663,10 @@ class KernelField(BaseField):
                     rel = rn / bn
         info = (float(iters), rel)
         t2 = time.perf_counter()
+        if fallbacks[0]:
+            import warnings
+            warnings.warn('%d segment(s) of the solve restarted with the Jacobi preconditioner alone (the coarse-level block lost '
+                          'definiteness: eigenvalue bound too small); the result is valid, the iteration count is higher' % fallbacks[0])
         self.alpha = x
         self.matrix = None
         self._fused_op, self._fused_reg = op, float(reg_weight)

@@ -1,5 +1,7 @@
 """Thin tensor-level wrappers over the C-ABI primitives (sort / unique / scan / compaction /
 hash).  PyTorch supplies device memory and the stream only."""
+import threading
+
 import torch
 
 from ._lib import call, ptr, stream, with_tmp
@@ -19,19 +21,26 @@ class KeyBits:
     (cell >> d) + 2^(20 - d); everything a hierarchy level, a site list or a footprint stream of this cloud
     holds lies within two cells of the box at its level, and all integers between two bounds share their common binary prefix."""
 
-    def __init__(self, lo, hi):
+    def __init__(self, lo, hi, depth=1):
         self.lo, self.hi = [int(v) for v in lo], [int(v) for v in hi]
+        # Sites sorted under the hint include voxel centres of COARSE levels keyed at level 0 (KernelField._sorted_sites: the normal
+        # sites of levels < adaptive_depth): a 27-neighbourhood voxel of level d lies up to 1.5 * 2^d level-0 cells past the box, so
+        # the box is widened by two cells of the coarsest level (in level-0 cells, shifted down with the level) on top of the
+        # two cells at the key's own level.  A bound too wide costs at most one radix pass; one too narrow a silently
+        # half-sorted list.
+        self.reach = 2 << max(int(depth) - 1, 0)
 
     def bits(self, level=0):
         b = 0
         for a in range(3):
             bias = 1 << (20 - level)
-            lo, hi = (self.lo[a] >> level) - 2 + bias, (self.hi[a] >> level) + 2 + bias
-            b = max(b, (lo ^ hi).bit_length())
+            lo = ((self.lo[a] - self.reach) >> level) - 2 + bias
+            hi = ((self.hi[a] + self.reach) >> level) + 2 + bias
+            b = max(b, (max(lo, 0) ^ hi).bit_length())
         return max(1, min(63, 3 * b))
 
 
-_key_hint = None
+_tls = threading.local()      # the hint is per thread: concurrent reconstructions must not see each other's boxes
 
 
 class key_hint:
@@ -41,13 +50,12 @@ class key_hint:
         self.kb = kb
 
     def __enter__(self):
-        global _key_hint
-        self.prev, _key_hint = _key_hint, self.kb
+        self.prev = getattr(_tls, 'hint', None)
+        _tls.hint = self.kb
         return self.kb
 
     def __exit__(self, *exc):
-        global _key_hint
-        _key_hint = self.prev
+        _tls.hint = self.prev
 
 
 def varying_bits(keys, level=None):
@@ -55,8 +63,9 @@ def varying_bits(keys, level=None):
     (always when the cloud lies in one octant of the biased lattice), and every 8 constant bits save one
     radix pass.  With a key_hint in force and a ``level`` given, the answer comes from the cloud's box (no device work);
     otherwise small inputs are not worth the host round trip and large ones are looked at."""
-    if level is not None and _key_hint is not None:
-        return _key_hint.bits(level)
+    hint = getattr(_tls, 'hint', None)
+    if level is not None and hint is not None:
+        return hint.bits(level)
     if keys.numel() < (1 << 17):
         return 63
     return max(1, int((keys ^ keys[:1]).max()).bit_length())

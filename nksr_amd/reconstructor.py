@@ -75,7 +75,7 @@ class Reconstructor:
             raise RuntimeError('coordinates out of range: |x| / voxel_size must stay below 2^20 (got %g); '
                                'recentre the cloud or use a larger voxel_size' % (amax * inv))
         import math
-        return ops.KeyBits([math.floor(c * inv) - 1 for c in v[:3]], [math.floor(c * inv) + 1 for c in v[3:6]])
+        return ops.KeyBits([math.floor(c * inv) - 1 for c in v[:3]], [math.floor(c * inv) + 1 for c in v[3:6]], depth=self.hparams.tree_depth)
 
     def _reconstruct_hinted(self, xyz, normal, approx_kernel_grad, solver_max_iter, solver_tol, fused_mode, chunks=None):
         hp = self.hparams

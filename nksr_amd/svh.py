@@ -93,7 +93,7 @@ class SparseFeatureHierarchy:
         if xyz.dtype != torch.float32 or xyz.dim() != 2 or xyz.shape[1] != 3:
             raise RuntimeError('xyz must be a float32 [N,3] tensor')
         _lib.require_gpu(xyz.device)
-        if xyz.shape[0] and ops._key_hint is None:        # (under a key_hint the caller has checked the cloud's box already)
+        if xyz.shape[0] and getattr(ops._tls, 'hint', None) is None:        # (under a key_hint the caller has checked the cloud's box already)
             amax = float(xyz.abs().max())
             if not (amax * self.inv_w0 < (1 << 20) - 8):     # also catches NaN / inf
                 raise RuntimeError('coordinates out of range: |x| / voxel_size must stay below 2^20 (got %g); '
