@@ -153,6 +153,14 @@ int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int appr
  * r_i = row_index ? row_index[i] : i * ncomp (ncomp = 1 for val, 3 for dval; ONE of val / dval when row_index is given) -- the layout
  * of the matrix-free solve (nksr_fused_op_t.rows_all): row_index lets several site sets share one Morton-ordered row list;
  * row_cells [L, level_stride] (may be NULL) receives the global unknown index of the level-d cell of every row written (-1 = none). */
+/* Rank-4 FACTORS of the same rows (kernel_dim 4 only; the matrix-free solve's row format since round 5, nksr_fused_op_t.fac_vec /
+ * fac_pos): per row and level one 16-byte record instead of 27 slots.  grad == 0: one row per site, vec = phi_d(x) * scale.
+ * grad != 0: FOUR rows per site -- a header row (vec = phi * scale) and one row per axis a (vec = d phi / d x_a * scale; 0 with
+ * approx != 0).  Row r of site i = (row_index ? row_index[i] : i * rows_per_site) + q.  vec_out [L][level_stride][4],
+ * pos_out [level_stride][4] = (x * inv_w0, kind bits), row_cells as for nksr_kernel_rows.  Rows of a site outside every active
+ * cell of a level are 0 there. */
+int nksr_kernel_factors(const nksr_hier_t* h, const float* xyz, int64_t n, int grad, int approx, float row_scale, const float* site_scale,
+                        int64_t level_stride, const int32_t* row_index, int32_t* row_cells, float* vec_out, float* pos_out, void* stream);
 /* f(x) (and gradient if grad_out != NULL): field.evaluate_f, models/loss.py:189-198.  alpha == NULL: the hierarchy's psi arrays
  * already hold alpha_j psi_j (one gather per neighbour instead of two).  A query outside every active cell of a level still sees the
  * voxels whose support covers it (hash lookups); active_only != 0 drops those levels instead -- the support of nksr_kernel_rows,
@@ -348,6 +356,15 @@ typedef struct {
     const int32_t* item_seg;   /* batched chunks (nksr_segments_t), both or neither: [ceil(rows_total / 32) + 1] segment of every 32-row window
                                 * of the row list (a segment's rows are padded to a multiple of 256) and                      */
     const int32_t* unknown_seg;/* [M] segment of every unknown: the solve skips the rows / unknowns of segments that have converged */
+    /* FACTOR FORM (kernel_dim 4; nksr_kernel_factors): fac_vec != NULL replaces rows_all (which may then be NULL) -- the sweep rebuilds the
+     * 27 slots of every row in registers from 16-byte records and the psi stencil of the row's cell.  A normal site owns FOUR rows
+     * of the list (header + one per axis); the header row is all-zero. */
+    const float* fac_vec;      /* [depth][rows_total][4] phi (position / header rows) or d phi / d x_a (gradient rows), times sqrt(w); 16-byte aligned */
+    const float* fac_pos;      /* [rows_total][4] x * inv_w0 (3 floats) + the row's kind as int bits: 0 position, 1 header, 2 + a gradient row of axis a */
+    const float* psi_all;      /* [M][4] psi of every unknown, levels concatenated (nksr_voxel_psi)                              */
+    float inv_w0;              /* 1 / finest voxel size (fp32, as in nksr_hier_t)                                               */
+    int32_t dense_from;        /* nksr_fused_rhs_diag / nksr_fused_expand_rows: the rebuilt rows of the levels >= dense_from are also written to */
+    float* dense_out;          /* [depth - dense_from][rows_total][27] (NULL: not wanted) -- what the coarse-level block of the preconditioner is assembled from */
 } nksr_fused_op_t;
 /* A UNIT is a maximal run of rows that lie in the same cell at every level (the rows of one level-0 cell); work item i of the sweep =
  * the units that start in the 32-row window [32 i, 32 i + 32) = rows [item_begin[i], item_begin[i + 1]); eight items are a workgroup.
@@ -363,6 +380,9 @@ int nksr_fused_tables(const nksr_hier_t* h, int64_t rows_total, const int32_t* i
 size_t nksr_fused_workspace_bytes(int64_t nblocks, int32_t M);
 /* b = sum_s R_s^T t_s and diag = reg + sum_s diag(R_s^T R_s) (either may be NULL): one sweep over the rows serves both. */
 int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* b_out, float* diag_out, void* stream);
+/* Factor form only: the rebuilt rows of the levels >= op->dense_from written dense into op->dense_out (one more set-up sweep;
+ * nksr_fused_rhs_diag does the same on its way when dense_out is set).  Scratch: the operator's workspace and cell_sums. */
+int nksr_fused_expand_rows(const nksr_fused_op_t* op, void* stream);
 /* y = (sum_s R_s^T R_s + reg I) x */
 int nksr_fused_apply(const nksr_fused_op_t* op, float reg, const float* x, float* y, void* stream);
 /* Jacobi-PCG with that operator; pcg_workspace: nksr_pcg_vector_workspace_bytes(M), or ..._seg(M, nseg, nranges) with segments.

@@ -47,7 +47,8 @@ class CellTableT(C.Structure):
 class FusedOpT(C.Structure):
     _fields_ = [('depth', _i32), ('M', _i32), ('n_multi', _i32), ('n_big', _i32), ('rows_total', _i64), ('rows_all', _vp),
                 ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('nbrT', _vp), ('item_begin', _vp), ('offsets', _vp), ('multi', _vp), ('nblocks', _i64),
-                ('nnz_counter', _vp), ('workspace', _vp), ('cell_sums', _vp), ('item_seg', _vp), ('unknown_seg', _vp)]
+                ('nnz_counter', _vp), ('workspace', _vp), ('cell_sums', _vp), ('item_seg', _vp), ('unknown_seg', _vp),
+                ('fac_vec', _vp), ('fac_pos', _vp), ('psi_all', _vp), ('inv_w0', _f32), ('dense_from', _i32), ('dense_out', _vp)]
 
 
 class ChunkGridT(C.Structure):
@@ -159,6 +160,8 @@ _PROTOS = {
     'nksr_fused_tables': [_P(HierT), _i64, _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_fused_rhs_diag': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
+    'nksr_fused_expand_rows': [_P(FusedOpT), _vp],
+    'nksr_kernel_factors': [_P(HierT), _vp, _i64, C.c_int, C.c_int, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(SegmentsT), _P(C.c_double), _vp],
     'nksr_coarse_lambda_max': [_vp, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _P(SegmentsT), _i32, _vp],
     'nksr_coarse_pack_count': [_vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp],

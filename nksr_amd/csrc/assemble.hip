@@ -182,7 +182,9 @@ __device__ __forceinline__ void asm_accumulate_lm(const AsmArgs& A, int d, int r
         const int dd = col / 27, sl = col - dd * 27;
         P.on[n] = col < T || (col == T && S.target);
         P.mul[n] = (col == T && S.target) ? 1 : 27;
-        P.p[n] = (col == T && S.target) ? S.target : S.val + (col < T ? (int64_t)(d + dd) * S.level_stride * 27 + sl : 0);
+        // (columns past T are never used but their loads are unconditional: they read level d -- the array may START at the first
+        // level that has cells, see KernelField.assemble: a base shifted below it must not be dereferenced)
+        P.p[n] = (col == T && S.target) ? S.target : S.val + (col < T ? (int64_t)(d + dd) * S.level_stride * 27 + sl : (int64_t)d * S.level_stride * 27);
     }
     const float w = S.weight;
     float bA[ASM_TRIP][NT], bB[ASM_TRIP][NT];

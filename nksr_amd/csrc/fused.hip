@@ -166,6 +166,13 @@ struct FusedArgs {               // uniform scalars and base pointers only
     int seg_stride;
     const int* seg_done_count;   // device: finished segments so far (may be NULL); the per-cell sums and the gather look at their
     int seg_gate;                // unknowns' segments only once >= seg_gate have finished (the look-up costs ~20 % of those passes)
+    // factor form (kernel_dim 4, see k_kernel_factors in kfield.hip): the rows are rebuilt in registers from 16-byte records
+    const float4* fac_vec;       // [depth][rows_total] phi (position / header rows) or J_a (gradient rows), times sqrt(w); NULL = dense rows
+    const float4* fac_pos;       // [rows_total] p = x * inv_w0 (3 floats) + the row's kind (int bits)
+    const float4* psi_all;       // [M] psi of every unknown (levels concatenated)
+    float inv_w0;
+    int dense_from;              // set-up pass: the rebuilt rows of the levels >= dense_from are also written out dense
+    float* dense_out;            // [depth - dense_from][rows_total][27] or NULL (the coarse-level block of the preconditioner reads them)
 };
 __device__ __forceinline__ bool fz_seg_done(const FusedArgs& A, const int32_t* seg_of, int64_t i) {
     return A.seg_done && seg_of && A.seg_done[(int64_t)seg_of[i] * A.seg_stride] != 0;
@@ -193,6 +200,39 @@ __device__ __forceinline__ int half_lane_i(int v, int l, bool upper) {
 }
 __device__ __forceinline__ float half_lane_f(float v, int l, bool upper) { return __int_as_float(half_lane_i(__float_as_int(v), l, upper)); }
 
+
+// ---- factor form: the 27 slots of a row from its 16-byte records -----------------------------------------------------------------
+// Quadratic B-spline weight of the centre at offset o - 1 for local coordinate u, written  a + b (u - c)^2  with per-lane constants
+// (o = 0: 0.5 (1 - u)^2, 1: 0.75 - (u - 0.5)^2, 2: 0.5 u^2); its derivative is 2 b (u - c).  u = frac(p 2^-level) is exact: the
+// level-d cell of a site is floor(p 2^-d), and p 2^-d - floor(p 2^-d) needs no rounding.
+// (Measured and dropped: the same sums on v_mfma_f32_4x4x1 -- one quad lane per row, weights as a K = 2 polynomial product,
+// dot products as K = 4: 65 matrix instructions per trip, 27.2 ms per application of the 64-chunk scene against 22.4 ms for
+// this plain vector form at 7.3e9 VALU instructions; the dense-row sweep issues 2.3e9 and takes 11 ms.)
+#define FZ_RCAP 288                        // rows of a workgroup whose records are staged in LDS (a workgroup holds ~256; a unit that runs
+                                           // past this reads its records from memory)
+struct FzSpline { float a[3], b[3], c[3]; };      // per axis, for the lane's slot:  w(u) = a + b (u - c)^2,  dw/du = 2 b (u - c)
+__device__ __forceinline__ FzSpline fz_spline_consts(int s) {
+    FzSpline q;
+    const int o[3] = {s / 9, (s / 3) % 3, s % 3};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {          // o = 0: 0.5 (1 - u)^2;  1: 0.75 - (u - 0.5)^2;  2: 0.5 u^2
+        q.a[ax] = o[ax] == 1 ? 0.75f : 0.f;
+        q.b[ax] = o[ax] == 1 ? -1.f : 0.5f;
+        q.c[ax] = o[ax] == 0 ? 1.f : (o[ax] == 1 ? 0.5f : 0.f);
+    }
+    return q;
+}
+template <bool DER>
+__device__ __forceinline__ void fz_axis(float p, float scale, float a, float b, float c, float k, float& w, float& dw) {
+    const float u = __builtin_amdgcn_fractf(p * scale);
+    const float t = u - c, bt = b * t;
+    w = fmaf(bt, t, a);
+    if (DER) dw = bt * k;
+}
+__device__ __forceinline__ float fz_dot4(const float4& a, const float4& b) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+
 // MODE 0: the operator (t from x).  MODE 1: the set-up pass -- right-hand side (t = target) into ct / part, Jacobi diagonal
 // (P2 += rows^2) into ct2 / part2, and the count of non-zero slots, all in one sweep over the rows.
 //
@@ -203,8 +243,15 @@ __device__ __forceinline__ float half_lane_f(float v, int l, bool upper) { retur
 // that every load of a trip is independent), level-0 blocks are always complete when their unit ends (no exchange), and the coarser
 // levels change cell only BETWEEN units -- no trip is ever cut.  The row-streaming version spent ~600 instructions per 8 rows on
 // finding out which rows change cell at which level (rows x levels masks, half-lane selects, the cut loop); this one ~150.
-template <int MODE, int D, int U>
-__global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 6 : 5))) __launch_bounds__(FZ_BLOCK) k_fz_cells(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
+//
+// FAC (round 5): the rows are not read but REBUILT -- the workgroup stages the 16-byte factor records of its ~256 rows in LDS (one
+// coalesced burst per level: the only streaming loads of the kernel, all in flight at once), every cell change also fetches the psi
+// stencil of the new cell next to its x stencil, and a trip turns records + stencil into the same w[u][d] the dense form loads:
+//   position rows (<= 4 per trip):   w = B_s(u) <phi, psi_s>
+//   a normal site (header + 3 rows): w_a = <phi, psi_s> dB_s/dx_a + <J_a, psi_s> B_s    (B, dB shared by the three rows)
+// Everything downstream of w -- both products, blocks, exchange, staging -- is the dense form's code.
+template <int MODE, int D, int U, bool FAC>
+__global__ void __attribute__((amdgpu_waves_per_eu(FAC ? 3 : (D <= 4 ? 6 : 5)))) __launch_bounds__(FZ_BLOCK) k_fz_cells(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
                                                       float* __restrict__ part2, float* __restrict__ ct, float* __restrict__ ct2,
                                                       const int* __restrict__ done) {
     if (done && *done) return;
@@ -221,7 +268,36 @@ __global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 6 : 5))) __launch_bo
     __shared__ float st0[CAP0 * 27], st1[CAP1 * 27];
     __shared__ float st0b[MODE == 1 ? CAP0 * 27 : 1], st1b[MODE == 1 ? CAP1 * 27 : 1];
     __shared__ int stf[CAP0 + CAP1];
+    static_assert(!FAC || U == 4, "a normal site is one trip of four rows");
+    // (+ four overflow slots per half-wave: the records of a trip past the staged window are copied there first)
+    constexpr int RS = FZ_RCAP + 4 * FZ_HW;
+    __shared__ float4 fv[FAC ? D * RS : 1], fp[FAC ? RS : 1];
     for (int i = threadIdx.x; i < CAP0 + CAP1; i += FZ_BLOCK) stf[i] = 0;
+    const int W0 = __builtin_amdgcn_readfirstlane(A.item_begin[blockIdx.x * FZ_HW]);
+    if (FAC) {
+        // the records of the workgroup's rows [W0, W1): (D + 1) coalesced bursts, all loads before the first store.  Rows past the
+        // last one (a trip reads four) are zeroed: never used (their t is 0) but they must be finite
+        const int W1 = __builtin_amdgcn_readfirstlane(A.item_begin[(blockIdx.x + 1) * FZ_HW]);
+        if (MODE == 0 && W1 > W0 && fz_seg_done(A, A.item_seg, W0 >> 5)) return;      // (a workgroup lies inside ONE segment)
+        const int nw = W1 - W0 < FZ_RCAP ? W1 - W0 : FZ_RCAP;
+        if (nw > 0) {
+            const int t0 = threadIdx.x, t1 = threadIdx.x + FZ_BLOCK;
+            float4 v0[D + 1], v1[D + 1];
+#pragma unroll
+            for (int d = 0; d <= D; ++d) {
+                const float4* src = (d < D ? A.fac_vec + (int64_t)d * A.rows_total : A.fac_pos) + W0;
+                v0[d] = src[t0 < nw ? t0 : nw - 1];
+                v1[d] = src[t1 < nw ? t1 : nw - 1];
+            }
+            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int d = 0; d <= D; ++d) {
+                float4* dst = d < D ? fv + d * RS : fp;
+                if (t0 < nw + 4 && t0 < FZ_RCAP) dst[t0] = t0 < nw ? v0[d] : zero;
+                if (t1 < nw + 4 && t1 < FZ_RCAP) dst[t1] = t1 < nw ? v1[d] : zero;
+            }
+        }
+    }
     __syncthreads();
     const int hwi = threadIdx.x >> 5;
     const int item = blockIdx.x * FZ_HW + hwi;
@@ -234,7 +310,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 6 : 5))) __launch_bo
     // (the rows of a segment whose conjugate gradients have finished are skipped: a workgroup lies inside ONE segment -- segments
     // are padded to whole workgroups)
     if (MODE == 0 && Re > Rb && fz_seg_done(A, A.item_seg, Rb >> 5)) Re = Rb;
-    const int W0 = __builtin_amdgcn_readfirstlane(A.item_begin[blockIdx.x * FZ_HW]);
     // first cell of the staged levels with rows in this workgroup (uniform)
     const int cw0 = __builtin_amdgcn_readfirstlane((int64_t)W0 < A.rows_total ? A.row_cells[W0] : -1);
     const int cw1 = __builtin_amdgcn_readfirstlane((D > 1 && (int64_t)W0 < A.rows_total) ? A.row_cells[A.rows_total + W0] : -1);
@@ -302,40 +377,53 @@ __global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 6 : 5))) __launch_bo
     int pos = 0, r = Rb, uend = unit_end(0);
     int c0 = __shfl(cells[0], 0, 32);
     int line0;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ps[FAC ? D : 1];                                          // FAC: the psi stencil of the current cell of every coarse level
     {
         int cd[D], nb0[D];
         float x0[D];
+        float4 p0[FAC ? D : 1];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             cd[d] = __shfl(cells[d], 0, 32);
             nb0[d] = A.nbr32[(int64_t)(cd[d] >= 0 ? cd[d] : 0) * 32 + s];
         }
 #pragma unroll
-        for (int d = 1; d < D; ++d) x0[d] = MODE == 0 ? x[(act && nb0[d] >= 0) ? nb0[d] : 0] : 0.f;
+        for (int d = 1; d < D; ++d) {
+            x0[d] = MODE == 0 ? x[(act && nb0[d] >= 0) ? nb0[d] : 0] : 0.f;
+            if (FAC) p0[d] = A.psi_all[(act && nb0[d] >= 0) ? nb0[d] : 0];
+        }
         line0 = nb0[0];
 #pragma unroll
         for (int d = 1; d < D; ++d) {
             have[d] = work && cd[d] >= 0;
             enter(d, nb0[d]);
             xs[d] = (have[d] && act && nb0[d] >= 0) ? x0[d] : 0.f;
+            if (FAC) ps[d] = (have[d] && act && nb0[d] >= 0) ? p0[d] : zero4;
         }
+        if (FAC) ps[0] = zero4;
     }
+    const FzSpline bq = fz_spline_consts(sc);
     int nnz = 0;                                                     // MODE 1: this lane's non-zero slots (stored entries of G and Q)
     // one pointer per level; the U rows of a trip are loaded at immediate offsets.  Rows past the unit's (or the item's) last one are
     // read too (the array is padded by 320 rows) and never used: their t is 0
     const float* wp[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) wp[d] = A.rows_all + (int64_t)d * A.rows_total * 27 + sc;
+    for (int d = 0; d < D; ++d) wp[d] = FAC ? nullptr : A.rows_all + (int64_t)d * A.rows_total * 27 + sc;
     while (__any(work)) {
         // all loads of the trip: U rows x D levels, the x stencil of the unit's level-0 cell, the neighbour row of the NEXT unit's
         // level-0 cell (all unconditional -- clamped addresses, results masked afterwards: a load under a branch makes the compiler
         // lose count of the outstanding loads and wait for all of them)
         float w[U][D];
-        #pragma unroll
-        for (int u = 0; u < U; ++u)
+        if (!FAC) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) w[u][d] = FZ_ROW_LOAD(wp[d] + ((int64_t)r + u) * 27);
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int d = 0; d < D; ++d) w[u][d] = FZ_ROW_LOAD(wp[d] + ((int64_t)r + u) * 27);
+        }
         const float xg = MODE == 0 ? x[(act && line0 >= 0) ? line0 : 0] : 0.f;
+        float4 pg = zero4;
+        if (FAC) pg = A.psi_all[(act && line0 >= 0) ? line0 : 0];
         float tg[U];
         if (MODE == 1) {
 #pragma unroll
@@ -344,7 +432,68 @@ __global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 6 : 5))) __launch_bo
         const int npos = uend - Rb;                                   // the next unit starts here, if the item goes on
         const int cn = __shfl(cells[0], npos & 31, 32);
         const int line0n = A.nbr32[(int64_t)((uend < Re && cn >= 0) ? cn : 0) * 32 + s];
-        const int nt = work ? (uend - r < U ? uend - r : U) : 0;      // rows of this trip
+        int nt = work ? (uend - r < U ? uend - r : U) : 0;            // rows of this trip
+        if (FAC) {
+            // the records of rows r .. r + 3 from LDS (all lanes of the half-wave read the same address: a broadcast)
+            int rl = r - W0;
+            if (rl + U > FZ_RCAP) {
+                // (rare: a unit that runs past the staged window -- a cell with dozens of points: its records are copied to the
+                // half-wave's four overflow slots first)
+                rl = FZ_RCAP + 4 * hwi;
+                if (s < 4) {
+                    fp[rl + s] = A.fac_pos[(int64_t)r + s];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) fv[d * RS + rl + s] = A.fac_vec[(int64_t)d * A.rows_total + r + s];
+                }
+            }
+            float4 pq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) pq[u] = fp[rl + u];
+            // a trip is EITHER a run of position rows OR one normal site (header + three gradient rows: always inside one unit)
+            const bool site = __float_as_int(pq[0].w) == 1;
+            const bool q1 = __float_as_int(pq[1].w) == 0, q2 = q1 && __float_as_int(pq[2].w) == 0, q3 = q2 && __float_as_int(pq[3].w) == 0;
+            const int np = site ? U : 1 + (q1 ? 1 : 0) + (q2 ? 1 : 0) + (q3 ? 1 : 0);
+            nt = nt < np ? nt : np;
+            ps[0] = (c0 >= 0 && act && line0 >= 0) ? pg : zero4;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const float scale = __int_as_float((127 - d) << 23);          // 2^-d
+                const float k2 = 2.f * A.inv_w0 * scale;                       // 2 / w_d
+                float4 vq[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) vq[u] = fv[d * RS + rl + u];
+                if (site) {
+                    float wx, wy, wz, dx, dy, dz;
+                    fz_axis<true>(pq[0].x, scale, bq.a[0], bq.b[0], bq.c[0], k2, wx, dx);
+                    fz_axis<true>(pq[0].y, scale, bq.a[1], bq.b[1], bq.c[1], k2, wy, dy);
+                    fz_axis<true>(pq[0].z, scale, bq.a[2], bq.b[2], bq.c[2], k2, wz, dz);
+                    const float yz = wy * wz, B = wx * yz;
+                    const float g = fz_dot4(vq[0], ps[d]);
+                    w[0][d] = 0.f;
+                    w[1][d] = fmaf(fz_dot4(vq[1], ps[d]), B, g * (dx * yz));
+                    w[2][d] = fmaf(fz_dot4(vq[2], ps[d]), B, g * ((wx * wz) * dy));
+                    w[3][d] = fmaf(fz_dot4(vq[3], ps[d]), B, g * ((wx * wy) * dz));
+                } else {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        float wx, wy, wz, unused;
+                        fz_axis<false>(pq[u].x, scale, bq.a[0], bq.b[0], bq.c[0], 0.f, wx, unused);
+                        fz_axis<false>(pq[u].y, scale, bq.a[1], bq.b[1], bq.c[1], 0.f, wy, unused);
+                        fz_axis<false>(pq[u].z, scale, bq.a[2], bq.b[2], bq.c[2], 0.f, wz, unused);
+                        w[u][d] = fz_dot4(vq[u], ps[d]) * (wx * (wy * wz));
+                    }
+                }
+            }
+            if (MODE == 1 && A.dense_out) {
+                // the coarse-level block of the preconditioner is assembled from DENSE rows: the levels it covers leave here
+#pragma unroll
+                for (int d = 0; d < D; ++d)
+                    if (d >= A.dense_from && act)
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+                            if (u < nt) A.dense_out[((int64_t)(d - A.dense_from) * A.rows_total + r + u) * 27 + s] = w[u][d];
+            }
+        }
         const float x0 = (c0 >= 0 && act && line0 >= 0) ? xg : 0.f;
         float t[U];
         if (MODE == 0) {
@@ -396,12 +545,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(D <= 4 ? 6 : 5))) __launch_bo
                         P[d] = 0.f;
                         if (MODE == 1) P2[d] = 0.f;
                         xs[d] = 0.f;
+                        if (FAC) ps[d] = zero4;
                         const int cd = __shfl(cells[d], pos, 32);
                         have[d] = cd >= 0;
                         if (have[d]) {
                             const int nbv = A.nbr32[(int64_t)cd * 32 + s];
                             enter(d, nbv);
                             if (MODE == 0 && act && nbv >= 0) xs[d] = x[nbv];
+                            if (FAC && act && nbv >= 0) ps[d] = A.psi_all[nbv];
                         }
                     }
             }
@@ -622,7 +773,12 @@ extern "C" int nksr_fused_tables(const nksr_hier_t* h, int64_t rows_total, const
 static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
     if (!op) return nksr_set_error(NKSR_ERR_ARG, "operator is NULL");
     if (op->depth < 1 || op->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", op->depth);
-    if (op->M > 0 && (!op->rows_all || !op->row_cells || !op->nbr32 || !op->nbrT || !op->item_begin || !op->offsets || !op->workspace || !op->cell_sums ||
+    const bool fac = op->fac_vec != nullptr;
+    if (fac && (!op->fac_pos || !op->psi_all || !(op->inv_w0 > 0.f) || (((uintptr_t)op->fac_vec | (uintptr_t)op->fac_pos | (uintptr_t)op->psi_all) & 15)))
+        return nksr_set_error(NKSR_ERR_ARG, "factor form: fac_pos / psi_all / inv_w0 missing or arrays not 16-byte aligned");
+    if (op->dense_out && (!fac || op->dense_from < 0 || op->dense_from >= op->depth))
+        return nksr_set_error(NKSR_ERR_ARG, "dense_out needs the factor form and 0 <= dense_from < depth");
+    if (op->M > 0 && ((!op->rows_all && !fac) || !op->row_cells || !op->nbr32 || !op->nbrT || !op->item_begin || !op->offsets || !op->workspace || !op->cell_sums ||
                       (op->n_multi > 0 && !op->multi) || op->n_big < 0 || op->n_big > op->n_multi))
         return nksr_set_error(NKSR_ERR_ARG, "operator has NULL arrays");
     if (op->rows_total < 0 || op->rows_total >= ((int64_t)1 << 31) - 2 * FZ_WG_ROWS || op->nblocks >= ((int64_t)1 << 31) - ((int64_t)1 << 26))
@@ -634,25 +790,32 @@ static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
     A.nnz_counter = (unsigned long long*)op->nnz_counter;
     A.item_seg = op->item_seg; A.unknown_seg = op->unknown_seg;
     A.hw_total = fz_items(op->rows_total);
+    A.fac_vec = (const float4*)op->fac_vec; A.fac_pos = (const float4*)op->fac_pos; A.psi_all = (const float4*)op->psi_all;
+    A.inv_w0 = op->inv_w0; A.dense_from = op->dense_from; A.dense_out = op->dense_out;
     return NKSR_OK;
 }
 
 // rows per trip
 #define FZ_ROWS_PER_TRIP 4
 
-template <int MODE>
-static void fz_sweep(const FusedArgs& A, const float* x, const FusedWork& w, const int* done, hipStream_t st) {
-    if (A.hw_total <= 0) return;
+template <int MODE, bool FAC>
+static void fz_sweep_launch(const FusedArgs& A, const float* x, const FusedWork& w, const int* done, hipStream_t st) {
     constexpr int U = FZ_ROWS_PER_TRIP;
     const dim3 grid(nksr_blocks((int64_t)A.hw_total, FZ_HW)), blk(FZ_BLOCK);
     switch (A.depth) {
-        case 1: hipLaunchKernelGGL((k_fz_cells<MODE, 1, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 2: hipLaunchKernelGGL((k_fz_cells<MODE, 2, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 3: hipLaunchKernelGGL((k_fz_cells<MODE, 3, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 4: hipLaunchKernelGGL((k_fz_cells<MODE, 4, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 5: hipLaunchKernelGGL((k_fz_cells<MODE, 5, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        default: hipLaunchKernelGGL((k_fz_cells<MODE, 6, U>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 1: hipLaunchKernelGGL((k_fz_cells<MODE, 1, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 2: hipLaunchKernelGGL((k_fz_cells<MODE, 2, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 3: hipLaunchKernelGGL((k_fz_cells<MODE, 3, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 4: hipLaunchKernelGGL((k_fz_cells<MODE, 4, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 5: hipLaunchKernelGGL((k_fz_cells<MODE, 5, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        default: hipLaunchKernelGGL((k_fz_cells<MODE, 6, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
     }
+}
+template <int MODE>
+static void fz_sweep(const FusedArgs& A, const float* x, const FusedWork& w, const int* done, hipStream_t st) {
+    if (A.hw_total <= 0) return;
+    if (A.fac_vec) fz_sweep_launch<MODE, true>(A, x, w, done, st);
+    else fz_sweep_launch<MODE, false>(A, x, w, done, st);
 }
 
 static void fz_cellsum(const FusedArgs& A, const float* part, float* ct, const int* done, hipStream_t st) {
@@ -709,6 +872,20 @@ extern "C" int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* 
     return NKSR_OK;
 }
 
+extern "C" int nksr_fused_expand_rows(const nksr_fused_op_t* op, void* stream) {
+    FusedArgs A;
+    if (int rc = fz_args(A, op)) return rc;
+    if (A.M <= 0) return NKSR_OK;
+    if (!A.fac_vec || !A.dense_out) return nksr_set_error(NKSR_ERR_ARG, "expand_rows needs the factor form and dense_out");
+    A.nnz_counter = nullptr;
+    const FusedWork w = fz_carve(op);
+    const float* nof = nullptr;
+    const int* nod = nullptr;
+    fz_sweep<1>(A, nof, w, nod, (hipStream_t)stream);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
 struct FusedOperator : PcgOperator {
     FusedArgs A; float reg; FusedWork w;
     int apply(const float* p, float* y, const int* done, const int* seg_done, int seg_stride, const int* seg_done_count, int seg_count,
@@ -735,6 +912,15 @@ struct FusedOperator : PcgOperator {
         *alg = 4.0 * stored + 4.0 * A.depth * (double)A.rows_total + (108.0 + 8.0) * A.M + 4.0;
         *phys = 4.0 * slots + 4.0 * A.depth * (double)A.rows_total + 2.0 * 128.0 * (double)A.nblocks + (128.0 + 3.0 * 108.0 + 12.0) * A.M;
         *survey = 2.0 * 8.0 * stored + 12.0 * A.M + 4.0;
+        if (A.fac_vec) {
+            // Factor form (round 5): the operator no longer holds the entries of G and Q -- it rebuilds them.  Its minimum is what
+            // defines it: one 16-byte record per row and level + one position record per row, the row -> cell map, and per cell the
+            // 27-entry stencil (108 bytes), psi (16 bytes, every unknown's once), x and y.  Physical adds the 128-byte neighbour row
+            // per cell, the slot-major per-cell sums written + read, the slot-major neighbour table and the partial blocks.
+            const double rec = 16.0 * (A.depth + 1) * (double)A.rows_total + 4.0 * A.depth * (double)A.rows_total;
+            *alg = rec + (108.0 + 16.0 + 8.0) * A.M + 4.0;
+            *phys = rec + 2.0 * 128.0 * (double)A.nblocks + (128.0 + 16.0 + 3.0 * 108.0 + 12.0) * A.M;
+        }
     }
 };
 

@@ -284,6 +284,62 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
     }
 }
 
+// ---- rank-K FACTORS of the kernel rows (kernel_dim 4; the matrix-free solve, csrc/fused.hip) --------------------------------------
+// A dense-slot row is a rank-K object:  row[s] = B_s(u) <phi, psi_s>  (position rows),  d/dx_a: <phi, psi_s> dB_s/dx_a + <J_a, psi_s> B_s
+// with phi = phi_d(x) (K floats), J_a = d phi / d x_a, u = the local coordinate of x in its level-d cell -- and u follows from the
+// ONE fp32 product p = x * inv_w0 at every level (u_d = frac(p 2^-d)).  Instead of 108 bytes per row and level this writes
+//   vec[d][row] (16 bytes):  position row: phi;  a normal site owns FOUR rows: a header row (phi) and one row per axis (J_a)
+//   pos[row]    (16 bytes):  p (3 floats) + the row's kind (int bits: 0 position, 1 header, 2 + a gradient row of axis a)
+// all pre-multiplied by sqrt(weight); the sweep rebuilds the 27 slots in registers from them and the psi stencil of the cell.
+// The header row is a row of the operator like any other (all-zero: it contributes nothing, its target is 0).
+// grid.y = level; one thread per site.
+template <int H, bool GRAD, bool JAC>
+__global__ void __launch_bounds__(128) k_kernel_factors(nksr_hier_t hier, const float* __restrict__ xyz, int64_t n, float row_scale_,
+                              const float* __restrict__ site_scale, int64_t level_stride, const int32_t* __restrict__ row_index,
+                              int32_t* __restrict__ row_cells, float4* __restrict__ vec, float4* __restrict__ pos) {
+    constexpr int K = 4;
+    const int d = blockIdx.y;
+    const nksr_level_t& lv = hier.lv[d];
+    __shared__ float w[MlpView<K, H>::SIZE];
+    for (int i = threadIdx.x; i < MlpView<K, H>::SIZE; i += blockDim.x) w[i] = lv.mlp[i];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
+    const float row_scale = site_scale ? site_scale[i] : row_scale_;
+    const SiteCell sc = locate_site(lv, d, hier.inv_w0, x);
+    constexpr int NR = GRAD ? 4 : 1;
+    const int64_t r0 = row_index ? row_index[i] : i * NR;
+    if (d == 0) {
+        const float px = __fmul_rn(x[0], hier.inv_w0), py = __fmul_rn(x[1], hier.inv_w0), pz = __fmul_rn(x[2], hier.inv_w0);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) pos[r0 + q] = make_float4(px, py, pz, __int_as_float(GRAD ? 1 + q : 0));
+    }
+    if (row_cells) {
+        const int cj = sc.cell >= 0 ? lv.offset + sc.cell : -1;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) row_cells[(int64_t)d * level_stride + r0 + q] = cj;
+    }
+    float4* out = vec + (int64_t)d * level_stride + r0;
+    if (sc.cell < 0) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) out[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
+    float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
+    trilerp_feat<K, JAC>(lv, d, sc, inv_w, t, Jt);
+    MlpView<K, H> m(w);
+    mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
+    out[0] = make_float4(phi[0] * row_scale, phi[1] * row_scale, phi[2] * row_scale, phi[3] * row_scale);
+    if (GRAD) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            out[1 + a] = JAC ? make_float4(J[0][a] * row_scale, J[1][a] * row_scale, J[2][a] * row_scale, J[3][a] * row_scale)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 // ---- f(x) = sum_d sum_s alpha_j K_d(x, c_j) ---------------------------------------------------
 template <int K, int H, bool GRAD, bool JAC>
 __global__ void __launch_bounds__(128) k_evaluate_f(nksr_hier_t hier, const float* __restrict__ alpha, const float* __restrict__ xyz,
@@ -405,6 +461,30 @@ extern "C" int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t 
         else if (approx) hipLaunchKernelGGL((k_kernel_rows<K, H, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, site_scale, level_stride, row_index, row_cells, val, dval);
         else hipLaunchKernelGGL((k_kernel_rows<K, H, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, site_scale, level_stride, row_index, row_cells, val, dval);
     })
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+extern "C" int nksr_kernel_factors(const nksr_hier_t* h, const float* xyz, int64_t n, int grad, int approx, float row_scale,
+                                   const float* site_scale, int64_t level_stride, const int32_t* row_index, int32_t* row_cells,
+                                   float* vec_out, float* pos_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (!h || !xyz || !vec_out || !pos_out || level_stride <= 0) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays / level_stride <= 0");
+    if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
+    if (h->kdim != 4 || (h->hidden != 16 && h->hidden != 32))
+        return nksr_set_error(NKSR_ERR_ARG, "kernel factors need kernel_dim 4 and hidden_dim 16 / 32 (got %d, %d)", h->kdim, h->hidden);
+    if (((uintptr_t)vec_out | (uintptr_t)pos_out) & 15) return nksr_set_error(NKSR_ERR_ARG, "factor arrays must be 16-byte aligned");
+    dim3 grid(nksr_blocks(n, 128), h->depth), block(128);
+    float4* vec = (float4*)vec_out;
+    float4* pos = (float4*)pos_out;
+#define NKSR_LAUNCH_FACTORS(H_)                                                                                                              \
+    do {                                                                                                                                     \
+        if (!grad) hipLaunchKernelGGL((k_kernel_factors<H_, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, site_scale, level_stride, row_index, row_cells, vec, pos); \
+        else if (approx) hipLaunchKernelGGL((k_kernel_factors<H_, true, false>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, site_scale, level_stride, row_index, row_cells, vec, pos); \
+        else hipLaunchKernelGGL((k_kernel_factors<H_, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz, n, row_scale, site_scale, level_stride, row_index, row_cells, vec, pos); \
+    } while (0)
+    if (h->hidden == 16) NKSR_LAUNCH_FACTORS(16); else NKSR_LAUNCH_FACTORS(32);
+#undef NKSR_LAUNCH_FACTORS
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }

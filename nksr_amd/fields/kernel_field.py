@@ -166,6 +166,24 @@ class KernelField(BaseField):
         call('nksr_kernel_rows', C.byref(self._hier), ptr(xyz), xyz.shape[0], int(self.approx_kernel_grad), float(scale), ptr(site_scale), int(level_stride),
              ptr(row_index), ptr(row_cells), None if grad else ptr(out), ptr(out) if grad else None, stream())
 
+    def kernel_factors_level_major(self, xyz, grad, scale, vec, pos, level_stride, row_index=None, row_cells=None, site_scale=None):
+        """The rank-4 factor records of the sites' rows (csrc/kfield.hip: k_kernel_factors; kernel_dim 4): ``vec`` [L, level_stride, 4],
+        ``pos`` [level_stride, 4]; a position site owns one row, a normal site (grad=True) four (header + one per axis)."""
+        call('nksr_kernel_factors', C.byref(self._hier), ptr(xyz), xyz.shape[0], int(bool(grad)), int(self.approx_kernel_grad), float(scale),
+             ptr(site_scale), int(level_stride), ptr(row_index), ptr(row_cells), ptr(vec), ptr(pos), stream())
+
+    def _row_format(self):
+        """'dense' (the default: 108 bytes per row and level, the sweep streams them -- HBM-bound) or 'factors' (kernel_dim 4 only,
+        opt-in by solver_config['row_format'] / NKSR_ROW_FORMAT: 16-byte records per row and level, the sweep rebuilds the 27
+        slots in registers -- a fifth of the memory (8 GB instead of 38 GB on the 64-chunk scene), but bound by vector-ALU issue:
+        22 ms per application there against 11 ms)."""
+        want = self.solver_config.get('row_format') or os.environ.get('NKSR_ROW_FORMAT') or 'auto'
+        if want not in ('auto', 'factors', 'dense'):
+            raise RuntimeError("row_format must be 'auto', 'factors' or 'dense'")
+        if want == 'factors' and self.kdim != 4:
+            raise RuntimeError('the factor form of the kernel rows needs kernel_dim 4')
+        return 'factors' if (want == 'factors' and self.kdim == 4) else 'dense'
+
     def _sorted_sites(self, xyz):
         """Permutation that Morton-sorts sites by their level-0 cell + the sorted keys."""
         n = xyz.shape[0]
@@ -209,7 +227,15 @@ class KernelField(BaseField):
             off = self.svh.offsets
             S = sets[0]
             S.n, S.ncomp, S.weight = fused_op['rows_total'], 1, 1.0
-            S.val, S.level_stride = ptr(fused_op['rows_all']), fused_op['rows_total']
+            if fused_op.get('row_format') == 'factors':
+                # the factor form holds no dense rows: those of the levels >= coarse_from were written out by the set-up sweep
+                # (or are expanded now); the array starts at level coarse_from, the assembly indexes levels absolutely
+                dense = self._dense_coarse_rows(fused_op, int(coarse_from))
+                S.val = dense.data_ptr() - int(coarse_from) * fused_op['rows_total'] * 27 * 4
+                keep.append(dense)
+            else:
+                S.val = ptr(fused_op['rows_all'])
+            S.level_stride = fused_op['rows_total']
             for d in range(self.svh.depth):
                 nd = self.svh.level(d).num_voxels
                 S.start[d], S.end[d] = ptr(st_all[off[d]:off[d] + nd]), ptr(en_all[off[d]:off[d] + nd])
@@ -351,9 +377,12 @@ class KernelField(BaseField):
         M, L = svh.num_unknowns, svh.depth
         if M == 0:
             raise RuntimeError('empty hierarchy')
+        fac = self._row_format() == 'factors'
         specs = []
+        # (ncomp = ROWS a site owns in the list: a normal site three -- or, in the factor form, four: a header row that carries phi
+        # and contributes nothing, then one row per axis)
         for xyz, target, weight, ncomp, pre in ((pos_xyz, pos_value, pos_weight, 1, pos_sorted_keys),
-                                                 (normal_xyz, normal_value, normal_weight, 3, normal_sorted_keys)):
+                                                 (normal_xyz, normal_value, normal_weight, 4 if fac else 3, normal_sorted_keys)):
             if xyz is None or xyz.shape[0] == 0:
                 continue
             per_site = torch.is_tensor(weight)            # batched chunks: every site carries its own chunk's sqrt(weight)
@@ -438,26 +467,43 @@ class KernelField(BaseField):
             row_index = list(torch.split(row_of_site, counts_s))
         td = _tick('_', time.perf_counter())
         pad = 320 * 27     # (the operator's loads are unconditional: the last workgroup reads up to 255 + 63 rows past the end)
-        rows_all = torch.empty(L * rows_total * 27 + pad, dtype=torch.float32, device=dev)
-        rows_all[L * rows_total * 27:].zero_()
+        rows_all = fac_vec = fac_pos = psi_all = None
+        if fac:
+            fac_vec = torch.empty(L * rows_total * 4 + 320 * 4, dtype=torch.float32, device=dev)
+            fac_vec[L * rows_total * 4:].zero_()
+            fac_pos = torch.empty((rows_total + 320) * 4, dtype=torch.float32, device=dev)
+            fac_pos[rows_total * 4:].zero_()
+            psi_all = torch.cat([p.reshape(-1, 4) for p in self._psi]).contiguous()
+            assert psi_all.shape[0] == M
+        else:
+            rows_all = torch.empty(L * rows_total * 27 + pad, dtype=torch.float32, device=dev)
+            rows_all[L * rows_total * 27:].zero_()
         row_cells = torch.empty((L, rows_total), dtype=torch.int32, device=dev)
         targets_all = torch.zeros(rows_total + 320, dtype=torch.float32, device=dev)[:rows_total]      # (readable past the end, like the rows)
         if pad_rows is not None and pad_rows.numel():
             row_cells[:, pad_rows] = -1
-            rows_all[:L * rows_total * 27].view(L, rows_total, 27)[:, pad_rows] = 0.0
-        keep = [rows_all, targets_all, row_cells]
+            if fac:
+                fac_vec[:L * rows_total * 4].view(L, rows_total, 4)[:, pad_rows] = 0.0
+                fac_pos[:rows_total * 4].view(rows_total, 4)[pad_rows] = 0.0                             # (kind 0: a position row without a cell)
+            else:
+                rows_all[:L * rows_total * 27].view(L, rows_total, 27)[:, pad_rows] = 0.0
+        keep = [rows_all, fac_vec, fac_pos, psi_all, targets_all, row_cells]
         td = _tick('op:alloc', td)
         for (xs, ks, perm, target, sw, ncomp), ri in zip(specs, row_index):
             ri = ri.contiguous()
-            if torch.is_tensor(sw):
-                self.kernel_rows_level_major(xs, ncomp == 3, 1.0, rows_all, rows_total, ri, row_cells, site_scale=sw)
+            tensor_w = torch.is_tensor(sw)
+            if fac:
+                self.kernel_factors_level_major(xs, ncomp == 4, 1.0 if tensor_w else sw, fac_vec, fac_pos, rows_total, ri, row_cells,
+                                                site_scale=sw if tensor_w else None)
             else:
-                self.kernel_rows_level_major(xs, ncomp == 3, sw, rows_all, rows_total, ri, row_cells)
+                self.kernel_rows_level_major(xs, ncomp == 3, 1.0 if tensor_w else sw, rows_all, rows_total, ri, row_cells,
+                                             site_scale=sw if tensor_w else None)
             if target is not None:
+                nc = 3 if ncomp >= 3 else 1                                                             # target components; the header row's is 0
                 tgt = target.detach().to(dev, torch.float32)
-                tgt = (tgt[perm] if perm is not None else tgt).reshape(xs.shape[0], ncomp)
-                tgt = tgt * (sw[:, None] if torch.is_tensor(sw) else sw)                               # row order (site, component)
-                targets_all[(ri.long()[:, None] + torch.arange(ncomp, device=dev)[None]).reshape(-1)] = tgt.reshape(-1)
+                tgt = (tgt[perm] if perm is not None else tgt).reshape(xs.shape[0], nc)
+                tgt = tgt * (sw[:, None] if tensor_w else sw)                                           # row order (site, component)
+                targets_all[(ri.long()[:, None] + (ncomp - nc) + torch.arange(nc, device=dev)[None]).reshape(-1)] = tgt.reshape(-1)
             keep += [xs, ri]
         td = _tick('op:kernel_rows', td)
         # work items = runs of 32 rows, eight of them a workgroup of the sweep; a cell whose rows lie inside one workgroup is finished
@@ -478,6 +524,8 @@ class KernelField(BaseField):
         op = FusedOpT()
         op.depth, op.M, op.n_multi, op.n_big, op.rows_total, op.nblocks = L, M, int(multi.numel()), int(big.numel()), rows_total, nblocks
         op.rows_all, op.targets_all, op.row_cells, op.nbr32, op.nbrT = ptr(rows_all), ptr(targets_all), ptr(row_cells), ptr(nbr32), ptr(nbrT)
+        if fac:
+            op.fac_vec, op.fac_pos, op.psi_all, op.inv_w0 = ptr(fac_vec), ptr(fac_pos), ptr(psi_all), float(svh.inv_w0)
         op.item_begin = ptr(item_begin)
         op.offsets, op.multi, op.workspace, op.cell_sums = ptr(offsets), (ptr(multi) if multi.numel() else None), ptr(ws), ptr(cell_sums)
         # SURVEY.md section 8d counts the operator's bytes per STORED entry; the dense-slot rows hold structural zeros (absent
@@ -490,14 +538,51 @@ class KernelField(BaseField):
         keep += [nbr32, nbrT, item_begin, offsets, multi, ws, cell_sums, nnz_counter]
         td = _tick('op:tables', td)
         return {'op': op, 'nsets': len(specs), 'nblocks': nblocks, 'rows_total': rows_total, 'n_multi': int(multi.numel()),
-                'nnz_counter': nnz_counter, 'keep': keep, 'span': span, 'rows_all': rows_all}
+                'nnz_counter': nnz_counter, 'keep': keep, 'span': span, 'rows_all': rows_all, 'row_format': 'factors' if fac else 'dense',
+                'fac_vec': fac_vec, 'fac_pos': fac_pos, 'row_cells': row_cells, 'targets_all': targets_all}
 
-    def fused_rhs_diag(self, op, reg_weight=1.0):
+    def fused_rhs_diag(self, op, reg_weight=1.0, dense_from=None):
+        """Right-hand side and Jacobi diagonal from ONE set-up sweep.  ``dense_from`` = c0 (factor form only): the sweep also leaves
+        the rebuilt rows of the levels >= c0 in op['dense'] -- what the coarse-level block of the preconditioner is assembled from."""
         M = self.svh.num_unknowns
         b = torch.empty(M, dtype=torch.float32, device=self.device)
         diag = torch.empty(M, dtype=torch.float32, device=self.device)
+        if dense_from is not None and op.get('row_format') == 'factors':
+            self._arm_dense(op, int(dense_from))
         call('nksr_fused_rhs_diag', C.byref(op['op']), float(reg_weight), ptr(b), ptr(diag), stream())
+        if op.get('dense') is not None:
+            op['op'].dense_out = None          # (written; later sweeps must not write it again)
         return b, diag
+
+    def _arm_dense(self, op, c0):
+        L = self.svh.depth
+        dense = torch.empty((L - c0, op['rows_total'], 27), dtype=torch.float32, device=self.device)
+        op['dense'], op['dense_from'] = dense, c0
+        op['op'].dense_from, op['op'].dense_out = c0, ptr(dense)
+        return dense
+
+    def _dense_coarse_rows(self, op, c0):
+        """[L - c0, rows_total, 27] dense rows of the levels >= c0 of a factor-form operator (taken over: the operator forgets them)."""
+        dense = op.get('dense')
+        if dense is None or op.get('dense_from') != c0:
+            dense = self._arm_dense(op, c0)
+            call('nksr_fused_expand_rows', C.byref(op['op']), stream())
+            op['op'].dense_out = None
+        op['dense'] = None
+        return dense
+
+    def _pc_first_level(self, segments=None):
+        """First level of the coarse-level block the solve is going to build at once, or None (see solve_fused / _coarse_precond)."""
+        cfg = self.solver_config.get('coarse_precond')
+        if cfg is False:
+            return None
+        auto = cfg is None and segments is None
+        if auto and self.svh.depth < 5:
+            return None
+        cfg = cfg if isinstance(cfg, dict) else {}
+        c0 = int(cfg.get('first_level', float(os.environ.get('NKSR_PC_LEVEL', 2))))
+        off, M = self.svh.offsets, self.svh.num_unknowns
+        return c0 if (0 < c0 < self.svh.depth and M - off[c0] >= 1) else None
 
     def stored_entries(self):
         """Non-zero entries of G and Q of the last matrix-free solve (counted by its diagonal pass; one small device read)."""
@@ -613,7 +698,7 @@ class KernelField(BaseField):
         td = _tick('fused_operator', td)
         dev = self.device
         M = self.svh.num_unknowns
-        b, diag = self.fused_rhs_diag(op, reg_weight)
+        b, diag = self.fused_rhs_diag(op, reg_weight, dense_from=self._pc_first_level(segments))
         td = _tick('rhs_diag', td)
         cfg, tol = self.solver_config, float(self.solver_config['tol'])
         max_iter, check_every = int(cfg['max_iter']), int(cfg['check_every'])
@@ -625,6 +710,7 @@ class KernelField(BaseField):
         # chunk's iterates depend on its batch mates.
         auto = cfg.get('coarse_precond') is None and segments is None
         pc = self._coarse_precond(op, reg_weight, segments) if (not auto or self.svh.depth >= 5) else None
+        op['dense'] = None                      # (dense coarse rows nobody took over)
         td = _tick('coarse_precond', td)
         if cfg.get('verbose') or cfg.get('sync_timing'):
             torch.cuda.current_stream().synchronize()

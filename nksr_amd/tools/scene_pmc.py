@@ -20,7 +20,10 @@ GROUPS = [
     ['TCC_HIT_sum', 'TCC_MISS_sum'],
     ['TCP_TOTAL_CACHE_ACCESSES_sum', 'TCP_TCC_READ_REQ_sum', 'TCP_PENDING_STALL_CYCLES_sum', 'TA_TA_BUSY_sum'],
     ['TA_ADDR_STALLED_BY_TC_CYCLES_sum', 'TA_DATA_STALLED_BY_TC_CYCLES_sum', 'TCP_TCP_TA_DATA_STALL_CYCLES_sum', 'TD_TD_BUSY_sum'],
+    ['SQ_ACTIVE_INST_LDS', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_WAIT_INST_LDS', 'SQ_INSTS_SMEM', 'SQ_ACTIVE_INST_SCA', 'SQ_INSTS_VMEM_WR', 'SQ_INSTS_FLAT'],
 ]
+if os.environ.get('NKSR_PMC_GROUPS'):       # e.g. "0,1,7": a quick look at the issue / wait split only
+    GROUPS = [GROUPS[int(i)] for i in os.environ['NKSR_PMC_GROUPS'].split(',')]
 LAST_BENCH_LINE = None
 KERNELS = ['k_cell_blocks', 'k_fz_cells', 'k_cheb16_step', 'k_kernel_rows', 'k_sparse_conv3', 'k_splat_mean32', 'k_splat_trilinear',
            'k_fz_gather', 'k_fz_cellsum', 'k_evaluate_f', 'k_build_nbr', 'k_row_count', 'k_row_fill']
@@ -104,6 +107,8 @@ def main():
     json.dump(rec, open(out, 'w'), indent=1, sort_keys=True)
     for k in sorted(rec['kernels'], key=lambda k: -rec['kernels'][k].get('us_pass0', 0)):
         e = rec['kernels'][k]
+        if os.environ.get('NKSR_PMC_GROUPS'):
+            print(k, {c: v for c, v in sorted(e.items())})
         print('%-42s %8.0f us  fetch %.2f TB/s  l2hit %.2f  wait %.2f  stall %.2f  active %.2f  waves %d' % (
             k, e.get('us_pass0', 0), e.get('fetch_TBps', 0), e.get('l2_hit', 0), e.get('SQ_WAIT_ANY_frac', 0), e.get('SQ_WAIT_INST_ANY_frac', 0),
             e.get('SQ_ACTIVE_INST_ANY_frac', 0), e.get('SQ_WAVES', 0)))

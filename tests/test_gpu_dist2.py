@@ -73,7 +73,7 @@ def _worker(rank, world, port, out_path, q):
                 if grid[a] > 1:
                     m &= (xyz[:, a] >= lo[a] + c3[a] * cs - band - 1e-3) & (xyz[:, a] < lo[a] + (c3[a] + 1) * cs + band + 1e-3)
             keep |= m
-        assert 0.3 < keep.mean() < 0.95                      # a real shard, not the whole cloud
+        assert 0.1 < keep.mean() < 0.95                      # a real shard, not the whole cloud
         t = lambda a: torch.from_numpy(a).to(dev)
         fld = rec.reconstruct(t(xyz[keep]), t(nrm[keep]), detail_level=None, chunk_size=cs, sharded_input=True, chunk_owner=owner,
                               chunk_bounds=([float(v) for v in lo], [float(v) for v in hi]))
@@ -105,19 +105,22 @@ def _position_canon(v, f):
     return v[np.argsort(vb, kind='stable')], tri[np.argsort(tb, kind='stable')]
 
 
-def test_two_ranks_one_gpu_equal_one_rank():
+@pytest.mark.parametrize('world', [2, 4])
+def test_ranks_on_one_gpu_equal_one_rank(world):
+    """2 and 4 processes (9 chunks: every rank owns a compact Morton block, ranks exchange halos with several neighbours and
+    rank 0 stitches up to four pieces)."""
     import nksr_amd
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    out_path = os.path.join(tempfile.gettempdir(), 'nksr_dist2_%d.npz' % os.getpid())
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out_path, q)) for r in range(2)]
+    out_path = os.path.join(tempfile.gettempdir(), 'nksr_dist%d_%d.npz' % (world, os.getpid()))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out_path, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in range(2)]
+    res = [q.get(timeout=600) for _ in range(world)]
     for p in procs:
         p.join(120)
-    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+    assert sorted(res) == [(r, 'ok') for r in range(world)], res
     got = np.load(out_path)
     os.remove(out_path)
     # single rank, full cloud, same chunking
@@ -156,3 +159,29 @@ def test_bench_gpus_2_spawns_two_ranks_on_one_gpu():
     assert [p['rank'] for p in per] == [0, 1] and all(p['chunks'] == 32 for p in per)
     assert all(p['t_exchange'] > 0 and p['t_pcg'] > 0 and p['t_mesh'] > 0 for p in per) and per[0]['t_gather'] > 0
     assert d['cpu_baseline'] is None and 'cloud_1m' not in d and d['value'] > 0
+
+
+def test_bench_gpus_8_gives_the_mesh_of_gpus_1_on_a_small_scene():
+    """The 8-rank path end to end on one GPU (eight processes, gloo): every rank owns eight chunks of the 8 x 8 scene, halos travel
+    between seven peers, rank 0 stitches eight pieces -- vertex and triangle counts of the merged mesh equal the single-process
+    run's.  (The full 10 M-point rehearsal: profiles/r05_bench_eight_processes_one_gpu.json -- 11 414 509 vertices and
+    22 801 560 triangles, the 1-rank numbers.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NKSR_DIST_BACKEND='gloo')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    got = {}
+    for n in (1, 8):
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '1', '--warmup', '0', '--scene-points', '640000',
+                              '--no-cpu-baseline', '--no-cloud', '--no-small-inputs'], capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+        assert len(lines) == 1
+        got[n] = json.loads(lines[0])
+    d1, d8 = got[1], got[8]
+    assert d8['n_gpus'] == 8 and d8['dist']['rccl_ranks_seen'] == 8 and [p['chunks'] for p in d8['dist']['per_rank']] == [8] * 8
+    assert d8['config']['mesh_vertices'] == d1['config']['mesh_vertices'] > 0
+    assert d8['config']['mesh_triangles'] == d1['config']['mesh_triangles'] > 0

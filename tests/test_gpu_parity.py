@@ -196,11 +196,14 @@ def test_assembly_and_spmv():
     assert float((s1[0] - s0[0]).abs().max()) <= 1e-4 * float(s1[0].abs().max())
 
 
+@pytest.mark.parametrize('row_format', ['factors', 'dense'])
 @pytest.mark.parametrize('approx', [False, True])
-def test_fused_operator_matches_the_assembled_matrix(approx):
+def test_fused_operator_matches_the_assembled_matrix(approx, row_format, monkeypatch):
     """fused_mode=True (examples/recons_waymo.py:33): the matrix-free operator, its right-hand side and diagonal against
-    the assembled CSR of the same system and against the oracle's matrix; fixed-iteration PCG iterates of the two solves."""
+    the assembled CSR of the same system and against the oracle's matrix; fixed-iteration PCG iterates of the two solves.
+    Both row formats of the operator: 16-byte factor records (the sweep rebuilds the slots) and dense 27-slot rows."""
     import scipy.sparse as sp
+    monkeypatch.setenv('NKSR_ROW_FORMAT', row_format)
     from nksr_amd import solver
     from nksr_amd.fields import KernelField
     from oracle import solve
@@ -213,6 +216,7 @@ def test_fused_operator_matches_the_assembled_matrix(approx):
     A, b, _, _, _ = solve.assemble(oh, feats, ointerps, xyz, nxyz, nval, wp, wn, 1.0, approx)
     rowptr, cols, vals, diag, gb = fld.assemble(t(xyz), t(nxyz), t(nval), wp, wn, 1.0)
     op = fld.fused_operator(t(xyz), t(nxyz), t(nval), wp, wn)
+    assert op['row_format'] == row_format
     M = A.shape[0]
     fb, fd = fld.fused_rhs_diag(op, 1.0)
     pu.check('fused:rhs_rel', np.abs(fb.cpu().numpy() - b).max() / np.abs(b).max(), 1e-5)
@@ -271,8 +275,12 @@ def test_row_order_by_rank_passes_equals_the_sorted_merge(monkeypatch):
     for mode in ('merge', 'sort'):
         monkeypatch.setenv('NKSR_ROW_ORDER', mode)
         op = fld.fused_operator(t(xyz), t(nxyz), t(nval), 1e4 / len(xyz), 1e2 / len(nxyz))
-        n = op['op'].depth * op['rows_total'] * 27
-        out[mode] = (op['rows_all'][:n].clone(), op['keep'][2].clone(), op['keep'][1].clone(), op['rows_total'])
+        if op['row_format'] == 'factors':
+            n = op['op'].depth * op['rows_total'] * 4
+            rows = torch.cat([op['fac_vec'][:n], op['fac_pos'][:op['rows_total'] * 4]])
+        else:
+            rows = op['rows_all'][:op['op'].depth * op['rows_total'] * 27]
+        out[mode] = (rows.clone(), op['row_cells'].clone(), op['targets_all'].clone(), op['rows_total'])
     assert out['merge'][3] == out['sort'][3]
     assert torch.equal(out['merge'][1], out['sort'][1]) and torch.equal(out['merge'][2], out['sort'][2])
     assert torch.equal(out['merge'][0].view(torch.int32), out['sort'][0].view(torch.int32))
