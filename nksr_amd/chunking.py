@@ -972,8 +972,10 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
         timing['t_exchange'] = _now(rec) - t_x          # halo exchange: pack, size + byte collectives, the remote field's tables
     # (batches parked on chunk_tmp_device stay there: the blend borrows one part at a time -- borrowed() -- so meshing a scene
     # whose chunks do not fit the GPU together works as the reference's small-memory recipe says, NKSR-USAGE.md:150-167)
-    return MultiChunkField(parts, cores, ov, lo, chunk_size, grid, owner, rank, ws, frame, interps, dev, distributed=active,
-                           adaptive_depth=int(hp.adaptive_depth))
+    mf = MultiChunkField(parts, cores, ov, lo, chunk_size, grid, owner, rank, ws, frame, interps, dev, distributed=active,
+                         adaptive_depth=int(hp.adaptive_depth))
+    mf.dual_graph = getattr(rec, 'dual_graph', 'lattice')      # ('adaptive' takes effect while ONE process holds the field, nksr_amd/meshing.py)
+    return mf
 
 
 def _now(rec):

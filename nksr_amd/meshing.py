@@ -30,9 +30,11 @@ def _cell_vertices(cell_keys_raw):
 
 def extract_dual_mesh(field, mise_iter=0, grid_upsample=1, max_points=-1):
     # field.dual_graph = 'adaptive': cells as large as the hierarchy level that carries them (the reference's dual graph of the
-    # flattened levels); 'lattice' (default): one uniform lattice over the adaptive support.  Chunked / distributed fields mesh
-    # on the lattice either way: their seams are stitched by lattice vertex keys.
-    if getattr(field, 'dual_graph', 'lattice') == 'adaptive' and not hasattr(field, 'finalize_mesh') and not hasattr(field, 'base_cell_mask'):
+    # flattened levels); 'lattice' (default): one uniform lattice over the adaptive support.
+    # A chunked field held by ONE process meshes its union hierarchy (levels < adaptive_depth on the global lattice) with the blended
+    # field like any other; only fields spread over several ranks stay on the lattice (their pieces are stitched by lattice vertex keys).
+    spread = hasattr(field, 'finalize_mesh') and (getattr(field, 'world_size', 1) > 1 or getattr(field, 'distributed', False))
+    if getattr(field, 'dual_graph', 'lattice') == 'adaptive' and not spread:
         return _extract_adaptive(field, mise_iter, grid_upsample, max_points)
     res = _extract(field, mise_iter, grid_upsample, max_points)
     if hasattr(field, 'finalize_mesh'):       # distributed fields gather + stitch the pieces (collective)

@@ -30,7 +30,7 @@ class Reconstructor:
         # chunk mode: ALL chunks of a rank are solved as one block-diagonal system (nksr_amd/chunking.py); chunk_batch_points caps the
         # points (band included) of one such batch -- ~2 KB of HBM per point at tree_depth 5 -- None = 2^25.  Results do not depend on it.
         self.chunk_batch_points = None
-        self.dual_graph = 'lattice'      # 'adaptive': extract_dual_mesh on the adaptive dual graph (cells as large as their level; nksr_amd/meshing.py); chunked fields always use the lattice
+        self.dual_graph = 'lattice'      # 'adaptive': extract_dual_mesh on the adaptive dual graph (cells as large as their level; nksr_amd/meshing.py); a chunked field spread over several ranks uses the lattice
         self.chunk_spill_dir = None      # chunk mode, batches parked on a CPU chunk_tmp_device: a directory -> the parked batches live in unlinked files there
         #                                  (chunking.spill_to_disk: out-of-core beyond host memory; not part of the reference surface)
         self.coarse_precond = None  # matrix-free solve: None = automatic (coarse-level block preconditioner for 5+ levels), False = Jacobi only,

@@ -141,8 +141,12 @@ class ChunkedField:
                 keep[sel] |= d < np.float32(f.get('udf_level_set', 2 * f['voxel_size']))
         return keep
 
-    def extract_dual_mesh(self, mise_iter=0, grid_upsample=1, info=None):
+    def extract_dual_mesh(self, mise_iter=0, grid_upsample=1, info=None, dual_graph='lattice'):
         has_mask = any(f.get('udf_feats') is not None for f in self.fields.values())
+        if dual_graph == 'adaptive':          # the dual graph of the UNION hierarchy's flattened levels, blended field values
+            from . import dual_adaptive
+            return dual_adaptive.extract(self.voxel_size, [L.ijk for L in self.union.levels[:self.adaptive_depth]], lambda p: self.evaluate(p)[0],
+                                         mise_iter, grid_upsample, mask_fn=(self.mask if has_mask else None), info=info)
         return meshing.extract(self.voxel_size, self.union.levels[0], lambda p: self.evaluate(p)[0], mise_iter, grid_upsample,
                                mask_fn=(self.mask if has_mask else None), info=info, coarser=self.union.levels[1:self.adaptive_depth])
 

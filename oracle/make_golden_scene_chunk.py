@@ -7,8 +7,8 @@ chunk_size = one tile), solved by the oracle -- the reference solves its chunks 
     python -m oracle.make_golden_scene_chunk [chunk id, default 27]        (tens of minutes of CPU, ~25 GB; run in the dev container)
 
 Writes tests/golden/scene_chunk<id>_golden.npz: the chunk's points count, per-level voxel counts and key digests, the converged
-coefficients alpha (fp32, solved to 3e-7), the iteration count of the oracle's Jacobi-PCG and a sample of field values at the
-chunk's own points.  tests/test_gpu_full_size.py compares the segment of the 64-chunk batch with it (check_alpha, 1e-4 of max|alpha|:
+coefficients alpha (fp32, solved to 3e-7), the iteration count of the oracle's Jacobi-PCG and field values + gradients at 4 500
+probes (input points and the same points half a voxel along +- their normals, in the chunk's slot of the exploded frame).  tests/test_gpu_full_size.py compares the segment of the 64-chunk batch with it (check_alpha, 1e-4 of max|alpha|:
 the SURVEY.md section 8c contract) -- the bench-scale SOLUTION pinned on the oracle, not only sampled operator rows.
 The inputs are regenerated from seeds (nksr_amd.utils.terrain_tile: numpy RandomState, bit-stable), not stored.
 """
@@ -82,10 +82,14 @@ def run(c=27):
            'alpha': fld['alpha'].astype(np.float32), 'iters': np.int64(fld['iters']), 'rel': np.float64(fld['rel']),
            'level_n': np.asarray([L.n for L in fld['hier'].levels], np.int64),
            'level_key_sha256': np.asarray([digest(L.keys.astype(np.int64)) for L in fld['hier'].levels])}
+    # field probes: input points of the chunk and the same points moved half a finest voxel along +- their normals
+    # (f ~ 0 on the data says little about the scale of f; half a voxel away it is O(gradient x 0.05))
     rs = np.random.RandomState(0)
-    pick = np.sort(rs.choice(xs.shape[0], 4000, replace=False))
-    f, g = pipeline.evaluate(fld, xs[pick], grad=True)
-    out['probe_index'], out['probe_f'], out['probe_grad'] = pick.astype(np.int64), f.astype(np.float32), g.astype(np.float32)
+    pick = np.sort(rs.choice(xs.shape[0], 1500, replace=False))
+    off = np.float32(0.5 * hp.voxel_size)
+    pxyz = np.concatenate([xs[pick], (xs[pick] + off * nrm[pick]).astype(np.float32), (xs[pick] - off * nrm[pick]).astype(np.float32)]).astype(np.float32)
+    f, g = pipeline.evaluate(fld, pxyz, grad=True)
+    out['probe_xyz'], out['probe_f'], out['probe_grad'] = pxyz, f.astype(np.float32), g.astype(np.float32)
     out['alpha_absmax'] = np.float64(np.abs(fld['alpha']).max())
     os.makedirs(GOLD, exist_ok=True)
     path = os.path.join(GOLD, 'scene_chunk%d_golden.npz' % c)

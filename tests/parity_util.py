@@ -225,3 +225,74 @@ def mesh_parity(name, fld, ofl, mise_iter, scale=1.0, grid_upsample=1, w0=0.1):
     mesh = fld.extract_dual_mesh(mise_iter=mise_iter, grid_upsample=grid_upsample)
     st = compare_meshes(name, *mesh_arrays(mesh, scale), ref, delta_f=delta, w0=w0)
     return st, mesh, (ov, of)
+
+
+def window_mesh_check(name, fld, scale, mise_iter, centre_ijk, radius, w0=0.1, min_triangles=200):
+    """Bench-scale meshes against the oracle where the oracle can go: a WINDOW of the finest level.
+
+    The voxels of ``fld.svh.level(0)`` inside the box centre +- radius become an oracle level; oracle.meshing.extract runs on it
+    with the HIP field's own lattice values (``_evaluate_f_model`` at the oracle's lattice positions -- the same positions, the same
+    kernel: the comparison isolates the integer / topology work and the vertex interpolation at the size bench.py times) and the
+    HIP mask.  Base cells at least two cells inside the box see exactly the neighbourhood they have in the full mesh (MISE's
+    hanging-vertex rule looks one cell around); every oracle triangle of those cells must be in the HIP mesh, in the same order,
+    every HIP triangle whose cell lies three cells inside must be in the oracle's, and common vertices agree to 1e-4 voxel (the
+    plain SURVEY.md section 8d bound -- no widening: both sides interpolate the same values)."""
+    import torch
+    from oracle import hierarchy as ohier
+    dev = fld.svh.level(0).ijk.device
+    g0 = fld.svh.level(0)
+    ijk = g0.ijk.cpu().numpy().astype(np.int64)
+    keys = g0.keys.cpu().numpy()
+    c = np.asarray(centre_ijk, np.int64)
+    lo, hi = c - radius, c + radius
+    inw = ((ijk >= lo[None]) & (ijk <= hi[None])).all(1)
+    lvl = ohier.Level(keys[inw], 0, w0)
+    lvl.build_nbr()
+
+    def ev(p):
+        t = torch.from_numpy(np.ascontiguousarray(p, np.float32)).to(dev)
+        return fld._evaluate_f_model(t, False, max_points=1 << 22).value.cpu().numpy()
+
+    def mk(p):
+        m = fld.mask_vertices(torch.from_numpy(np.ascontiguousarray(p, np.float32)).to(dev))
+        return np.ones(len(p), bool) if m is None else m.cpu().numpy()
+    info = {}
+    ov, of = omesh.extract(w0, lvl, ev, mise_iter=mise_iter, grid_upsample=1, mask_fn=mk, info=info)
+    to = canonical_triangles(of, info['vert_vkey'], info['vert_axis'])
+    base_o = info['tri_cell'].astype(np.int64) >> mise_iter
+    in2 = ((base_o >= (lo + 2)[None]) & (base_o <= (hi - 3)[None])).all(1)          # (a base cell spans ijk .. ijk + 1)
+    # the HIP mesh, cut down on the device to the triangles around the window before anything moves to the host
+    mesh = fld.extract_dual_mesh(mise_iter=mise_iter)
+    vm = mesh.v * float(scale)
+    blo = torch.tensor(((lo - 1) * w0).tolist(), dtype=torch.float32, device=vm.device)
+    bhi = torch.tensor(((hi + 2) * w0).tolist(), dtype=torch.float32, device=vm.device)
+    vin = ((vm >= blo[None]) & (vm <= bhi[None])).all(1)
+    tin = torch.nonzero(vin[mesh.f].all(1)).reshape(-1)
+    gf = mesh.f[tin].cpu().numpy()
+    uv, inv = np.unique(gf.reshape(-1), return_inverse=True)
+    gf = inv.reshape(-1, 3)
+    sel = torch.from_numpy(uv).to(vm.device)
+    gv, gk, ga = vm[sel].cpu().numpy(), mesh.edge_vkey[sel].cpu().numpy(), mesh.edge_axis[sel].cpu().numpy().astype(np.int64)
+    tg = canonical_triangles(gf, gk, ga)
+    vg, vo = _rows_view(tg), _rows_view(to)
+    pos_in_hip = {k.tobytes(): i for i, k in enumerate(vg)}
+    where = np.asarray([pos_in_hip.get(k.tobytes(), -1) for k in vo[in2]], np.int64)
+    missing = int((where < 0).sum())
+    ordered = bool((np.diff(where[where >= 0]) > 0).all())
+    clo, chi = triangle_cells(tg)
+    in3 = (((clo >> mise_iter) >= (lo + 3)[None]) & ((chi >> mise_iter) <= (hi - 4)[None])).all(1)
+    extra = int((~np.isin(vg[in3], vo)).sum())
+    idg = _rows_view(np.stack([gk.astype(np.int64), ga], 1))
+    ido = _rows_view(np.stack([info['vert_vkey'].astype(np.int64), info['vert_axis'].astype(np.int64)], 1))
+    inner_v = np.zeros(len(ido), bool)                       # vertices of the compared triangles only: at the window's rim the oracle's
+    inner_v[np.asarray(of)[in2].reshape(-1)] = True          # hanging-vertex rule sees cells the full mesh has and the window lacks
+    _, ig, io = np.intersect1d(idg, ido[inner_v], return_indices=True)
+    io = np.nonzero(inner_v)[0][io]
+    dv = float(np.abs(gv[ig].astype(np.float64) - ov[io].astype(np.float64)).max() / w0) if len(ig) else 0.0
+    report(name, window_voxels=int(inw.sum()), oracle_triangles=len(to), compared=int(in2.sum()), hip_inner=int(in3.sum()), missing=missing,
+           extra=extra, ordered=ordered, common_vertices=len(ig), max_dv_voxel=dv)
+    assert int(in2.sum()) >= min_triangles, '%s: window holds only %d triangles' % (name, int(in2.sum()))
+    assert missing == 0 and extra == 0, '%s: %d oracle triangles missing from the HIP mesh, %d HIP triangles unknown to the oracle' % (name, missing, extra)
+    assert ordered, '%s: same triangles in a different order' % name
+    check(name + ':vertex_dv_voxel', dv, 1e-4)
+    return {'compared': int(in2.sum()), 'max_dv_voxel': dv}

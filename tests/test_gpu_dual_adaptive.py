@@ -117,3 +117,24 @@ def test_uniform_hierarchy_gives_the_lattice_mesh(sphere_field):
     finally:
         fld.dual_graph, fld.meshing_depth = 'lattice', depth
     assert a.f.shape[0] > 1000 and torch.equal(a.f, b.f) and torch.equal(a.v, b.v)
+
+
+@pytest.mark.parametrize('mise_iter', [0, 1])
+def test_chunked_field_meshes_on_the_adaptive_dual_graph_of_its_union_hierarchy(mise_iter):
+    """reconstruct(chunk_size=) with adaptive_depth 2, held by one process: ``dual_graph='adaptive'`` meshes the union hierarchy of the
+    chunks (levels 0 and 1 on the global lattice) with the BLENDED field -- against oracle/dual_adaptive.py on the same two levels,
+    fed with the same blended values (the seam crosses the window: both chunks and the partition-of-unity weights enter)."""
+    import nksr_amd
+    from nksr_amd import configs, utils
+    from oracle import dual_adaptive as da
+    xyz, nrm = utils.synth_terrain_patch(16000, seed=7, extent=(8.0, 4.0))
+    rec = nksr_amd.Reconstructor(_dev(), hparams=configs.get_hparams('ks', adaptive_depth=2))
+    rec.dual_graph = 'adaptive'
+    fld = rec.reconstruct(torch.from_numpy(xyz).to(_dev()), torch.from_numpy(nrm).to(_dev()), detail_level=None, chunk_size=4.0 + 1e-3)
+    assert len(fld.fields) >= 2 and fld.meshing_depth == 2 and fld.dual_graph == 'adaptive'
+    levels = [fld.svh.level(d).ijk.cpu().numpy() for d in range(2)]
+    assert all(len(l) for l in levels)
+    ov, of = da.extract(fld.svh.voxel_size, levels, _eval(fld), mise_iter, 1, mask_fn=_mask(fld))
+    mesh = fld.extract_dual_mesh(mise_iter=mise_iter)
+    assert len(of) > 1000
+    _compare('dual_adaptive[chunked,mise=%d]' % mise_iter, mesh, ov, of, getattr(fld, 'scale', 1.0))

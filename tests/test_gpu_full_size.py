@@ -1,6 +1,9 @@
 """BASELINE.json's full single-GPU size (configs[2]: 1 000 000 points, detail_level=1.0): size-independent properties
  and -- what the oracle CAN do at this size -- the voxel hierarchy bit for bit, and kernel rows /
 rows of the normal-equation operator against the oracle on a sample of sites / unknowns."""
+import hashlib
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -254,6 +257,18 @@ def test_mesh_is_watertight_and_on_the_data(big, mise_iter):
     assert bool(torch.isfinite(mesh.v).all())
 
 
+@pytest.mark.parametrize('mise_iter', [0, 1])
+def test_full_size_mesh_window_matches_the_oracle_mesher(big, mise_iter):
+    """The 1 M-point mesh against oracle/meshing.py on a window of ~20^3 finest voxels (the oracle cannot mesh 750 000 voxels, it can
+    mesh a few thousand): the oracle mesher runs on the window's voxels with the HIP field's lattice values; triangles of the
+    window's inner cells index-exact and in the same order, vertices within 1e-4 voxel."""
+    import parity_util as pu
+    rec, fld, xyz, nrm = big
+    g0 = fld.svh.level(0)
+    centre = g0.ijk[g0.num_voxels // 2].tolist()
+    pu.window_mesh_check('full_size:mesh_window[mise=%d]' % mise_iter, fld, fld.scale, mise_iter, centre, 10, w0=rec.hparams.voxel_size)
+
+
 # ---- BASELINE.json configs[4] at its full size: the 64-chunk batch of bench.py -------------------------------------------------------
 def _bench():
     import importlib.util
@@ -359,8 +374,37 @@ def test_bench_scale_batch_is_its_solo_chunks_bit_for_bit_and_its_operator_rows_
     pu.report('bench_scale:operator_rows', chunk=c, unknowns=int(U.size), pos_sites=int(psel.size), normal_sites=int(qsel.size), batch_M=M)
     pu.check('bench_scale:fused_apply_rows', (np.abs(yf[U] - y[U]) / mag[U]).max(), 3e-6)
 
+    # ---- the mesh at a chunk SEAM against the oracle mesher (a window of ~20^3 finest voxels across the plane between chunk
+    # columns 3 | 4, inside the blend zone: both chunks' fields and the partition-of-unity weights enter every lattice value)
+    w0 = hp.voxel_size
+    seam_x = int(round(4 * b.TILE * scale / w0))
+    ug = fld.svh.level(0)
+    cand = torch.nonzero(ug.ijk[:, 0] == seam_x).reshape(-1)
+    assert cand.numel() > 0
+    centre = ug.ijk[cand[cand.numel() // 2]].tolist()
+    pu.window_mesh_check('bench_scale:seam_mesh_window', fld, getattr(fld, 'scale', 1.0), 1, centre, 10, w0=w0)
+
+    # ---- ONE FULL CHUNK against the oracle's complete solve of it (tests/golden/scene_chunk27_golden.npz, oracle/make_golden_scene_chunk.py:
+    # the reference solves its chunks one at a time, examples/recons_by_chunk.py:26-30 -- the oracle did exactly that for chunk 27)
+    gpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'scene_chunk%d_golden.npz' % c)
+    assert os.path.exists(gpath), 'missing fixture %s (python -m oracle.make_golden_scene_chunk %d)' % (gpath, c)
+    gold = np.load(gpath)
+    assert int(gold['points']) == p1 - p0 and float(gold['scale']) == float(scale)
+    assert [int(v) for v in gold['level_n']] == [int(hi[i, d] - lo[i, d]) for d in range(L)]
+    for d in range(L):
+        assert hashlib.sha256(np.ascontiguousarray(batch[c][0][d].cpu().numpy().astype(np.int64)).tobytes()).hexdigest() == str(gold['level_key_sha256'][d]), \
+            'chunk %d level %d: voxel keys differ from the oracle run' % (c, d)
+    amax = float(gold['alpha_absmax'])
+    pq = torch.from_numpy(gold['probe_xyz']).to(dev)
+    ev = bf._evaluate_f_model(pq, True)
+    fscale = float(np.abs(gold['probe_f']).max())
+    pu.report('bench_scale:golden_chunk', chunk=c, M=int(gold['alpha'].size), oracle_iters=int(gold['iters']), hip_iters=batch[c][2],
+              alpha_rel_at_default_tol=float(np.abs(batch[c][1].cpu().numpy() - gold['alpha']).max() / amax))
+    pu.check('bench_scale:golden_chunk:field_rel', float(np.abs(ev.value.cpu().numpy() - gold['probe_f']).max() / fscale), 1e-4)
+    pu.check('bench_scale:golden_chunk:gradient_abs', float(np.abs(ev.gradient.cpu().numpy() - gold['probe_grad']).max()), 1e-3)
+
     # ---- every chunk alone
-    del fld, part, bf, inp, seg
+    del fld, part, bf, inp, seg, ev
     torch.cuda.empty_cache()
     rec.keep_solve_inputs = False
     rec.chunk_batch_points = 1
@@ -373,3 +417,15 @@ def test_bench_scale_batch_is_its_solo_chunks_bit_for_bit_and_its_operator_rows_
             assert torch.equal(p.field.svh.level(d).keys, keys_b[d]), 'chunk %d level %d: voxel keys differ between batch and solo' % (c, d)
         assert p.field.solve_info['iters'] == it_b, 'chunk %d: %d iterations alone, %d in the batch' % (c, p.field.solve_info['iters'], it_b)
         assert torch.equal(p.field.alpha, alpha_b), 'chunk %d: coefficients differ between batch and solo' % c
+    # ---- converged coefficients: the same scene solved to 1e-6, chunk 27's segment against the oracle's alpha (1e-4)
+    del solo
+    torch.cuda.empty_cache()
+    rec.chunk_batch_points = None
+    rec.keep_solve_inputs = True
+    tight = rec.reconstruct(xyz, nrm, solver_tol=1e-6, **kw)
+    tb = tight.parts[0].field
+    tseg = tb._solve_inputs['segments']
+    tlo, thi = tseg.lo.cpu().numpy(), tseg.hi.cpu().numpy()
+    ti = tight.parts[0].ids.index(27)
+    a27 = torch.cat([tb.alpha[tlo[ti, d]:thi[ti, d]] for d in range(L)]).cpu().numpy()
+    pu.check('bench_scale:golden_chunk:alpha_rel', float(np.abs(a27 - gold['alpha']).max() / float(gold['alpha_absmax'])), pu.ALPHA_TOL)
