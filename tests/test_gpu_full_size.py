@@ -318,7 +318,7 @@ def test_bench_scale_batch_is_its_solo_chunks_bit_for_bit_and_its_operator_rows_
     assert max(v[2] for v in batch.values()) <= 40 and float(info[:, 1].max()) <= 1e-5
 
     # ---- one chunk of the batch against the oracle
-    i = 27
+    i = part.ids.index(27)                                          # chunk id 27 = tile (3, 3): the one the oracle solved in full (tests/golden)
     c = part.ids[i]
     pk = inp['pos_sorted_keys']
     p0, p1 = [int(v) for v in torch.searchsorted(pk, torch.stack([seg.key_lo[i], seg.key_hi[i]])).tolist()]
