@@ -92,6 +92,33 @@ def load_traffic_fused(bytes_per_launch):
     return _load_pmc('_fused_pmc.json', 'physical_bytes_per_application', 'hbm_bytes_per_application', bytes_per_launch, 'fused')
 
 
+def live_traffic_fused(flags, timeout_s=600):
+    """HBM bytes of one operator application collected IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- they do not
+    fit one pass; --kernel-trace only, no other trace domain) over one untimed step of the same scene in child processes, after the
+    timed region (nksr_amd/tools/scene_pmc.py, corrections as in MI355X_MICROARCH.md: KiB units, FETCH_SIZE doubled on gfx950).
+    Returns (bytes or None, per-kernel record or None, note)."""
+    import shutil
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, None, 'rocprofv3 not on PATH'
+    fd, path = tempfile.mkstemp(suffix='.json', prefix='nksr_live_pmc_')
+    os.close(fd)
+    env = dict(os.environ, NKSR_PMC_GROUPS='2,3', NKSR_BENCH_CHILD='1', TMPDIR='/tmp')
+    try:
+        r = subprocess.run([sys.executable, '-m', 'nksr_amd.tools.scene_pmc', path] + list(flags), env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
+        rec = json.load(open(path))
+        if 'hbm_bytes_per_application' not in rec:
+            return None, None, 'counter passes gave no operator record: %s' % (r.stderr[-300:].replace('\n', ' '))
+        return float(rec['hbm_bytes_per_application']), rec.get('operator_application'), None
+    except Exception as e:      # (a profiler that fails must not fail the measurement)
+        return None, None, 'live counter passes failed: %r' % (e,)
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+
+
 def roofline_record(ms, launches, alg, phys, survey, fused=False):
     """The CG operator application ("SpMV") measured live with HIP events on the solve stream inside the timed region.
     achieved / frac   = ALGORITHMIC bytes / time, a fraction of the 8 TB/s HBM peak (always <= 1):
@@ -204,6 +231,7 @@ def main():
     ap.add_argument('--no-cloud', action='store_true', help='skip the configs[2] sub-record (and with it spmv_csr_roofline)')
     ap.add_argument('--no-other-mode', action='store_true', help='skip the assembled-solve leg of the configs[2] sub-record')
     ap.add_argument('--no-small-inputs', action='store_true')
+    ap.add_argument('--no-live-pmc', action='store_true', help='do not collect roofline.traffic with rocprofv3 in this run (two counter passes over one extra step)')
     ap.add_argument('--cloud-steps', type=int, default=3)
     ap.add_argument('--dist-probe', action='store_true', help='launch check only: start the N ranks, run the handshake collectives over the '
                                                               'backend, print the ``dist`` record and exit (no reconstruction)')
@@ -399,6 +427,19 @@ def main():
         extra = None
     if world == 1 and not args.no_small_inputs:
         out['small_inputs'] = small_inputs(dev)
+    if rank == 0 and world == 1 and not args.no_live_pmc and not os.environ.get('NKSR_BENCH_CHILD') and out.get('roofline'):
+        # same-run counter figure for roofline.traffic (the committed record of profiles/ stays the fallback)
+        torch.cuda.empty_cache()
+        tb, per_kernel, note = live_traffic_fused(['--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-cloud', '--no-small-inputs', '--no-live-pmc',
+                                                   '--scene-points', str(args.scene_points), '--mise-iter', str(args.mise_iter),
+                                                   '--chunk-batch-points', str(args.chunk_batch_points)])
+        if tb is not None:
+            out['roofline']['traffic'] = tb
+            out['roofline']['traffic_source'] = 'live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over one step of this run (nksr_amd/tools/scene_pmc.py)'
+            out['roofline']['traffic_per_kernel'] = per_kernel
+            out['roofline'].pop('traffic_note', None)
+        elif note:
+            out['roofline']['traffic_live_note'] = note
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(dev, args, extra)
     elif rank == 0:

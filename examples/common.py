@@ -45,3 +45,18 @@ def load_waymo_example(n=1_500_000):
 
 def warning_on_low_memory(threshold_mb):
     utils.warning_on_low_memory(threshold_mb)
+
+
+def load_scannet_example(n=400_000):
+    """Stand-in for the downloadable ScanNet room (examples/common.py of the reference): an indoor-sized scene in metres -- a few
+    objects in an 8 x 6 x 3 m box, oriented, 5 mm noise -- so that voxel_size=0.02 (examples/recons_scannet.py:28) means what it
+    means there."""
+    return utils.synth_scene(n, seed=1, extent=(8.0, 6.0, 3.0), noise=0.005, n_objects=6)
+
+
+def load_las_example(n=300_000):
+    """Stand-in for the aerial LAS tile of examples/gis_app.py:14-30: terrain in metres with a large coordinate offset (the
+    example subtracts the mean before reconstruction and adds it back to mesh.v), seen from one sensor high above."""
+    xyz, _ = utils.synth_terrain(n, seed=2, extent=(40.0, 40.0))
+    offset = np.array([433_200.0, 5_213_400.0, 310.0])
+    return xyz.astype(np.float64) + offset[None], offset

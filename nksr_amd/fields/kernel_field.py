@@ -830,7 +830,11 @@ class KernelField(BaseField):
         theta = self._theta()
         if not theta:
             return []
-        if os.environ.get('NKSR_THETA_VJP', 'hip') != 'torch' and all(not torch.is_tensor(sw) for _, _, sw, _ in sets):
+        if os.environ.get('NKSR_THETA_VJP', 'hip') != 'torch':
+            # the product path: HIP kernels.  (The torch statement below is the REFERENCE the tests differentiate -- reached only
+            # with NKSR_THETA_VJP=torch; it is never a fallback.)
+            if any(torch.is_tensor(sw) for _, _, sw, _ in sets):
+                raise RuntimeError('the backward pass of a batched chunk solve (per-site weights) is not supported: train on single fields')
             return self._theta_vjp_hip(sets, alpha, lam)
         with torch.enable_grad():
             S = torch.zeros((), dtype=torch.float32, device=self.device)

@@ -68,7 +68,7 @@ def run_pass(counters, flags, tag):
 
 def main():
     out = sys.argv[1]
-    flags = sys.argv[2:] or ['--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-cloud', '--no-small-inputs']
+    flags = sys.argv[2:] or ['--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--no-cloud', '--no-small-inputs', '--no-live-pmc']
     rec = {'command': 'bench.py ' + ' '.join(flags), 'kernels': {}}
     for gi, g in enumerate(GROUPS):
         res = run_pass(g, flags, 'g%d' % gi)

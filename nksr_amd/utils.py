@@ -76,6 +76,16 @@ def write_ply_mesh(path, v, f, c=None):
         out.write(rec.tobytes())
 
 
+def write_obj_mesh(path, v, f):
+    """Wavefront OBJ (what the reference's examples write through pycg.vis.to_file, examples/gis_app.py:55).  ``v`` may be float64 in
+    a projected coordinate system (1e5 .. 1e6 metres): positions are written with 6 decimals, not through fp32."""
+    v = np.asarray(v.detach().cpu() if torch.is_tensor(v) else v, np.float64)
+    f = np.asarray(f.detach().cpu() if torch.is_tensor(f) else f, np.int64) + 1
+    with open(path, 'w') as out:
+        out.write(''.join('v %.6f %.6f %.6f\n' % (p[0], p[1], p[2]) for p in v))
+        out.write(''.join('f %d %d %d\n' % (t[0], t[1], t[2]) for t in f))
+
+
 def warning_on_low_memory(threshold_mb):
     if torch.cuda.is_available():
         free, _ = torch.cuda.mem_get_info()

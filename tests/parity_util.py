@@ -133,7 +133,7 @@ def tainted_cells(levels, eps):
     return out
 
 
-def compare_meshes(name, gv, gf, gvkey, gaxis, ref, delta_f, w0=0.1, max_tainted_frac=0.06, eps=None):
+def compare_meshes(name, gv, gf, gvkey, gaxis, ref, delta_f, w0=0.1, max_tainted_frac=0.06, eps=None, max_over_plain_frac=1e-3):
     """Unconditional topology + vertex-position comparison (positions in model units) of a HIP mesh against a
     reference record (ref_from_info / ref_from_golden).  ``delta_f``: measured max |f_hip - f_oracle| at the
     oracle's lattice vertices.  Returns a stats dict."""
@@ -176,6 +176,11 @@ def compare_meshes(name, gv, gf, gvkey, gaxis, ref, delta_f, w0=0.1, max_tainted
     if exact:   # identical triangle sets: the ORDER must be identical too (cell-major, table order) => index-exact faces
         assert np.array_equal(tg, to), '%s: same triangles in a different order' % name
         assert np.array_equal(np.asarray(gf, np.int64), np.asarray(of, np.int64)), '%s: face indices differ' % name
+    # vertices beyond the PLAIN contract (1e-4 voxel) -- allowed only through the widened bound above (an edge
+    # whose end values nearly coincide amplifies the field's own 1e-6 difference): tracked, and capped at one vertex in a thousand
+    # (round 4 measured 14 / 42 282 on street8, 27 / 65 386 on terrain5, <= 3 elsewhere)
+    if max_over_plain_frac is not None:
+        assert n_over_plain <= max(2, max_over_plain_frac * len(common)), '%s: %d of %d vertices beyond 1e-4 voxel' % (name, n_over_plain, len(common))
     if not (dv <= bound).all():
         w = int(np.argmax(dv / bound))
         raise AssertionError('%s: %d vertices beyond their bound; worst: off by %.3e voxel, bound %.3e voxel, |f0 - f1| = %.3e, at %s (oracle %s)' % (

@@ -39,7 +39,7 @@ def test_compare_meshes_localises_sign_flips():
     delta, _ = pu.lattice_delta(noisy, ref)
     assert 0 < delta <= amp * 1.01
     st = pu.compare_meshes('perturbed', v3, f3, info3['vert_vkey'], info3['vert_axis'], ref, delta_f=delta,
-                           max_tainted_frac=1.0, eps=delta * 1.0001)     # tightest valid eps: exactly the noise amplitude
+                           max_tainted_frac=1.0, eps=delta * 1.0001, max_over_plain_frac=None)     # tightest valid eps: exactly the noise amplitude
     assert st['only_hip'] + st['only_oracle'] > 0, 'perturbation too small to exercise the tainted-cell logic'
     assert st['outside_tainted'] == 0 and st['tainted_cells'] < 0.5 * st['final_cells']
 
