@@ -28,6 +28,7 @@ collective on the solve path, one all_gather of the chunk HALOS before meshing, 
 mesh pieces to rank 0 after it.
 """
 import contextlib
+import os
 import ctypes as C
 import math
 import weakref
@@ -903,7 +904,20 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     # (non-finite normals: caught by the box readback every batch starts with, Reconstructor._key_bits)
     # sub-batches of whole chunks (memory: ~2 KB per point at tree_depth 5), chunks of a batch in slot order
     jobs.sort(key=lambda c: frame.key_range(c)[0])
-    budget = int(getattr(rec, 'chunk_batch_points', 0) or (1 << 25))
+    budget = int(getattr(rec, 'chunk_batch_points', 0) or 0)
+    if budget <= 0:
+        # automatic: as many chunks per solve as the FREE memory of the device holds (the reference's chunk mode exists to bound
+        # memory, examples/recons_by_chunk.py:17-18) -- at most 2^25 points.  A batched solve takes ~4.5 KB of HBM per solved point
+        # at tree_depth 5 (84.7 GB for the 19.7 M band-included points of the 64-chunk scene; kernel rows are 45 % of it), in
+        # proportion to the depth; 70 % of what is free (+ what torch's allocator holds unused) may be planned with.  Results do not
+        # depend on the split (tests/test_gpu_full_size.py: a chunk alone == the chunk in the batch, bit for bit).
+        budget = 1 << 25
+        if dev.type == 'cuda' and fused_mode:
+            free = float(os.environ.get('NKSR_FREE_HBM_GB', 0)) * 1e9
+            if free <= 0:
+                free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            per_point = 4500.0 * hp.tree_depth / 5.0 * (0.6 if str(getattr(rec, 'row_format', None) or os.environ.get('NKSR_ROW_FORMAT')) == 'factors' else 1.0)
+            budget = int(max(min(budget, 0.7 * free / per_point), 1))
     if not fused_mode:
         budget = 0        # the assembled solve (fused_mode=False) has no segmented form: one chunk per solve, as the reference runs them
     batches, cur, acc = [], [], 0

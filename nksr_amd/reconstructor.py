@@ -35,6 +35,8 @@ class Reconstructor:
         #                                  (chunking.spill_to_disk: out-of-core beyond host memory; not part of the reference surface)
         self.coarse_precond = None  # matrix-free solve: None = automatic (coarse-level block preconditioner for 5+ levels), False = Jacobi only,
         #                             or {'first_level', 'steps', 'ratio'} (fields/kernel_field.py _coarse_precond)
+        self.row_format = None      # matrix-free solve: None / 'dense' = 27-slot kernel rows (the fast one), 'factors' = 16-byte factor records the sweep
+        #                             rebuilds the rows from (kernel_dim 4: a fifth of the row memory, twice the time per application; fields/kernel_field.py)
         self.keep_solve_inputs = False   # parity tests: the field keeps the site sets / weights of its solve (field._solve_inputs)
         self.col_format = 1        # physical layout of the assembled matrix (include/nksr_hip.h); int32 columns when M > 2^21
 
@@ -95,7 +97,7 @@ class Reconstructor:
         field = KernelField(svh=dec_svh, interpolator=self.network.interpolators, features=feat.basis_features,
                             approx_kernel_grad=approx_kernel_grad)
         field.solver_config.update({'max_iter': int(solver_max_iter), 'tol': float(solver_tol), 'sync_timing': self.sync_timing,
-                                    'col_format': self.col_format, 'coarse_precond': self.coarse_precond})
+                                    'col_format': self.col_format, 'coarse_precond': self.coarse_precond, 'row_format': self.row_format})
         normal_xyz = torch.cat([dec_svh.get_voxel_centers(d) for d in range(hp.adaptive_depth)])
         normal_value = torch.cat([feat.normal_features[d] for d in range(hp.adaptive_depth)])
         if self.sync_timing:

@@ -363,3 +363,33 @@ def test_parked_batches_spill_to_disk_and_mesh_bit_identically(tmp_path):
             assert tns.device.type == 'cpu' and (tns.numel() == 0 or tns.untyped_storage().filename is not None)
     mesh = field.extract_dual_mesh(mise_iter=1)
     assert torch.equal(mesh.v, m0.v) and torch.equal(mesh.f, m0.f)
+
+
+def test_chunk_batches_follow_the_free_memory_and_do_not_change_the_result(monkeypatch):
+    """chunk_batch_points = None: the chunks of a rank are split into batches by the FREE device memory (the reference's chunk mode
+    bounds memory, examples/recons_by_chunk.py:17-18).  With 0.35 GB declared free the scene takes several batches instead of one;
+    the mesh is the one-batch mesh bit for bit.  The factor form of the kernel rows (Reconstructor.row_format = 'factors') plans
+    with less memory per point and solves the same system (alpha within 1e-5 of the dense-row solve)."""
+    import nksr_amd
+    from nksr_amd import utils
+    xyz, nrm = utils.synth_scene(300000, seed=5, extent=(32.0, 24.0, 6.0), noise=0.0, n_objects=8)
+    xyz = (xyz - xyz.min(0)).astype(np.float32)
+    dev = torch.device('cuda:0')
+    t = lambda a: torch.from_numpy(a).to(dev)
+    out = {}
+    for name, free, fmt in (('one', None, None), ('split', '0.35', None), ('factors', None, 'factors')):
+        if free:
+            monkeypatch.setenv('NKSR_FREE_HBM_GB', free)
+        else:
+            monkeypatch.delenv('NKSR_FREE_HBM_GB', raising=False)
+        rec = nksr_amd.Reconstructor(dev)
+        rec.row_format = fmt
+        fld = rec.reconstruct(t(xyz), t(nrm), detail_level=None, chunk_size=8.1)
+        mesh = fld.extract_dual_mesh(mise_iter=1)
+        out[name] = (len([p for p in fld.parts if p.solved]), mesh.v.clone(), mesh.f.clone(), fld)
+    assert out['one'][0] == 1 and out['split'][0] >= 3
+    assert torch.equal(out['one'][1], out['split'][1]) and torch.equal(out['one'][2], out['split'][2])
+    assert out['factors'][0] == 1 and out['factors'][3].parts[0].field.solve_info['fused']
+    a0, a1 = out['one'][3].parts[0].field.alpha, out['factors'][3].parts[0].field.alpha
+    assert a0.shape == a1.shape and float((a0 - a1).abs().max() / a0.abs().max()) < 1e-4
+    assert abs(out['factors'][1].shape[0] - out['one'][1].shape[0]) <= max(8, out['one'][1].shape[0] // 1000)
