@@ -74,13 +74,16 @@ def main():
         res = run_pass(g, flags, 'g%d' % gi)
         for k, v in res.items():
             e = rec['kernels'].setdefault(k, {})
-            e['us_pass%d' % gi] = v.pop('us')
+            e['us_pass%d' % gi] = v['us']
+            if 'FETCH_SIZE' in g:
+                e['us_fetch_pass'] = v['us']
+            v.pop('us')
             e['dispatches'] = v.pop('dispatches')
             e.update(v)
     for k, e in rec['kernels'].items():
         if 'FETCH_SIZE' in e:
             e['fetch_bytes'] = 2.0 * 1024.0 * e['FETCH_SIZE']
-            e['fetch_TBps'] = e['fetch_bytes'] / e.get('us_pass2', 1e9) / 1e6
+            e['fetch_TBps'] = e['fetch_bytes'] / e.get('us_fetch_pass', 1e9) / 1e6
         if 'WRITE_SIZE' in e:
             e['write_bytes'] = 1024.0 * e['WRITE_SIZE']
         if e.get('SQ_WAVE_CYCLES'):
@@ -93,7 +96,7 @@ def main():
     op = [k for k in rec['kernels'] if k.startswith(('k_fz_cells<0', 'k_fz_cellsILi0', 'k_fz_cellsum', 'k_fz_gather<0', 'k_fz_gatherILi0'))]
     if len(op) == 3 and all('fetch_bytes' in rec['kernels'][k] and 'write_bytes' in rec['kernels'][k] for k in op):
         rec['operator_application'] = {k: {'fetch_bytes': rec['kernels'][k]['fetch_bytes'], 'write_bytes': rec['kernels'][k]['write_bytes'],
-                                           'us': rec['kernels'][k].get('us_pass2')} for k in op}
+                                           'us': rec['kernels'][k].get('us_fetch_pass')} for k in op}
         rec['hbm_bytes_per_application'] = sum(rec['kernels'][k]['fetch_bytes'] + rec['kernels'][k]['write_bytes'] for k in op)
         if LAST_BENCH_LINE:
             try:
