@@ -47,6 +47,10 @@ def test_oracle_chunk_blend_is_a_partition_of_unity_and_closes_the_seam():
     pu.assert_closed(t, 'chunked oracle mesh')
     e = np.sort(np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]]), 1)
     assert len(v) - len(np.unique(e, axis=0)) + len(t) == 4          # two spheres
+    # the adaptive dual graph of the UNION hierarchy (one level here: the lattice mesher's cells, same surface)
+    va, ta = cf.extract_dual_mesh(0, dual_graph='adaptive')
+    pu.assert_closed(ta, 'chunked oracle mesh, adaptive dual graph')
+    assert len(ta) == len(t)
 
 
 def test_oracle_normals_recipe_on_a_sphere():
