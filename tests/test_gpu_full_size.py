@@ -316,6 +316,7 @@ def test_bench_scale_batch_is_its_solo_chunks_bit_for_bit_and_its_operator_rows_
         batch[c] = ([bf.svh.level(d).keys[lo[i, d] - off[d]:hi[i, d] - off[d]].clone() for d in range(L)],
                     torch.cat([bf.alpha[lo[i, d]:hi[i, d]] for d in range(L)]).clone(), int(info[i, 0]))
     assert max(v[2] for v in batch.values()) <= 40 and float(info[:, 1].max()) <= 1e-5
+    assert bf.solve_info['jacobi_fallbacks'] == 0          # no segment lost its coarse-level block (a fallback changes iteration counts, not results)
 
     # ---- one chunk of the batch against the oracle
     i = part.ids.index(27)                                          # chunk id 27 = tile (3, 3): the one the oracle solved in full (tests/golden)
