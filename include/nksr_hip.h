@@ -93,6 +93,12 @@ int nksr_hash_query(const int64_t* q, int64_t nq, const int64_t* hkeys, const in
                     int32_t* idx_out, void* stream);
 int nksr_build_nbr(const int32_t* ijk, int32_t n, int level, const int64_t* hkeys, const int32_t* hvals,
                    int32_t hcap, int32_t* nbr_out, void* stream);
+/* The same table derived from the next-coarser level (every voxel's parent active): parent_idx [n] = index of voxel i's parent in
+ * the coarse level (-1: none -- then the whole level falls back to the hash, decided on the device), coarse_nbr [n_coarse, 27],
+ * work = 2 n_coarse + 1 int32, the first n_coarse and the last ZEROED by the caller.  Same result as nksr_build_nbr. */
+int nksr_build_nbr_from_parent(const int32_t* ijk, const int64_t* keys, int32_t n, int level, const int64_t* hkeys, const int32_t* hvals,
+                               int32_t hcap, const int32_t* parent_idx, const int32_t* coarse_nbr, int32_t n_coarse, int32_t* work,
+                               int32_t* nbr_out, void* stream);
 /* start/end of the sites (sorted level-0 Morton keys) that fall inside each level-d voxel */
 int nksr_site_ranges(const int64_t* site_keys, int64_t ns, const int64_t* vox_keys, int32_t n, int level,
                      int32_t* start_out, int32_t* end_out, void* stream);

@@ -130,6 +130,7 @@ _PROTOS = {
     'nksr_hash_build': [_vp, _i32, _vp, _vp, _i32, _vp],
     'nksr_hash_query': [_vp, _i64, _vp, _vp, _i32, _vp, _vp],
     'nksr_build_nbr': [_vp, _i32, C.c_int, _vp, _vp, _i32, _vp, _vp],
+    'nksr_build_nbr_from_parent': [_vp, _vp, _i32, C.c_int, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp],
     'nksr_site_ranges': [_vp, _i64, _vp, _i32, C.c_int, _vp, _vp, _vp],
     'nksr_sorted_lookup': [_vp, _i64, _vp, _i64, _vp, _vp],
     'nksr_rank_sorted': [_vp, _i64, _vp, _i64, C.c_int, _vp, _vp],

@@ -87,6 +87,42 @@ __global__ void k_build_nbr(const int32_t* __restrict__ ijk, int n, int bias, co
     nbr[t] = (s == 13) ? i : hash_find(hkeys, hvals, hcap, morton_biased(x, y, z, bias));
 }
 
+// The same table from the NEXT-COARSER level instead of 27 hash probes per voxel (round 5).  Every voxel's parent is active in the
+// hierarchies this package builds, so the neighbour q = i + o of a fine voxel exists only under a coarse voxel
+// that is a neighbour of parent(i): its index comes out of the parent's OWN neighbour row, and the child inside it from two small
+// per-coarse-voxel tables (8-bit child mask, index of the first child: the children of a voxel are one run of the sorted fine keys,
+// in octant order) -- three reads from L2-resident arrays against a probe of a hash table of 12 bytes x 4 n.  Should any voxel
+// lack its parent (a foreign key list), the device flag sends every thread down the hash path: same result either way.
+__global__ void k_child_tables(const int64_t* __restrict__ fkeys, int nf, const int32_t* __restrict__ parent, int32_t* __restrict__ mask,
+                               int32_t* __restrict__ first, int* __restrict__ orphan) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    const int p = parent[i];
+    if (p < 0) { atomicOr(orphan, 1); return; }
+    atomicOr(&mask[p], 1 << (int)(fkeys[i] & 7));                      // (integer OR: order-free)
+    if (i == 0 || parent[i - 1] != p) first[p] = i;
+}
+__global__ void k_build_nbr_parent(const int32_t* __restrict__ ijk, int n, int bias, const int64_t* __restrict__ hkeys,
+                                   const int32_t* __restrict__ hvals, int hcap, const int32_t* __restrict__ parent,
+                                   const int32_t* __restrict__ nbr_c, const int32_t* __restrict__ mask_c, const int32_t* __restrict__ first_c,
+                                   const int* __restrict__ orphan, int32_t* __restrict__ nbr) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * 27) return;
+    const int i = (int)(t / 27), s = (int)(t % 27);
+    if (s == 13) { nbr[t] = i; return; }
+    const int x = ijk[i * 3], y = ijk[i * 3 + 1], z = ijk[i * 3 + 2];
+    const int qx = x + s / 9 - 1, qy = y + (s / 3) % 3 - 1, qz = z + s % 3 - 1;
+    if (*orphan) { nbr[t] = hash_find(hkeys, hvals, hcap, morton_biased(qx, qy, qz, bias)); return; }
+    const int sp = ((qx >> 1) - (x >> 1) + 1) * 9 + ((qy >> 1) - (y >> 1) + 1) * 3 + ((qz >> 1) - (z >> 1) + 1);
+    const int N = nbr_c[(int64_t)parent[i] * 27 + sp];
+    int r = -1;
+    if (N >= 0) {
+        const int m = mask_c[N], oct = (qx & 1) | ((qy & 1) << 1) | ((qz & 1) << 2);
+        if ((m >> oct) & 1) r = first_c[N] + __popc(m & ((1 << oct) - 1));
+    }
+    nbr[t] = r;
+}
+
 __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t v) {
     int64_t lo = 0, hi = n;
     while (lo < hi) {
@@ -180,6 +216,21 @@ extern "C" int nksr_hash_query(const int64_t* q, int64_t nq, const int64_t* hkey
 extern "C" int nksr_build_nbr(const int32_t* ijk, int32_t n, int level, const int64_t* hkeys, const int32_t* hvals,
                               int32_t hcap, int32_t* nbr_out, void* stream) {
     LAUNCH1D(k_build_nbr, (int64_t)n * 27, stream, ijk, n, NKSR_BIAS0 >> level, hkeys, hvals, hcap, nbr_out);
+    return NKSR_OK;
+}
+extern "C" int nksr_build_nbr_from_parent(const int32_t* ijk, const int64_t* keys, int32_t n, int level, const int64_t* hkeys, const int32_t* hvals,
+                                          int32_t hcap, const int32_t* parent_idx, const int32_t* coarse_nbr, int32_t n_coarse, int32_t* work,
+                                          int32_t* nbr_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (!ijk || !keys || !hkeys || !hvals || !parent_idx || !coarse_nbr || !work || !nbr_out || n_coarse <= 0)
+        return nksr_set_error(NKSR_ERR_ARG, "build_nbr_from_parent: NULL arrays");
+    // work: [n_coarse] child masks (ZEROED by the caller) | [n_coarse] first child | [1] orphan flag (ZEROED by the caller)
+    int32_t* mask = work;
+    int32_t* first = work + n_coarse;
+    int* orphan = work + 2 * (int64_t)n_coarse;
+    hipLaunchKernelGGL(k_child_tables, dim3(nksr_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, keys, n, parent_idx, mask, first, orphan);
+    LAUNCH1D(k_build_nbr_parent, (int64_t)n * 27, stream, ijk, n, NKSR_BIAS0 >> level, hkeys, hvals, hcap, parent_idx, coarse_nbr,
+             (const int32_t*)mask, (const int32_t*)first, (const int*)orphan, nbr_out);
     return NKSR_OK;
 }
 extern "C" int nksr_site_ranges(const int64_t* site_keys, int64_t ns, const int64_t* vox_keys, int32_t n, int level,

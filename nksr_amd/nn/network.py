@@ -269,7 +269,7 @@ class StructureUNet(nn.Module):
                 ok = (par >= 0) & keep_up[par.clamp_min(0).long()]
                 if not bool(ok.all()):
                     keys = keys[ok].contiguous()
-                    gc = SparseGrid(keys, d, enc_svh.voxel_size)
+                    gc = SparseGrid(keys, d, enc_svh.voxel_size, coarse=dec_levels[d + 1])
                     par = dec_levels[d + 1].hash.query((keys >> 3).contiguous())
             je = enc_svh.level(d).hash.query(keys)
             t = gather_rows(x[d], je)
@@ -283,7 +283,7 @@ class StructureUNet(nn.Module):
                 tape['dec'][d] = dict(je=je, par=par if d < D - 1 else None, t=t, nbr=gc.nbr, y_pre=y, exist=None if bool(exist.all()) else exist)
             if not bool(exist.all()):          # prune "not-exist" voxels (needs a re-indexed grid)
                 y, s, status = y[exist].contiguous(), s[exist].contiguous(), status[exist]
-                gc = SparseGrid(keys[exist].contiguous(), d, enc_svh.voxel_size)
+                gc = SparseGrid(keys[exist].contiguous(), d, enc_svh.voxel_size, coarse=dec_levels[d + 1] if d < D - 1 else None)
             dec_levels[d] = gc
             feat.structure_features[d] = s
             feat.trunk_features[d] = y

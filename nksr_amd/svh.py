@@ -13,6 +13,7 @@ ascending Morton key order produced by the device radix sort, so topology is ind
 independent of atomics.  All heavy lifting happens in nksr_amd/csrc/hierarchy.hip.
 """
 import enum
+import os
 
 import numpy as np
 import torch
@@ -37,7 +38,10 @@ def inv_w0_f32(voxel_size):
 class SparseGrid:
     """One level: sorted Morton keys, ijk, hash table and the 27-neighbour table."""
 
-    def __init__(self, keys, level, base_voxel_size):
+    def __init__(self, keys, level, base_voxel_size, coarse=None):
+        """``coarse``: the next-coarser level of the same hierarchy, already built -- the neighbour table is then derived from ITS
+        table and the children of its voxels (csrc/hierarchy.hip: k_build_nbr_parent) instead of 27 hash probes per voxel; the
+        result is the same table (a level whose voxels lack parents falls back to the hash by itself, on the device)."""
         self.level = level
         self.voxel_size = float(base_voxel_size) * (1 << level)
         self.keys = keys
@@ -47,8 +51,14 @@ class SparseGrid:
         call('nksr_decode_keys', ptr(keys), n, level, ptr(self.ijk), stream())
         self.hash = ops.HashTable(keys)
         self.nbr = torch.empty((n, 27), dtype=torch.int32, device=self.device)
-        call('nksr_build_nbr', ptr(self.ijk), n, level, ptr(self.hash.hkeys), ptr(self.hash.hvals), self.hash.cap,
-             ptr(self.nbr), stream())
+        if coarse is not None and coarse.num_voxels > 0 and n > 0 and coarse.level == level + 1 and os.environ.get('NKSR_NBR_FROM_PARENT', '1') != '0':
+            parent = coarse.hash.query((keys >> 3).contiguous())
+            work = torch.zeros(2 * coarse.num_voxels + 1, dtype=torch.int32, device=self.device)
+            call('nksr_build_nbr_from_parent', ptr(self.ijk), ptr(keys), n, level, ptr(self.hash.hkeys), ptr(self.hash.hvals), self.hash.cap,
+                 ptr(parent), ptr(coarse.nbr), coarse.num_voxels, ptr(work), ptr(self.nbr), stream())
+        else:
+            call('nksr_build_nbr', ptr(self.ijk), n, level, ptr(self.hash.hkeys), ptr(self.hash.hvals), self.hash.cap,
+                 ptr(self.nbr), stream())
 
     def active_grid_coords(self):
         return self.ijk
@@ -104,12 +114,15 @@ class SparseFeatureHierarchy:
         xyz = self._check_xyz(xyz)
         n = xyz.shape[0]
         per = 8 if mode == 0 else 27
-        for d in range(self.depth):
+        for d in range(self.depth - 1, -1, -1):          # coarse -> fine: a level's neighbour table comes from the level above it
             raw = torch.empty(n * per, dtype=torch.int64, device=self.device)
             call('nksr_splat_keys', ptr(xyz), n, self.inv_w0, d, mode, ptr(raw), stream())
             keys = ops.sort_unique(raw, level=d)
-            self._levels[d] = SparseGrid(keys, d, self.voxel_size)
+            self._levels[d] = SparseGrid(keys, d, self.voxel_size, coarse=self._coarse(d))
         return self
+
+    def _coarse(self, d):
+        return self._levels[d + 1] if d + 1 < self.depth else None
 
     def build_point_splatting(self, xyz):
         """Activate the 8 voxel centres nearest to every point at every level
@@ -157,19 +170,20 @@ class SparseFeatureHierarchy:
             raw = self._dedup(xyz_sorted, None, n, 0, 0, raw)
         else:
             call('nksr_splat_keys', ptr(xyz_sorted), n, self.inv_w0, 0, 0, ptr(raw), stream())
-        self._levels[0] = SparseGrid(ops.sort_unique(raw, level=0), 0, self.voxel_size)
+        keys0 = ops.sort_unique(raw, level=0)
         if cells is None and self.depth > 1:
             cells = self.cells_with_points(point_keys_sorted, self.depth - 1)
-        for d in range(1, self.depth):
-            self._levels[d] = SparseGrid(self._footprint(cells[d - 1], d - 1, 0), d, self.voxel_size)
+        for d in range(self.depth - 1, 0, -1):
+            self._levels[d] = SparseGrid(self._footprint(cells[d - 1], d - 1, 0), d, self.voxel_size, coarse=self._coarse(d))
+        self._levels[0] = SparseGrid(keys0, 0, self.voxel_size, coarse=self._coarse(0))
         return self
 
     def build_point_neighborhood_sorted(self, point_keys_sorted, cells=None):
         """Same result as build_point_neighborhood from the unique cells that hold points."""
         if cells is None:
             cells = self.cells_with_points(point_keys_sorted, self.depth)
-        for d in range(self.depth):
-            self._levels[d] = SparseGrid(self._footprint(cells[d], d, 1), d, self.voxel_size)
+        for d in range(self.depth - 1, -1, -1):
+            self._levels[d] = SparseGrid(self._footprint(cells[d], d, 1), d, self.voxel_size, coarse=self._coarse(d))
         return self
 
     def build_adaptive_normal_variation(self, xyz, normal, tau=0.1, adaptive_depth=1):
@@ -196,17 +210,17 @@ class SparseFeatureHierarchy:
             pts = xs if bool(alive.all()) else xs[alive].contiguous()
             raw = torch.empty(pts.shape[0] * 8, dtype=torch.int64, device=self.device)
             call('nksr_splat_keys', ptr(pts), pts.shape[0], self.inv_w0, d, 0, ptr(raw), stream())
-            self._levels[d] = SparseGrid(ops.sort_unique(raw), d, self.voxel_size)
+            self._levels[d] = SparseGrid(ops.sort_unique(raw), d, self.voxel_size, coarse=self._coarse(d))
         return self
 
     def build_from_keys(self, keys_per_level, sorted_unique=False):
         """``sorted_unique``: the keys are already in canonical order (a packed field's payload)."""
-        for d in range(self.depth):
+        for d in range(self.depth - 1, -1, -1):
             k = keys_per_level[d]
             if k is None:
                 k = torch.empty(0, dtype=torch.int64, device=self.device)
             k = k.to(self.device).contiguous()
-            self._levels[d] = SparseGrid(k if sorted_unique else ops.sort_unique(k), d, self.voxel_size)
+            self._levels[d] = SparseGrid(k if sorted_unique else ops.sort_unique(k), d, self.voxel_size, coarse=self._coarse(d))
         return self
 
     def build_from_grid_coords(self, depth, ijk):
