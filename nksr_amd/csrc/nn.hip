@@ -193,80 +193,81 @@ __global__ void k_fill_f32(float* __restrict__ p, int64_t n, float v) {
 // out[i] = act( b + sum_s W[s]^T in[nbr[i][s]] ),  W [27, Cin, Cout] row-major, optional residual add.
 // mfma_f32_32x32x2f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
 // accumulator register r of lane l is D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31].
-// The taps are software-pipelined: while the 16 products of tap s run, the gathered rows and the weights of tap s + 1 and the
-// neighbour indices of tap s + 2 are already requested (all loads unconditional -- clamped index, masked value).  One tap after
-// the other -- index -> rows -> LDS -> products -- left the matrix cores idle for the two round trips of every tap: 14.5 ms for the
-// 1.7e7-voxel level of the 64-chunk scene against 6 ms of fp32 MFMA time.  Same products in the same order as before.
+//
+// Round 5: the A operand comes STRAIGHT from the gathered rows.  The two lanes of a voxel (l and l + 32) split its 32 input
+// channels in HALVES -- lane (i, h) holds channels 16 h .. 16 h + 15 of in[nbr[i][s]] (four 16-byte loads of ITS OWN row) and
+// feeds channel 16 h + kk to product kk, next to B = W[s][16 h + kk][col]: a tap sums its channels in the order 0, 16, 1, 17, ...
+// (a fixed order; the sum over k of a matrix instruction has no preferred one).  Rounds 2-4 dealt the channels even / odd, which
+// needed every row transposed through LDS first: 16 ds_write + 16 ds_read per tap and their waits between the loads and the
+// products -- with 112 VGPRs (4 waves per SIMD, 2.5 resident on average by the counters) the matrix pipe sat at 54 % of its
+// fp32 rate (`profiles/r05_scene_fused_pmc.json`: SQ_VALU_MFMA_BUSY_CYCLES).  Dropping that staging alone changed nothing (24.5 ms
+// per scene step against 23.4): the vector-memory data path was the busy unit (TD_TD_BUSY 86 %) -- see the weight tile below.
+// The taps are still software-pipelined: while the 16 products of tap s run, the rows and weights of tap s + 1 and the neighbour indices of tap
+// s + 2 are in flight (all loads unconditional -- clamped index, masked value).
 __global__ void __launch_bounds__(256) k_sparse_conv3(const float* __restrict__ in, const int32_t* __restrict__ nbr, int n,
                                                       const float* __restrict__ W, const float* __restrict__ bias,
                                                       const float* __restrict__ residual, int relu, float* __restrict__ out) {
-    __shared__ float tile[4][32][NN_C + 1];
+    // the weights of a tap (32 x 32 floats) are shared by the four wavefronts of the workgroup: ONE 16-byte load per thread and tap
+    // into a double-buffered LDS tile instead of 16 four-byte loads per lane (the vector-memory data path was 86 % busy,
+    // TD_TD_BUSY, with the matrix pipe at 54 %); one barrier per tap
+    __shared__ float4 wt[2][NN_C * NN_C / 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int base = (blockIdx.x * 4 + wave) * 32;
-    if (base >= n) return;   // whole wavefront; no block-level barrier below
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float(*T)[NN_C + 1] = tile[wave];
     const int col = lane & 31, kh = lane >> 5;
-    const int ch = (lane & 7) * 4;
-    // the lane stages rows q * 8 + lane / 8 (q = 0..3), four channels each
-    int64_t nrow[4];
-    bool live[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int vi = base + q * 8 + (lane >> 3);
-        live[q] = vi < n;
-        nrow[q] = (int64_t)(live[q] ? vi : n - 1) * 27;
-    }
-    int jc[4], jn[4];
+    const int vi = base + col;
+    const bool live = vi < n;                                       // (a wavefront past the end keeps step with the barriers)
+    const int64_t nrow = (int64_t)(live ? vi : n - 1) * 27;
+    const float4* W4 = reinterpret_cast<const float4*>(W);
+    int jc = nbr[nrow], jn = nbr[nrow + 1];
     float4 vc[4], vn[4];
-    float bc[NN_C / 2], bn[NN_C / 2];
+    {
+        const float4* row = reinterpret_cast<const float4*>(in + (int64_t)(live && jc >= 0 ? jc : 0) * NN_C + 16 * kh);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) jc[q] = nbr[nrow[q]];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) jn[q] = nbr[nrow[q] + 1];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) vc[q] = *reinterpret_cast<const float4*>(in + (int64_t)(live[q] && jc[q] >= 0 ? jc[q] : 0) * NN_C + ch);
-#pragma unroll
-    for (int kk = 0; kk < NN_C / 2; ++kk) bc[kk] = W[(kk * 2 + kh) * NN_C + col];
+        for (int q = 0; q < 4; ++q) vc[q] = row[q];
+    }
+    wt[0][threadIdx.x] = W4[threadIdx.x];
+    __syncthreads();
     for (int s = 0; s < 27; ++s) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = q * 8 + (lane >> 3);
-            const bool ok = live[q] && jc[q] >= 0;
-            T[row][ch] = ok ? vc[q].x : 0.f; T[row][ch + 1] = ok ? vc[q].y : 0.f; T[row][ch + 2] = ok ? vc[q].z : 0.f; T[row][ch + 3] = ok ? vc[q].w : 0.f;
-        }
         // requests for the taps to come (the last ones repeat tap 26: harmless)
         const int s1 = s + 1 < 27 ? s + 1 : 26, s2 = s + 2 < 27 ? s + 2 : 26;
+        const float4 wnext = W4[(int64_t)s1 * (NN_C * NN_C / 4) + threadIdx.x];
+        {
+            const float4* row = reinterpret_cast<const float4*>(in + (int64_t)(live && jn >= 0 ? jn : 0) * NN_C + 16 * kh);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) vn[q] = *reinterpret_cast<const float4*>(in + (int64_t)(live[q] && jn[q] >= 0 ? jn[q] : 0) * NN_C + ch);
-        const float* Wn = W + (int64_t)s1 * NN_C * NN_C;
-#pragma unroll
-        for (int kk = 0; kk < NN_C / 2; ++kk) bn[kk] = Wn[(kk * 2 + kh) * NN_C + col];
-        int j2[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) j2[q] = nbr[nrow[q] + s2];
-#pragma unroll
-        for (int kk = 0; kk < NN_C / 2; ++kk) {
-            const float a = T[col][kk * 2 + kh];            // A[i = lane & 31][k]
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bc[kk], acc, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) vn[q] = row[q];
         }
+        const int j2 = nbr[nrow + s2];
+        const float* wl = reinterpret_cast<const float*>(wt[s & 1]) + (16 * kh) * NN_C + col;      // W[s][16 kh + kk][col]
+        float bc[NN_C / 2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { jc[q] = jn[q]; jn[q] = j2[q]; vc[q] = vn[q]; }
+        for (int kk = 0; kk < NN_C / 2; ++kk) bc[kk] = wl[kk * NN_C];
+        const bool ok = live && jc >= 0;
 #pragma unroll
-        for (int kk = 0; kk < NN_C / 2; ++kk) bc[kk] = bn[kk];
+        for (int q = 0; q < 4; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? vc[q].x : 0.f, bc[4 * q], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? vc[q].y : 0.f, bc[4 * q + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? vc[q].z : 0.f, bc[4 * q + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? vc[q].w : 0.f, bc[4 * q + 3], acc, 0, 0, 0);
+        }
+        jc = jn; jn = j2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vc[q] = vn[q];
+        wt[(s + 1) & 1][threadIdx.x] = wnext;          // (the tile of tap s - 1: every wavefront finished reading it before the last barrier)
+        __syncthreads();
     }
     const float bj = bias ? bias[col] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const int vi = base + row;
-        if (vi < n) {
+        const int vo = base + row;
+        if (vo < n) {
             float v = acc[r] + bj;
-            if (residual) v += residual[(int64_t)vi * NN_C + col];
+            if (residual) v += residual[(int64_t)vo * NN_C + col];
             if (relu) v = v > 0.f ? v : 0.f;
-            out[(int64_t)vi * NN_C + col] = v;
+            out[(int64_t)vo * NN_C + col] = v;
         }
     }
 }
