@@ -171,6 +171,49 @@ __device__ __forceinline__ void trilerp_feat(const nksr_level_t& lv, int level, 
     }
 }
 
+// neighbour of the trilinear corner (cx, cy, cz) out of the ALREADY LOADED neighbour row of an active cell: slot (hb0 + cx, hb1 +
+// cy, hb2 + cz) -- seven selects on the half bits instead of one more dependent load per corner (the row is needed for the psi
+// gathers anyway: eight of the ~44 gather instructions of a (site, level) were the same 27 words read a second time)
+template <int CX, int CY, int CZ>
+__device__ __forceinline__ int corner_of_row(const int nb[27], const int hb[3]) {
+    constexpr int B = CX * 9 + CY * 3 + CZ;
+    const int a00 = hb[2] ? nb[B + 1] : nb[B], a01 = hb[2] ? nb[B + 4] : nb[B + 3];
+    const int a10 = hb[2] ? nb[B + 10] : nb[B + 9], a11 = hb[2] ? nb[B + 13] : nb[B + 12];
+    const int b0 = hb[1] ? a01 : a00, b1 = hb[1] ? a11 : a10;
+    return hb[0] ? b1 : b0;
+}
+template <int K, bool JAC>
+__device__ __forceinline__ void trilerp_feat_row(const nksr_level_t& lv, const SiteCell& sc, const int nb[27], float inv_w, float t[K],
+                                                 float Jt[K][3]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) { t[k] = 0.f; if (JAC) { Jt[k][0] = Jt[k][1] = Jt[k][2] = 0.f; } }
+    float v[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v[a] = sc.u[a] + 0.5f - (float)sc.hb[a];
+    int jc[8];
+    jc[0] = corner_of_row<0, 0, 0>(nb, sc.hb); jc[1] = corner_of_row<0, 0, 1>(nb, sc.hb);
+    jc[2] = corner_of_row<0, 1, 0>(nb, sc.hb); jc[3] = corner_of_row<0, 1, 1>(nb, sc.hb);
+    jc[4] = corner_of_row<1, 0, 0>(nb, sc.hb); jc[5] = corner_of_row<1, 0, 1>(nb, sc.hb);
+    jc[6] = corner_of_row<1, 1, 0>(nb, sc.hb); jc[7] = corner_of_row<1, 1, 1>(nb, sc.hb);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {             // (same corners, same order, same arithmetic as trilerp_feat)
+        const int cx = c >> 2, cy = (c >> 1) & 1, cz = c & 1;
+        const int j = jc[c];
+        if (j < 0) continue;
+        float wx = cx ? v[0] : 1.f - v[0], wy = cy ? v[1] : 1.f - v[1], wz = cz ? v[2] : 1.f - v[2];
+        float w = wx * wy * wz;
+        float gx = (cx ? 1.f : -1.f) * wy * wz * inv_w, gy = wx * (cy ? 1.f : -1.f) * wz * inv_w,
+              gz = wx * wy * (cz ? 1.f : -1.f) * inv_w;
+        const float* f = lv.feat + (int64_t)j * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float fk = f[k];
+            t[k] = fmaf(fk, w, t[k]);
+            if (JAC) { Jt[k][0] = fmaf(fk, gx, Jt[k][0]); Jt[k][1] = fmaf(fk, gy, Jt[k][1]); Jt[k][2] = fmaf(fk, gz, Jt[k][2]); }
+        }
+    }
+}
+
 // ---- psi_j = feat_j + MLP(feat_j) -----------------------------------------------------------
 template <int K, int H>
 __global__ void k_voxel_psi(const float* __restrict__ feat, int n, const float* __restrict__ mlp, float* __restrict__ psi) {
@@ -238,14 +281,14 @@ __global__ void __launch_bounds__(128) k_kernel_rows(nksr_hier_t hier, const flo
     }
     float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
     float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
-    trilerp_feat<K, JAC>(lv, d, sc, inv_w, t, Jt);
+    int nb[27];
+    load_nbr_row(lv.nbr + (int64_t)sc.cell * 27, nb);
+    trilerp_feat_row<K, JAC>(lv, sc, nb, inv_w, t, Jt);
     MlpView<K, H> m(w);
     mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
     float bw[3][3], bd[3][3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
-    int nb[27];
-    load_nbr_row(lv.nbr + (int64_t)sc.cell * 27, nb);
     // All 27 (x 4 with gradients) results stay in registers and every output row leaves as one burst of
     // 16-byte stores: written word by word across the slot loop, the 108-byte rows kept ~10^6 partially
     // filled cache lines in flight and the kernel ran at 0.5 TB/s of useful stores.
@@ -386,6 +429,8 @@ __global__ void __launch_bounds__(128) k_evaluate_f(nksr_hier_t hier, const floa
         if (active_only && sc.cell < 0) continue;      // the support of the kernel ROWS (training path: forward = what backward differentiates)
         float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
         float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
+        // (the corners are NOT taken from the neighbour row here as k_kernel_rows does: with the row live across the interpolator this
+        // kernel needs 98 instead of 72 registers -- four waves per SIMD instead of six -- and ran 21 % slower, 1 240 against 1 027 us)
         trilerp_feat<K, JAC, true>(lv, d, sc, inv_w, t, Jt);
         MlpView<K, H> m(wall + d * MlpView<K, H>::SIZE);
         mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
