@@ -92,7 +92,7 @@ def load_traffic_fused(bytes_per_launch):
     return _load_pmc('_fused_pmc.json', 'physical_bytes_per_application', 'hbm_bytes_per_application', bytes_per_launch, 'fused')
 
 
-def live_traffic_fused(flags, timeout_s=600):
+def live_traffic_fused(flags, timeout_s=240):
     """HBM bytes of one operator application collected IN THIS RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- they do not
     fit one pass; --kernel-trace only, no other trace domain) over one untimed step of the same scene in child processes, after the
     timed region (nksr_amd/tools/scene_pmc.py, corrections as in MI355X_MICROARCH.md: KiB units, FETCH_SIZE doubled on gfx950).
