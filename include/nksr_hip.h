@@ -159,6 +159,19 @@ int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int appr
  * r_i = row_index ? row_index[i] : i * ncomp (ncomp = 1 for val, 3 for dval; ONE of val / dval when row_index is given) -- the layout
  * of the matrix-free solve (nksr_fused_op_t.rows_all): row_index lets several site sets share one Morton-ordered row list;
  * row_cells [L, level_stride] (may be NULL) receives the global unknown index of the level-d cell of every row written (-1 = none). */
+/* The rows of BOTH site sets of the matrix-free operator in ONE pass over its merged row list (kernel_dim 4; KernelField.solve,
+ * models/nksr_net.py:105-112 with fused_mode, examples/recons_waymo.py:33): rows_out [L][rows_total][27], row r of the list is
+ * row_src[r] = (site << 2) | kind -- kind 0: the value row of position site `site` (xyz_pos), kind 1 + a: the d/dx_a row of normal
+ * site `site` (xyz_nrm); row_src[r] < 0: a pad row (zeros, row_cells -1).  One launch writes every 128-byte line of rows_out whole
+ * (a launch per set writes the interleaved rows as partial lines: 1.1 - 1.8 TB/s against 5.7); values bit-identical to
+ * nksr_kernel_rows.  scale_* (device, per site) or row_scale_* as for nksr_kernel_rows; either set may be absent (xyz NULL).
+ * sites < 2^29 per set. */
+int nksr_kernel_rows_merged(const nksr_hier_t* h, const float* xyz_pos, const float* scale_pos, float row_scale_pos,
+                            const float* xyz_nrm, const float* scale_nrm, float row_scale_nrm, int approx, const int32_t* row_src,
+                            int64_t rows_total, int32_t* row_cells, float* rows_out, void* stream);
+/* row_src of nksr_kernel_rows_merged from the sets' first rows: row_src[first_row[i] + c] = (i << 2) | (kind0 + c), c < ncomp
+ * (ncomp 1, kind0 0: position sites; ncomp 3, kind0 1: normal sites).  The caller pre-fills row_src with -1. */
+int nksr_row_sources(const int32_t* first_row, int64_t n, int ncomp, int kind0, int32_t* row_src, void* stream);
 /* Rank-4 FACTORS of the same rows (kernel_dim 4 only; the matrix-free solve's row format since round 5, nksr_fused_op_t.fac_vec /
  * fac_pos): per row and level one 16-byte record instead of 27 slots.  grad == 0: one row per site, vec = phi_d(x) * scale.
  * grad != 0: FOUR rows per site -- a header row (vec = phi * scale) and one row per axis a (vec = d phi / d x_a * scale; 0 with

@@ -100,7 +100,10 @@ __device__ __forceinline__ int half_index(float x, float inv_w0, float& p) {
 }
 
 // quadratic B-spline weights of the centres at offset -1,0,+1 for local coordinate u
+// (contraction off: left to the compiler, 0.75 - uc * uc became a fused multiply-add for one axis and a product + subtraction for
+// another inside the same kernel; every kernel that forms these weights -- one lane per site or one lane per slot -- must round alike)
 __device__ __forceinline__ void bspline3(float u, float w[3], float dw[3]) {
+#pragma clang fp contract(off)
     float um = 1.0f - u, uc = u - 0.5f;
     w[0] = 0.5f * um * um;
     w[1] = 0.75f - uc * uc;

@@ -489,10 +489,29 @@ class KernelField(BaseField):
                 rows_all[:L * rows_total * 27].view(L, rows_total, 27)[:, pad_rows] = 0.0
         keep = [rows_all, fac_vec, fac_pos, psi_all, targets_all, row_cells]
         td = _tick('op:alloc', td)
+        # kernel_dim 4, dense rows: ONE launch writes the rows of both sets (csrc/kfield.hip: k_kernel_rows_merged -- the interleaved rows
+        # of two launches reach HBM as partial lines); NKSR_ROWS_KERNEL=site keeps the launch per set (bit-identical rows)
+        merged = (not fac and self.kdim == 4 and self.hidden in (16, 32) and os.environ.get('NKSR_ROWS_KERNEL', 'merged') == 'merged'
+                  and max(counts_s) < 2 ** 29)
+        if merged:
+            row_src = torch.full((rows_total,), -1, dtype=torch.int32, device=dev)
+            args = {1: (None, None, 1.0), 3: (None, None, 1.0)}
+            for (xs, ks, perm, target, sw, ncomp), ri in zip(specs, row_index):
+                ri = ri.contiguous()
+                call('nksr_row_sources', ptr(ri), xs.shape[0], ncomp, 0 if ncomp == 1 else 1, ptr(row_src), stream())
+                tw = torch.is_tensor(sw)
+                args[ncomp] = (xs, sw if tw else None, 1.0 if tw else sw)
+                keep += [xs, ri]
+            (xa, sa, fa_), (xb, sb, fb_) = args[1], args[3]
+            call('nksr_kernel_rows_merged', C.byref(self._hier), ptr(xa), ptr(sa), float(fa_), ptr(xb), ptr(sb), float(fb_),
+                 int(self.approx_kernel_grad), ptr(row_src), rows_total, ptr(row_cells), ptr(rows_all), stream())
+            keep.append(row_src)
         for (xs, ks, perm, target, sw, ncomp), ri in zip(specs, row_index):
             ri = ri.contiguous()
             tensor_w = torch.is_tensor(sw)
-            if fac:
+            if merged:
+                pass
+            elif fac:
                 self.kernel_factors_level_major(xs, ncomp == 4, 1.0 if tensor_w else sw, fac_vec, fac_pos, rows_total, ri, row_cells,
                                                 site_scale=sw if tensor_w else None)
             else:

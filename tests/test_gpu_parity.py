@@ -286,6 +286,32 @@ def test_row_order_by_rank_passes_equals_the_sorted_merge(monkeypatch):
     assert torch.equal(out['merge'][0].view(torch.int32), out['sort'][0].view(torch.int32))
 
 
+@pytest.mark.parametrize('approx', [False, True])
+@pytest.mark.parametrize('hidden', [16, 32])
+def test_merged_rows_equal_the_rows_of_a_launch_per_set_bit_for_bit(approx, hidden, monkeypatch):
+    """nksr_kernel_rows_merged (one lane per ROW of the operator's merged row list, value + one tangent channel as packed pairs, rows
+    leaving as contiguous wavefront images) against nksr_kernel_rows with a row index (one lane per site, a launch per site set):
+    rows, row cells and targets bit for bit -- exact and approximate gradients, both interpolator widths, one site set alone."""
+    from nksr_amd.fields import KernelField
+    xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=3000, init_scale=0.3, H=hidden)
+    fld = KernelField(svh, net.interpolators, [torch.from_numpy(f) for f in feats], approx_kernel_grad=approx)
+    t = lambda x: torch.from_numpy(x).to(_dev())
+    nxyz = np.concatenate([oh.levels[0].centers(), oh.levels[1].centers()])
+    nval = np.random.RandomState(5).randn(len(nxyz), 3).astype(np.float32)
+    far = (xyz[:40] + np.float32(3.0)).astype(np.float32)                      # sites outside every cell of the fine levels: zero rows, cell -1
+    for pos, nrm_sites in ((np.concatenate([xyz, far]), nxyz), (xyz, None), (None, nxyz)):
+        out = {}
+        for mode in ('site', 'merged'):
+            monkeypatch.setenv('NKSR_ROWS_KERNEL', mode)
+            op = fld.fused_operator(t(pos) if pos is not None else None, t(nrm_sites) if nrm_sites is not None else None,
+                                    t(nval) if nrm_sites is not None else None, 1e4 / 3000, 1e2 / len(nxyz))
+            assert op['row_format'] == 'dense'
+            out[mode] = (op['rows_all'][:op['op'].depth * op['rows_total'] * 27].clone(), op['row_cells'].clone(), op['targets_all'].clone())
+        assert torch.equal(out['site'][1], out['merged'][1]) and torch.equal(out['site'][2], out['merged'][2])
+        assert torch.equal(out['site'][0].view(torch.int32), out['merged'][0].view(torch.int32))
+        assert float(out['merged'][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize('fused', [False, True])
 def test_solve_is_differentiable_wrt_the_normal_targets(fused):
     """SURVEY.md section 8(f)-4, the part that is built: under autograd, solve*() makes alpha a differentiable function of
