@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libnksr_hip.so')
-SOURCES = ['prims.hip', 'hierarchy.hip', 'kfield.hip', 'rows.hip', 'assemble.hip', 'pcg.hip', 'fused.hip', 'meshing.hip', 'nn.hip', 'knn.hip', 'chunks.hip']
+SOURCES = ['prims.hip', 'hierarchy.hip', 'kfield.hip', 'rows.hip', 'evalf.hip', 'assemble.hip', 'pcg.hip', 'fused.hip', 'meshing.hip', 'nn.hip', 'knn.hip', 'chunks.hip']
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result'] + os.environ.get('NKSR_EXTRA_HIPCC_FLAGS', '').split()
 

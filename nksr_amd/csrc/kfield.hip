@@ -175,106 +175,7 @@ __global__ void __launch_bounds__(128) k_kernel_factors(nksr_hier_t hier, const 
     }
 }
 
-// ---- f(x) = sum_d sum_s alpha_j K_d(x, c_j) ---------------------------------------------------
-template <int K, int H, bool GRAD, bool JAC>
-__global__ void __launch_bounds__(128) k_evaluate_f(nksr_hier_t hier, const float* __restrict__ alpha, const float* __restrict__ xyz,
-                             int64_t n, float* __restrict__ fout, float* __restrict__ gout, int active_only) {
-    extern __shared__ __attribute__((aligned(16))) float wall[];
-    const int L = hier.depth;
-    for (int d = 0; d < L; ++d)
-        for (int i = threadIdx.x; i < MlpView<K, H>::SIZE; i += blockDim.x)
-            wall[d * MlpView<K, H>::SIZE + i] = hier.lv[d].mlp[i];
-    __syncthreads();
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float x[3] = {xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]};
-    float f = 0.f, gr[3] = {0.f, 0.f, 0.f};
-    // the containing cell at EVERY level first: the home-slot probes of all levels go out together (one round trip instead of one per
-    // level at the head of each level's chain  cell -> neighbour row -> features / psi)
-    int cellv[NKSR_MAX_DEPTH];
-    {
-        int64_t key[NKSR_MAX_DEPTH], k0[NKSR_MAX_DEPTH];
-        uint32_t slot[NKSR_MAX_DEPTH];
-        int v0[NKSR_MAX_DEPTH];
-#pragma unroll
-        for (int d = 0; d < NKSR_MAX_DEPTH; ++d) {
-            key[d] = 0; k0[d] = -1; slot[d] = 0; v0[d] = -1;
-            if (d < L && hier.lv[d].n > 0) {               // uniform
-                const SiteCell g = site_geometry(d, hier.inv_w0, x);
-                key[d] = morton_biased(g.I[0], g.I[1], g.I[2], NKSR_BIAS0 >> d);
-                slot[d] = hash_slot(key[d], hier.lv[d].hcap);
-                k0[d] = hier.lv[d].hkeys[slot[d]];
-                v0[d] = hier.lv[d].hvals[slot[d]];
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < NKSR_MAX_DEPTH; ++d)
-            cellv[d] = (d < L && hier.lv[d].n > 0) ? hash_find_after(hier.lv[d].hkeys, hier.lv[d].hvals, hier.lv[d].hcap, key[d], slot[d], k0[d], v0[d]) : -1;
-    }
-#pragma unroll
-    for (int d = 0; d < NKSR_MAX_DEPTH; ++d) {
-        if (d >= L) break;
-        const nksr_level_t& lv = hier.lv[d];
-        if (lv.n == 0) continue;
-        SiteCell sc = site_geometry(d, hier.inv_w0, x);
-        sc.cell = cellv[d];
-        if (active_only && sc.cell < 0) continue;      // the support of the kernel ROWS (training path: forward = what backward differentiates)
-        float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
-        float t[K], phi[K], Jt[JAC ? K : 1][3], J[JAC ? K : 1][3];
-        // (the corners are NOT taken from the neighbour row here as k_kernel_rows does: with the row live across the interpolator this
-        // kernel needs 98 instead of 72 registers -- four waves per SIMD instead of six -- and ran 21 % slower, 1 240 against 1 027 us)
-        trilerp_feat<K, JAC, true>(lv, d, sc, inv_w, t, Jt);
-        MlpView<K, H> m(wall + d * MlpView<K, H>::SIZE);
-        mlp_residual<K, H, JAC>(m, t, Jt, phi, J);
-        float bw[3][3], bd[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) bspline3(sc.u[a], bw[a], bd[a]);
-        float fl = 0.f, gl[3] = {0.f, 0.f, 0.f};
-        int nbv[27];
-        if (sc.cell >= 0) load_nbr_row(lv.nbr + (int64_t)sc.cell * 27, nbv);
-        else {
-#pragma unroll
-            for (int s = 0; s < 27; ++s) nbv[s] = nbr_of<true>(lv, d, sc, s);
-        }
-#pragma unroll
-        for (int s = 0; s < 27; ++s) {
-            const int j = nbv[s];
-            if (j < 0) continue;
-            const int ox = s / 9, oy = (s / 3) % 3, oz = s % 3;
-            const float* ps = lv.psi + (int64_t)j * K;
-            float dot = 0.f, jd[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float pk = ps[k];
-                dot = fmaf(phi[k], pk, dot);
-                if (JAC) { jd[0] = fmaf(J[k][0], pk, jd[0]); jd[1] = fmaf(J[k][1], pk, jd[1]); jd[2] = fmaf(J[k][2], pk, jd[2]); }
-            }
-            const float a = alpha ? alpha[lv.offset + j] : 1.f;      // alpha == NULL: psi arrives pre-multiplied by it
-            float bx = sel3(bw[0], ox), by = sel3(bw[1], oy), bz = sel3(bw[2], oz);
-            float B = bx * by * bz;
-            fl = fmaf(a, dot * B, fl);
-            if (GRAD) {
-                float g0 = dot * (sel3(bd[0], ox) * by * bz * inv_w), g1 = dot * (bx * sel3(bd[1], oy) * bz * inv_w),
-                      g2 = dot * (bx * by * sel3(bd[2], oz) * inv_w);
-                if (JAC) { g0 = fmaf(jd[0], B, g0); g1 = fmaf(jd[1], B, g1); g2 = fmaf(jd[2], B, g2); }
-                gl[0] = fmaf(a, g0, gl[0]); gl[1] = fmaf(a, g1, gl[1]); gl[2] = fmaf(a, g2, gl[2]);
-            }
-        }
-        f += fl;
-        if (GRAD) { gr[0] += gl[0]; gr[1] += gl[1]; gr[2] += gl[2]; }
-    }
-    fout[i] = f;
-    if (GRAD) { gout[i * 3] = gr[0]; gout[i * 3 + 1] = gr[1]; gout[i * 3 + 2] = gr[2]; }
-}
-
 // ---- dispatch on (K, H) ------------------------------------------------------------------------
-#define DISPATCH_KH(K_, H_, ...)                                  \
-    if (K_ == 4 && H_ == 16) { constexpr int K = 4, H = 16; __VA_ARGS__ } \
-    else if (K_ == 16 && H_ == 32) { constexpr int K = 16, H = 32; __VA_ARGS__ } \
-    else if (K_ == 4 && H_ == 32) { constexpr int K = 4, H = 32; __VA_ARGS__ } \
-    else if (K_ == 16 && H_ == 16) { constexpr int K = 16, H = 16; __VA_ARGS__ } \
-    else return nksr_set_error(NKSR_ERR_ARG, "unsupported (kernel_dim, hidden_dim) = (%d, %d)", K_, H_);
-
 extern "C" int nksr_voxel_psi(const float* feat, int32_t n, int kdim, int hidden, const float* mlp, float* psi_out,
                               void* stream) {
     if (n <= 0) return NKSR_OK;
@@ -338,21 +239,6 @@ extern "C" int nksr_kernel_factors(const nksr_hier_t* h, const float* xyz, int64
     } while (0)
     if (h->hidden == 16) NKSR_LAUNCH_FACTORS(16); else NKSR_LAUNCH_FACTORS(32);
 #undef NKSR_LAUNCH_FACTORS
-    NKSR_CHECK_LAUNCH();
-    return NKSR_OK;
-}
-
-extern "C" int nksr_evaluate_f(const nksr_hier_t* h, const float* alpha, const float* xyz, int64_t n, int approx, int active_only,
-                               float* f_out, float* grad_out, void* stream) {
-    if (n <= 0) return NKSR_OK;
-    if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
-    dim3 grid(nksr_blocks(n, 128)), block(128);
-    DISPATCH_KH(h->kdim, h->hidden, {
-        size_t lds = (size_t)h->depth * MlpView<K, H>::SIZE * sizeof(float);
-        if (!grad_out) hipLaunchKernelGGL((k_evaluate_f<K, H, false, false>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out, active_only);
-        else if (approx) hipLaunchKernelGGL((k_evaluate_f<K, H, true, false>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out, active_only);
-        else hipLaunchKernelGGL((k_evaluate_f<K, H, true, true>), grid, block, lds, (hipStream_t)stream, *h, alpha, xyz, n, f_out, grad_out, active_only);
-    })
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }

@@ -17,8 +17,19 @@ struct MlpView {
 // exists, so only layer 1 (h1, d1) and the outputs are live -- 4 (H + K) instead of 8 H + 8 K registers with tangents (the
 // K=16 / H=32 instantiations spilled to scratch and the K=4 / H=16 one sat at 196 VGPRs when all three layers were arrays).
 // phi / J may alias t / Jt.
-template <int K, int H, bool JAC>
-__device__ __forceinline__ void mlp_residual(const MlpView<K, H>& m, const float t[K], const float Jt[K][3],
+// the same weights read through the scalar cache into SGPRs (constant address space, uniform addresses): they are the same for every
+// lane -- as LDS reads they cost a ds_read per four weights and the registers to hold them
+typedef const __attribute__((address_space(4))) float nksr_cfloat;
+template <int K, int H>
+struct MlpViewC {
+    nksr_cfloat *W1, *b1, *W2, *b2, *W3, *b3;
+    __device__ explicit MlpViewC(const float* w) {
+        W1 = (nksr_cfloat*)(uintptr_t)w; b1 = W1 + H * K; W2 = b1 + H; b2 = W2 + H * H; W3 = b2 + H; b3 = W3 + K * H;
+    }
+};
+
+template <int K, int H, bool JAC, typename View>
+__device__ __forceinline__ void mlp_residual(const View& m, const float t[K], const float Jt[K][3],
                                              float phi[K], float J[K][3]) {
     float h1[H];
     float d1[JAC ? H : 1][3];
@@ -213,3 +224,12 @@ __device__ __forceinline__ void trilerp_feat_row(const nksr_level_t& lv, const S
 
 // 27 consecutive floats / one psi or feature vector at a 4-byte aligned address
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+// ---- dispatch on (kernel_dim, hidden_dim) ---------------------------------------------------------
+#define DISPATCH_KH(K_, H_, ...)                                  \
+    if (K_ == 4 && H_ == 16) { constexpr int K = 4, H = 16; __VA_ARGS__ } \
+    else if (K_ == 16 && H_ == 32) { constexpr int K = 16, H = 32; __VA_ARGS__ } \
+    else if (K_ == 4 && H_ == 32) { constexpr int K = 4, H = 32; __VA_ARGS__ } \
+    else if (K_ == 16 && H_ == 16) { constexpr int K = 16, H = 16; __VA_ARGS__ } \
+    else return nksr_set_error(NKSR_ERR_ARG, "unsupported (kernel_dim, hidden_dim) = (%d, %d)", K_, H_);
+
