@@ -119,7 +119,7 @@ def live_traffic_fused(flags, timeout_s=240):
             pass
 
 
-def roofline_record(ms, launches, alg, phys, survey, fused=False):
+def roofline_record(ms, launches, alg, phys, survey, fused=False, samples=None):
     """The CG operator application ("SpMV") measured live with HIP events on the solve stream inside the timed region.
     achieved / frac   = ALGORITHMIC bytes / time, a fraction of the 8 TB/s HBM peak (always <= 1):
                         assembled CSR: SURVEY.md section 8d, 8 nnz + 12 M + 4;
@@ -148,6 +148,12 @@ def roofline_record(ms, launches, alg, phys, survey, fused=False):
            'bytes_per_launch': a, 'physical_bytes_per_launch': p, 'avg_launch_us': avg_s * 1e6, 'launches_timed': launches}
     if note:
         rec['traffic_note'] = note
+    if samples:
+        # the launches one by one (same HIP events): a slow box or a few slow launches show in min / median, not in the mean
+        us = sorted(1e3 * v for v in samples)
+        med = us[len(us) // 2]
+        rec.update(launch_us_min=us[0], launch_us_median=med, launch_us_max=us[-1],
+                   frac_median=(a / (med * 1e-6) / HBM_PEAK if med > 0 else 0.0), frac_best=(a / (us[0] * 1e-6) / HBM_PEAK if us[0] > 0 else 0.0))
     if fused:
         rec['survey_formula_bytes_per_launch'] = sv
         rec['survey_formula_frac'] = rate(sv) / HBM_PEAK
@@ -314,12 +320,13 @@ def main():
                  'device_frees_per_step': (ms1.get('num_device_free', 0) - ms0.get('num_device_free', 0)) / steps,
                  'reserved_GB': ms1.get('reserved_bytes.all.current', 0) / 1e9, 'peak_allocated_GB': ms1.get('allocated_bytes.all.peak', 0) / 1e9}
         ms, launches = solver.profile_spmv(False)
+        samples = solver.profile_spmv_samples()
         alg, phys, survey = solver.profile_spmv_bytes()
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() != 'gloo' else 'cpu')
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt, out, (ms, launches, alg, phys, survey), alloc
+        return dt, out, (ms, launches, alg, phys, survey, samples), alloc
 
     def acc_stages(acc, timing, extra):
         if acc is not None:
@@ -399,7 +406,7 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
         'data': 'synthetic', 'headline_config': 'configs[4]',      # (the top-level workload since round 4; rounds 1-3 quoted configs[2], now the cloud_1m sub-record)
-        'config': cfg, 'roofline': roofline_record(*prof, fused=True), 'stages_s_per_step': stages, 'allocator': alloc,
+        'config': cfg, 'roofline': roofline_record(*prof[:5], fused=True, samples=prof[5]), 'stages_s_per_step': stages, 'allocator': alloc,
         'dist': {'backend': (dist.get_backend() if dist is not None else None), 'world_size': world, 'rccl_ranks_seen': ranks_seen,
                  'launcher': 'bench.py self-spawn (torch.distributed.run)' if os.environ.get('NKSR_BENCH_SPAWNED') else ('external' if world > 1 else 'single process')},
     }
@@ -414,13 +421,15 @@ def main():
         torch.cuda.empty_cache()
         cdt, cn, ccfg, cprof, cstages, calloc, extra = run_cloud(args.cloud_steps, 1, True)
         cloud = {'value': cn * args.cloud_steps / cdt, 'unit': 'points/s', 'ms_per_step': cdt / args.cloud_steps * 1e3, 'steps': args.cloud_steps, 'warmup': 1,
-                 'config': ccfg, 'roofline': roofline_record(*cprof, fused=True), 'stages_s_per_step': cstages, 'allocator': calloc}
+                 'config': ccfg, 'roofline': roofline_record(*cprof[:5], fused=True, samples=cprof[5]), 'stages_s_per_step': cstages, 'allocator': calloc}
         if not args.no_other_mode:
             # the same workload through the other solve: assembled CSR + streaming SpMV (solve_non_fused, the path training needs)
-            odt, _, ocfg, oprof, ostages, oalloc, _ = run_cloud(2, 1, False)
-            cloud['other_solve_mode'] = {'fused_mode': False, 'value': cn * 2 / odt, 'unit': 'points/s', 'ms_per_step': odt / 2 * 1e3, 'steps': 2,
+            # (five steps: >= 50 timed SpMV launches)
+            OSTEPS = 5
+            odt, _, ocfg, oprof, ostages, oalloc, _ = run_cloud(OSTEPS, 1, False)
+            cloud['other_solve_mode'] = {'fused_mode': False, 'value': cn * OSTEPS / odt, 'unit': 'points/s', 'ms_per_step': odt / OSTEPS * 1e3, 'steps': OSTEPS,
                                          'warmup': 1, 'unknowns_M': ocfg['unknowns_M'], 'nnz_A': ocfg['nnz_A'], 'pcg_iters': ocfg['pcg_iters'],
-                                         'roofline': roofline_record(*oprof, fused=False), 'stages_s_per_step': ostages, 'allocator': oalloc}
+                                         'roofline': roofline_record(*oprof[:5], fused=False, samples=oprof[5]), 'stages_s_per_step': ostages, 'allocator': oalloc}
             # north_star's KPI at the top level of every N = 1 line: the CSR SpMV roofline (target 0.70 of 8 TB/s)
             out['spmv_csr_roofline'] = cloud['other_solve_mode']['roofline']
         out['cloud_1m'] = cloud

@@ -282,6 +282,9 @@ int nksr_pcg_solve(const int32_t* rowptr, const void* cols, const float* vals, c
 /* Live profiling of the SpMV launches inside nksr_pcg_solve (HIP events on the solve's stream).
  * Returns and resets the accumulated milliseconds / launch count, then sets the enable flag. */
 int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_out);
+/* Durations (milliseconds) of the individual applications behind the totals the last nksr_pcg_profile call returned (host array,
+ * at most `capacity` written); returns how many there were. */
+int64_t nksr_pcg_profile_samples(float* ms_out, int64_t capacity);
 /* Bytes of the launches timed since the last call (then reset): the algorithmic figure -- CSR: 8 nnz + 12 M + 4 per launch
  * (SURVEY.md section 8d); matrix-free operator: its algorithmic minimum, 4 bytes per stored entry + 4 per row and level (row ->
  * cell) + 116 per unknown (stencil, x, y) -- and the bytes the physical layout streams (col_format, padding, partial blocks). */

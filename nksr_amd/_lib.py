@@ -110,6 +110,8 @@ lib.nksr_pcg_vector_workspace_bytes.restype = _sz
 lib.nksr_pcg_vector_workspace_bytes.argtypes = [_i32]
 lib.nksr_pcg_profile_survey_bytes.restype = C.c_double
 lib.nksr_pcg_profile_survey_bytes.argtypes = []
+lib.nksr_pcg_profile_samples.restype = _i64
+lib.nksr_pcg_profile_samples.argtypes = [_vp, _i64]
 lib.nksr_pcg_vector_workspace_bytes_seg.restype = _sz
 lib.nksr_pcg_vector_workspace_bytes_seg.argtypes = [_i32, _i32, _i32]
 
@@ -207,7 +209,7 @@ for _name, _args in _PROTOS.items():
     _fn.argtypes = _args
     _fn.restype = C.c_int
 
-EXPORTED = ['nksr_conv3_wgrad_chunks', 'nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
+EXPORTED = ['nksr_conv3_wgrad_chunks', 'nksr_pcg_profile_samples', 'nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
             'nksr_assemble_split_bytes',
             'nksr_fused_workspace_bytes', 'nksr_fused_item_entries', 'nksr_pcg_vector_workspace_bytes', 'nksr_pcg_vector_workspace_bytes_seg', 'nksr_pcg_profile_survey_bytes', 'nksr_bbox_work_floats'] + sorted(_PROTOS)
 

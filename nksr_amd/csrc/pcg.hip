@@ -590,6 +590,8 @@ static double g_prof_alg_bytes = 0.0, g_prof_phys_bytes = 0.0, g_prof_survey_byt
 // adds to the shared accumulators under a lock
 static thread_local std::vector<hipEvent_t> g_prof_events;
 static std::mutex g_prof_mutex;
+static std::vector<float> g_prof_last_samples;
+static std::vector<float> g_prof_samples;      // milliseconds of every timed application since the last nksr_pcg_profile call (at most 65536)
 
 // bytes one SpMV launch moves: algorithmic CSR figure of SURVEY.md section 8d (8 nnz + 12 M + 4) and what the physical
 // layout actually streams (values + packed / int32 columns over the padded storage + row pointers + x + y)
@@ -622,7 +624,17 @@ extern "C" int nksr_pcg_profile(int enable, double* ms_out, int64_t* launches_ou
     g_prof_ms = 0.0;
     g_prof_launches = 0;
     g_prof_enable = enable;
+    g_prof_last_samples.swap(g_prof_samples);
+    g_prof_samples.clear();
     return NKSR_OK;
+}
+// the individual durations (milliseconds) behind the totals the LAST nksr_pcg_profile call returned: a slow box or a slow launch is
+// visible in min / median, not in a mean
+extern "C" int64_t nksr_pcg_profile_samples(float* ms_out, int64_t capacity) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    const int64_t n = (int64_t)g_prof_last_samples.size() < capacity ? (int64_t)g_prof_last_samples.size() : capacity;
+    for (int64_t i = 0; i < n && ms_out; ++i) ms_out[i] = g_prof_last_samples[i];
+    return (int64_t)g_prof_last_samples.size();
 }
 
 // ---- coarse-level block preconditioner -------------------------------------------------------------------------------------------
@@ -1148,6 +1160,7 @@ int nksr_pcg_run(PcgOperator& A, const float* diag, int32_t M, const float* b, f
                 if (hipEventElapsedTime(&ms, g_prof_events[2 * c], g_prof_events[2 * c + 1]) == hipSuccess) {
                     g_prof_ms += ms;
                     g_prof_launches += 1;
+                    if (g_prof_samples.size() < 65536) g_prof_samples.push_back(ms);
                     g_prof_alg_bytes += ba;
                     g_prof_phys_bytes += bp;
                     g_prof_survey_bytes += bs;

@@ -29,6 +29,8 @@ def pack_interpolator(interp):
 
 PC_RATIO = 40.0          # Chebyshev interval [lambda_max / PC_RATIO, lambda_max] of the coarse block (100 until late round 3: 11.16 -> 10.9
 #                          PCG iterations per chunk of the 64-chunk scene at the same step count; 10..20 are worse again, 200 much worse)
+SMALL_FIELD_UNKNOWNS = 1 << 16      # single fields up to this size take the coarse-level block at once, from level 1 (solve_fused)
+SMALL_FIELD_PC = {'first_level': 1, 'steps': 8, 'ratio': 40.0}
 PC_DROP_TOL = 0.005        # packed coarse block: off-diagonal entries below this fraction of the (unit) diagonal are left out
 _DETAIL = os.environ.get('NKSR_TIMING_DETAIL', '') == '1'
 DETAIL_TIMES = {}
@@ -590,15 +592,20 @@ class KernelField(BaseField):
         op['dense'] = None
         return dense
 
+    def _small_field(self):
+        """Single fields of at most 2^16 unknowns (configs[1], one scan of examples/recons_waymo_cpu.py): the policy takes the block of
+        the levels >= 1 at once -- see solve_fused."""
+        return 2 <= self.svh.depth < 5 and self.svh.num_unknowns <= SMALL_FIELD_UNKNOWNS      # (5+ levels: the block of the levels >= 2, as ever)
+
     def _pc_first_level(self, segments=None):
         """First level of the coarse-level block the solve is going to build at once, or None (see solve_fused / _coarse_precond)."""
         cfg = self.solver_config.get('coarse_precond')
         if cfg is False:
             return None
         auto = cfg is None and segments is None
-        if auto and self.svh.depth < 5:
+        if auto and self.svh.depth < 5 and not self._small_field():
             return None
-        cfg = cfg if isinstance(cfg, dict) else {}
+        cfg = cfg if isinstance(cfg, dict) else (dict(SMALL_FIELD_PC) if auto and self._small_field() else {})
         c0 = int(cfg.get('first_level', float(os.environ.get('NKSR_PC_LEVEL', 2))))
         off, M = self.svh.offsets, self.svh.num_unknowns
         return c0 if (0 < c0 < self.svh.depth and M - off[c0] >= 1) else None
@@ -614,7 +621,7 @@ class KernelField(BaseField):
         call('nksr_fused_apply', C.byref(op['op']), float(reg_weight), ptr(x.contiguous()), ptr(y), stream())
         return y
 
-    def _coarse_precond(self, op, reg_weight, segments=None, sites=None):
+    def _coarse_precond(self, op, reg_weight, segments=None, sites=None, override=None):
         """Block preconditioner of the coarse levels (nksr_coarse_precond_t, csrc/pcg.hip): the diagonal block of the levels >= c0
         assembled as a small plain CSR + the largest Jacobi-scaled eigenvalue of every segment's block (left on the device: no
         host sync).  solver_config['coarse_precond']: None = automatic (see solve_fused), False = off, or a dict
@@ -623,7 +630,7 @@ class KernelField(BaseField):
         L = self.svh.depth
         if cfg is False:
             return None
-        cfg = dict(cfg) if isinstance(cfg, dict) else {}
+        cfg = dict(cfg) if isinstance(cfg, dict) else dict(override or {})
         for k, e in (('first_level', 'NKSR_PC_LEVEL'), ('steps', 'NKSR_PC_STEPS'), ('ratio', 'NKSR_PC_RATIO')):      # tuning knobs
             if e in os.environ and k not in cfg:
                 cfg[k] = float(os.environ[e])
@@ -727,8 +734,12 @@ class KernelField(BaseField):
         # sensor-only inputs and adaptive_depth 2 take 100+ Jacobi iterations at depth 4 too).
         # Batched chunk solves (``segments``) always take the block at once: a restart decided on the joint residual would make a
         # chunk's iterates depend on its batch mates.
+        # Small single fields (<= 2^16 unknowns; round 6): the block of the levels >= 1 at once, eight steps on [lmax / 40, lmax] -- the
+        # block is a few thousand unknowns there and costs little, and one failed Jacobi round was most of the solve (configs[1] 39 ->
+        # 18 iterations, the 10 000-point bunny scan 93 -> 53, the smoke sphere 94 -> 57: tools/small_pc_sweep.py).
         auto = cfg.get('coarse_precond') is None and segments is None
-        pc = self._coarse_precond(op, reg_weight, segments) if (not auto or self.svh.depth >= 5) else None
+        small = auto and self._small_field()
+        pc = self._coarse_precond(op, reg_weight, segments, override=SMALL_FIELD_PC if small else None) if (not auto or small or self.svh.depth >= 5) else None
         op['dense'] = None                      # (dense coarse rows nobody took over)
         td = _tick('coarse_precond', td)
         if cfg.get('verbose') or cfg.get('sync_timing'):

@@ -34,7 +34,12 @@ def extract_dual_mesh(field, mise_iter=0, grid_upsample=1, max_points=-1):
     # A chunked field held by ONE process meshes its union hierarchy (levels < adaptive_depth on the global lattice) with the blended
     # field like any other; only fields spread over several ranks stay on the lattice (their pieces are stitched by lattice vertex keys).
     spread = hasattr(field, 'finalize_mesh') and (getattr(field, 'world_size', 1) > 1 or getattr(field, 'distributed', False))
-    if getattr(field, 'dual_graph', 'lattice') == 'adaptive' and not spread:
+    if getattr(field, 'dual_graph', 'lattice') == 'adaptive':
+        if spread:
+            # (never a silent lattice mesh where the adaptive dual graph was asked for)
+            raise RuntimeError("dual_graph='adaptive' is not available for a chunked field spread over several ranks: the seam merge "
+                               "names vertices by lattice keys (nksr_amd/dist.py).  Mesh with dual_graph='lattice', or hold all "
+                               "chunks in one process")
         return _extract_adaptive(field, mise_iter, grid_upsample, max_points)
     res = _extract(field, mise_iter, grid_upsample, max_points)
     if hasattr(field, 'finalize_mesh'):       # distributed fields gather + stitch the pieces (collective)

@@ -57,6 +57,14 @@ def profile_spmv(enable):
     return float(ms.value), int(n.value)
 
 
+def profile_spmv_samples():
+    """Milliseconds of every application behind the totals the last profile_spmv() call returned."""
+    n = int(lib.nksr_pcg_profile_samples(None, 0))
+    buf = (C.c_float * max(n, 1))()
+    lib.nksr_pcg_profile_samples(C.cast(buf, C.c_void_p), n)
+    return [float(buf[i]) for i in range(n)]
+
+
 def profile_spmv_bytes():
     """(algorithmic, physical, SURVEY-formula) bytes of the operator applications timed since the last call."""
     a, b = C.c_double(0.0), C.c_double(0.0)

@@ -35,3 +35,26 @@ def test_gis_app_example(tmp_path):
     # the mesh came back in the caller's projected coordinates (offsets of 1e5 .. 1e6 m), within the 20 m region of interest
     c = v.mean(0)
     assert abs(c[0] - 433_220.0) < 40 and abs(c[1] - 5_213_420.0) < 40 and np.ptp(v[:, 0]) < 45
+
+
+def test_recons_colored_mesh_example(tmp_path):
+    """reference examples/recons_colored_mesh.py:25-31: reconstruct, set_texture_field(PCNNField(xyz, colour)), extract_dual_mesh(max_points=2**22,
+    mise_iter=1), a PLY with per-vertex colours."""
+    from nksr_amd import utils
+    out = _run('recons_colored_mesh.py', tmp_path)
+    p = tmp_path / 'recons_colored.ply'
+    assert p.exists() and 'V=' in out and '(coloured)' in out
+    head = open(p, 'rb').read(600).decode('latin1')
+    assert 'property uchar red' in head and 'element face' in head
+    n = int(head.split('element vertex')[1].split()[0])
+    assert n > 1000
+
+
+def test_recons_waymo_example(tmp_path):
+    """reference examples/recons_waymo.py:24-43: sensor-only input, chunk_tmp_device = cpu, approx_kernel_grad, solver_tol=1e-4, fused_mode,
+    kNN-PCA normals (64 neighbours, 85 degrees), extract_dual_mesh(mise_iter=1)."""
+    out = _run('recons_waymo.py', tmp_path)
+    p = tmp_path / 'recons_waymo.ply'
+    assert p.exists() and p.stat().st_size > 1_000_000 and 'V=' in out
+    v = int(out.split('V=')[1].split()[0])
+    assert v > 100_000

@@ -865,13 +865,16 @@ def test_a_coarse_block_that_loses_definiteness_falls_back_to_jacobi_on_the_devi
         pu.check('coarse_precond:fallback_alpha_vs_jacobi_rel[fused=%s]' % fused, float((ab - aj).abs().max() / aj.abs().max()), pu.ALPHA_TOL)
 
 
-def test_shallow_hierarchies_switch_to_the_coarse_block_when_jacobi_stalls():
-    """Depth-4 hierarchies start with Jacobi (the dense 1M-point cloud converges in 11 iterations) and restart on the residual with
-    the coarse-level block after one unconverged round of check_every iterations: sparse input with normal sites on two levels
-    (adaptive_depth 2, the carla preset's) takes 100+ Jacobi iterations.  Same solution, fewer iterations, deterministic."""
+@pytest.mark.parametrize('n,voxel', [(2500, 0.02), (12000, 0.009)])
+def test_shallow_hierarchies_take_the_coarse_block_small_ones_at_once_large_ones_when_jacobi_stalls(n, voxel):
+    """Depth-4 single fields: up to 2^16 unknowns the block of the levels >= 1 is taken from the first iteration (round 6: one failed
+    Jacobi round was most of a small solve); larger ones start with Jacobi (the dense 1M-point cloud converges in 11 iterations) and
+    restart on the residual with the block of the levels >= 2 after one unconverged round of check_every iterations.  Sparse input
+    with normal sites on two levels (adaptive_depth 2, the carla preset's) takes 100+ Jacobi iterations either way.  Same solution,
+    fewer iterations, deterministic."""
     import nksr_amd
     from nksr_amd import configs
-    n = 2500
+    from nksr_amd.fields.kernel_field import SMALL_FIELD_UNKNOWNS
     k = np.arange(n) + 0.5
     phi, z = np.pi * (1 + 5 ** 0.5) * k, 1 - 2 * k / n
     nrm = np.stack([np.cos(phi) * np.sqrt(1 - z * z), np.sin(phi) * np.sqrt(1 - z * z), z], 1).astype(np.float32)
@@ -882,12 +885,15 @@ def test_shallow_hierarchies_switch_to_the_coarse_block_when_jacobi_stalls():
     for name, pc in (('jacobi', False), ('auto', None), ('auto2', None)):
         rec = nksr_amd.Reconstructor(_dev(), hparams=hp)
         rec.coarse_precond = pc
-        fld = rec.reconstruct(t(xyz), t(nrm), voxel_size=0.02, solver_tol=1e-6)
+        fld = rec.reconstruct(t(xyz), t(nrm), voxel_size=voxel, solver_tol=1e-6)
         assert fld.svh.depth == 4 and fld.solve_info['rel_residual'] <= 1e-6
-        res[name] = (fld.alpha.clone(), fld.solve_info['iters'], fld.solve_info['coarse_precond'])
-    pu.report('coarse_precond:adaptive_iters', auto=res['auto'][1], jacobi_only=res['jacobi'][1])
-    assert res['jacobi'][1] > 48 and res['jacobi'][2] is None, res['jacobi'][1]          # otherwise this input does not exercise the switch
+        res[name] = (fld.alpha.clone(), fld.solve_info['iters'], fld.solve_info['coarse_precond'], fld.solve_info['M'])
+    M = res['auto'][3]
+    assert (M <= SMALL_FIELD_UNKNOWNS) == (n == 2500), M                                  # one case on either side of the policy's bound
+    pu.report('coarse_precond:adaptive_iters[M=%d]' % M, auto=res['auto'][1], jacobi_only=res['jacobi'][1], first_level=res['auto'][2]['first_level'])
+    assert res['jacobi'][1] > (48 if n == 2500 else 16) and res['jacobi'][2] is None, res['jacobi'][1]    # (more than one round of check_every: otherwise the input does not exercise the switch)
     assert res['auto'][2] is not None and res['auto'][1] < res['jacobi'][1]
+    assert res['auto'][2]['first_level'] == (1 if M <= SMALL_FIELD_UNKNOWNS else 2)
     assert torch.equal(res['auto'][0], res['auto2'][0]) and res['auto'][1] == res['auto2'][1]
     pu.check('coarse_precond:adaptive_alpha_vs_jacobi_rel', float((res['auto'][0] - res['jacobi'][0]).abs().max() / res['jacobi'][0].abs().max()),
              pu.ALPHA_TOL)
