@@ -168,7 +168,13 @@ int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int appr
  * sites < 2^29 per set. */
 int nksr_kernel_rows_merged(const nksr_hier_t* h, const float* xyz_pos, const float* scale_pos, float row_scale_pos,
                             const float* xyz_nrm, const float* scale_nrm, float row_scale_nrm, int approx, const int32_t* row_src,
-                            int64_t rows_total, int32_t* row_cells, float* rows_out, void* stream);
+                            int64_t rows_total, int32_t* row_cells, const int32_t* compact_nbr32, float* rows_out, void* stream);
+/* compact_nbr32 == NULL: dense rows as above, row_cells (may be NULL) is WRITTEN.  compact_nbr32 = nksr_fused_op_t.nbr32: COMPACT rows
+ * (nksr_fused_op_t.compact) -- row_cells [L][rows_total] is READ (nksr_row_cells_merged made it before the tables could be built) and
+ * every wavefront writes the words of its 64 rows, level by level, as one contiguous run of the compact array.
+ * nksr_row_cells_merged: row_cells_out[d][r] = global unknown index of the level-d cell of row r's site, -1 = none (pad rows: -1). */
+int nksr_row_cells_merged(const nksr_hier_t* h, const float* xyz_pos, const float* xyz_nrm, const int32_t* row_src, int64_t rows_total,
+                          int32_t* row_cells_out, void* stream);
 /* row_src of nksr_kernel_rows_merged from the sets' first rows: row_src[first_row[i] + c] = (i << 2) | (kind0 + c), c < ncomp
  * (ncomp 1, kind0 0: position sites; ncomp 3, kind0 1: normal sites).  The caller pre-fills row_src with -1. */
 int nksr_row_sources(const int32_t* first_row, int64_t n, int ncomp, int kind0, int32_t* row_src, void* stream);
@@ -216,6 +222,8 @@ typedef struct {
     int64_t level_stride;      /* 0: val is site-major as above.  > 0: val is the LEVEL-MAJOR array of the matrix-free operator
                                 * ([L, level_stride, 27], nksr_fused_op_t.rows_all) and site i owns the rows row_index[i] .. + ncomp */
     const int32_t* row_index;  /* [n] first row of every site (level-major layout; NULL = i * ncomp) */
+    const int32_t* compact_cells; /* COMPACT rows of the matrix-free operator (nksr_fused_op_t.compact): its row_cells [L][level_stride] and */
+    const int32_t* compact_nbr32; /* nbr32 [M][32]; NULL = dense rows.  val is then the compact array, one row per "site" (ncomp 1, no row_index) */
 } nksr_siteset_t;
 
 /* Structure pass.  Per row: rowcount = structural upper entries (column voxel exists, B-spline supports
@@ -364,7 +372,7 @@ typedef struct {
     const float* targets_all;  /* [rows_total] right-hand side values pre-multiplied by sqrt(w) (0 for rows without a target); may be NULL if unused */
     const int32_t* row_cells;  /* [depth][rows_total] GLOBAL unknown index of the row's level-d cell, -1 = none (nksr_kernel_rows) */
     const int32_t* nbr32;      /* [M, 32]: [0..26] GLOBAL unknown index of every neighbour voxel or -1; [27] block base, [28] / [29] first / last row of
-                                * the cell (nksr_fused_tables) */
+                                * the cell, [30] first word / 4 of the cell's rows in the compact array, [31] mask of the existing neighbours (nksr_fused_tables) */
     const int32_t* nbrT;       /* [27, M]: the same neighbour indices SLOT-MAJOR (the second product's gather runs one lane per unknown) */
     const int32_t* item_begin; /* [nksr_fused_item_entries(rows_total)] first row of every work item of the sweep (nksr_fused_block_counts) */
     const int32_t* offsets;    /* [M + 1] partial blocks of a cell = [offsets[j], offsets[j + 1])                             */
@@ -387,6 +395,12 @@ typedef struct {
     float inv_w0;              /* 1 / finest voxel size (fp32, as in nksr_hier_t)                                               */
     int32_t dense_from;        /* nksr_fused_rhs_diag / nksr_fused_expand_rows: the rebuilt rows of the levels >= dense_from are also written to */
     float* dense_out;          /* [depth - dense_from][rows_total][27] (NULL: not wanted) -- what the coarse-level block of the preconditioner is assembled from */
+    /* COMPACT rows (round 6; nksr_fused_row_sizes, nksr_kernel_rows_merged): compact != 0 => rows_all holds, for every row, only the slots
+     * of its cell's EXISTING neighbours (a quarter of the dense slots of a chunked scene are structural zeros).  Cell j owns the words
+     * [4 nbr32[j][30], + rows_j popcount(nbr32[j][31])) in row order, slots in slot order, every block padded to 16 bytes with zeros;
+     * words 0..3 of rows_all are zero.  rows_words = length of rows_all in words (without the tail padding). */
+    int32_t compact;
+    int64_t rows_words;
 } nksr_fused_op_t;
 /* A UNIT is a maximal run of rows that lie in the same cell at every level (the rows of one level-0 cell); work item i of the sweep =
  * the units that start in the 32-row window [32 i, 32 i + 32) = rows [item_begin[i], item_begin[i + 1]); eight items are a workgroup.
@@ -398,7 +412,11 @@ int64_t nksr_fused_item_entries(int64_t rows_total);
 int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_total, const int32_t* row_cells, int32_t* span_out, int32_t* item_begin_out,
                             int32_t* counts_out, void* stream);
 int nksr_fused_tables(const nksr_hier_t* h, int64_t rows_total, const int32_t* item_begin, const int32_t* offsets, const int32_t* span,
-                      int32_t* nbr32_out, int32_t* nbrT_out, void* stream);
+                      const int32_t* rowbase4, int32_t* nbr32_out, int32_t* nbrT_out, void* stream);
+/* COMPACT rows: sizes4_out [M + 1] (int64; last entry 0) = 16-byte units of the rows of every cell, (rows of the cell) x (its existing
+ * neighbours), rounded up; rowbase4 [M] (int32; may be NULL: dense rows) = 1 + the exclusive scan of sizes4 (unit 0 is the zero block)
+ * goes to nksr_fused_tables, which writes it to nbr32[j][30] next to the neighbour mask nbr32[j][31]. */
+int nksr_fused_row_sizes(const nksr_hier_t* h, const int32_t* span, int64_t* sizes4_out, void* stream);
 size_t nksr_fused_workspace_bytes(int64_t nblocks, int32_t M);
 /* b = sum_s R_s^T t_s and diag = reg + sum_s diag(R_s^T R_s) (either may be NULL): one sweep over the rows serves both. */
 int nksr_fused_rhs_diag(const nksr_fused_op_t* op, float reg, float* b_out, float* diag_out, void* stream);

@@ -48,7 +48,7 @@ class FusedOpT(C.Structure):
     _fields_ = [('depth', _i32), ('M', _i32), ('n_multi', _i32), ('n_big', _i32), ('rows_total', _i64), ('rows_all', _vp),
                 ('targets_all', _vp), ('row_cells', _vp), ('nbr32', _vp), ('nbrT', _vp), ('item_begin', _vp), ('offsets', _vp), ('multi', _vp), ('nblocks', _i64),
                 ('nnz_counter', _vp), ('workspace', _vp), ('cell_sums', _vp), ('item_seg', _vp), ('unknown_seg', _vp),
-                ('fac_vec', _vp), ('fac_pos', _vp), ('psi_all', _vp), ('inv_w0', _f32), ('dense_from', _i32), ('dense_out', _vp)]
+                ('fac_vec', _vp), ('fac_pos', _vp), ('psi_all', _vp), ('inv_w0', _f32), ('dense_from', _i32), ('dense_out', _vp), ('compact', _i32), ('rows_words', _i64)]
 
 
 class ChunkGridT(C.Structure):
@@ -71,7 +71,7 @@ PC_MAX_STEPS = 16
 
 class SiteSetT(C.Structure):
     _fields_ = [('n', _i64), ('ncomp', _i32), ('weight', _f32), ('val', _vp), ('target', _vp),
-                ('start', _vp * MAX_DEPTH), ('end', _vp * MAX_DEPTH), ('level_stride', _i64), ('row_index', _vp)]
+                ('start', _vp * MAX_DEPTH), ('end', _vp * MAX_DEPTH), ('level_stride', _i64), ('row_index', _vp), ('compact_cells', _vp), ('compact_nbr32', _vp)]
 
 
 def _load():
@@ -160,11 +160,13 @@ _PROTOS = {
     'nksr_spmv_csr': [_vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _vp, _vp],
     'nksr_pcg_solve': [_vp, _vp, _vp, _vp, _i32, _i64, C.c_int, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(C.c_double), _vp],
     'nksr_fused_block_counts': [_i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp],
-    'nksr_fused_tables': [_P(HierT), _i64, _vp, _vp, _vp, _vp, _vp, _vp],
+    'nksr_fused_tables': [_P(HierT), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    'nksr_fused_row_sizes': [_P(HierT), _vp, _vp, _vp],
+    'nksr_row_cells_merged': [_P(HierT), _vp, _vp, _vp, _i64, _vp, _vp],
     'nksr_fused_rhs_diag': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_fused_expand_rows': [_P(FusedOpT), _vp],
-    'nksr_kernel_rows_merged': [_P(HierT), _vp, _vp, _f32, _vp, _vp, _f32, C.c_int, _vp, _i64, _vp, _vp, _vp],
+    'nksr_kernel_rows_merged': [_P(HierT), _vp, _vp, _f32, _vp, _vp, _f32, C.c_int, _vp, _i64, _vp, _vp, _vp, _vp],
     'nksr_row_sources': [_vp, _i64, C.c_int, C.c_int, _vp, _vp],
     'nksr_kernel_factors': [_P(HierT), _vp, _i64, C.c_int, C.c_int, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(SegmentsT), _P(C.c_double), _vp],

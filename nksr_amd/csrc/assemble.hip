@@ -185,6 +185,26 @@ __device__ __forceinline__ void asm_accumulate_lm(const AsmArgs& A, int d, int r
         // (columns past T are never used but their loads are unconditional: they read level d -- the array may START at the first
         // level that has cells, see KernelField.assemble: a base shifted below it must not be dereferenced)
         P.p[n] = (col == T && S.target) ? S.target : S.val + (col < T ? (int64_t)(d + dd) * S.level_stride * 27 + sl : (int64_t)d * S.level_stride * 27);
+        if (S.compact_nbr32 && !(col == T && S.target)) {
+            // COMPACT rows (csrc/fused.hip, k_fz_row_sizes): the rows r_lo .. r_hi of this cell lie in ONE cell of every coarser level too;
+            // that cell's block holds, per row, the slots of its existing neighbours.  A column whose neighbour does not exist (or past
+            // T) reads the zero word of the array at stride 0.
+            P.mul[n] = 0;
+            P.p[n] = S.val;
+            if (col < T) {
+                const int cj = S.compact_cells[(int64_t)(d + dd) * S.level_stride + r_lo];
+                if (cj >= 0) {
+                    const int32_t* tb = S.compact_nbr32 + (int64_t)cj * 32;
+                    const unsigned m = (unsigned)tb[31];
+                    if ((m >> sl) & 1u) {
+                        const int k = __popc(m);
+                        P.mul[n] = k;
+                        // (indexed by the ABSOLUTE row below: the pointer is taken back by the cell's first row)
+                        P.p[n] = S.val + ((int64_t)tb[30] * 4 + __popc(m & ((1u << sl) - 1u)) - (int64_t)tb[28] * k);
+                    }
+                }
+            }
+        }
     }
     const float w = S.weight;
     float bA[ASM_TRIP][NT], bB[ASM_TRIP][NT];

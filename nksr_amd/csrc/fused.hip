@@ -22,6 +22,7 @@
 // twice, t through memory: 1.05 ms per application at the bench workload.)
 #include "common.h"
 #include "pcg_core.h"
+#include <stdlib.h>
 
 #define FZ_RC 32
 // (round 3: reading the kernel rows with the non-temporal hint made the sweep 9-13 % SLOWER -- a 108-byte row shares its cache lines
@@ -111,9 +112,11 @@ __device__ __forceinline__ int fz_level(const nksr_hier_t& h, int j) {
 }
 
 // nbr32[j][0..26]: global unknown index of the neighbour voxels or -1;  [27]: (first block of j) - (first workgroup of j), so that
-// the block of workgroup w is nbr32[j][27] + w;  [28] / [29]: first / last row of the cell (-1: none)
+// the block of workgroup w is nbr32[j][27] + w;  [28] / [29]: first / last row of the cell (-1: none);  [30] / [31]: where the cell's
+// rows lie in the COMPACT row array (see below): first word / 4, and the 27-bit mask of the neighbours that exist
 __global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__ offsets, const int32_t* __restrict__ first,
-                            const int32_t* __restrict__ last, const int32_t* __restrict__ wgfirst, int32_t* __restrict__ nbr32) {
+                            const int32_t* __restrict__ last, const int32_t* __restrict__ wgfirst, const int32_t* __restrict__ rowbase4,
+                            int32_t* __restrict__ nbr32) {
     const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (lin >= (int64_t)M * 32) return;
     const int j = (int)(lin >> 5), s = (int)(lin & 31);
@@ -128,8 +131,34 @@ __global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__
         v = first[j];
     } else if (s == 29) {
         v = last[j];
+    } else if (s == 30) {
+        v = rowbase4 ? rowbase4[j] : 0;
+    } else {
+        const int d = fz_level(hier, j), c = j - hier.lv[d].offset;
+        unsigned m = 0;
+        for (int q = 0; q < 27; ++q) m |= (hier.lv[d].nbr[(int64_t)c * 27 + q] >= 0 ? 1u : 0u) << q;
+        v = (int)m;
     }
     nbr32[lin] = v;
+}
+// ---- COMPACT rows (round 6).  A slot of a kernel row whose neighbour voxel does not exist is a structural zero -- a quarter of the
+// slots of the 64-chunk scene (rim cells).  All rows of a cell share the cell's 27-bit neighbour mask, so they are stored with the
+// k = popcount(mask) existing slots only, in slot order: cell j (rows first .. last of the list, one contiguous run at every level)
+// owns the words [4 b4, 4 b4 + rows k) of ONE array (levels follow each other; within a level the cells lie in row order, every
+// block padded to 16 bytes with zeros); words 0 .. 3 of the array are zero: a lane whose slot does not exist reads word 0 at
+// stride 0.  sizes4[j] = 16-byte units of cell j's block (the caller's exclusive scan + 1 gives b4).
+__global__ void k_fz_row_sizes(nksr_hier_t hier, int M, const int32_t* __restrict__ first, const int32_t* __restrict__ last,
+                               int64_t* __restrict__ sizes4) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > M) return;
+    int64_t v = 0;
+    if (j < M && first[j] >= 0) {
+        const int d = fz_level(hier, j), c = j - hier.lv[d].offset;
+        int k = 0;
+        for (int q = 0; q < 27; ++q) k += hier.lv[d].nbr[(int64_t)c * 27 + q] >= 0 ? 1 : 0;
+        v = ((int64_t)(last[j] - first[j] + 1) * k + 3) >> 2;
+    }
+    sizes4[j] = v;
 }
 // nbrT[s][j]: the same neighbour indices slot-major (the gather's table), transposed through LDS 64 unknowns at a time
 __global__ void __launch_bounds__(256) k_fz_nbrT(int M, const int32_t* __restrict__ nbr32, int32_t* __restrict__ nbrT) {
@@ -173,6 +202,8 @@ struct FusedArgs {               // uniform scalars and base pointers only
     float inv_w0;
     int dense_from;              // set-up pass: the rebuilt rows of the levels >= dense_from are also written out dense
     float* dense_out;            // [depth - dense_from][rows_total][27] or NULL (the coarse-level block of the preconditioner reads them)
+    int compact;                 // rows_all is the COMPACT array (k_fz_row_sizes): a row holds the slots of its cell's existing neighbours only
+    int64_t rows_words;          // words of rows_all the sweep streams (dense: 27 depth rows_total)
 };
 __device__ __forceinline__ bool fz_seg_done(const FusedArgs& A, const int32_t* seg_of, int64_t i) {
     return A.seg_done && seg_of && A.seg_done[(int64_t)seg_of[i] * A.seg_stride] != 0;
@@ -250,7 +281,7 @@ __device__ __forceinline__ float fz_dot4(const float4& a, const float4& b) {
 //   position rows (<= 4 per trip):   w = B_s(u) <phi, psi_s>
 //   a normal site (header + 3 rows): w_a = <phi, psi_s> dB_s/dx_a + <J_a, psi_s> B_s    (B, dB shared by the three rows)
 // Everything downstream of w -- both products, blocks, exchange, staging -- is the dense form's code.
-template <int MODE, int D, int U, bool FAC>
+template <int MODE, int D, int U, bool FAC, bool CMP = false>
 __global__ void __attribute__((amdgpu_waves_per_eu(FAC ? 3 : (D <= 4 ? 6 : 5)))) __launch_bounds__(FZ_BLOCK) k_fz_cells(FusedArgs A, const float* __restrict__ x, float* __restrict__ part,
                                                       float* __restrict__ part2, float* __restrict__ ct, float* __restrict__ ct2,
                                                       const int* __restrict__ done) {
@@ -375,6 +406,27 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FAC ? 3 : (D <= 4 ? 6 : 5))))
     // ---- the first unit: its stencils at all levels (one round trip for the neighbour rows, one for x)
     bool work = Rb < Re;
     int pos = 0, r = Rb, uend = unit_end(0);
+    // DENSE rows: one pointer per level (slot s of row 0), the U rows of a trip at immediate offsets.  COMPACT rows (CMP): the lane's
+    // word of row r and the lane's row stride = the k existing slots of the cell (pointer = the lane's rank among them) -- or stride
+    // 0 at word 0 of the array, a zero, when the lane's neighbour does not exist (or the row has no cell at the level); re-based
+    // whenever the cell of a level changes, advanced by the rows of every trip.  Rows past the unit's (or the item's) last one are
+    // read too (the words that follow: other rows, the array is padded) and never used: their t is 0
+    const float* wp[D];
+    int kq[CMP ? D : 1];
+    auto locate = [&](int d, int nbv, int cell, int rcur) {
+        if (!CMP) return;
+        const unsigned m = (unsigned)__shfl(nbv, 31, 32);
+        const int first = __shfl(nbv, 28, 32), b4 = __shfl(nbv, 30, 32);
+        const bool pres = cell >= 0 && act && ((m >> s) & 1u);
+        const int k = __popc(m);
+        kq[CMP ? d : 0] = pres ? k : 0;
+        wp[d] = pres ? A.rows_all + ((int64_t)b4 * 4 + (int64_t)(rcur - first) * k + __popc(m & ((1u << s) - 1u))) : A.rows_all;
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if (CMP) kq[CMP ? d : 0] = 0;
+        wp[d] = FAC ? nullptr : (CMP ? A.rows_all : A.rows_all + (int64_t)d * A.rows_total * 27 + sc);
+    }
     int c0 = __shfl(cells[0], 0, 32);
     int line0;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -394,10 +446,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FAC ? 3 : (D <= 4 ? 6 : 5))))
             if (FAC) p0[d] = A.psi_all[(act && nb0[d] >= 0) ? nb0[d] : 0];
         }
         line0 = nb0[0];
+        locate(0, nb0[0], cd[0], r);
 #pragma unroll
         for (int d = 1; d < D; ++d) {
             have[d] = work && cd[d] >= 0;
             enter(d, nb0[d]);
+            locate(d, nb0[d], cd[d], r);
             xs[d] = (have[d] && act && nb0[d] >= 0) ? x0[d] : 0.f;
             if (FAC) ps[d] = (have[d] && act && nb0[d] >= 0) ? p0[d] : zero4;
         }
@@ -405,11 +459,6 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FAC ? 3 : (D <= 4 ? 6 : 5))))
     }
     const FzSpline bq = fz_spline_consts(sc);
     int nnz = 0;                                                     // MODE 1: this lane's non-zero slots (stored entries of G and Q)
-    // one pointer per level; the U rows of a trip are loaded at immediate offsets.  Rows past the unit's (or the item's) last one are
-    // read too (the array is padded by 320 rows) and never used: their t is 0
-    const float* wp[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) wp[d] = FAC ? nullptr : A.rows_all + (int64_t)d * A.rows_total * 27 + sc;
     while (__any(work)) {
         // all loads of the trip: U rows x D levels, the x stencil of the unit's level-0 cell, the neighbour row of the NEXT unit's
         // level-0 cell (all unconditional -- clamped addresses, results masked afterwards: a load under a branch makes the compiler
@@ -419,7 +468,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FAC ? 3 : (D <= 4 ? 6 : 5))))
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int d = 0; d < D; ++d) w[u][d] = FZ_ROW_LOAD(wp[d] + ((int64_t)r + u) * 27);
+                for (int d = 0; d < D; ++d) w[u][d] = CMP ? FZ_ROW_LOAD(wp[d] + u * kq[CMP ? d : 0]) : FZ_ROW_LOAD(wp[d] + ((int64_t)r + u) * 27);
         }
         const float xg = MODE == 0 ? x[(act && line0 >= 0) ? line0 : 0] : 0.f;
         float4 pg = zero4;
@@ -524,6 +573,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FAC ? 3 : (D <= 4 ? 6 : 5))))
                 if (MODE == 1) P2[d] = fmaf(w[u][d], w[u][d], P2[d]);
             }
         r += nt;
+        if (CMP) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) wp[d] += nt * kq[CMP ? d : 0];
+        }
         if (work && r >= uend) {
             // the unit is done: its level-0 block is final
             if (c0 >= 0) finish(0, c0, P[0], P2[0]);
@@ -534,6 +587,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FAC ? 3 : (D <= 4 ? 6 : 5))))
                 pos = npos;
                 c0 = cn;
                 line0 = line0n;
+                locate(0, line0, c0, r);
                 uend = unit_end(pos);
                 // coarse levels whose cell changes with this unit: the finished block leaves, the new stencil is fetched (rare: a
                 // level-1 cell holds ~8 units)
@@ -548,9 +602,11 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FAC ? 3 : (D <= 4 ? 6 : 5))))
                         if (FAC) ps[d] = zero4;
                         const int cd = __shfl(cells[d], pos, 32);
                         have[d] = cd >= 0;
+                        if (!have[d]) locate(d, 0, -1, r);
                         if (have[d]) {
                             const int nbv = A.nbr32[(int64_t)cd * 32 + s];
                             enter(d, nbv);
+                            locate(d, nbv, cd, r);
                             if (MODE == 0 && act && nbv >= 0) xs[d] = x[nbv];
                             if (FAC && act && nbv >= 0) ps[d] = A.psi_all[nbv];
                         }
@@ -757,14 +813,24 @@ extern "C" int nksr_fused_block_counts(int32_t depth, int32_t M, int64_t rows_to
     return NKSR_OK;
 }
 
+extern "C" int nksr_fused_row_sizes(const nksr_hier_t* h, const int32_t* span, int64_t* sizes4_out, void* stream) {
+    if (!h || h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad hierarchy");
+    const int M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
+    if (M <= 0) return NKSR_OK;
+    if (!span || !sizes4_out) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
+    hipLaunchKernelGGL(k_fz_row_sizes, dim3(nksr_blocks((int64_t)M + 1, 256)), dim3(256), 0, (hipStream_t)stream, *h, M, span, span + M, sizes4_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
 extern "C" int nksr_fused_tables(const nksr_hier_t* h, int64_t rows_total, const int32_t* item_begin, const int32_t* offsets, const int32_t* span,
-                                 int32_t* nbr32_out, int32_t* nbrT_out, void* stream) {
+                                 const int32_t* rowbase4, int32_t* nbr32_out, int32_t* nbrT_out, void* stream) {
     if (!h || h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad hierarchy");
     const int M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
     if (M <= 0) return NKSR_OK;
     if (!offsets || !span || !nbr32_out || !nbrT_out || !item_begin) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
     hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)M * 32, 256)), dim3(256), 0, (hipStream_t)stream, *h, M, offsets, span, span + M,
-                       span + 2 * (int64_t)M, nbr32_out);
+                       span + 2 * (int64_t)M, rowbase4, nbr32_out);
     hipLaunchKernelGGL(k_fz_nbrT, dim3(nksr_blocks(M, 64)), dim3(256), 0, (hipStream_t)stream, M, (const int32_t*)nbr32_out, nbrT_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
@@ -792,30 +858,34 @@ static int fz_args(FusedArgs& A, const nksr_fused_op_t* op) {
     A.hw_total = fz_items(op->rows_total);
     A.fac_vec = (const float4*)op->fac_vec; A.fac_pos = (const float4*)op->fac_pos; A.psi_all = (const float4*)op->psi_all;
     A.inv_w0 = op->inv_w0; A.dense_from = op->dense_from; A.dense_out = op->dense_out;
+    A.compact = op->compact;
+    A.rows_words = op->compact ? op->rows_words : (int64_t)27 * op->depth * op->rows_total;
+    if (op->compact && (fac || op->rows_words < 4)) return nksr_set_error(NKSR_ERR_ARG, "compact rows: not with the factor form; rows_words counts the leading zero block");
     return NKSR_OK;
 }
 
 // rows per trip
 #define FZ_ROWS_PER_TRIP 4
 
-template <int MODE, bool FAC>
+template <int MODE, bool FAC, bool CMP>
 static void fz_sweep_launch(const FusedArgs& A, const float* x, const FusedWork& w, const int* done, hipStream_t st) {
     constexpr int U = FZ_ROWS_PER_TRIP;
     const dim3 grid(nksr_blocks((int64_t)A.hw_total, FZ_HW)), blk(FZ_BLOCK);
     switch (A.depth) {
-        case 1: hipLaunchKernelGGL((k_fz_cells<MODE, 1, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 2: hipLaunchKernelGGL((k_fz_cells<MODE, 2, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 3: hipLaunchKernelGGL((k_fz_cells<MODE, 3, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 4: hipLaunchKernelGGL((k_fz_cells<MODE, 4, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        case 5: hipLaunchKernelGGL((k_fz_cells<MODE, 5, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
-        default: hipLaunchKernelGGL((k_fz_cells<MODE, 6, U, FAC>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 1: hipLaunchKernelGGL((k_fz_cells<MODE, 1, U, FAC, CMP>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 2: hipLaunchKernelGGL((k_fz_cells<MODE, 2, U, FAC, CMP>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 3: hipLaunchKernelGGL((k_fz_cells<MODE, 3, U, FAC, CMP>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 4: hipLaunchKernelGGL((k_fz_cells<MODE, 4, U, FAC, CMP>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        case 5: hipLaunchKernelGGL((k_fz_cells<MODE, 5, U, FAC, CMP>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
+        default: hipLaunchKernelGGL((k_fz_cells<MODE, 6, U, FAC, CMP>), grid, blk, 0, st, A, x, w.part, w.part2, w.ct, w.ct2, done); break;
     }
 }
 template <int MODE>
 static void fz_sweep(const FusedArgs& A, const float* x, const FusedWork& w, const int* done, hipStream_t st) {
     if (A.hw_total <= 0) return;
-    if (A.fac_vec) fz_sweep_launch<MODE, true>(A, x, w, done, st);
-    else fz_sweep_launch<MODE, false>(A, x, w, done, st);
+    if (A.fac_vec) fz_sweep_launch<MODE, true, false>(A, x, w, done, st);
+    else if (A.compact) fz_sweep_launch<MODE, false, true>(A, x, w, done, st);
+    else fz_sweep_launch<MODE, false, false>(A, x, w, done, st);
 }
 
 static void fz_cellsum(const FusedArgs& A, const float* part, float* ct, const int* done, hipStream_t st) {
@@ -910,7 +980,8 @@ struct FusedOperator : PcgOperator {
         if (A.nnz_counter) (void)hipMemcpy(&nnz, A.nnz_counter, sizeof(nnz), hipMemcpyDeviceToHost);
         const double stored = nnz > 0 ? (double)nnz : slots;
         *alg = 4.0 * stored + 4.0 * A.depth * (double)A.rows_total + (108.0 + 8.0) * A.M + 4.0;
-        *phys = 4.0 * slots + 4.0 * A.depth * (double)A.rows_total + 2.0 * 128.0 * (double)A.nblocks + (128.0 + 3.0 * 108.0 + 12.0) * A.M;
+        // (compact rows: the words the array holds -- the slots of existing neighbours + 16-byte padding per cell -- instead of every dense slot)
+        *phys = 4.0 * (A.compact ? (double)A.rows_words : slots) + 4.0 * A.depth * (double)A.rows_total + 2.0 * 128.0 * (double)A.nblocks + (128.0 + 3.0 * 108.0 + 12.0) * A.M;
         *survey = 2.0 * 8.0 * stored + 12.0 * A.M + 4.0;
         if (A.fac_vec) {
             // Factor form (round 5): the operator no longer holds the entries of G and Q -- it rebuilds them.  Its minimum is what

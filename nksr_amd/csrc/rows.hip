@@ -39,18 +39,24 @@ __device__ __forceinline__ v2f pk_dot4(v4f a, const v2f b[4], v2f c) {
     return c;
 }
 
-template <int H, bool JAC>
+// CMP: COMPACT rows (nksr_fused_op_t.compact, csrc/fused.hip): a row keeps the slots of its cell's existing neighbours only; the cell
+// comes from row_cells (made before the cells' places in the array could be laid out: nksr_row_cells_merged) and cmp = the operator's
+// nbr32 table tells where the cell's rows lie.  The words of a wavefront's 64 rows are still ONE contiguous run of the array (cells
+// lie in row order), now of variable length and starting at any word: it is staged in LDS at the same offset mod 4 it has in
+// memory, so that 16-byte pieces of the image are 16-byte pieces of the array.
+template <int H, bool JAC, bool CMP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H == 16 ? 4 : 2))) k_kernel_rows_merged(nksr_hier_t hier, const float* __restrict__ xyz_a, const float* __restrict__ ss_a, float rs_a,
                               const float* __restrict__ xyz_b, const float* __restrict__ ss_b, float rs_b, const int32_t* __restrict__ row_src,
-                              int64_t rows_total, int32_t* __restrict__ row_cells, float* __restrict__ rows_out, uint32_t level_map) {
+                              int64_t rows_total, int32_t* __restrict__ row_cells, const int32_t* __restrict__ cmp, float* __restrict__ rows_out, uint32_t level_map) {
     constexpr int K = 4;
     const int d = (level_map >> (4 * blockIdx.y)) & 15;
     const nksr_level_t& lv = hier.lv[d];
-    __shared__ __attribute__((aligned(16))) float img[4][64 * 27];
+    constexpr int IMG = CMP ? 64 * 30 + 8 : 64 * 27;      // (compact: up to three pad words behind every row that ends a cell, + the shift)
+    __shared__ __attribute__((aligned(16))) float img[4][IMG];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t R0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
     if (R0 >= rows_total) return;
-    float* im = img[wv] + 27 * lane;
+    float* im = img[wv] + 27 * lane;                           // the lane's 27 words: its neighbour row waits here, then (dense) its row
     const int64_t R = R0 + lane;
     const int src = R < rows_total ? row_src[R] : -1;
     const int kind = src & 3, site = src >> 2;
@@ -58,17 +64,51 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H == 1
     int cell = -1;
     SiteCell sc;
     float scale = 0.f;
+    // compact: the lane's words of the run -- image offset io, k of them (+ pad zeros behind a cell's last row), mask of its cell
+    int io = 0, kc = 0, padz = 0, shift = 0, nrun = 0;
+    unsigned cmask = 0;
+    int64_t G = 0;
     if (src >= 0) {
         const float* xp = (kind == 0 ? xyz_a : xyz_b) + (int64_t)site * 3;
         const float x[3] = {xp[0], xp[1], xp[2]};
         scale = kind == 0 ? (ss_a ? ss_a[site] : rs_a) : (ss_b ? ss_b[site] : rs_b);
-        sc = locate_site(lv, d, hier.inv_w0, x);
-        cell = sc.cell;
+        if (CMP) {
+            sc = site_geometry(d, hier.inv_w0, x);
+            const int cj = row_cells[(int64_t)d * rows_total + R];
+            cell = cj >= 0 ? cj - lv.offset : -1;
+            sc.cell = cell;
+        } else {
+            sc = locate_site(lv, d, hier.inv_w0, x);
+            cell = sc.cell;
+        }
     }
-    if (row_cells && R < rows_total) row_cells[(int64_t)d * rows_total + R] = cell >= 0 ? lv.offset + cell : -1;
+    if (!CMP && row_cells && R < rows_total) row_cells[(int64_t)d * rows_total + R] = cell >= 0 ? lv.offset + cell : -1;
+    if (CMP) {
+        int64_t g = 0;
+        int nw = 0;
+        if (cell >= 0) {
+            const int4 tb = *reinterpret_cast<const int4*>(cmp + ((int64_t)(lv.offset + cell) * 32 + 28));      // first row, last row, first word / 4, mask
+            cmask = (unsigned)tb.w;
+            kc = __popc(cmask);
+            g = (int64_t)tb.z * 4 + (int64_t)((int)R - tb.x) * kc;
+            padz = (int)R == tb.y ? (int)((-(int64_t)(tb.y - tb.x + 1) * kc) & 3) : 0;
+            nw = kc + padz;
+        }
+        const unsigned long long bal = __ballot(nw > 0);
+        if (bal == 0ull) return;                               // (no words at this level: rows without a cell, pad rows)
+        const int fl = __builtin_ctzll(bal), ll = 63 - __builtin_clzll(bal);
+        const int glo = (int)(g & 0xffffffffll), ghi = (int)(g >> 32);
+        G = ((int64_t)__shfl(ghi, fl) << 32) | (unsigned)__shfl(glo, fl);
+        const int64_t gl = ((int64_t)__shfl(ghi, ll) << 32) | (unsigned)__shfl(glo, ll);
+        shift = (int)(G & 3);
+        nrun = (int)(gl - G) + __shfl(nw, ll);
+        io = nw > 0 ? (int)(g - G) + shift : 0;
+    }
     if (cell < 0) {
+        if (!CMP) {
 #pragma unroll
-        for (int q = 0; q < 27; ++q) im[q] = 0.f;
+            for (int q = 0; q < 27; ++q) im[q] = 0.f;
+        }
     } else {
         const float inv_w = hier.inv_w0 * __int_as_float((127 - d) << 23);
         // a value row's lane carries NO tangent (factor 0 at its source) and scales by 1 where a gradient row scales by 1 / w:
@@ -150,30 +190,73 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H == 1
             for (int o = 0; o < 3; ++o) C[a][o] = ax == a ? bd[a][o] : bw[a][o];
         }
         // the 27 psi vectors in three batches of nine, each batch's loads issued together (absent neighbour: voxel 0, result 0)
+        if (!CMP) {
 #pragma unroll
-        for (int q0 = 0; q0 < 27; q0 += 9) {
-            f32x4_u ps[9];
-            int nb[9];
+            for (int q0 = 0; q0 < 27; q0 += 9) {
+                f32x4_u ps[9];
+                int nb[9];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) nb[i] = __float_as_int(im[q0 + i]);
+                for (int i = 0; i < 9; ++i) nb[i] = __float_as_int(im[q0 + i]);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) ps[i] = psi4[nb[i] >= 0 ? nb[i] : 0];
+                for (int i = 0; i < 9; ++i) ps[i] = psi4[nb[i] >= 0 ? nb[i] : 0];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int q = q0 + i;
-                const int ox = q / 9, oy = (q / 3) % 3, oz = q % 3;
-                const v4f p4 = {ps[i].x, ps[i].y, ps[i].z, ps[i].w};
-                const v2f dj = pk_dot4(p4, out, v2f{0.f, 0.f});   // (<phi, psi>, <d phi / d x_ax, psi>)
-                float r = dj.x * (C[0][ox] * C[1][oy] * C[2][oz] * iw_r);
-                if (JAC) r = fmaf(dj.y, bw[0][ox] * bw[1][oy] * bw[2][oz], r);
-                im[q] = (nb[i] >= 0 ? r : 0.f) * scale;
+                for (int i = 0; i < 9; ++i) {
+                    const int q = q0 + i;
+                    const int ox = q / 9, oy = (q / 3) % 3, oz = q % 3;
+                    const v4f p4 = {ps[i].x, ps[i].y, ps[i].z, ps[i].w};
+                    const v2f dj = pk_dot4(p4, out, v2f{0.f, 0.f});   // (<phi, psi>, <d phi / d x_ax, psi>)
+                    float r = dj.x * (C[0][ox] * C[1][oy] * C[2][oz] * iw_r);
+                    if (JAC) r = fmaf(dj.y, bw[0][ox] * bw[1][oy] * bw[2][oz], r);
+                    im[q] = (nb[i] >= 0 ? r : 0.f) * scale;
+                }
             }
+        }
+        if (CMP) {
+            // every lane takes its neighbour row back first: the image is about to be overwritten, at offsets that are other lanes'
+            int nbq[27];
+#pragma unroll
+            for (int q = 0; q < 27; ++q) nbq[q] = __float_as_int(im[q]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            float* dst = img[wv] + io;                         // the lane's k words, slots of existing neighbours in slot order
+#pragma unroll
+            for (int q0 = 0; q0 < 27; q0 += 9) {
+                f32x4_u ps[9];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) ps[i] = psi4[nbq[q0 + i] >= 0 ? nbq[q0 + i] : 0];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    const int q = q0 + i;
+                    const int ox = q / 9, oy = (q / 3) % 3, oz = q % 3;
+                    const v4f p4 = {ps[i].x, ps[i].y, ps[i].z, ps[i].w};
+                    const v2f dj = pk_dot4(p4, out, v2f{0.f, 0.f});
+                    float r = dj.x * (C[0][ox] * C[1][oy] * C[2][oz] * iw_r);
+                    if (JAC) r = fmaf(dj.y, bw[0][ox] * bw[1][oy] * bw[2][oz], r);
+                    if (nbq[q] >= 0) dst[__popc(cmask & ((1u << q) - 1u))] = r * scale;
+                }
+            }
+            for (int q = 0; q < padz; ++q) dst[kc + q] = 0.f;
         }
     }
     // the wavefront's 64 rows as one contiguous run
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int64_t left = rows_total - R0;
     const float* wimg = img[wv];
+    if (CMP) {
+        // image words [shift, shift + nrun) <-> array words [G, G + nrun); piece p = image words 4 p .. 4 p + 3 <-> array words G - shift + 4 p ..
+        float* gbase = rows_out + (G - shift);
+        const int end = shift + nrun;
+        for (int p = lane; 4 * p < end; p += 64) {
+            const int w0 = 4 * p;
+            if (w0 >= shift && w0 + 3 < end) {
+                *reinterpret_cast<float4*>(gbase + w0) = *reinterpret_cast<const float4*>(wimg + w0);
+            } else {
+                for (int q = w0; q < w0 + 4; ++q)
+                    if (q >= shift && q < end) gbase[q] = wimg[q];
+            }
+        }
+        return;
+    }
+    const int64_t left = rows_total - R0;
     float* gbase = rows_out + ((int64_t)d * rows_total + R0) * 27;
     if (left >= 64) {                                          // 432 16-byte pieces: six full instructions + 48 lanes of a seventh
 #pragma unroll
@@ -190,11 +273,47 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H == 1
     }
 }
 
+// row -> cell at every level (the compact layout needs the cells' row spans before the rows can be written): one lane per row, the
+// home-slot probes of all levels issued together
+__global__ void __launch_bounds__(256) k_row_cells_merged(nksr_hier_t hier, const float* __restrict__ xyz_a, const float* __restrict__ xyz_b,
+                                                          const int32_t* __restrict__ row_src, int64_t rows_total, int32_t* __restrict__ row_cells) {
+    const int64_t R = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (R >= rows_total) return;
+    const int L = hier.depth;
+    const int src = row_src[R];
+    if (src < 0) {
+        for (int d = 0; d < L; ++d) row_cells[(int64_t)d * rows_total + R] = -1;
+        return;
+    }
+    const float* xp = ((src & 3) == 0 ? xyz_a : xyz_b) + (int64_t)(src >> 2) * 3;
+    const float x[3] = {xp[0], xp[1], xp[2]};
+    int64_t key[NKSR_MAX_DEPTH], k0[NKSR_MAX_DEPTH];
+    uint32_t slot[NKSR_MAX_DEPTH];
+    int v0[NKSR_MAX_DEPTH];
+#pragma unroll
+    for (int d = 0; d < NKSR_MAX_DEPTH; ++d) {
+        key[d] = 0; k0[d] = -1; slot[d] = 0; v0[d] = -1;
+        if (d < L && hier.lv[d].n > 0) {
+            const SiteCell g = site_geometry(d, hier.inv_w0, x);
+            key[d] = morton_biased(g.I[0], g.I[1], g.I[2], NKSR_BIAS0 >> d);
+            slot[d] = hash_slot(key[d], hier.lv[d].hcap);
+            k0[d] = hier.lv[d].hkeys[slot[d]];
+            v0[d] = hier.lv[d].hvals[slot[d]];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < NKSR_MAX_DEPTH; ++d) {
+        if (d >= L) break;
+        const int c = hier.lv[d].n > 0 ? hash_find_after(hier.lv[d].hkeys, hier.lv[d].hvals, hier.lv[d].hcap, key[d], slot[d], k0[d], v0[d]) : -1;
+        row_cells[(int64_t)d * rows_total + R] = c >= 0 ? hier.lv[d].offset + c : -1;
+    }
+}
+
 uint32_t nksr_rows_level_map(int depth, int* nlev);          // (csrc/kfield.hip)
 
 extern "C" int nksr_kernel_rows_merged(const nksr_hier_t* h, const float* xyz_pos, const float* scale_pos, float row_scale_pos,
                                        const float* xyz_nrm, const float* scale_nrm, float row_scale_nrm, int approx, const int32_t* row_src,
-                                       int64_t rows_total, int32_t* row_cells, float* rows_out, void* stream) {
+                                       int64_t rows_total, int32_t* row_cells, const int32_t* compact_nbr32, float* rows_out, void* stream) {
     if (rows_total <= 0) return NKSR_OK;
     if (!h || !row_src || !rows_out || (!xyz_pos && !xyz_nrm)) return nksr_set_error(NKSR_ERR_ARG, "merged rows: NULL arrays");
     if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
@@ -204,11 +323,27 @@ extern "C" int nksr_kernel_rows_merged(const nksr_hier_t* h, const float* xyz_po
     const uint32_t level_map = nksr_rows_level_map(h->depth, &nlev);
     dim3 grid(nksr_blocks(rows_total, 256), nlev), block(256);
     const bool jac = xyz_nrm && !approx;
-#define NKSR_LAUNCH_MERGED(H_, J_) hipLaunchKernelGGL((k_kernel_rows_merged<H_, J_>), grid, block, 0, (hipStream_t)stream, *h, xyz_pos, scale_pos, row_scale_pos, \
-                                                      xyz_nrm, scale_nrm, row_scale_nrm, row_src, rows_total, row_cells, rows_out, level_map)
+    if (compact_nbr32 && (!row_cells || ((uintptr_t)rows_out & 15))) return nksr_set_error(NKSR_ERR_ARG, "compact rows need row_cells (nksr_row_cells_merged) and a 16-byte aligned array");
+#define NKSR_LAUNCH_MERGED(H_, J_)                                                                                                             \
+    do {                                                                                                                                       \
+        if (compact_nbr32) hipLaunchKernelGGL((k_kernel_rows_merged<H_, J_, true>), grid, block, 0, (hipStream_t)stream, *h, xyz_pos, scale_pos, row_scale_pos, \
+                                              xyz_nrm, scale_nrm, row_scale_nrm, row_src, rows_total, row_cells, compact_nbr32, rows_out, level_map); \
+        else hipLaunchKernelGGL((k_kernel_rows_merged<H_, J_, false>), grid, block, 0, (hipStream_t)stream, *h, xyz_pos, scale_pos, row_scale_pos, \
+                                xyz_nrm, scale_nrm, row_scale_nrm, row_src, rows_total, row_cells, compact_nbr32, rows_out, level_map);          \
+    } while (0)
     if (h->hidden == 16) { if (jac) NKSR_LAUNCH_MERGED(16, true); else NKSR_LAUNCH_MERGED(16, false); }
     else { if (jac) NKSR_LAUNCH_MERGED(32, true); else NKSR_LAUNCH_MERGED(32, false); }
 #undef NKSR_LAUNCH_MERGED
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
+
+extern "C" int nksr_row_cells_merged(const nksr_hier_t* h, const float* xyz_pos, const float* xyz_nrm, const int32_t* row_src, int64_t rows_total,
+                                     int32_t* row_cells_out, void* stream) {
+    if (rows_total <= 0) return NKSR_OK;
+    if (!h || !row_src || !row_cells_out || (!xyz_pos && !xyz_nrm)) return nksr_set_error(NKSR_ERR_ARG, "row cells: NULL arrays");
+    if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
+    hipLaunchKernelGGL(k_row_cells_merged, dim3(nksr_blocks(rows_total, 256)), dim3(256), 0, (hipStream_t)stream, *h, xyz_pos, xyz_nrm, row_src, rows_total, row_cells_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }

@@ -237,6 +237,8 @@ class KernelField(BaseField):
                 keep.append(dense)
             else:
                 S.val = ptr(fused_op['rows_all'])
+                if fused_op.get('compact'):      # the compact array: the assembly finds a cell's rows through the operator's tables
+                    S.compact_cells, S.compact_nbr32 = ptr(fused_op['row_cells']), ptr(fused_op['nbr32'])
             S.level_stride = fused_op['rows_total']
             for d in range(self.svh.depth):
                 nd = self.svh.level(d).num_voxels
@@ -469,32 +471,32 @@ class KernelField(BaseField):
             row_index = list(torch.split(row_of_site, counts_s))
         td = _tick('_', time.perf_counter())
         pad = 320 * 27     # (the operator's loads are unconditional: the last workgroup reads up to 255 + 63 rows past the end)
-        rows_all = fac_vec = fac_pos = psi_all = None
-        if fac:
-            fac_vec = torch.empty(L * rows_total * 4 + 320 * 4, dtype=torch.float32, device=dev)
-            fac_vec[L * rows_total * 4:].zero_()
-            fac_pos = torch.empty((rows_total + 320) * 4, dtype=torch.float32, device=dev)
-            fac_pos[rows_total * 4:].zero_()
-            psi_all = torch.cat([p.reshape(-1, 4) for p in self._psi]).contiguous()
-            assert psi_all.shape[0] == M
-        else:
-            rows_all = torch.empty(L * rows_total * 27 + pad, dtype=torch.float32, device=dev)
-            rows_all[L * rows_total * 27:].zero_()
-        row_cells = torch.empty((L, rows_total), dtype=torch.int32, device=dev)
-        targets_all = torch.zeros(rows_total + 320, dtype=torch.float32, device=dev)[:rows_total]      # (readable past the end, like the rows)
-        if pad_rows is not None and pad_rows.numel():
-            row_cells[:, pad_rows] = -1
-            if fac:
-                fac_vec[:L * rows_total * 4].view(L, rows_total, 4)[:, pad_rows] = 0.0
-                fac_pos[:rows_total * 4].view(rows_total, 4)[pad_rows] = 0.0                             # (kind 0: a position row without a cell)
-            else:
-                rows_all[:L * rows_total * 27].view(L, rows_total, 27)[:, pad_rows] = 0.0
-        keep = [rows_all, fac_vec, fac_pos, psi_all, targets_all, row_cells]
-        td = _tick('op:alloc', td)
-        # kernel_dim 4, dense rows: ONE launch writes the rows of both sets (csrc/kfield.hip: k_kernel_rows_merged -- the interleaved rows
-        # of two launches reach HBM as partial lines); NKSR_ROWS_KERNEL=site keeps the launch per set (bit-identical rows)
+        # kernel_dim 4, dense-slot rows: ONE launch writes the rows of both sets (csrc/rows.hip: k_kernel_rows_merged -- the interleaved
+        # rows of two launches reach HBM as partial lines).  NKSR_ROWS_KERNEL=site keeps the launch per set (bit-identical rows).
+        # NKSR_ROWS_LAYOUT=compact (opt-in, round 6): only the slots of a cell's EXISTING neighbours are stored and streamed.  Built for
+        # the "quarter of structural zeros" the round-5 review quoted for the 64-chunk scene -- measured there: 3.3 % fewer words (absent
+        # neighbours are 4 % of the slots of a 26-connected band; the rest of the physical-vs-algorithmic gap is tables, not zeros), and
+        # more than 2^31 16-byte units in one batch.  It pays on thin structures only; the default stays the 27-slot row.
         merged = (not fac and self.kdim == 4 and self.hidden in (16, 32) and os.environ.get('NKSR_ROWS_KERNEL', 'merged') == 'merged'
                   and max(counts_s) < 2 ** 29)
+        compact = merged and os.environ.get('NKSR_ROWS_LAYOUT', 'dense') == 'compact'
+        rows_all = fac_vec = fac_pos = psi_all = None
+        row_cells = torch.empty((L, rows_total), dtype=torch.int32, device=dev)
+        targets_all = torch.zeros(rows_total + 320, dtype=torch.float32, device=dev)[:rows_total]      # (readable past the end, like the rows)
+        keep = [targets_all, row_cells]
+        span = torch.empty((3, M), dtype=torch.int32, device=dev)          # first / last row of every cell, first workgroup
+        counts = torch.empty(M + 1, dtype=torch.int32, device=dev)
+        item_begin = torch.empty(int(_lib.lib.nksr_fused_item_entries(rows_total)), dtype=torch.int32, device=dev)
+        nbr32 = torch.empty((M, 32), dtype=torch.int32, device=dev)
+        nbrT = torch.empty((27, M), dtype=torch.int32, device=dev)
+
+        def tables(rowbase4=None):
+            # work items = runs of 32 rows, eight of them a workgroup of the sweep; a cell whose rows lie inside one workgroup is finished
+            # there, a cell that reaches into k > 1 workgroups owns k partial blocks (the coarse cells: ~1 % of all)
+            call('nksr_fused_block_counts', L, M, rows_total, ptr(row_cells), ptr(span), ptr(item_begin), ptr(counts), stream())
+            return ops.exclusive_sum_i32(counts)
+
+        rows_words = 0
         if merged:
             row_src = torch.full((rows_total,), -1, dtype=torch.int32, device=dev)
             args = {1: (None, None, 1.0), 3: (None, None, 1.0)}
@@ -505,9 +507,48 @@ class KernelField(BaseField):
                 args[ncomp] = (xs, sw if tw else None, 1.0 if tw else sw)
                 keep += [xs, ri]
             (xa, sa, fa_), (xb, sb, fb_) = args[1], args[3]
-            call('nksr_kernel_rows_merged', C.byref(self._hier), ptr(xa), ptr(sa), float(fa_), ptr(xb), ptr(sb), float(fb_),
-                 int(self.approx_kernel_grad), ptr(row_src), rows_total, ptr(row_cells), ptr(rows_all), stream())
             keep.append(row_src)
+            if compact:
+                # cells of all rows first: the cells' row spans decide where their rows lie in the compact array
+                call('nksr_row_cells_merged', C.byref(self._hier), ptr(xa), ptr(xb), ptr(row_src), rows_total, ptr(row_cells), stream())
+                offsets = tables()
+                sizes4 = torch.empty(M + 1, dtype=torch.int64, device=dev)
+                call('nksr_fused_row_sizes', C.byref(self._hier), ptr(span), ptr(sizes4), stream())
+                ends4 = torch.cumsum(sizes4, 0)
+                nblocks, total4 = [int(v) for v in torch.stack([offsets[M].long(), ends4[M]]).tolist()]          # (ONE readback)
+                if total4 + 1 >= 2 ** 31:
+                    raise RuntimeError('too many kernel-row entries for one solve (%d x 16 bytes): pass chunk_size= / a smaller chunk_batch_points' % total4)
+                rowbase4 = (ends4[:M] - sizes4[:M] + 1).to(torch.int32)                                          # (unit 0 = the zero block)
+                rows_words = 4 * (total4 + 1)
+                rows_all = torch.empty(rows_words + pad, dtype=torch.float32, device=dev)
+                rows_all[:4].zero_()
+                rows_all[rows_words:].zero_()
+                call('nksr_fused_tables', C.byref(self._hier), rows_total, ptr(item_begin), ptr(offsets), ptr(span), ptr(rowbase4), ptr(nbr32), ptr(nbrT), stream())
+                call('nksr_kernel_rows_merged', C.byref(self._hier), ptr(xa), ptr(sa), float(fa_), ptr(xb), ptr(sb), float(fb_),
+                     int(self.approx_kernel_grad), ptr(row_src), rows_total, ptr(row_cells), ptr(nbr32), ptr(rows_all), stream())
+                del sizes4, ends4, rowbase4
+        if fac:
+            fac_vec = torch.empty(L * rows_total * 4 + 320 * 4, dtype=torch.float32, device=dev)
+            fac_vec[L * rows_total * 4:].zero_()
+            fac_pos = torch.empty((rows_total + 320) * 4, dtype=torch.float32, device=dev)
+            fac_pos[rows_total * 4:].zero_()
+            psi_all = torch.cat([p.reshape(-1, 4) for p in self._psi]).contiguous()
+            assert psi_all.shape[0] == M
+        elif not compact:
+            rows_all = torch.empty(L * rows_total * 27 + pad, dtype=torch.float32, device=dev)
+            rows_all[L * rows_total * 27:].zero_()
+        if not compact and pad_rows is not None and pad_rows.numel():
+            row_cells[:, pad_rows] = -1
+            if fac:
+                fac_vec[:L * rows_total * 4].view(L, rows_total, 4)[:, pad_rows] = 0.0
+                fac_pos[:rows_total * 4].view(rows_total, 4)[pad_rows] = 0.0                             # (kind 0: a position row without a cell)
+            else:
+                rows_all[:L * rows_total * 27].view(L, rows_total, 27)[:, pad_rows] = 0.0
+        keep += [rows_all, fac_vec, fac_pos, psi_all]
+        td = _tick('op:alloc', td)
+        if merged and not compact:
+            call('nksr_kernel_rows_merged', C.byref(self._hier), ptr(xa), ptr(sa), float(fa_), ptr(xb), ptr(sb), float(fb_),
+                 int(self.approx_kernel_grad), ptr(row_src), rows_total, ptr(row_cells), None, ptr(rows_all), stream())
         for (xs, ks, perm, target, sw, ncomp), ri in zip(specs, row_index):
             ri = ri.contiguous()
             tensor_w = torch.is_tensor(sw)
@@ -527,24 +568,18 @@ class KernelField(BaseField):
                 targets_all[(ri.long()[:, None] + (ncomp - nc) + torch.arange(nc, device=dev)[None]).reshape(-1)] = tgt.reshape(-1)
             keep += [xs, ri]
         td = _tick('op:kernel_rows', td)
-        # work items = runs of 32 rows, eight of them a workgroup of the sweep; a cell whose rows lie inside one workgroup is finished
-        # there, a cell that reaches into k > 1 workgroups owns k partial blocks (the coarse cells: ~1 % of all)
-        span = torch.empty((3, M), dtype=torch.int32, device=dev)          # first / last row of every cell, first workgroup
-        counts = torch.empty(M + 1, dtype=torch.int32, device=dev)
-        item_begin = torch.empty(int(_lib.lib.nksr_fused_item_entries(rows_total)), dtype=torch.int32, device=dev)
-        call('nksr_fused_block_counts', L, M, rows_total, ptr(row_cells), ptr(span), ptr(item_begin), ptr(counts), stream())
-        offsets = ops.exclusive_sum_i32(counts)
-        nbr32 = torch.empty((M, 32), dtype=torch.int32, device=dev)
-        nbrT = torch.empty((27, M), dtype=torch.int32, device=dev)
-        call('nksr_fused_tables', C.byref(self._hier), rows_total, ptr(item_begin), ptr(offsets), ptr(span), ptr(nbr32), ptr(nbrT), stream())
+        if not compact:
+            offsets = tables()
+            call('nksr_fused_tables', C.byref(self._hier), rows_total, ptr(item_begin), ptr(offsets), ptr(span), None, ptr(nbr32), ptr(nbrT), stream())
+            nblocks = int(offsets[M].item())
         big = torch.nonzero(counts[:M] > 16).reshape(-1).to(torch.int32)          # coarse cells: a workgroup each in the per-cell sum
         multi = torch.cat([big, torch.nonzero((counts[:M] > 1) & (counts[:M] <= 16)).reshape(-1).to(torch.int32)])
-        nblocks = int(offsets[M].item())
         ws = torch.empty(int(_lib.lib.nksr_fused_workspace_bytes(nblocks, M)), dtype=torch.uint8, device=dev)
         cell_sums = torch.zeros((27, M), dtype=torch.float32, device=dev)
         op = FusedOpT()
         op.depth, op.M, op.n_multi, op.n_big, op.rows_total, op.nblocks = L, M, int(multi.numel()), int(big.numel()), rows_total, nblocks
         op.rows_all, op.targets_all, op.row_cells, op.nbr32, op.nbrT = ptr(rows_all), ptr(targets_all), ptr(row_cells), ptr(nbr32), ptr(nbrT)
+        op.compact, op.rows_words = int(compact), int(rows_words)
         if fac:
             op.fac_vec, op.fac_pos, op.psi_all, op.inv_w0 = ptr(fac_vec), ptr(fac_pos), ptr(psi_all), float(svh.inv_w0)
         op.item_begin = ptr(item_begin)
@@ -560,7 +595,33 @@ class KernelField(BaseField):
         td = _tick('op:tables', td)
         return {'op': op, 'nsets': len(specs), 'nblocks': nblocks, 'rows_total': rows_total, 'n_multi': int(multi.numel()),
                 'nnz_counter': nnz_counter, 'keep': keep, 'span': span, 'rows_all': rows_all, 'row_format': 'factors' if fac else 'dense',
+                'compact': bool(compact), 'rows_words': rows_words, 'nbr32': nbr32,
                 'fac_vec': fac_vec, 'fac_pos': fac_pos, 'row_cells': row_cells, 'targets_all': targets_all}
+
+    def dense_rows(self, op):
+        """[L, rows_total, 27] dense-slot rows of a matrix-free operator, whatever its layout (test / export helper)."""
+        L, R = self.svh.depth, op['rows_total']
+        if not op.get('compact'):
+            return op['rows_all'][:L * R * 27].view(L, R, 27)
+        out = torch.zeros((L, R, 27), dtype=torch.float32, device=self.device)
+        cells = op['row_cells'].long()
+        tb = op['nbr32'].long()
+        rr = torch.arange(R, device=self.device)
+        for d in range(L):
+            c = cells[d]
+            ok = c >= 0
+            cj = c.clamp(min=0)
+            mask, first, b4 = tb[cj, 31], tb[cj, 28], tb[cj, 30]
+            k = torch.zeros_like(mask)
+            for q in range(27):
+                k += (mask >> q) & 1
+            rank = torch.zeros_like(mask)
+            for q in range(27):
+                pres = ok & (((mask >> q) & 1) == 1)
+                idx = b4 * 4 + (rr - first) * k + rank
+                out[d, pres, q] = op['rows_all'][idx[pres]]
+                rank = rank + ((mask >> q) & 1)
+        return out
 
     def fused_rhs_diag(self, op, reg_weight=1.0, dense_from=None):
         """Right-hand side and Jacobi diagonal from ONE set-up sweep.  ``dense_from`` = c0 (factor form only): the sweep also leaves

@@ -31,6 +31,7 @@ def main():
     x = torch.randn(M, device=dev)
     y_csr = solver.spmv(rowptr, cols, vals, x)
     y_f = f.fused_apply(op, x)
+    print('compact=%s rows_words=%d (dense slots %d)' % (op.get('compact'), op.get('rows_words', 0), 27 * f.svh.depth * op['rows_total']))
     print('M=%d rows=%d partial blocks=%d  max|y_fused - y_csr| / max|y| = %.3e' % (M, op['rows_total'], op['nblocks'],
                                                                                  float((y_f - y_csr).abs().max() / y_csr.abs().max())))
     for _ in range(3):
@@ -44,8 +45,8 @@ def main():
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     slots = 27 * f.svh.depth * op['rows_total']
-    phys = 4 * slots + 4 * f.svh.depth * op['rows_total'] + 2 * 128 * op['nblocks'] + (128 + 3 * 108 + 12) * M      # csrc/fused.hip FusedOperator::bytes
-    nnz = int(torch.count_nonzero(op['keep'][0]).item())
+    phys = 4 * (op['rows_words'] if op.get('compact') else slots) + 4 * f.svh.depth * op['rows_total'] + 2 * 128 * op['nblocks'] + (128 + 3 * 108 + 12) * M      # csrc/fused.hip FusedOperator::bytes
+    nnz = int(torch.count_nonzero(op['rows_all']).item())
     alg = 16.0 * nnz + 12 * M + 4
     print('fused apply: %.1f us  physical %.3f GB -> %.2f TB/s (%.1f%% of 8 TB/s);  SURVEY 8d figure (16 B x %d non-zero slots of %d) %.3f GB -> %.2f TB/s'
           % (ms * 1e3, phys / 1e9, phys / ms / 1e9, phys / ms / 1e9 / 8 * 100, nnz, slots, alg / 1e9, alg / ms / 1e9))

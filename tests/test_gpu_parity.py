@@ -279,7 +279,7 @@ def test_row_order_by_rank_passes_equals_the_sorted_merge(monkeypatch):
             n = op['op'].depth * op['rows_total'] * 4
             rows = torch.cat([op['fac_vec'][:n], op['fac_pos'][:op['rows_total'] * 4]])
         else:
-            rows = op['rows_all'][:op['op'].depth * op['rows_total'] * 27]
+            rows = fld.dense_rows(op).reshape(-1)
         out[mode] = (rows.clone(), op['row_cells'].clone(), op['targets_all'].clone(), op['rows_total'])
     assert out['merge'][3] == out['sort'][3]
     assert torch.equal(out['merge'][1], out['sort'][1]) and torch.equal(out['merge'][2], out['sort'][2])
@@ -291,7 +291,10 @@ def test_row_order_by_rank_passes_equals_the_sorted_merge(monkeypatch):
 def test_merged_rows_equal_the_rows_of_a_launch_per_set_bit_for_bit(approx, hidden, monkeypatch):
     """nksr_kernel_rows_merged (one lane per ROW of the operator's merged row list, value + one tangent channel as packed pairs, rows
     leaving as contiguous wavefront images) against nksr_kernel_rows with a row index (one lane per site, a launch per site set):
-    rows, row cells and targets bit for bit -- exact and approximate gradients, both interpolator widths, one site set alone."""
+    rows, row cells and targets bit for bit -- exact and approximate gradients, both interpolator widths, one site set alone; in the
+    dense layout and in the COMPACT one (only the slots of a cell's existing neighbours are stored: expanded through the operator's
+    tables, the absent slots must be the zeros the dense rows hold there).  The operator and its set-up sums are the same bits in
+    both layouts."""
     from nksr_amd.fields import KernelField
     xyz, nrm, oh, svh, feats, ointerps, net = _setup(n=3000, init_scale=0.3, H=hidden)
     fld = KernelField(svh, net.interpolators, [torch.from_numpy(f) for f in feats], approx_kernel_grad=approx)
@@ -299,17 +302,35 @@ def test_merged_rows_equal_the_rows_of_a_launch_per_set_bit_for_bit(approx, hidd
     nxyz = np.concatenate([oh.levels[0].centers(), oh.levels[1].centers()])
     nval = np.random.RandomState(5).randn(len(nxyz), 3).astype(np.float32)
     far = (xyz[:40] + np.float32(3.0)).astype(np.float32)                      # sites outside every cell of the fine levels: zero rows, cell -1
+    xv = torch.randn(svh.num_unknowns, device=_dev(), generator=torch.Generator(device=_dev()).manual_seed(3))
     for pos, nrm_sites in ((np.concatenate([xyz, far]), nxyz), (xyz, None), (None, nxyz)):
         out = {}
-        for mode in ('site', 'merged'):
+        for mode, layout in (('site', 'dense'), ('merged', 'dense'), ('merged', 'compact')):
             monkeypatch.setenv('NKSR_ROWS_KERNEL', mode)
+            monkeypatch.setenv('NKSR_ROWS_LAYOUT', layout)
             op = fld.fused_operator(t(pos) if pos is not None else None, t(nrm_sites) if nrm_sites is not None else None,
                                     t(nval) if nrm_sites is not None else None, 1e4 / 3000, 1e2 / len(nxyz))
-            assert op['row_format'] == 'dense'
-            out[mode] = (op['rows_all'][:op['op'].depth * op['rows_total'] * 27].clone(), op['row_cells'].clone(), op['targets_all'].clone())
-        assert torch.equal(out['site'][1], out['merged'][1]) and torch.equal(out['site'][2], out['merged'][2])
-        assert torch.equal(out['site'][0].view(torch.int32), out['merged'][0].view(torch.int32))
-        assert float(out['merged'][0].abs().max()) > 0
+            assert op['row_format'] == 'dense' and op['compact'] == (layout == 'compact')
+            b, dg = fld.fused_rhs_diag(op, 1.0)
+            out[(mode, layout)] = (fld.dense_rows(op).clone(), op['row_cells'].clone(), op['targets_all'].clone(), b, dg, fld.fused_apply(op, xv), op)
+        ref = out[('site', 'dense')]
+        for key in (('merged', 'dense'), ('merged', 'compact')):
+            o = out[key]
+            assert torch.equal(ref[1], o[1]) and torch.equal(ref[2], o[2]), key
+            assert torch.equal(ref[0].view(torch.int32), o[0].view(torch.int32)), key
+            assert torch.equal(ref[3], o[3]) and torch.equal(ref[4], o[4]) and torch.equal(ref[5], o[5]), key      # rhs, diagonal, A x: same bits
+        cop = out[('merged', 'compact')][6]
+        assert float(ref[0].abs().max()) > 0
+        if pos is not None and nrm_sites is not None:
+            assert cop['rows_words'] < ref[0].numel()      # (smaller: absent neighbours; a set of one-row cells can lose that to the 16-byte padding)
+        # the coarse-level block of the preconditioner from compact rows == from dense rows
+        if pos is not None and nrm_sites is not None:
+            blk = {}
+            for key in (('merged', 'dense'), ('merged', 'compact')):
+                rp, cc, vv, dd, _ = fld.assemble(None, None, None, 1.0, 1.0, 1.0, coarse_from=2, fused_op=out[key][6])
+                blk[key] = (rp, cc, vv, dd)
+            for a_, b_ in zip(blk[('merged', 'dense')], blk[('merged', 'compact')]):
+                assert torch.equal(a_, b_)
 
 
 @pytest.mark.parametrize('fused', [False, True])
