@@ -21,6 +21,7 @@
 //     entries) orders every row's mirrors by ascending source row; k_place_mirrors drops them into
 //     the CSR.  Deterministic and exactly symmetric, no float atomics, no full COO.
 #include "common.h"
+#include <stdlib.h>
 
 #define ASM_WAVES 1
 
@@ -168,14 +169,13 @@ __device__ __forceinline__ void asm_lm_mfma(const AsmLanePtr<NT>& P, int r0, int
         for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, v[n], acc[n], 0, 0, 0);
     }
 }
+// lane pointers of level d's column tiles for the rows r_lo .. of ONE level-d cell (dense rows: they do not depend on the cell)
 template <int NT>
-__device__ __forceinline__ void asm_accumulate_lm(const AsmArgs& A, int d, int r_lo, int r_hi, int lane, asm_f32x16 (&acc)[NT]) {
-    if (r_hi <= r_lo) return;
+__device__ __forceinline__ void asm_lm_pointers(const AsmArgs& A, int d, int r_lo, int lane, AsmLanePtr<NT>& P) {
     const nksr_siteset_t& S = A.sets[0];
     const int L = A.hier.depth;
     const int T = (L - d) * 27;
-    const int j = lane & 31, half = lane >> 5;
-    AsmLanePtr<NT> P;
+    const int j = lane & 31;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int col = 32 * n + j;
@@ -206,6 +206,14 @@ __device__ __forceinline__ void asm_accumulate_lm(const AsmArgs& A, int d, int r
             }
         }
     }
+}
+template <int NT>
+__device__ __forceinline__ void asm_accumulate_lm(const AsmArgs& A, int d, int r_lo, int r_hi, int lane, asm_f32x16 (&acc)[NT]) {
+    if (r_hi <= r_lo) return;
+    const nksr_siteset_t& S = A.sets[0];
+    const int j = lane & 31, half = lane >> 5;
+    AsmLanePtr<NT> P;
+    asm_lm_pointers<NT>(A, d, r_lo, lane, P);
     const float w = S.weight;
     float bA[ASM_TRIP][NT], bB[ASM_TRIP][NT];
     asm_lm_load<NT>(P, r_lo, r_lo, r_hi, half, bA);

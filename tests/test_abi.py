@@ -133,7 +133,7 @@ def test_c_abi_argument_errors_without_a_gpu():
     hh = _lib.HierT()
     hh.depth = 4
     hh.lv[3].n = 5
-    assert lib.nksr_fused_tables(C.byref(hh), C.c_int64(0), null, null, null, null, null, null) != 0 and 'NULL' in err()
+    assert lib.nksr_fused_tables(C.byref(hh), C.c_int64(0), null, null, null, null, null, null, null) != 0 and 'NULL' in err()
     assert lib.nksr_coarse_lambda_max(null, null, null, null, C.c_int32(5), C.c_int(8), null, null, None, C.c_int32(0), null) != 0 and 'NULL' in err()
     one = (C.c_float * 8)()
     assert lib.nksr_sdf_from_points(one, one, null, null, null, null, null, C.c_int32(0), C.c_float(1.0), C.c_float(1.0), one, C.c_int64(1), C.c_int(0),
