@@ -160,6 +160,30 @@ def roofline_record(ms, launches, alg, phys, survey, fused=False, samples=None):
     return rec
 
 
+def mesh_adaptive_record(field, mise_iter, repeats=2):
+    """The SAME solved field meshed on the adaptive dual graph (field.dual_graph = 'adaptive': cells as large as the level that
+    carries them, models/nksr_net.py:132,214,284) and on the uniform lattice (the default), outside the timed region: milliseconds
+    and triangle counts of both."""
+    out = {}
+    keep = getattr(field, 'dual_graph', 'lattice')
+    try:
+        for mode in ('lattice', 'adaptive'):
+            field.dual_graph = mode
+            m = field.extract_dual_mesh(mise_iter=mise_iter)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(repeats):
+                m = field.extract_dual_mesh(mise_iter=mise_iter)
+            torch.cuda.synchronize()
+            out[mode] = {'ms': (time.perf_counter() - t0) / repeats * 1e3, 'vertices': int(m.v.shape[0]), 'triangles': int(m.f.shape[0])}
+        out['adaptive_over_lattice'] = out['adaptive']['ms'] / max(out['lattice']['ms'], 1e-9)
+    except Exception as e:      # (reported, never fatal: the headline is the lattice mesh)
+        out['error'] = str(e)[:300]
+    finally:
+        field.dual_graph = keep
+    return out
+
+
 # ---- configs[4]: the scaling scene ------------------------------------------------------------------------------------
 def terrain_setup(rec, dev, n_total, rank, world):
     """Sharded input of the 10M-point scene: the tiles of this rank's chunks and of their neighbours.  The chunk ->
@@ -237,6 +261,7 @@ def main():
     ap.add_argument('--no-cloud', action='store_true', help='skip the configs[2] sub-record (and with it spmv_csr_roofline)')
     ap.add_argument('--no-other-mode', action='store_true', help='skip the assembled-solve leg of the configs[2] sub-record')
     ap.add_argument('--no-small-inputs', action='store_true')
+    ap.add_argument('--no-adaptive', action='store_true', help='skip the mesh_adaptive sub-records (the adaptive dual graph timed beside the lattice mesher, outside the timed region)')
     ap.add_argument('--no-live-pmc', action='store_true', help='do not collect roofline.traffic with rocprofv3 in this run (two counter passes over one extra step)')
     ap.add_argument('--cloud-steps', type=int, default=3)
     ap.add_argument('--dist-probe', action='store_true', help='launch check only: start the N ranks, run the handshake collectives over the '
@@ -353,6 +378,7 @@ def main():
 
         acc = {}
         dt, (field, mesh), prof, alloc = timed_loop(step, steps, warmup, acc)
+        adaptive = mesh_adaptive_record(field, args.mise_iter) if (world == 1 and not args.no_adaptive) else None
         infos = field.chunk_infos()
         cfg = {'workload': 'configs[4]: synthetic %d-point km-scale terrain + boxes (8x8 tiles of 125 m), tree_depth=5, chunk_size=125 m '
                            '(64 chunks), reconstruct(chunk_size=)+extract_dual_mesh(mise_iter=%d), the same scene at every N (strong scaling)' % (n_scene, args.mise_iter),
@@ -370,6 +396,8 @@ def main():
         from nksr_amd.fields import kernel_field as _kf
         if _kf.DETAIL_TIMES:
             cfg['detail_ms_total'] = {k: round(v * 1e3, 1) for k, v in sorted(_kf.DETAIL_TIMES.items()) if k != '_'}
+        if adaptive is not None:
+            cfg['mesh_adaptive'] = adaptive
         return dt, n_scene, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}, alloc
 
     # ---- configs[2]: the single-field roofline workload -----------------------------------------------------------------
@@ -389,6 +417,7 @@ def main():
 
         acc = {}
         dt, (field, mesh), prof, alloc = timed_loop(step, steps, warmup, acc)
+        adaptive = mesh_adaptive_record(field, args.mise_iter) if (fused and not args.no_adaptive) else None
         info = field.solve_info
         cfg = {'workload': 'configs[2]: synthetic %d-point oriented cloud (8 spheres/tori in a 40x40x10 box, sigma=0.01), '
                            'detail_level=%.1f, reconstruct()+extract_dual_mesh(mise_iter=%d)' % (args.points, args.detail_level, args.mise_iter),
@@ -396,6 +425,8 @@ def main():
                'unknowns_M': info['M'], 'nnz_A': info['nnz'], 'kernel_row_slots': info.get('kernel_row_slots'),
                'stored_entries_G_Q': field.stored_entries() if fused else None, 'pcg_iters': info['iters'], 'pcg_rel_residual': info['rel_residual'],
                'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]), 'global_scale': field.scale}
+        if adaptive is not None:
+            cfg['mesh_adaptive'] = adaptive
         return dt, args.points, cfg, prof, {k: v / steps for k, v in sorted(acc.items())}, alloc, (rec, xyz_np, nrm_np, field.scale)
 
     # The headline runs through the API default, fused_mode=True (what the reference's examples pass): chunk mode = the batched

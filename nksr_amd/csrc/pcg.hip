@@ -869,12 +869,16 @@ __global__ void __launch_bounds__(256) k_cheb16_init(int n, const float* __restr
     y[i] = 0.f;
 }
 
-// One wavefront per CHEB16_ROWS consecutive rows; LAST: the step also leaves z = D^-1/2 (y' + d') in the PCG's order.  POWER: out = S v
-// only (eigenvalue bound).  A row holds ~240 entries -- one trip of four 64-entry groups: with a wavefront per row the step was a chain
-// of three dependent round trips per wavefront (row pointers -> entries -> gathered d) and ran at the latency, not the bandwidth
-// (0.69 ms per step on the 64-chunk scene with 8-byte AND with 4-byte entries).  Four rows per wavefront put 16 entry loads and then
-// 16 gathers in flight at once.
-#define CHEB16_ROWS 4
+// One wavefront per CHEB16_ROWS = 16 consecutive rows, 16 lanes per row: lane (g, l) = (lane >> 4, lane & 15) works for the four rows
+// i0 + 4 g + r, r < 4, and takes entries l, l + 16, ... of each.  LAST: the step also leaves z = D^-1/2 (y' + d') in the PCG's order.
+// POWER: out = S v only (eigenvalue bound).
+// Round 6.  After the drop (entries below 0.5 % of the unit diagonal) a row of the 64-chunk scene keeps 37 entries on average (median
+// 28, a tenth none, 1 % more than 300: tools/cheb_rows_probe.py), not the ~240 it is assembled with.  Rounds 3-5 gave every row one
+// 256-entry trip of a whole wavefront (four rows per wavefront: 16 entry loads + 16 gathers, ~85 % of their lanes clamped and masked)
+// and ran at the latency of row pointers -> entries -> gathered vector over 380 000 wavefronts per step.  Sixteen lanes per row put
+// the same 16 + 16 loads in flight for FOUR times the rows -- a row's partial sums depend on its own length only, so its result does
+// not depend on its wave mates (a chunk alone == the chunk in a batch).
+#define CHEB16_ROWS 16
 template <bool POWER>
 __global__ void __launch_bounds__(256) k_cheb16_step(int n, const int32_t* __restrict__ prow, const uint32_t* __restrict__ pk,
                                                      const float* __restrict__ coef, int step, const int32_t* __restrict__ row_seg,
@@ -884,7 +888,8 @@ __global__ void __launch_bounds__(256) k_cheb16_step(int n, const int32_t* __res
                                                      const int32_t* __restrict__ old_of_new, const float* __restrict__ dis) {
     const int i0 = ((blockIdx.x * 256 + threadIdx.x) >> 6) * CHEB16_ROWS, lane = threadIdx.x & 63;
     if (i0 >= n) return;
-    // per-row scalars: lane r (< CHEB16_ROWS) owns row i0 + r; the row pointers come as one load of CHEB16_ROWS + 1 lanes
+    const int g = lane >> 4, l = lane & 15;
+    // per-row scalars: lane q (< 16) owns row i0 + q; the row pointers come as one load of 17 lanes
     const int ir = i0 + (lane < CHEB16_ROWS ? lane : 0), irc = ir < n ? ir : n - 1;
     const int pl = prow[(i0 + lane <= n && lane <= CHEB16_ROWS) ? i0 + lane : n];
     const int sg = row_seg[irc];
@@ -896,47 +901,47 @@ __global__ void __launch_bounds__(256) k_cheb16_step(int n, const int32_t* __res
         rs = res[irc]; yj = y[irc];
         ca = coef[(int64_t)sg * CHEB_STRIDE + 1 + 2 * step]; cb = coef[(int64_t)sg * CHEB_STRIDE + 2 + 2 * step];
     }
-    int k0[CHEB16_ROWS], k1[CHEB16_ROWS], base_r[CHEB16_ROWS];
-    bool live[CHEB16_ROWS];
+    // the four rows of this lane's group: first / last entry, vector base of their segment (a dead row is empty)
+    int k0[4], k1[4], base_r[4];
     int maxlen = 0;
 #pragma unroll
-    for (int r = 0; r < CHEB16_ROWS; ++r) {
-        k0[r] = __builtin_amdgcn_readlane(pl, r);
-        k1[r] = __builtin_amdgcn_readlane(pl, r + 1);
-        base_r[r] = __builtin_amdgcn_readlane(sb, r);
-        live[r] = __builtin_amdgcn_readlane((int)live_l, r) != 0;
-        if (!live[r]) k1[r] = k0[r];
+    for (int r = 0; r < 4; ++r) {
+        const int q = 4 * g + r;
+        k0[r] = __shfl(pl, q);
+        k1[r] = __shfl(pl, q + 1);
+        base_r[r] = __shfl(sb, q);
+        if (!__shfl((int)live_l, q)) k1[r] = k0[r];
         maxlen = (k1[r] - k0[r]) > maxlen ? (k1[r] - k0[r]) : maxlen;
     }
-    float t[CHEB16_ROWS][4];
 #pragma unroll
-    for (int r = 0; r < CHEB16_ROWS; ++r)
+    for (int o = 32; o >= 16; o >>= 1) { const int m = __shfl_xor(maxlen, o); maxlen = m > maxlen ? m : maxlen; }     // (over the four groups: one trip count per wavefront)
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < maxlen; b += 64) {                     // four 16-entry trips of every row at once: 16 loads, then 16 gathers
+        uint32_t w[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[r][q] = 0.f;
-    for (int b = 0; b < maxlen; b += 256) {
-        uint32_t w[CHEB16_ROWS][4];
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int r = 0; r < CHEB16_ROWS; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int k = k0[r] + b + 64 * q + lane;
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0[r] + b + 16 * q + l;
                 const int kc = k < k1[r] ? k : (k1[r] > k0[r] ? k1[r] - 1 : 0);          // clamped address, value masked below
-                w[r][q] = pk[kc];
-                if (k >= k1[r]) w[r][q] = 0u;                                              // value +0.0, column 0 of the segment
+                w[q][r] = pk[kc];
+                if (k >= k1[r]) w[q][r] = 0u;                                              // value +0.0, column 0 of the segment
             }
 #pragma unroll
-        for (int r = 0; r < CHEB16_ROWS; ++r)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                t[r][q] = fmaf(__half2float(__ushort_as_half((unsigned short)(w[r][q] >> 16))), d_old[base_r[r] + (int)(w[r][q] & 0xFFFFu)], t[r][q]);
+            for (int r = 0; r < 4; ++r)
+                t[r] = fmaf(__half2float(__ushort_as_half((unsigned short)(w[q][r] >> 16))), d_old[base_r[r] + (int)(w[q][r] & 0xFFFFu)], t[r]);
     }
-    float tot = 0.f;                                                     // lane r ends up with the sum of row r
+    // the 16 lanes of a group sum every row (fixed tree); lane q of the wavefront ends up with the sum of row q
+    float tot = 0.f;
 #pragma unroll
-    for (int r = 0; r < CHEB16_ROWS; ++r) {
-        float tt = (t[r][0] + t[r][1]) + (t[r][2] + t[r][3]);
+    for (int r = 0; r < 4; ++r) {
+        float tt = t[r];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) tt += __shfl_xor(tt, o);
-        if (lane == r) tot = tt;
+        for (int o = 8; o > 0; o >>= 1) tt += __shfl_xor(tt, o);
+        const float got = __shfl(tt, 16 * (lane >> 2) + 0);   // row q = 4 g' + r lives in group g' = q >> 2: lane 16 g' holds its sum
+        if (lane < CHEB16_ROWS && (lane & 3) == r) tot = got;
     }
     if (live_l) {
         tot += dj;                                                        // the unit diagonal
