@@ -118,7 +118,7 @@ __global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__
                             const int32_t* __restrict__ last, const int32_t* __restrict__ wgfirst, const int32_t* __restrict__ rowbase4,
                             int32_t* __restrict__ nbr32) {
     const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin >= (int64_t)M * 32) return;
+    if (lin >= (int64_t)M * 32) return;                        // (M * 32 entries: whole half-waves -- the ballot below is safe)
     const int j = (int)(lin >> 5), s = (int)(lin & 31);
     int v = 0;
     if (s < 27) {
@@ -133,16 +133,14 @@ __global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__
         v = last[j];
     } else if (s == 30) {
         v = rowbase4 ? rowbase4[j] : 0;
-    } else {
-        const int d = fz_level(hier, j), c = j - hier.lv[d].offset;
-        unsigned m = 0;
-        for (int q = 0; q < 27; ++q) m |= (hier.lv[d].nbr[(int64_t)c * 27 + q] >= 0 ? 1u : 0u) << q;
-        v = (int)m;
     }
+    // the mask of the existing neighbours: the 27 lanes of this half-wave have just decided it
+    const unsigned m = (unsigned)(__ballot(s < 27 && v >= 0) >> ((threadIdx.x & 32) ? 32 : 0)) & 0x7FFFFFFu;
+    if (s == 31) v = (int)m;
     nbr32[lin] = v;
 }
 // ---- COMPACT rows (round 6).  A slot of a kernel row whose neighbour voxel does not exist is a structural zero -- a quarter of the
-// slots of the 64-chunk scene (rim cells).  All rows of a cell share the cell's 27-bit neighbour mask, so they are stored with the
+// slots by the round-5 review's count; 4 % on the 64-chunk scene when measured: HISTORY.md).  All rows of a cell share the cell's 27-bit neighbour mask, so they are stored with the
 // k = popcount(mask) existing slots only, in slot order: cell j (rows first .. last of the list, one contiguous run at every level)
 // owns the words [4 b4, 4 b4 + rows k) of ONE array (levels follow each other; within a level the cells lie in row order, every
 // block padded to 16 bytes with zeros); words 0 .. 3 of the array are zero: a lane whose slot does not exist reads word 0 at
