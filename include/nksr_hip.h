@@ -168,8 +168,10 @@ int nksr_kernel_rows(const nksr_hier_t* h, const float* xyz, int64_t n, int appr
  * sites < 2^29 per set. */
 int nksr_kernel_rows_merged(const nksr_hier_t* h, const float* xyz_pos, const float* scale_pos, float row_scale_pos,
                             const float* xyz_nrm, const float* scale_nrm, float row_scale_nrm, int approx, const int32_t* row_src,
-                            int64_t rows_total, int32_t* row_cells, const int32_t* compact_nbr32, float* rows_out, void* stream);
-/* compact_nbr32 == NULL: dense rows as above, row_cells (may be NULL) is WRITTEN.  compact_nbr32 = nksr_fused_op_t.nbr32: COMPACT rows
+                            int64_t rows_total, int32_t* row_cells, int cells_given, const int32_t* compact_nbr32, float* rows_out, void* stream);
+/* cells_given == 0: row_cells (may be NULL) is WRITTEN (a hash probe per row and level); != 0: row_cells is READ (nksr_row_cells_merged
+ * made it: one pass with the probes of all levels in flight together, and the row kernel's chain of dependent loads loses two links).
+ * compact_nbr32 == NULL: dense rows as above.  compact_nbr32 = nksr_fused_op_t.nbr32: COMPACT rows
  * (nksr_fused_op_t.compact) -- row_cells [L][rows_total] is READ (nksr_row_cells_merged made it before the tables could be built) and
  * every wavefront writes the words of its 64 rows, level by level, as one contiguous run of the compact array.
  * nksr_row_cells_merged: row_cells_out[d][r] = global unknown index of the level-d cell of row r's site, -1 = none (pad rows: -1). */

@@ -166,7 +166,7 @@ _PROTOS = {
     'nksr_fused_rhs_diag': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_fused_apply': [_P(FusedOpT), _f32, _vp, _vp, _vp],
     'nksr_fused_expand_rows': [_P(FusedOpT), _vp],
-    'nksr_kernel_rows_merged': [_P(HierT), _vp, _vp, _f32, _vp, _vp, _f32, C.c_int, _vp, _i64, _vp, _vp, _vp, _vp],
+    'nksr_kernel_rows_merged': [_P(HierT), _vp, _vp, _f32, _vp, _vp, _f32, C.c_int, _vp, _i64, _vp, C.c_int, _vp, _vp, _vp],
     'nksr_row_sources': [_vp, _i64, C.c_int, C.c_int, _vp, _vp],
     'nksr_kernel_factors': [_P(HierT), _vp, _i64, C.c_int, C.c_int, _f32, _vp, _i64, _vp, _vp, _vp, _vp, _vp],
     'nksr_pcg_solve_fused': [_P(FusedOpT), _f32, _vp, _vp, _vp, _f32, C.c_int, C.c_int, _vp, _P(CoarsePrecondT), _P(SegmentsT), _P(C.c_double), _vp],

@@ -44,7 +44,10 @@ __device__ __forceinline__ v2f pk_dot4(v4f a, const v2f b[4], v2f c) {
 // nbr32 table tells where the cell's rows lie.  The words of a wavefront's 64 rows are still ONE contiguous run of the array (cells
 // lie in row order), now of variable length and starting at any word: it is staged in LDS at the same offset mod 4 it has in
 // memory, so that 16-byte pieces of the image are 16-byte pieces of the array.
-template <int H, bool JAC, bool CMP>
+// PRE: the rows' cells are given (row_cells, nksr_row_cells_merged) instead of looked up: the look-up heads the kernel's chain of
+// dependent loads (row source -> position -> hash probe -> neighbour row -> features); given, the cell is one coalesced load that
+// does not wait for the position (CMP implies PRE).
+template <int H, bool JAC, bool CMP, bool PRE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H == 16 ? 4 : 2))) k_kernel_rows_merged(nksr_hier_t hier, const float* __restrict__ xyz_a, const float* __restrict__ ss_a, float rs_a,
                               const float* __restrict__ xyz_b, const float* __restrict__ ss_b, float rs_b, const int32_t* __restrict__ row_src,
                               int64_t rows_total, int32_t* __restrict__ row_cells, const int32_t* __restrict__ cmp, float* __restrict__ rows_out, uint32_t level_map) {
@@ -59,6 +62,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H == 1
     float* im = img[wv] + 27 * lane;                           // the lane's 27 words: its neighbour row waits here, then (dense) its row
     const int64_t R = R0 + lane;
     const int src = R < rows_total ? row_src[R] : -1;
+    const int cj_given = (PRE && R < rows_total) ? row_cells[(int64_t)d * rows_total + R] : -1;
     const int kind = src & 3, site = src >> 2;
     const int ax = kind - 1;                                   // the lane's gradient axis (-1: a value row)
     int cell = -1;
@@ -72,17 +76,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H == 1
         const float* xp = (kind == 0 ? xyz_a : xyz_b) + (int64_t)site * 3;
         const float x[3] = {xp[0], xp[1], xp[2]};
         scale = kind == 0 ? (ss_a ? ss_a[site] : rs_a) : (ss_b ? ss_b[site] : rs_b);
-        if (CMP) {
+        if (PRE) {
             sc = site_geometry(d, hier.inv_w0, x);
-            const int cj = row_cells[(int64_t)d * rows_total + R];
-            cell = cj >= 0 ? cj - lv.offset : -1;
+            cell = cj_given >= 0 ? cj_given - lv.offset : -1;
             sc.cell = cell;
         } else {
             sc = locate_site(lv, d, hier.inv_w0, x);
             cell = sc.cell;
         }
     }
-    if (!CMP && row_cells && R < rows_total) row_cells[(int64_t)d * rows_total + R] = cell >= 0 ? lv.offset + cell : -1;
+    if (!PRE && row_cells && R < rows_total) row_cells[(int64_t)d * rows_total + R] = cell >= 0 ? lv.offset + cell : -1;
     if (CMP) {
         int64_t g = 0;
         int nw = 0;
@@ -313,7 +316,7 @@ uint32_t nksr_rows_level_map(int depth, int* nlev);          // (csrc/kfield.hip
 
 extern "C" int nksr_kernel_rows_merged(const nksr_hier_t* h, const float* xyz_pos, const float* scale_pos, float row_scale_pos,
                                        const float* xyz_nrm, const float* scale_nrm, float row_scale_nrm, int approx, const int32_t* row_src,
-                                       int64_t rows_total, int32_t* row_cells, const int32_t* compact_nbr32, float* rows_out, void* stream) {
+                                       int64_t rows_total, int32_t* row_cells, int cells_given, const int32_t* compact_nbr32, float* rows_out, void* stream) {
     if (rows_total <= 0) return NKSR_OK;
     if (!h || !row_src || !rows_out || (!xyz_pos && !xyz_nrm)) return nksr_set_error(NKSR_ERR_ARG, "merged rows: NULL arrays");
     if (h->depth < 1 || h->depth > NKSR_MAX_DEPTH) return nksr_set_error(NKSR_ERR_ARG, "bad depth %d", h->depth);
@@ -324,11 +327,14 @@ extern "C" int nksr_kernel_rows_merged(const nksr_hier_t* h, const float* xyz_po
     dim3 grid(nksr_blocks(rows_total, 256), nlev), block(256);
     const bool jac = xyz_nrm && !approx;
     if (compact_nbr32 && (!row_cells || ((uintptr_t)rows_out & 15))) return nksr_set_error(NKSR_ERR_ARG, "compact rows need row_cells (nksr_row_cells_merged) and a 16-byte aligned array");
+    if (cells_given && !row_cells) return nksr_set_error(NKSR_ERR_ARG, "cells_given without row_cells");
 #define NKSR_LAUNCH_MERGED(H_, J_)                                                                                                             \
     do {                                                                                                                                       \
-        if (compact_nbr32) hipLaunchKernelGGL((k_kernel_rows_merged<H_, J_, true>), grid, block, 0, (hipStream_t)stream, *h, xyz_pos, scale_pos, row_scale_pos, \
+        if (compact_nbr32) hipLaunchKernelGGL((k_kernel_rows_merged<H_, J_, true, true>), grid, block, 0, (hipStream_t)stream, *h, xyz_pos, scale_pos, row_scale_pos, \
                                               xyz_nrm, scale_nrm, row_scale_nrm, row_src, rows_total, row_cells, compact_nbr32, rows_out, level_map); \
-        else hipLaunchKernelGGL((k_kernel_rows_merged<H_, J_, false>), grid, block, 0, (hipStream_t)stream, *h, xyz_pos, scale_pos, row_scale_pos, \
+        else if (cells_given) hipLaunchKernelGGL((k_kernel_rows_merged<H_, J_, false, true>), grid, block, 0, (hipStream_t)stream, *h, xyz_pos, scale_pos, row_scale_pos, \
+                                                 xyz_nrm, scale_nrm, row_scale_nrm, row_src, rows_total, row_cells, compact_nbr32, rows_out, level_map); \
+        else hipLaunchKernelGGL((k_kernel_rows_merged<H_, J_, false, false>), grid, block, 0, (hipStream_t)stream, *h, xyz_pos, scale_pos, row_scale_pos, \
                                 xyz_nrm, scale_nrm, row_scale_nrm, row_src, rows_total, row_cells, compact_nbr32, rows_out, level_map);          \
     } while (0)
     if (h->hidden == 16) { if (jac) NKSR_LAUNCH_MERGED(16, true); else NKSR_LAUNCH_MERGED(16, false); }

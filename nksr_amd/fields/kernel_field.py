@@ -525,7 +525,7 @@ class KernelField(BaseField):
                 rows_all[rows_words:].zero_()
                 call('nksr_fused_tables', C.byref(self._hier), rows_total, ptr(item_begin), ptr(offsets), ptr(span), ptr(rowbase4), ptr(nbr32), ptr(nbrT), stream())
                 call('nksr_kernel_rows_merged', C.byref(self._hier), ptr(xa), ptr(sa), float(fa_), ptr(xb), ptr(sb), float(fb_),
-                     int(self.approx_kernel_grad), ptr(row_src), rows_total, ptr(row_cells), ptr(nbr32), ptr(rows_all), stream())
+                     int(self.approx_kernel_grad), ptr(row_src), rows_total, ptr(row_cells), 1, ptr(nbr32), ptr(rows_all), stream())
                 del sizes4, ends4, rowbase4
         if fac:
             fac_vec = torch.empty(L * rows_total * 4 + 320 * 4, dtype=torch.float32, device=dev)
@@ -547,8 +547,12 @@ class KernelField(BaseField):
         keep += [rows_all, fac_vec, fac_pos, psi_all]
         td = _tick('op:alloc', td)
         if merged and not compact:
+            # the rows' cells first (one pass, the probes of all levels in flight together): the row kernel then starts from them
+            pre = os.environ.get('NKSR_ROWS_PRECELLS', '1') != '0'
+            if pre:
+                call('nksr_row_cells_merged', C.byref(self._hier), ptr(xa), ptr(xb), ptr(row_src), rows_total, ptr(row_cells), stream())
             call('nksr_kernel_rows_merged', C.byref(self._hier), ptr(xa), ptr(sa), float(fa_), ptr(xb), ptr(sb), float(fb_),
-                 int(self.approx_kernel_grad), ptr(row_src), rows_total, ptr(row_cells), None, ptr(rows_all), stream())
+                 int(self.approx_kernel_grad), ptr(row_src), rows_total, ptr(row_cells), int(pre), None, ptr(rows_all), stream())
         for (xs, ks, perm, target, sw, ncomp), ri in zip(specs, row_index):
             ri = ri.contiguous()
             tensor_w = torch.is_tensor(sw)

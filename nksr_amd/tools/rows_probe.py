@@ -92,11 +92,14 @@ def main():
 
     def merged():
         (xa, sa, fa), (xb, sb, fb) = margs[1], margs[3]
+        pre = os.environ.get('NKSR_ROWS_PRECELLS', '1') != '0'
+        if pre:
+            call('nksr_row_cells_merged', C.byref(fld._hier), ptr(xa), ptr(xb), ptr(row_src), nrows, ptr(calls[0][7]), stream())
         call('nksr_kernel_rows_merged', C.byref(fld._hier), ptr(xa), ptr(sa), float(fa), ptr(xb), ptr(sb), float(fb), int(fld.approx_kernel_grad),
-             ptr(row_src), nrows, ptr(calls[0][7]), ptr(rows), stream())
+             ptr(row_src), nrows, ptr(calls[0][7]), int(pre), None, ptr(rows), stream())
 
     def run_merged(env):
-        for k in ('NKSR_ROWS_KERNEL', 'NKSR_ROWS_LEVELS', 'NKSR_ROWS_DBG'):
+        for k in ('NKSR_ROWS_KERNEL', 'NKSR_ROWS_LEVELS', 'NKSR_ROWS_DBG', 'NKSR_ROWS_PRECELLS'):
             os.environ.pop(k, None)
         os.environ.update(env)
         merged()
@@ -130,7 +133,8 @@ def main():
     r = run({'NKSR_ROWS_KERNEL': 'site'})
     show('site (one lane per site)', r)
     print('%-34s sum  %8.3f ms' % ('', sum(r)))
-    print('%-34s both %8.3f ms' % ('merged (one lane per row)', run_merged({})))
+    print('%-34s both %8.3f ms' % ('merged, cells looked up in the kernel', run_merged({'NKSR_ROWS_PRECELLS': '0'})))
+    print('%-34s both %8.3f ms' % ('merged, cells given (incl. their pass)', run_merged({'NKSR_ROWS_PRECELLS': '1'})))
     for d in range(L):
         print('%-34s both %8.3f ms' % ('merged level %d' % d, run_merged({'NKSR_ROWS_LEVELS': str(d)})))
     show('coop', run({'NKSR_ROWS_KERNEL': 'coop'}))
