@@ -105,7 +105,23 @@ def live_traffic_fused(flags, timeout_s=240):
     os.close(fd)
     env = dict(os.environ, NKSR_PMC_GROUPS='2,3', NKSR_BENCH_CHILD='1', TMPDIR='/tmp')
     try:
-        r = subprocess.run([sys.executable, '-m', 'nksr_amd.tools.scene_pmc', path] + list(flags), env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
+        # (its own session: on a timeout the whole group goes -- scene_pmc -> rocprofv3 -> bench.py, not just the direct child, which
+        # would leave a 10 M-point step running on the GPU under the measurements that follow)
+        import signal
+        proc = subprocess.Popen([sys.executable, '-m', 'nksr_amd.tools.scene_pmc', path] + list(flags), env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            _, err = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.communicate()
+            raise
+
+        class r:
+            stderr = err
         rec = json.load(open(path))
         if 'hbm_bytes_per_application' not in rec:
             return None, None, 'counter passes gave no operator record: %s' % (r.stderr[-300:].replace('\n', ' '))

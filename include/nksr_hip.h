@@ -120,7 +120,7 @@ int nksr_splat_mean(const float* xyz_sorted, const float* feat_sorted, int C, co
                     const int32_t* end, const int32_t* nbr, const int32_t* ijk, int32_t n, float inv_w, float* out,
                     void* stream);
 /* 3x3x3 submanifold sparse convolution on the fp32 matrix cores: out = act(b + sum_s W[s]^T in[nbr[:,s]]
- * (+ residual)),  W [27, C, C] */
+ * (+ residual)),  W [27, C, C]  in / W: 16-byte aligned (NKSR_ERR_ARG otherwise). */
 int nksr_sparse_conv3(const float* in, const int32_t* nbr, int32_t n, int C, const float* W, const float* bias,
                       const float* residual, int relu, float* out, void* stream);
 /* Weight gradient of nksr_sparse_conv3 (training path, network.unet under autograd, models/nksr_net.py:74-78):

@@ -916,7 +916,7 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
             free = float(os.environ.get('NKSR_FREE_HBM_GB', 0)) * 1e9
             if free <= 0:
                 free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-            per_point = 4500.0 * hp.tree_depth / 5.0 * (0.6 if str(getattr(rec, 'row_format', None) or os.environ.get('NKSR_ROW_FORMAT')) == 'factors' else 1.0)
+            per_point = 4500.0 * hp.tree_depth / 5.0 * (0.9 if str(getattr(rec, 'row_format', None) or os.environ.get('NKSR_ROW_FORMAT')) == 'factors' else 1.0)      # (factor records are a fifth of the rows, but the set-up sweep holds the dense rows of the coarse levels beside them: peak ~0.9)
             budget = int(max(min(budget, 0.7 * free / per_point), 1))
     if not fused_mode:
         budget = 0        # the assembled solve (fused_mode=False) has no segmented form: one chunk per solve, as the reference runs them

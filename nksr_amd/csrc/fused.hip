@@ -492,6 +492,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(FAC ? 3 : (D <= 4 ? 6 : 5))))
 #pragma unroll
                     for (int d = 0; d < D; ++d) fv[d * RS + rl + s] = A.fac_vec[(int64_t)d * A.rows_total + r + s];
                 }
+                __builtin_amdgcn_wave_barrier();                  // (lanes s < 4 write, every lane of the half-wave reads)
             }
             float4 pq[U];
 #pragma unroll

@@ -390,6 +390,7 @@ extern "C" int nksr_sparse_conv3(const float* in, const int32_t* nbr, int32_t n,
                                  const float* residual, int relu, float* out, void* stream) {
     if (C != NN_C) return nksr_set_error(NKSR_ERR_ARG, "unet.f_maps must be %d", NN_C);
     if (n <= 0) return NKSR_OK;
+    if (((uintptr_t)in | (uintptr_t)W) & 15) return nksr_set_error(NKSR_ERR_ARG, "sparse_conv3: in and W must be 16-byte aligned (16-byte row / weight loads)");
     hipLaunchKernelGGL(k_sparse_conv3, dim3(nksr_blocks(n, 128)), dim3(256), 0, (hipStream_t)stream, in, nbr, n, W, bias,
                        residual, relu, out);
     NKSR_CHECK_LAUNCH();

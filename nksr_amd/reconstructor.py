@@ -28,7 +28,9 @@ class Reconstructor:
         self.timing = {}
         self.sync_timing = False   # insert stream syncs so that per-stage wall times are exact
         # chunk mode: ALL chunks of a rank are solved as one block-diagonal system (nksr_amd/chunking.py); chunk_batch_points caps the
-        # points (band included) of one such batch -- ~2 KB of HBM per point at tree_depth 5 -- None = 2^25.  Results do not depend on it.
+        # points (band included) of one such batch.  None = automatic: the batches follow the FREE device memory (~4.5 KB of HBM per solved
+        # point at tree_depth 5; 70 % of what is free + what torch's allocator holds unused -- NKSR_FREE_HBM_GB overrides the free figure --,
+        # at most 2^25 points).  Results do not depend on it.
         self.chunk_batch_points = None
         self.dual_graph = 'lattice'      # 'adaptive': extract_dual_mesh on the adaptive dual graph (cells as large as their level; nksr_amd/meshing.py); a chunked field spread over several ranks uses the lattice
         self.chunk_spill_dir = None      # chunk mode, batches parked on a CPU chunk_tmp_device: a directory -> the parked batches live in unlinked files there

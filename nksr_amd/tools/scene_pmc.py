@@ -35,8 +35,9 @@ def short(name):
 
 
 def run_pass(counters, flags, tag):
-    out = '/tmp/pmc_%s' % tag
-    subprocess.run(['rm', '-rf', out])
+    import shutil
+    import tempfile
+    out = tempfile.mkdtemp(prefix='pmc_%s_' % tag, dir='/tmp')      # (per invocation: two runs at once must not share counter files)
     env = dict(os.environ, TMPDIR='/tmp')
     root = os.environ.get('GRAFT_REPO_ROOT', os.getcwd())
     cmd = ['rocprofv3', '--pmc'] + counters + ['--kernel-trace', '--output-format', 'csv', '-d', out, '--', sys.executable, os.path.join(root, 'bench.py')] + flags
@@ -63,6 +64,7 @@ def run_pass(counters, flags, tag):
         res[k] = dict(disp[best], us=dur.get(best, 0.0), dispatches=len(disp))
     if not res:
         sys.stderr.write('pass %s gave no counters: %s\n' % (tag, r.stderr[-600:]))
+    shutil.rmtree(out, ignore_errors=True)
     return res
 
 
