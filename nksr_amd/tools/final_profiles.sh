@@ -8,7 +8,7 @@ tail -2 gpurun_out/${tag}_pytest.log
 # the bench line as the driver runs it
 timeout 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 # per-kernel tables: the configs[4] scene (the headline), the configs[2] cloud through both solves
-KSTATS_ROWS=60 KSTATS_TOP=6 timeout 400 bash nksr_amd/tools/kstats.sh ${tag}_scene --no-cloud --no-small-inputs > /dev/null
+KSTATS_ROWS=60 KSTATS_TOP=6 timeout 400 bash nksr_amd/tools/kstats.sh ${tag}_scene --no-cloud --no-small-inputs --no-adaptive --no-live-pmc > /dev/null
 KSTATS_ROWS=60 KSTATS_TOP=6 timeout 300 bash nksr_amd/tools/kprof.sh ${tag}_cloud_fused python -m nksr_amd.tools.prof_cloud 1000000 3 > /dev/null
 KSTATS_ROWS=60 KSTATS_TOP=6 timeout 300 bash nksr_amd/tools/kprof.sh ${tag}_cloud_csr python -m nksr_amd.tools.prof_cloud 1000000 3 --non-fused > /dev/null
 # HBM traffic from the counters (separate --pmc passes, --kernel-trace only): operator probe, CSR SpMV probe, the scene step
@@ -24,6 +24,6 @@ timeout 300 python -m nksr_amd.tools.small_pc_sweep > gpurun_out/${tag}_small_pc
 # everything ONE rank of 8 does after its solve, on one GPU (collectives replaced by a dictionary)
 timeout 600 python -m nksr_amd.tools.prof_rank_tail 8 3 > gpurun_out/${tag}_rank_tail_8.txt 2>&1
 # the N = 2 launch path on this one GPU (gloo: two ranks share the device; a protocol run, not a scaling measurement)
-NKSR_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 1 --warmup 1 > gpurun_out/${tag}_bench_two_processes_one_gpu.json 2> /dev/null
-NKSR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 1 --warmup 1 > gpurun_out/${tag}_bench_eight_processes_one_gpu.json 2> /dev/null
+NKSR_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 1 --warmup 1 2> /dev/null | grep '^{' > gpurun_out/${tag}_bench_two_processes_one_gpu.json
+NKSR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 1 --warmup 1 2> /dev/null | grep '^{' > gpurun_out/${tag}_bench_eight_processes_one_gpu.json
 ls -la gpurun_out | grep ${tag}_
