@@ -114,30 +114,43 @@ __device__ __forceinline__ int fz_level(const nksr_hier_t& h, int j) {
 // nbr32[j][0..26]: global unknown index of the neighbour voxels or -1;  [27]: (first block of j) - (first workgroup of j), so that
 // the block of workgroup w is nbr32[j][27] + w;  [28] / [29]: first / last row of the cell (-1: none);  [30] / [31]: where the cell's
 // rows lie in the COMPACT row array (see below): first word / 4, and the 27-bit mask of the neighbours that exist
-__global__ void k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__ offsets, const int32_t* __restrict__ first,
-                            const int32_t* __restrict__ last, const int32_t* __restrict__ wgfirst, const int32_t* __restrict__ rowbase4,
-                            int32_t* __restrict__ nbr32) {
-    const int64_t lin = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (lin >= (int64_t)M * 32) return;                        // (M * 32 entries: whole half-waves -- the ballot below is safe)
-    const int j = (int)(lin >> 5), s = (int)(lin & 31);
-    int v = 0;
-    if (s < 27) {
-        const int d = fz_level(hier, j), c = j - hier.lv[d].offset;
-        const int nb = hier.lv[d].nbr[(int64_t)c * 27 + s];
-        v = nb >= 0 ? nb + hier.lv[d].offset : -1;
-    } else if (s == 27) {
-        v = offsets[j] - wgfirst[j];
-    } else if (s == 28) {
-        v = first[j];
-    } else if (s == 29) {
-        v = last[j];
-    } else if (s == 30) {
-        v = rowbase4 ? rowbase4[j] : 0;
+// One workgroup per 64 unknowns writes BOTH tables from one read of the hierarchy's neighbour rows: nbr32 row-major as it is formed,
+// nbrT slot-major out of an LDS tile (round 6: two kernels read the rows, then nbr32 again: 3.7 + 1.4 ms per scene step).
+__global__ void __launch_bounds__(256) k_fz_tables(nksr_hier_t hier, int M, const int32_t* __restrict__ offsets, const int32_t* __restrict__ first,
+                                                   const int32_t* __restrict__ last, const int32_t* __restrict__ wgfirst,
+                                                   const int32_t* __restrict__ rowbase4, int32_t* __restrict__ nbr32, int32_t* __restrict__ nbrT) {
+    __shared__ int32_t tile[64][33];
+    const int j0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {         // (i >> 5 is uniform over a half-wave: the ballot below is one unknown's)
+        const int jj = i >> 5, s = i & 31, j = j0 + jj;
+        int v = -1;
+        if (j < M) {
+            v = 0;
+            if (s < 27) {
+                const int d = fz_level(hier, j), c = j - hier.lv[d].offset;
+                const int nb = hier.lv[d].nbr[(int64_t)c * 27 + s];
+                v = nb >= 0 ? nb + hier.lv[d].offset : -1;
+            } else if (s == 27) {
+                v = offsets[j] - wgfirst[j];
+            } else if (s == 28) {
+                v = first[j];
+            } else if (s == 29) {
+                v = last[j];
+            } else if (s == 30) {
+                v = rowbase4 ? rowbase4[j] : 0;
+            }
+        }
+        // the mask of the existing neighbours: the 27 lanes of this half-wave have just decided it
+        const unsigned m = (unsigned)(__ballot(s < 27 && v >= 0) >> ((threadIdx.x & 32) ? 32 : 0)) & 0x7FFFFFFu;
+        if (s == 31 && j < M) v = (int)m;
+        tile[jj][s] = v;
+        if (j < M) nbr32[(int64_t)j * 32 + s] = v;
     }
-    // the mask of the existing neighbours: the 27 lanes of this half-wave have just decided it
-    const unsigned m = (unsigned)(__ballot(s < 27 && v >= 0) >> ((threadIdx.x & 32) ? 32 : 0)) & 0x7FFFFFFu;
-    if (s == 31) v = (int)m;
-    nbr32[lin] = v;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
+        const int s = i >> 6, jj = i & 63;
+        if (j0 + jj < M) nbrT[(int64_t)s * M + j0 + jj] = tile[jj][s];
+    }
 }
 // ---- COMPACT rows (round 6).  A slot of a kernel row whose neighbour voxel does not exist is a structural zero -- a quarter of the
 // slots by the round-5 review's count; 4 % on the 64-chunk scene when measured: HISTORY.md).  All rows of a cell share the cell's 27-bit neighbour mask, so they are stored with the
@@ -158,21 +171,6 @@ __global__ void k_fz_row_sizes(nksr_hier_t hier, int M, const int32_t* __restric
     }
     sizes4[j] = v;
 }
-// nbrT[s][j]: the same neighbour indices slot-major (the gather's table), transposed through LDS 64 unknowns at a time
-__global__ void __launch_bounds__(256) k_fz_nbrT(int M, const int32_t* __restrict__ nbr32, int32_t* __restrict__ nbrT) {
-    __shared__ int32_t tile[64][33];
-    const int j0 = blockIdx.x * 64;
-    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
-        const int jj = i >> 5, s = i & 31;
-        tile[jj][s] = j0 + jj < M ? nbr32[(int64_t)(j0 + jj) * 32 + s] : -1;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 27 * 64; i += 256) {
-        const int s = i >> 6, jj = i & 63;
-        if (j0 + jj < M) nbrT[(int64_t)s * M + j0 + jj] = tile[jj][s];
-    }
-}
-
 // ---- the operator ----------------------------------------------------------------------------------------------------------
 struct FusedArgs {               // uniform scalars and base pointers only
     const float* rows_all;       // [depth][rows_total][27]
@@ -828,9 +826,8 @@ extern "C" int nksr_fused_tables(const nksr_hier_t* h, int64_t rows_total, const
     const int M = h->lv[h->depth - 1].offset + h->lv[h->depth - 1].n;
     if (M <= 0) return NKSR_OK;
     if (!offsets || !span || !nbr32_out || !nbrT_out || !item_begin) return nksr_set_error(NKSR_ERR_ARG, "NULL arrays");
-    hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks((int64_t)M * 32, 256)), dim3(256), 0, (hipStream_t)stream, *h, M, offsets, span, span + M,
-                       span + 2 * (int64_t)M, rowbase4, nbr32_out);
-    hipLaunchKernelGGL(k_fz_nbrT, dim3(nksr_blocks(M, 64)), dim3(256), 0, (hipStream_t)stream, M, (const int32_t*)nbr32_out, nbrT_out);
+    hipLaunchKernelGGL(k_fz_tables, dim3(nksr_blocks(M, 64)), dim3(256), 0, (hipStream_t)stream, *h, M, offsets, span, span + M,
+                       span + 2 * (int64_t)M, rowbase4, nbr32_out, nbrT_out);
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
