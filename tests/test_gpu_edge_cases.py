@@ -189,3 +189,28 @@ def test_reconstruct_is_bitwise_deterministic():
         assert a[6] == b[6]
         for u, v in zip(a[:6], b[:6]):
             assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize('drop', [0.0, 0.3])
+def test_neighbour_table_from_the_parent_level_equals_the_hashed_one_also_when_parents_are_missing(drop):
+    """csrc/hierarchy.hip: a level's 27-neighbour table is derived from the next-coarser table and its voxels' children
+    (k_build_nbr_parent); a key list whose voxels lack parents (drop > 0: a foreign list, no hierarchy builder makes one)
+    takes the hash path on the device (k_build_nbr_orphans). Either way the table is the one 27 hash probes per voxel give."""
+    from nksr_amd import ops
+    from nksr_amd._lib import call, ptr, stream
+    from nksr_amd.svh import SparseGrid
+    g = torch.Generator(device='cpu').manual_seed(11)
+    blob = (torch.randn(60000, 3, generator=g) * 9).round().to(torch.int32)
+    ijk = torch.cat([blob, torch.tensor([[-40, 3, 7], [41, 41, -41]], dtype=torch.int32)]).to(DEV).contiguous()
+    keys = torch.empty(ijk.shape[0], dtype=torch.int64, device=DEV)
+    call('nksr_encode_keys', ptr(ijk), ijk.shape[0], 0, ptr(keys), stream())
+    keys = ops.sort_unique(keys)
+    pk = ops.sort_unique((keys >> 3).contiguous())
+    if drop:
+        keep = torch.rand(pk.numel(), generator=g) >= drop
+        pk = pk[keep.to(DEV)].contiguous()
+    coarse = SparseGrid(pk, 1, 0.1)
+    want = SparseGrid(keys, 0, 0.1).nbr                       # 27 hash probes per voxel
+    got = SparseGrid(keys, 0, 0.1, coarse=coarse).nbr
+    assert want.shape[0] > 20000 and int((want >= 0).sum()) > 3 * want.shape[0]
+    assert torch.equal(got, want)
