@@ -63,7 +63,9 @@ def needs_build():
 
 
 def _compile(src):
-    obj = os.path.join(CSRC, src.replace('.hip', '.o'))
+    extra = os.environ.get('NKSR_EXTRA_HIPCC_FLAGS', '')
+    tag = '.' + hashlib.sha1(extra.encode()).hexdigest()[:8] if extra else ''       # (objects of a probe build do not pass for the product's)
+    obj = os.path.join(CSRC, src.replace('.hip', tag + '.o'))
     hdr_t = max(os.path.getmtime(f) for f in _deps() if f.endswith('.h'))
     if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(os.path.join(CSRC, src)), hdr_t):
         return obj
