@@ -203,19 +203,30 @@ def _udf_levels(f):
     return n
 
 
-def exchange_band(core, cidx3, grid, ov, w0):
+def halo_inner(voxel_size, adaptive_depth=1, dual_graph='lattice'):
+    """How far INSIDE a neighbour's core a rank evaluates the blend (model units).  Lattice mesher: 2.5 finest voxels (the one-ring
+    of halo cells and its refined lattice).  Adaptive dual graph: the hexahedra around a rank's own octree corners reach one leaf
+    across the seam and the MISE split of that leaf looks one more leaf out -- leaves up to 2^(A-1) voxels wide, the rings of
+    the finer MISE rounds half as deep each: 3 * 2^(A-1) + 1 voxels cover any mise_iter."""
+    if dual_graph != 'adaptive':
+        return 2.5 * voxel_size
+    return (3.0 * (1 << (max(1, int(adaptive_depth)) - 1)) + 1.0) * voxel_size
+
+
+def exchange_band(core, cidx3, grid, ov, w0, inner=None):
     """Where OTHER ranks evaluate this chunk's field: along every split axis with a neighbouring chunk, from
-    2.5 finest voxels inside the shared face (their one-ring of halo cells and its refined lattice) to ``ov``
-    outside it (the end of the blend weight).  Returns [(axis, lo, hi), ...]; see pack_field(band=)."""
+    ``inner`` (default 2.5 finest voxels: their one-ring of halo cells and its refined lattice; halo_inner) inside the shared
+    face to ``ov`` outside it (the end of the blend weight).  Returns [(axis, lo, hi), ...]; see pack_field(band=)."""
     clo, chi = core
+    inner = 2.5 * w0 if inner is None else float(inner)
     out = []
     for a in range(3):
         if grid[a] <= 1:
             continue
         if cidx3[a] > 0:
-            out.append((a, clo[a] - ov, clo[a] + 2.5 * w0))
+            out.append((a, clo[a] - ov, clo[a] + inner))
         if cidx3[a] < grid[a] - 1:
-            out.append((a, chi[a] - 2.5 * w0, chi[a] + ov))
+            out.append((a, chi[a] - inner, chi[a] + ov))
     return out
 
 
@@ -543,8 +554,9 @@ class MultiChunkField(BaseField):
     meshes) and must not be used elsewhere -- ``extract_dual_mesh`` respects that and gathers the pieces."""
 
     def __init__(self, parts, cores, ov, origin, chunk_size, grid, owner, rank, world_size, frame, interpolators, device, distributed=False,
-                 adaptive_depth=1):
+                 adaptive_depth=1, halo_inner=None):
         self.parts = [p for p in parts if p.ids]
+        self.halo_inner = halo_inner          # (model units; None: the lattice mesher's 2.5 voxels -- chunking.halo_inner)
         self.cores = cores                # {chunk id: (lo[3], hi[3])} model units
         self.ov = float(ov)
         self.origin, self.chunk_size, self.grid = origin, float(chunk_size), grid
@@ -679,10 +691,24 @@ class MultiChunkField(BaseField):
         the cells across a rank seam were refined, so they are evaluated (but not meshed) here too."""
         if self.world_size == 1:
             return torch.ones(ijk.shape[0], dtype=torch.bool, device=ijk.device)
-        own = torch.tensor(self.owner, dtype=torch.long, device=ijk.device)
         w = self.svh.voxel_size
-        centers = (ijk.to(torch.float32) + 0.5) * w
-        # chunk index of centre - w / centre / centre + w along every split axis; only voxels next to a chunk
+        return self.near_owned((ijk.to(torch.float32) + 0.5) * w, w)
+
+    def owns_points(self, xyz):
+        """Points (model units) inside a core this rank owns."""
+        if self.world_size == 1:
+            return torch.ones(xyz.shape[0], dtype=torch.bool, device=xyz.device)
+        own = torch.tensor(self.owner, dtype=torch.long, device=xyz.device)
+        return own[self.chunk_of(xyz)] == self.rank
+
+    def near_owned(self, centers, reach):
+        """Points whose box centre +- ``reach`` (along the split axes) touches a core this rank owns."""
+        if self.world_size == 1:
+            return torch.ones(centers.shape[0], dtype=torch.bool, device=centers.device)
+        dev = centers.device
+        own = torch.tensor(self.owner, dtype=torch.long, device=dev)
+        w = reach
+        # chunk index of centre - w / centre / centre + w along every split axis; only points next to a chunk
         # boundary (lo != hi on some axis) can see a different owner than their own chunk's
         split = [a for a in range(3) if self.grid[a] > 1]
         idx = {}
@@ -691,7 +717,7 @@ class MultiChunkField(BaseField):
                 idx[(a, k)] = torch.floor((centers[:, a] + off - self.origin[a]) / self.chunk_size).long().clamp_(0, self.grid[a] - 1)
 
         def lin(sel, ks):
-            out = torch.zeros(1, dtype=torch.long, device=ijk.device)
+            out = torch.zeros(1, dtype=torch.long, device=dev)
             for a in range(3):
                 ia = idx[(a, ks[a])][sel] if a in split else 0
                 out = out * self.grid[a] + ia
@@ -699,7 +725,7 @@ class MultiChunkField(BaseField):
 
         every = slice(None)
         m = own[lin(every, (1, 1, 1))] == self.rank
-        near = torch.zeros(ijk.shape[0], dtype=torch.bool, device=ijk.device)
+        near = torch.zeros(centers.shape[0], dtype=torch.bool, device=dev)
         for a in split:
             near |= idx[(a, 0)] != idx[(a, 2)]
         sel = torch.nonzero(near).reshape(-1)
@@ -729,11 +755,30 @@ class MultiChunkField(BaseField):
         res.c = self.texture_field.evaluate_color(v) if self.texture_field is not None else None
         return res
 
+    def finalize_mesh_named(self, res):
+        """The adaptive dual graph's pieces: vertices named by the ordered pair of primal cells they join -- (size, key) names, the
+        same on every rank -- gathered on rank 0 and merged there (dist.merge_named)."""
+        if self.world_size == 1 and not self.distributed:
+            return res
+        import time
+        on_gpu = res.v.is_cuda and torch.cuda.is_available()
+        if on_gpu:
+            torch.cuda.current_stream().synchronize()
+        t0 = time.perf_counter()
+        v, f, names = D.gather_named(res.v, res.f, res.vertex_names5)
+        if on_gpu:
+            torch.cuda.current_stream().synchronize()
+        self.last_gather_s = time.perf_counter() - t0
+        res.v, res.f, res.vertex_names5 = v, f, names
+        res.c = self.texture_field.evaluate_color(v) if self.texture_field is not None else None
+        return res
+
     def for_rank(self, rank, world_size, fields):
         """Same scene seen from another (simulated) rank holding the per-chunk ``fields`` -- test helper."""
         parts = [ChunkPart(f, [c], self.frame, solved=bool(f.solve_info)) for c, f in sorted(fields.items())]
         return MultiChunkField(parts, self.cores, self.ov, self.origin, self.chunk_size, self.grid, self.owner, rank,
-                               world_size, self.frame, self.interpolators, self.svh.device, adaptive_depth=self.meshing_depth)
+                               world_size, self.frame, self.interpolators, self.svh.device, adaptive_depth=self.meshing_depth,
+                               halo_inner=self.halo_inner)
 
     def to_(self, device):
         """``to_('cpu')`` parks the parts and the union grid on the host (NKSR-USAGE.md:163: "Put everything onto CPU"); evaluation
@@ -961,11 +1006,12 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     rec.timing = timing
     interps = rec.network.interpolators
     t_x = _now(rec)
+    inner = halo_inner(hp.voxel_size, hp.adaptive_depth, getattr(rec, 'dual_graph', 'lattice'))      # how deep a halo reaches into its own core
     if active or (sim is not None and sim_exchange is not None):
         # the exchange carries the halo of every chunk (the voxels other ranks can touch), not the whole field; which
         # chunks were actually solved travels with it (a sparse chunk may have been skipped by its owner)
         def band_of(c):
-            return exchange_band(cores[c], frame.chunk3(c), grid, ov, hp.voxel_size)
+            return exchange_band(cores[c], frame.chunk3(c), grid, ov, hp.voxel_size, inner)
         local = {}
         for p in parts:
             local.update(p.pack_halos({c: band_of(c) for c in p.ids}))
@@ -973,7 +1019,7 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
         # weight support (core +- ov) reaches there -- its spatial neighbours, not all N.  Who needs what is geometry (cores, owners,
         # which cores hold points): every rank computes the same table, so a halo is SENT only to the ranks that need it
         # (all_to_all with per-pair sizes; a chunk its owner skipped is simply not sent)
-        dest_of = halo_destinations(cores, ov + 2.5 * hp.voxel_size, grid, owner, counts, ws)
+        dest_of = halo_destinations(cores, ov + inner, grid, owner, counts, ws)
         payload = D.exchange_payloads_to(local, dest_of) if active else sim_exchange(local, dest_of)
         mine = set(local)
         need = sorted(c for c in payload if c not in mine)
@@ -987,8 +1033,8 @@ def reconstruct_by_chunk(rec, xyz, normal, sensor, chunk_size, overlap_ratio, ap
     # (batches parked on chunk_tmp_device stay there: the blend borrows one part at a time -- borrowed() -- so meshing a scene
     # whose chunks do not fit the GPU together works as the reference's small-memory recipe says, NKSR-USAGE.md:150-167)
     mf = MultiChunkField(parts, cores, ov, lo, chunk_size, grid, owner, rank, ws, frame, interps, dev, distributed=active,
-                         adaptive_depth=int(hp.adaptive_depth))
-    mf.dual_graph = getattr(rec, 'dual_graph', 'lattice')      # ('adaptive' takes effect while ONE process holds the field, nksr_amd/meshing.py)
+                         adaptive_depth=int(hp.adaptive_depth), halo_inner=inner)
+    mf.dual_graph = getattr(rec, 'dual_graph', 'lattice')
     return mf
 
 

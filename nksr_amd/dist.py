@@ -310,3 +310,51 @@ def gather_meshes(v, f, vkey, axis, dst=0):
         return v, f
     pieces = [(a.view(-1, 3), b.view(-1, 3), c, d) for a, b, c, d in got]
     return merge_meshes(pieces)
+
+
+def merge_named(pieces):
+    """``pieces``: list of (v [V,3] f32, f [T,3] i64, names [V,5] i64) -- the adaptive dual graph's mesh pieces, a vertex named by
+    the ordered pair of primal cells its cube edge joins: (size A, key A, axis, size B, key B), the same on every rank
+    (nksr_amd/meshing.py).  Vertices with the same name are one vertex.  Deterministic: output vertices in lexicographic name
+    order -- the order of the single-process mesh --, faces in piece order, the representative of a merged vertex its first
+    occurrence.  On the GPU four stable radix sorts (key B; axis and size B; key A; size A) + a flag scan; CPU tensors (the gloo
+    tests) take torch.unique over the rows."""
+    v = torch.cat([p[0] for p in pieces])
+    names = torch.cat([p[2].reshape(-1, 5) for p in pieces])
+    offs, faces = 0, []
+    for p in pieces:
+        faces.append(p[1] + offs)
+        offs += p[0].shape[0]
+    f = torch.cat(faces)
+    n = v.shape[0]
+    if n == 0:
+        return v, f, names
+    if v.is_cuda:
+        from . import ops
+        order = torch.arange(n, dtype=torch.int32, device=v.device)
+        for col in (names[:, 4], names[:, 2] * 256 + names[:, 3], names[:, 1], names[:, 0]):       # least significant first; stable
+            _, order = ops.sort_pairs(col[order.long()].contiguous(), order)
+        srt = names[order.long()]
+        head = torch.ones(n, dtype=torch.bool, device=v.device)
+        head[1:] = (srt[1:] != srt[:-1]).any(1)
+        group = torch.cumsum(head.to(torch.int64), 0) - 1
+        new_index = torch.empty(n, dtype=torch.int64, device=v.device)
+        new_index[order.long()] = group
+        first = order.long()[head]                                     # stable sorts: the first of a group is its first occurrence
+        return v[first], new_index[f], srt[head]
+    un, inv = torch.unique(names, dim=0, sorted=True, return_inverse=True)
+    first = torch.full((un.shape[0],), n, dtype=torch.int64)
+    first.scatter_reduce_(0, inv, torch.arange(n, dtype=torch.int64), reduce='amin')
+    return v[first], inv[f], un
+
+
+def gather_named(v, f, names, dst=0):
+    """gather_meshes for pieces whose vertices carry five-word names (merge_named): the pieces go to rank ``dst`` only, which
+    merges the seams; the other ranks keep their own piece."""
+    rank, ws = world()
+    if not active():
+        return v, f, names
+    got = gather_tensors([v.reshape(-1).contiguous(), f.reshape(-1).contiguous(), names.reshape(-1).contiguous()], dst)
+    if rank != dst:
+        return v, f, names
+    return merge_named([(a.view(-1, 3), b.view(-1, 3), c.view(-1, 5)) for a, b, c in got])

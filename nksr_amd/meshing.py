@@ -31,16 +31,22 @@ def _cell_vertices(cell_keys_raw):
 def extract_dual_mesh(field, mise_iter=0, grid_upsample=1, max_points=-1):
     # field.dual_graph = 'adaptive': cells as large as the hierarchy level that carries them (the reference's dual graph of the
     # flattened levels); 'lattice' (default): one uniform lattice over the adaptive support.
-    # A chunked field held by ONE process meshes its union hierarchy (levels < adaptive_depth on the global lattice) with the blended
-    # field like any other; only fields spread over several ranks stay on the lattice (their pieces are stitched by lattice vertex keys).
+    # A chunked field meshes its union hierarchy (levels < adaptive_depth on the global lattice) with the blended field like any
+    # other.  Spread over several ranks, every rank meshes the hexahedra around the octree corners inside its own cores (the leaves
+    # one halo deep across the seam are its neighbours' -- chunking.halo_inner) and rank 0 merges the pieces by the vertices'
+    # (size, key) pair names (dist.merge_named).
     spread = hasattr(field, 'finalize_mesh') and (getattr(field, 'world_size', 1) > 1 or getattr(field, 'distributed', False))
     if getattr(field, 'dual_graph', 'lattice') == 'adaptive':
-        if spread:
-            # (never a silent lattice mesh where the adaptive dual graph was asked for)
-            raise RuntimeError("dual_graph='adaptive' is not available for a chunked field spread over several ranks: the seam merge "
-                               "names vertices by lattice keys (nksr_amd/dist.py).  Mesh with dual_graph='lattice', or hold all "
-                               "chunks in one process")
-        return _extract_adaptive(field, mise_iter, grid_upsample, max_points)
+        if not spread:
+            return _extract_adaptive(field, mise_iter, grid_upsample, max_points)
+        from . import chunking
+        need = chunking.halo_inner(field.svh.voxel_size, getattr(field, 'meshing_depth', 1), 'adaptive')
+        if getattr(field, 'halo_inner', None) is None or field.halo_inner < need - 1e-6 * need:
+            # (never a mesh from halos that are too thin for it: the field was reconstructed for the lattice mesher)
+            raise RuntimeError("dual_graph='adaptive' on a chunked field spread over several ranks needs halos %.3g deep (set "
+                               "Reconstructor.dual_graph = 'adaptive' BEFORE reconstruct(); this field's are %s)"
+                               % (need, getattr(field, 'halo_inner', None)))
+        return field.finalize_mesh_named(_extract_adaptive(field, mise_iter, grid_upsample, max_points, owned=True))
     res = _extract(field, mise_iter, grid_upsample, max_points)
     if hasattr(field, 'finalize_mesh'):       # distributed fields gather + stitch the pieces (collective)
         res = field.finalize_mesh(res)
@@ -246,8 +252,17 @@ class _CellTable:
         self.f = torch.cat(fs) if fs else torch.zeros(0, dtype=torch.float32, device=dev)
 
 
-def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=None):
-    """``level_ijk`` (tests): the voxel coordinates per level instead of the field's hierarchy."""
+def _names5(uek, tab):
+    """Local vertex names (cell id A 2^33 + axis 2^31 + cell id B) -> [n, 5] (size A, key A, axis, size B, key B): what the
+    ids stand for, the same on every rank; ids ascend with (size, key), so the lexicographic order of the rows is the order of uek."""
+    a, b = (uek >> 33).long(), (uek & 0x7FFFFFFF).long()
+    return torch.stack([tab.lam[a].to(torch.int64), tab.key[a], (uek >> 31) & 3, tab.lam[b].to(torch.int64), tab.key[b]], 1).contiguous()
+
+
+def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=None, owned=False):
+    """``level_ijk`` (tests): the voxel coordinates per level instead of the field's hierarchy.  ``owned`` (a field spread over
+    ranks): only the cells within the halo depth of this rank's cores enter (the field is exact there and nowhere else), every
+    dual cell is configured and takes part in the MISE splits, and the hexahedra around the corners inside this rank's cores emit."""
     svh = field.svh
     dev = svh.device
     w0 = svh.voxel_size
@@ -262,7 +277,7 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
     else:
         leaf = _leaf_coordinates(_LevelsOnly(level_ijk, w0, dev), len(level_ijk))
     if not any(c.numel() for c in leaf):
-        return empty
+        return _empty_named(empty, dev) if owned else empty
     reach = max(((int(c.abs().max()) + 2) << d) for d, c in enumerate(leaf) if c.numel()) * U * (1 << M) + 2
     if reach >= (1 << 20):
         raise RuntimeError('mesh lattice out of range: |ijk| * grid_upsample * 2^mise_iter = %d >= 2^20; recentre the cloud '
@@ -276,8 +291,17 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
         cc = (c[:, None, :] * U + sub[None]).reshape(-1, 3).contiguous()
         k = torch.empty(cc.shape[0], dtype=torch.int64, device=dev)
         call('nksr_encode_keys', ptr(cc), cc.shape[0], -1, ptr(k), stream())
-        keys_by[d + M] = ops.sort_unique(k)
-        f_by[d + M] = torch.full((keys_by[d + M].numel(),), float('nan'), dtype=torch.float32, device=dev)
+        k = ops.sort_unique(k)
+        if owned and k.numel():
+            cp = torch.empty((k.numel(), 3), dtype=torch.float32, device=dev)
+            call('nksr_adaptive_positions', ptr(k), ptr(torch.full((k.numel(),), d + M, dtype=torch.int32, device=dev)), k.numel(), float(u), ptr(cp), stream())
+            k = k[field.near_owned(cp, float(field.halo_inner) - 0.5 * w0)].contiguous()
+            if not k.numel():
+                continue
+        keys_by[d + M] = k
+        f_by[d + M] = torch.full((k.numel(),), float('nan'), dtype=torch.float32, device=dev)
+    if not keys_by:
+        return _empty_named(empty, dev) if owned else empty
     for m in range(M + 1):
         tab = _CellTable(keys_by, f_by, dev)
         pos = torch.empty((tab.n, 3), dtype=torch.float32, device=dev)
@@ -304,7 +328,8 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
         cidx = cidx[whole.long()].contiguous()
         nc = cidx.shape[0]
         if nc == 0:
-            return empty
+            return _empty_named(empty, dev) if owned else empty
+        corner = ckeys[whole.long()].contiguous() if owned else None
         config = torch.empty(nc, dtype=torch.int32, device=dev)
         ntri = torch.empty(nc + 1, dtype=torch.int32, device=dev)
         ntri[nc] = 0
@@ -314,7 +339,7 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
             call('nksr_cell_active_flags', ptr(config), nc, ptr(act), stream())
             asel = ops.compact(act)
             if asel.numel() == 0:
-                return empty
+                return _empty_named(empty, dev) if owned else empty
             split = torch.zeros(tab.n, dtype=torch.bool, device=dev)
             split[cidx[asel.long()].reshape(-1).long()] = True
             split &= tab.lam > 0
@@ -334,17 +359,23 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
                     f_by.setdefault(l - 1, []).append(torch.full((ch.numel(),), float('nan'), dtype=torch.float32, device=dev))
             keys_by = {l: torch.cat(v) for l, v in keys_by.items()}
             f_by = {l: torch.cat(v) for l, v in f_by.items()}
+    if owned:           # the hexahedron of corner k (its key is that of k - 1) emits on the rank whose core holds k
+        kc = torch.empty((nc, 3), dtype=torch.int32, device=dev)
+        call('nksr_decode_keys', ptr(corner), nc, -1, ptr(kc), stream())
+        keep_c = field.owns_points((kc + 1).to(torch.float32) * float(u)).to(torch.int32)
+        ntri[:nc] *= keep_c
+        config = (config * keep_c).contiguous()     # configuration 0 emits nothing
     tri_off = ops.exclusive_sum_i32(ntri)
     T = int(tri_off[nc].item())
     if T == 0:
-        return empty
+        return _empty_named(empty, dev) if owned else empty
     names = torch.empty(T * 3, dtype=torch.int64, device=dev)
     call('nksr_mc_emit_pairs', ptr(cidx), ptr(config), ptr(tri_off), nc, ptr(names), stream())
     names = names.view(T, 3)
     good = (names[:, 0] != names[:, 1]) & (names[:, 1] != names[:, 2]) & (names[:, 0] != names[:, 2])     # collapsed edges of degenerate cells
     names = names[good].contiguous().reshape(-1)
     if names.numel() == 0:
-        return empty
+        return _empty_named(empty, dev) if owned else empty
     uek = ops.sort_unique(names)
     faces = ops.HashTable(uek).query(names).view(-1, 3)
     ne = uek.numel()
@@ -353,7 +384,14 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
     verts, faces, (uek,) = _trim(field, verts, faces, (uek,), masked=True)
     res = _result(field, verts, faces)
     res.vertex_name, res.cell_key, res.cell_lam, res.cell_f, res.fine_unit = uek, tab.key, tab.lam, f, u
+    if owned:
+        res.vertex_names5 = _names5(uek, tab)
     return res
+
+
+def _empty_named(empty, dev):
+    empty.vertex_names5 = torch.zeros((0, 5), dtype=torch.int64, device=dev)
+    return empty
 
 
 class _LevelsOnly:

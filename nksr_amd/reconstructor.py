@@ -32,7 +32,7 @@ class Reconstructor:
         # point at tree_depth 5; 70 % of what is free + what torch's allocator holds unused -- NKSR_FREE_HBM_GB overrides the free figure --,
         # at most 2^25 points).  Results do not depend on it.
         self.chunk_batch_points = None
-        self.dual_graph = 'lattice'      # 'adaptive': extract_dual_mesh on the adaptive dual graph (cells as large as their level; nksr_amd/meshing.py); a chunked field spread over several ranks uses the lattice
+        self.dual_graph = 'lattice'      # 'adaptive': extract_dual_mesh on the adaptive dual graph (cells as large as their level; nksr_amd/meshing.py); set it BEFORE reconstruct() when the field is spread over ranks: the halos are deeper for it, chunking.halo_inner
         self.chunk_spill_dir = None      # chunk mode, batches parked on a CPU chunk_tmp_device: a directory -> the parked batches live in unlinked files there
         #                                  (chunking.spill_to_disk: out-of-core beyond host memory; not part of the reference surface)
         self.coarse_precond = None  # matrix-free solve: None = automatic (coarse-level block preconditioner for 5+ levels), False = Jacobi only,

@@ -74,6 +74,15 @@ def _worker(rank, world, port, q):
             assert (cnt == 2).sum() == 3          # two diagonals + the stitched seam edge
         else:
             assert mv.shape[0] == 4 and mf.shape[0] == 2   # non-destination ranks keep their piece
+        # --- the same two quads with five-word vertex names (the adaptive dual graph's pieces: dist.gather_named / merge_named)
+        names = torch.stack([torch.ones(4, dtype=torch.int64), key, torch.zeros(4, dtype=torch.int64), torch.zeros(4, dtype=torch.int64), key + 100], 1)
+        nv, nf, nn = D.gather_named(v, f, names)
+        if rank == 0:
+            assert nv.shape[0] == 6 and nf.shape[0] == 4 and nn[:, 1].tolist() == [10, 11, 12, 13, 21, 22]      # name order
+            assert torch.equal(nv[nf], torch.cat([torch.tensor([[0., 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])[f],
+                                                  torch.tensor([[1., 0, 0], [2, 0, 0], [2, 1, 0], [1, 1, 0]])[f]]))
+        else:
+            assert nv.shape[0] == 4 and nf.shape[0] == 2
         # --- an idle rank (more ranks than chunks) owns nothing but still receives everything
         one = {0: (torch.arange(5, dtype=torch.int64), torch.ones(3))} if rank == 1 else {}
         got1 = D.exchange_payloads(one, [0])

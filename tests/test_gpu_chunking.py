@@ -132,6 +132,68 @@ def test_simulated_two_ranks_equal_one_rank(scene):
     assert np.array_equal(fm, f1)                                                  # index-exact topology
 
 
+@pytest.mark.parametrize('adaptive_depth,mise_iter', [(2, 0), (2, 1), (2, 2), (3, 1), (1, 1)])
+def test_simulated_two_ranks_mesh_the_adaptive_dual_graph_of_one_process(adaptive_depth, mise_iter):
+    """``dual_graph='adaptive'`` on a field spread over ranks (adaptive_depth 2: leaves of two sizes): every simulated rank goes
+    through the real halo step (pack_halos with the deeper bands of chunking.halo_inner -> unpack), meshes the hexahedra around
+    the octree corners inside its own cores, and dist.merge_named stitches the pieces by the (size, key) pair names -- the mesh
+    of the single process bit for bit: same names, same positions, same triangles."""
+    from types import SimpleNamespace
+    import nksr_amd
+    from nksr_amd import chunking, configs, dist, meshing, utils
+    dev = torch.device('cuda:0')
+    xyz, nrm = utils.synth_terrain_patch(16000, seed=7, extent=(8.0, 4.0))
+    rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', adaptive_depth=adaptive_depth))
+    rec.dual_graph = 'adaptive'
+    t = lambda a: torch.from_numpy(a).to(dev)
+    args = (rec, t(xyz), t(nrm), None, 4.0 + 1e-3, 0.05, False, 2000, 1e-5, True, None)
+    one = chunking.reconstruct_by_chunk(*args)
+    assert len(one.fields) >= 2 and one.meshing_depth == adaptive_depth and one.dual_graph == 'adaptive'
+    m1 = one.extract_dual_mesh(mise_iter=mise_iter)
+    assert m1.f.shape[0] > 1000 and len(torch.unique(m1.cell_lam)) >= min(2, adaptive_depth + mise_iter)           # cells of several sizes
+    n1 = meshing._names5(m1.vertex_name, SimpleNamespace(lam=m1.cell_lam, key=m1.cell_key))
+    sent = {}
+
+    def record(r):
+        def ex(local, dest_of):
+            sent[r] = dict(local)
+            return dict(local)
+        return ex
+
+    def deliver(r):
+        def ex(local, dest_of):
+            out = dict(local)
+            for c, (ints, flts) in sent[1 - r].items():
+                if r in dest_of.get(c, ()):
+                    out[c] = (ints.clone(), flts.clone())
+            assert len(out) > len(local)              # a neighbour's halo arrives
+            return out
+        return ex
+
+    for r in (0, 1):
+        chunking.reconstruct_by_chunk(*args, sim=(r, 2), sim_exchange=record(r))
+    pieces = []
+    for r in (0, 1):
+        mf = chunking.reconstruct_by_chunk(*args, sim=(r, 2), sim_exchange=deliver(r))
+        assert mf.world_size == 2 and mf.dual_graph == 'adaptive' and mf.halo_inner > 2.5 * rec.hparams.voxel_size
+        p = meshing._extract_adaptive(mf, mise_iter, 1, -1, owned=True)
+        assert 0 < p.f.shape[0] < m1.f.shape[0]
+        pieces.append((p.v, p.f, p.vertex_names5))
+    v, f, names = dist.merge_named(pieces)
+    assert sum(p[0].shape[0] for p in pieces) > v.shape[0]                         # seam vertices came from both sides
+    assert torch.equal(names, n1)                                                   # same vertex set, same order
+    assert torch.equal(v, m1.v)                                                     # bit-identical positions
+    canon = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+    assert np.array_equal(canon(f.cpu().numpy()), canon(m1.f.cpu().numpy()))        # index-exact topology
+    if mise_iter == 0:
+        # halos cut for the lattice mesher are too thin for the adaptive graph: refused, never meshed
+        rec.dual_graph = 'lattice'
+        thin = chunking.reconstruct_by_chunk(*args, sim=(0, 2), sim_exchange=lambda local, dest_of: dict(local))
+        thin.dual_graph = 'adaptive'
+        with pytest.raises(RuntimeError):
+            thin.extract_dual_mesh()
+
+
 def test_batched_halo_pack_equals_the_per_chunk_pack_bit_for_bit():
     """ChunkPart.pack_halos (all chunks of a rank at once: one mask + one compaction per level) against pack_chunk(c, band) chunk by
     chunk -- the payloads of the halo exchange, integers and floats bit for bit; with and without the UDF mask features."""

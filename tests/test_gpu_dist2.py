@@ -29,6 +29,17 @@ def _scene():
     return (xyz - xyz.min(0)).astype(np.float32), nrm
 
 
+def _session(dev, graph):
+    """'adaptive': the adaptive dual graph over two levels (adaptive_depth 2), asked for BEFORE reconstruct -- the halos are deeper."""
+    import nksr_amd
+    from nksr_amd import configs
+    if graph == 'lattice':
+        return nksr_amd.Reconstructor(dev)
+    rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', adaptive_depth=2))
+    rec.dual_graph = 'adaptive'
+    return rec
+
+
 def _canon(v, f, key, ax):
     order = np.lexsort((key, ax))
     inv = np.empty_like(order)
@@ -38,7 +49,7 @@ def _canon(v, f, key, ax):
     return key[order], ax[order], v[order], f
 
 
-def _worker(rank, world, port, out_path, q):
+def _worker(rank, world, port, out_path, q, graph='lattice'):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -50,7 +61,7 @@ def _worker(rank, world, port, out_path, q):
         from nksr_amd import chunking, dist as D
         dev = torch.device('cuda:0')
         xyz, nrm = _scene()
-        rec = nksr_amd.Reconstructor(dev)
+        rec = _session(dev, graph)
         cs = 8.1
         lo, hi = xyz.min(0), xyz.max(0)
         grid = chunking.chunk_grid([float(v) for v in lo], [float(v) for v in hi], cs)
@@ -105,16 +116,16 @@ def _position_canon(v, f):
     return v[np.argsort(vb, kind='stable')], tri[np.argsort(tb, kind='stable')]
 
 
-@pytest.mark.parametrize('world', [2, 4])
-def test_ranks_on_one_gpu_equal_one_rank(world):
+@pytest.mark.parametrize('world,graph', [(2, 'lattice'), (4, 'lattice'), (2, 'adaptive'), (4, 'adaptive')])
+def test_ranks_on_one_gpu_equal_one_rank(world, graph):
     """2 and 4 processes (9 chunks: every rank owns a compact Morton block, ranks exchange halos with several neighbours and
-    rank 0 stitches up to four pieces)."""
-    import nksr_amd
+    rank 0 stitches up to four pieces).  'adaptive': every rank meshes the hexahedra around the octree corners inside its own
+    cores, rank 0 merges by the vertices' (size, key) pair names (dist.merge_named)."""
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    out_path = os.path.join(tempfile.gettempdir(), 'nksr_dist%d_%d.npz' % (world, os.getpid()))
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out_path, q)) for r in range(world)]
+    out_path = os.path.join(tempfile.gettempdir(), 'nksr_dist%d_%s_%d.npz' % (world, graph, os.getpid()))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out_path, q, graph)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in range(world)]
@@ -126,9 +137,10 @@ def test_ranks_on_one_gpu_equal_one_rank(world):
     # single rank, full cloud, same chunking
     dev = torch.device('cuda:0')
     xyz, nrm = _scene()
-    rec = nksr_amd.Reconstructor(dev)
+    rec = _session(dev, graph)
     one = rec.reconstruct(torch.from_numpy(xyz).to(dev), torch.from_numpy(nrm).to(dev), detail_level=None, chunk_size=8.1)
     m1 = one.extract_dual_mesh(mise_iter=1)
+    assert m1.f.shape[0] > 10000 and one.dual_graph == graph
     v1, f1 = _position_canon(m1.v.cpu().numpy(), m1.f.cpu().numpy())
     v2, f2 = _position_canon(got['v'], got['f'])
     assert v1.shape == v2.shape and f1.shape == f2.shape
