@@ -137,9 +137,12 @@ __global__ void k_cell_config(const int32_t* __restrict__ corner_idx, const floa
                               int32_t* __restrict__ config, int32_t* __restrict__ ntri) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncell) return;
-    int cfg = 0;
+    int cfg = 0, j[8], lowest = 0;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) cfg |= (f[corner_idx[i * 8 + c]] > 0.f) ? (1 << c) : 0;
+    for (int c = 0; c < 8; ++c) { j[c] = corner_idx[i * 8 + c]; lowest = j[c] < lowest ? j[c] : lowest; }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cfg |= (f[j[c] < 0 ? 0 : j[c]] > 0.f) ? (1 << c) : 0;
+    if (lowest < 0) cfg = 0;                              // (adaptive dual graph: a corner that lacks one of its eight cells emits nothing)
     config[i] = cfg;
     ntri[i] = MC_NTRI[cfg];
 }

@@ -224,22 +224,35 @@ def _leaf_coordinates(svh, adaptive):
 
 class _CellTable:
     """The primal cells of all sizes as one table, smallest first, each size sorted by key: id = offset + rank (csrc/meshing.hip
-    nksr_cell_table_t).  ``f`` rides along (NaN = not evaluated yet)."""
+    nksr_cell_table_t).  ``pieces[lam]`` = list of (sorted keys, values or None = not evaluated yet); a size that comes as ONE piece
+    is in order already, several pieces (kept cells + the children of split ones) are merged by a radix sort.  ``f`` rides along
+    (NaN = not evaluated yet; ``all_new`` / ``any_new`` say so on the host)."""
 
-    def __init__(self, keys_by_lam, f_by_lam, dev):
+    def __init__(self, pieces, dev):
         from ._lib import CELL_SIZES, CellTableT
-        self.lams = sorted(l for l in keys_by_lam if keys_by_lam[l].numel())
+        self.lams = sorted(l for l in pieces if sum(p[0].numel() for p in pieces[l]))
         if len(self.lams) > CELL_SIZES:
             raise RuntimeError('adaptive dual graph: more than %d cell sizes' % CELL_SIZES)
         self.keys, self.hashes, self.offset = {}, {}, {}
         t = CellTableT()
         n, fs, ks, ls = 0, [], [], []
+        self.all_new = all(p[1] is None for l in self.lams for p in pieces[l] if p[0].numel())
+        self.any_new = any(p[1] is None for l in self.lams for p in pieces[l] if p[0].numel())
+        nan = float('nan')
         for i, l in enumerate(self.lams):
-            k, f = keys_by_lam[l], f_by_lam[l]
-            ko, order = ops.sort_pairs(k.contiguous(), torch.arange(k.numel(), dtype=torch.int32, device=dev))
+            ps = [p for p in pieces[l] if p[0].numel()]
+            if len(ps) == 1:
+                ko = ps[0][0].contiguous()
+                f = ps[0][1] if ps[0][1] is not None else (None if self.all_new else torch.full((ko.numel(),), nan, dtype=torch.float32, device=dev))
+            else:
+                k = torch.cat([p[0] for p in ps])
+                ko, order = ops.sort_pairs(k, torch.arange(k.numel(), dtype=torch.int32, device=dev))
+                f = None
+                if not self.all_new:
+                    f = torch.cat([p[1] if p[1] is not None else torch.full((p[0].numel(),), nan, dtype=torch.float32, device=dev) for p in ps])[order.long()]
             self.keys[l], self.hashes[l], self.offset[l] = ko, ops.HashTable(ko), n
             t.lam[i], t.offset[i], t.hcap[i], t.hkeys[i], t.hvals[i] = l, n, self.hashes[l].cap, ptr(self.hashes[l].hkeys), ptr(self.hashes[l].hvals)
-            fs.append(f[order.long()])
+            fs.append(f)
             ks.append(ko)
             ls.append(torch.full((ko.numel(),), l, dtype=torch.int32, device=dev))
             n += ko.numel()
@@ -247,9 +260,10 @@ class _CellTable:
         self.struct, self.n = t, n
         if n >= (1 << 30):
             raise RuntimeError('adaptive dual graph: %d cells (vertex names hold 30-bit cell ids)' % n)
-        self.key = torch.cat(ks) if ks else torch.zeros(0, dtype=torch.int64, device=dev)
-        self.lam = torch.cat(ls) if ls else torch.zeros(0, dtype=torch.int32, device=dev)
-        self.f = torch.cat(fs) if fs else torch.zeros(0, dtype=torch.float32, device=dev)
+        one = len(ks) == 1
+        self.key = (ks[0] if one else torch.cat(ks)) if ks else torch.zeros(0, dtype=torch.int64, device=dev)
+        self.lam = (ls[0] if one else torch.cat(ls)) if ls else torch.zeros(0, dtype=torch.int32, device=dev)
+        self.f = None if self.all_new else ((fs[0] if one else torch.cat(fs)) if fs else torch.zeros(0, dtype=torch.float32, device=dev))
 
 
 def _names5(uek, tab):
@@ -262,7 +276,8 @@ def _names5(uek, tab):
 def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=None, owned=False):
     """``level_ijk`` (tests): the voxel coordinates per level instead of the field's hierarchy.  ``owned`` (a field spread over
     ranks): only the cells within the halo depth of this rank's cores enter (the field is exact there and nowhere else), every
-    dual cell is configured and takes part in the MISE splits, and the hexahedra around the corners inside this rank's cores emit."""
+    dual cell is configured and takes part in the MISE splits, and the hexahedra around the corners inside this rank's cores emit.
+    Host syncs: one per size that must reach the host (unique corners, active cells, split / kept cells per size, triangles, vertices)."""
     svh = field.svh
     dev = svh.device
     w0 = svh.voxel_size
@@ -270,6 +285,8 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
     if U < 1 or U > 8 or M < 0:
         raise RuntimeError('grid_upsample must be in [1, 8] and mise_iter >= 0')
     empty = MeshingResult(torch.zeros((0, 3), dtype=torch.float32, device=dev), torch.zeros((0, 3), dtype=torch.int64, device=dev))
+    if owned:
+        empty.vertex_names5 = torch.zeros((0, 5), dtype=torch.int64, device=dev)
     batch = max_points if (max_points is not None and max_points > 0) else (1 << 22)
     if level_ijk is None:
         adaptive = max(1, min(int(getattr(field, 'meshing_depth', 1)), svh.depth))
@@ -277,59 +294,52 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
     else:
         leaf = _leaf_coordinates(_LevelsOnly(level_ijk, w0, dev), len(level_ijk))
     if not any(c.numel() for c in leaf):
-        return _empty_named(empty, dev) if owned else empty
+        return empty
     reach = max(((int(c.abs().max()) + 2) << d) for d, c in enumerate(leaf) if c.numel()) * U * (1 << M) + 2
     if reach >= (1 << 20):
         raise RuntimeError('mesh lattice out of range: |ijk| * grid_upsample * 2^mise_iter = %d >= 2^20; recentre the cloud '
                            '(or lower mise_iter / grid_upsample)' % reach)
     u = w0 / U / (1 << M)
     sub = torch.tensor([[a, b, c] for a in range(U) for b in range(U) for c in range(U)], dtype=torch.int32, device=dev)
-    keys_by, f_by = {}, {}
+    pieces = {}
     for d, c in enumerate(leaf):
         if not c.numel():
             continue
-        cc = (c[:, None, :] * U + sub[None]).reshape(-1, 3).contiguous()
+        cc = c.contiguous() if U == 1 else (c[:, None, :] * U + sub[None]).reshape(-1, 3).contiguous()
         k = torch.empty(cc.shape[0], dtype=torch.int64, device=dev)
         call('nksr_encode_keys', ptr(cc), cc.shape[0], -1, ptr(k), stream())
-        k = ops.sort_unique(k)
+        k = ops.sort_unique(k, maybe_sorted=(U == 1 and d == 0))       # (the finest voxels come in key order)
         if owned and k.numel():
             cp = torch.empty((k.numel(), 3), dtype=torch.float32, device=dev)
             call('nksr_adaptive_positions', ptr(k), ptr(torch.full((k.numel(),), d + M, dtype=torch.int32, device=dev)), k.numel(), float(u), ptr(cp), stream())
             k = k[field.near_owned(cp, float(field.halo_inner) - 0.5 * w0)].contiguous()
-            if not k.numel():
-                continue
-        keys_by[d + M] = k
-        f_by[d + M] = torch.full((k.numel(),), float('nan'), dtype=torch.float32, device=dev)
-    if not keys_by:
-        return _empty_named(empty, dev) if owned else empty
+        if k.numel():
+            pieces[d + M] = [(k, None)]
+    if not pieces:
+        return empty
     for m in range(M + 1):
-        tab = _CellTable(keys_by, f_by, dev)
+        tab = _CellTable(pieces, dev)
         pos = torch.empty((tab.n, 3), dtype=torch.float32, device=dev)
         call('nksr_adaptive_positions', ptr(tab.key), ptr(tab.lam), tab.n, float(u), ptr(pos), stream())
-        new = torch.isnan(tab.f)
-        f = tab.f
-        if bool(new.all()):
+        if tab.all_new:
             f = field._evaluate_f_model(pos, False, max_points=batch).value.contiguous()
-        elif bool(new.any()):
-            sel = torch.nonzero(new).flatten()
-            f = f.clone()
-            f[sel] = field._evaluate_f_model(pos[sel].contiguous(), False, max_points=batch).value
-        # dual cells: the corners of all cells, sorted by the key of k - 1; the eight cells around each
+        else:
+            f = tab.f
+            if tab.any_new:
+                sel = torch.nonzero(torch.isnan(f)).flatten()
+                f[sel] = field._evaluate_f_model(pos[sel].contiguous(), False, max_points=batch).value
+        # dual cells: the corners of all cells, sorted by the key of k - 1; the eight cells around each (a corner that lacks one
+        # keeps its -1: configuration 0, nothing emitted, csrc/meshing.hip k_cell_config)
         ck = []
         for l in tab.lams:
             o = torch.empty(tab.keys[l].numel() * 8, dtype=torch.int64, device=dev)
             call('nksr_adaptive_corner_keys', ptr(tab.keys[l]), tab.keys[l].numel(), l, ptr(o), stream())
             ck.append(o)
-        ckeys = ops.sort_unique(torch.cat(ck))
-        nk = ckeys.numel()
-        cidx = torch.empty((nk, 8), dtype=torch.int32, device=dev)
-        call('nksr_adaptive_dual_cells', ptr(ckeys), nk, tab.struct, ptr(cidx), stream())
-        whole = ops.compact((cidx >= 0).all(1).to(torch.int32).contiguous())
-        cidx = cidx[whole.long()].contiguous()
-        nc = cidx.shape[0]
-        if nc == 0:
-            return _empty_named(empty, dev) if owned else empty
-        corner = ckeys[whole.long()].contiguous() if owned else None
+        ck = ck[0] if len(ck) == 1 else torch.cat(ck)
+        ckeys = ops.sort_unique(ops.dedup_keys(ck) if ck.numel() >= (1 << 19) else ck)      # (a corner is named by up to eight cells)
+        nc = ckeys.numel()
+        cidx = torch.empty((nc, 8), dtype=torch.int32, device=dev)
+        call('nksr_adaptive_dual_cells', ptr(ckeys), nc, tab.struct, ptr(cidx), stream())
         config = torch.empty(nc, dtype=torch.int32, device=dev)
         ntri = torch.empty(nc + 1, dtype=torch.int32, device=dev)
         ntri[nc] = 0
@@ -339,44 +349,43 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
             call('nksr_cell_active_flags', ptr(config), nc, ptr(act), stream())
             asel = ops.compact(act)
             if asel.numel() == 0:
-                return _empty_named(empty, dev) if owned else empty
-            split = torch.zeros(tab.n, dtype=torch.bool, device=dev)
-            split[cidx[asel.long()].reshape(-1).long()] = True
-            split &= tab.lam > 0
-            keys_by, f_by = {}, {}
+                return empty
+            split = torch.zeros(tab.n, dtype=torch.int32, device=dev)
+            split[cidx[asel.long()].reshape(-1).long()] = 1
+            pieces = {}
             for l in tab.lams:
                 lo, n_l = tab.offset[l], tab.keys[l].numel()
-                sp = split[lo:lo + n_l]
-                keep = ~sp
-                if bool(keep.any()):
-                    keys_by.setdefault(l, []).append(tab.keys[l][keep])
-                    f_by.setdefault(l, []).append(f[lo:lo + n_l][keep])
-                ssel = ops.compact(sp.to(torch.int32).contiguous())
+                fl = f[lo:lo + n_l]
+                if l == 0:                                                   # (the finest unit is not split)
+                    pieces.setdefault(l, []).append((tab.keys[l], fl))
+                    continue
+                sp = split[lo:lo + n_l].contiguous()
+                ssel = ops.compact(sp)
+                if ssel.numel() < n_l:
+                    ksel = (ops.compact(1 - sp) if ssel.numel() else torch.arange(n_l, dtype=torch.int32, device=dev)).long()
+                    pieces.setdefault(l, []).append((tab.keys[l][ksel], fl[ksel]))
                 if ssel.numel():
                     ch = torch.empty(ssel.numel() * 8, dtype=torch.int64, device=dev)
                     call('nksr_cell_children', ptr(tab.keys[l]), ptr(ssel), ssel.numel(), ptr(ch), stream())
-                    keys_by.setdefault(l - 1, []).append(ch)
-                    f_by.setdefault(l - 1, []).append(torch.full((ch.numel(),), float('nan'), dtype=torch.float32, device=dev))
-            keys_by = {l: torch.cat(v) for l, v in keys_by.items()}
-            f_by = {l: torch.cat(v) for l, v in f_by.items()}
+                    pieces.setdefault(l - 1, []).append((ops.sort_keys(ch), None))        # (nksr_cell_children writes corner order, not key order)
     if owned:           # the hexahedron of corner k (its key is that of k - 1) emits on the rank whose core holds k
         kc = torch.empty((nc, 3), dtype=torch.int32, device=dev)
-        call('nksr_decode_keys', ptr(corner), nc, -1, ptr(kc), stream())
+        call('nksr_decode_keys', ptr(ckeys), nc, -1, ptr(kc), stream())
         keep_c = field.owns_points((kc + 1).to(torch.float32) * float(u)).to(torch.int32)
         ntri[:nc] *= keep_c
         config = (config * keep_c).contiguous()     # configuration 0 emits nothing
     tri_off = ops.exclusive_sum_i32(ntri)
     T = int(tri_off[nc].item())
     if T == 0:
-        return _empty_named(empty, dev) if owned else empty
+        return empty
     names = torch.empty(T * 3, dtype=torch.int64, device=dev)
     call('nksr_mc_emit_pairs', ptr(cidx), ptr(config), ptr(tri_off), nc, ptr(names), stream())
     names = names.view(T, 3)
     good = (names[:, 0] != names[:, 1]) & (names[:, 1] != names[:, 2]) & (names[:, 0] != names[:, 2])     # collapsed edges of degenerate cells
     names = names[good].contiguous().reshape(-1)
     if names.numel() == 0:
-        return _empty_named(empty, dev) if owned else empty
-    uek = ops.sort_unique(names)
+        return empty
+    uek = ops.sort_unique(ops.dedup_keys(names) if names.numel() >= (1 << 19) else names)       # every vertex is named by ~6 triangle corners
     faces = ops.HashTable(uek).query(names).view(-1, 3)
     ne = uek.numel()
     verts = torch.empty((ne, 3), dtype=torch.float32, device=dev)
@@ -387,11 +396,6 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
     if owned:
         res.vertex_names5 = _names5(uek, tab)
     return res
-
-
-def _empty_named(empty, dev):
-    empty.vertex_names5 = torch.zeros((0, 5), dtype=torch.int64, device=dev)
-    return empty
 
 
 class _LevelsOnly:
