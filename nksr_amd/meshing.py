@@ -330,12 +330,9 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
                 f[sel] = field._evaluate_f_model(pos[sel].contiguous(), False, max_points=batch).value
         # dual cells: the corners of all cells, sorted by the key of k - 1; the eight cells around each (a corner that lacks one
         # keeps its -1: configuration 0, nothing emitted, csrc/meshing.hip k_cell_config)
-        ck = []
+        ck = torch.empty(tab.n * 8, dtype=torch.int64, device=dev)
         for l in tab.lams:
-            o = torch.empty(tab.keys[l].numel() * 8, dtype=torch.int64, device=dev)
-            call('nksr_adaptive_corner_keys', ptr(tab.keys[l]), tab.keys[l].numel(), l, ptr(o), stream())
-            ck.append(o)
-        ck = ck[0] if len(ck) == 1 else torch.cat(ck)
+            call('nksr_adaptive_corner_keys', ptr(tab.keys[l]), tab.keys[l].numel(), l, ptr(ck[tab.offset[l] * 8:]), stream())
         ckeys = ops.sort_unique(ops.dedup_keys(ck) if ck.numel() >= (1 << 19) else ck)      # (a corner is named by up to eight cells)
         nc = ckeys.numel()
         cidx = torch.empty((nc, 8), dtype=torch.int32, device=dev)
