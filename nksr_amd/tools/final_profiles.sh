@@ -23,6 +23,7 @@ timeout 300 python -m nksr_amd.tools.cheb_rows_probe > gpurun_out/${tag}_cheb_ro
 timeout 300 python -m nksr_amd.tools.small_pc_sweep > gpurun_out/${tag}_small_pc_sweep.txt 2>&1
 # everything ONE rank of 8 does after its solve, on one GPU (collectives replaced by a dictionary)
 timeout 600 python -m nksr_amd.tools.prof_rank_tail 8 3 > gpurun_out/${tag}_rank_tail_8.txt 2>&1
+NKSR_TAIL_GRAPH=adaptive timeout 600 python -m nksr_amd.tools.prof_rank_tail 8 3 > gpurun_out/${tag}_rank_tail_8_adaptive.txt 2>&1
 # the N = 2 launch path on this one GPU (gloo: two ranks share the device; a protocol run, not a scaling measurement)
 NKSR_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 1 --warmup 1 2> /dev/null | grep '^{' > gpurun_out/${tag}_bench_two_processes_one_gpu.json
 NKSR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 1 --warmup 1 2> /dev/null | grep '^{' > gpurun_out/${tag}_bench_eight_processes_one_gpu.json

@@ -18,6 +18,9 @@ def main():
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000
     dev = torch.device('cuda:0')
     rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', tree_depth=5))
+    import os
+    graph = os.environ.get('NKSR_TAIL_GRAPH', 'lattice')      # 'adaptive': deeper halos, cell-pair vertex names, dist.merge_named
+    rec.dual_graph = graph
     sent = {}            # chunk -> (payload, destination ranks): what every simulated rank packs
 
     inputs = {}
@@ -67,7 +70,6 @@ def main():
         tm = {k: round(v * 1e3, 1) for k, v in rec.timing.items()}
         print('rep %d: setup + solve + exchange step + union grid %.1f ms %s | mesh of own cells %.1f ms (V=%d T=%d)' % (
             rep, (t1 - t0) * 1e3, tm, (t2 - t1) * 1e3, res.v.shape[0], res.f.shape[0]))
-    import os
     if os.environ.get('NKSR_CPROFILE'):
         import cProfile
         import pstats
@@ -81,15 +83,22 @@ def main():
         pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
     recv = [c for c, (p, rs) in sent.items() if rank in rs]
     print('halos received: %d chunks, %.2f MB' % (len(recv), sum(sent[c][0][0].numel() * 8 + sent[c][0][1].numel() * 4 for c in recv) / 1e6))
-    pieces = [(res.v, res.f, res.edge_vkey + r * 7919, res.edge_axis) for r in range(world)]
+    if graph == 'adaptive':
+        def shifted(r):
+            nm = res.vertex_names5.clone()
+            nm[:, 1] += r * 7919
+            return nm
+        pieces = [(res.v, res.f, shifted(r)) for r in range(world)]
+    else:
+        pieces = [(res.v, res.f, res.edge_vkey + r * 7919, res.edge_axis) for r in range(world)]
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        v, ff = dist.merge_meshes(pieces)
+        v, ff = (dist.merge_named(pieces)[:2] if graph == 'adaptive' else dist.merge_meshes(pieces))
         torch.cuda.synchronize()
-        print('rank-0 merge of %d pieces: %.1f ms (V=%d T=%d, %.0f MB gathered)' % (
-            world, (time.perf_counter() - t0) * 1e3, v.shape[0], ff.shape[0],
-            (world - 1) * (res.v.numel() * 4 + res.f.numel() * 8 + res.edge_vkey.numel() * 9) / 1e6))
+        print('rank-0 merge of %d pieces (%s): %.1f ms (V=%d T=%d, %.0f MB gathered)' % (
+            world, graph, (time.perf_counter() - t0) * 1e3, v.shape[0], ff.shape[0],
+            (world - 1) * (res.v.numel() * 4 + res.f.numel() * 8 + res.v.shape[0] * (40 if graph == 'adaptive' else 9)) / 1e6))
 
 
 if __name__ == '__main__':
