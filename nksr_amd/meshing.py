@@ -41,7 +41,7 @@ def extract_dual_mesh(field, mise_iter=0, grid_upsample=1, max_points=-1):
             return _extract_adaptive(field, mise_iter, grid_upsample, max_points)
         from . import chunking
         need = chunking.halo_inner(field.svh.voxel_size, getattr(field, 'meshing_depth', 1), 'adaptive')
-        if getattr(field, 'halo_inner', None) is None or field.halo_inner < need - 1e-6 * need:
+        if getattr(field, 'world_size', 1) > 1 and (getattr(field, 'halo_inner', None) is None or field.halo_inner < need - 1e-6 * need):
             # (never a mesh from halos that are too thin for it: the field was reconstructed for the lattice mesher)
             raise RuntimeError("dual_graph='adaptive' on a chunked field spread over several ranks needs halos %.3g deep (set "
                                "Reconstructor.dual_graph = 'adaptive' BEFORE reconstruct(); this field's are %s)"
@@ -312,7 +312,7 @@ def _extract_adaptive(field, mise_iter, grid_upsample, max_points, level_ijk=Non
         if owned and k.numel():
             cp = torch.empty((k.numel(), 3), dtype=torch.float32, device=dev)
             call('nksr_adaptive_positions', ptr(k), ptr(torch.full((k.numel(),), d + M, dtype=torch.int32, device=dev)), k.numel(), float(u), ptr(cp), stream())
-            k = k[field.near_owned(cp, float(field.halo_inner) - 0.5 * w0)].contiguous()
+            k = k[field.near_owned(cp, float(field.halo_inner or 0.0) - 0.5 * w0)].contiguous()      # (one rank: everything)
         if k.numel():
             pieces[d + M] = [(k, None)]
     if not pieces:

@@ -81,6 +81,8 @@ def main():
         torch.cuda.synchronize()
         pr.disable()
         pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
+    if os.environ.get('NKSR_TAIL_STEPS_ONLY'):      # (for a kernel trace whose last milliseconds are one rank's step)
+        return
     recv = [c for c, (p, rs) in sent.items() if rank in rs]
     print('halos received: %d chunks, %.2f MB' % (len(recv), sum(sent[c][0][0].numel() * 8 + sent[c][0][1].numel() * 4 for c in recv) / 1e6))
     if graph == 'adaptive':

@@ -90,6 +90,10 @@ def _worker(port, q):
                                chunk_bounds=([float(v) for v in lo], [float(v) for v in hi]), chunk_owner=[0] * len(plain.cores))
         m2 = fld2.extract_dual_mesh(mise_iter=1)
         assert _same(m0, m2)
+        # the adaptive dual graph's pieces through the same transport (dist.gather_named: five-word vertex names)
+        plain.dual_graph = fld2.dual_graph = 'adaptive'
+        a0, a2 = plain.extract_dual_mesh(mise_iter=1), fld2.extract_dual_mesh(mise_iter=1)
+        assert a0.f.shape[0] > 1000 and _same(a0, a2) and a2.vertex_names5.shape == (a2.v.shape[0], 5)
         q.put('ok')
     except Exception as e:  # surface the failure in the parent
         import traceback
