@@ -465,6 +465,12 @@ int nksr_chunk_pair_fill(const nksr_chunk_grid_t* grid, int mode, const float* x
  * gradient when pair_grad / grad_out are given). */
 int nksr_chunk_blend(int64_t n, const int32_t* offsets, const float* pair_w, const float* pair_f, const float* pair_grad,
                      float* f_out, float* grad_out, void* stream);
+/* Halo selection of a batch of chunks, one level (the payload of the rank exchange; chunking.pack_halos):
+ * voxel i (keys ascending) belongs to chunk seg = the last of the ascending key ranges klo [nchunk] that starts at or before its key;
+ * flag = 1 when its centre (ijk + 0.5) w - shift[seg] lies in one of the chunk's band intervals [tlo, thi] ([nchunk, 3, 2] each, an
+ * unused interval = (+inf, -inf)) along some axis. */
+int nksr_halo_band_flags(const int64_t* keys, const int32_t* ijk, int64_t n, const int64_t* klo, int32_t nchunk, const float* shift,
+                         const float* tlo, const float* thi, float w, int32_t* seg_out, int32_t* flags_out, void* stream);
 
 /* ---- grid-hash nearest neighbours (csrc/knn.hip) ----------------------------------------------------
  * Points Morton-sorted by a uniform grid of size `cell` (keys from nksr_point_keys with inv_w0 =

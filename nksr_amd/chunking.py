@@ -393,18 +393,16 @@ class ChunkPart:
                 cnt.append(torch.zeros(nc, dtype=torch.long, device=dev))
                 continue
             w = g.voxel_size
-            seg = torch.bucketize(g.keys, klo >> (3 * d), right=True) - 1
-            # (thresholds in double, compared in fp32, as pack_field does with Python scalars)
+            # (thresholds in double, compared in fp32, as pack_field does with Python scalars; csrc/chunks.hip k_halo_band_flags)
             tlo = torch.from_numpy((blo - 2.5 * w).astype(np.float32)).to(dev)
             thi = torch.from_numpy((bhi + 2.5 * w).astype(np.float32)).to(dev)
-            m = torch.zeros(g.num_voxels, dtype=torch.bool, device=dev)
-            for a in range(3):
-                ca = (g.ijk[:, a].to(torch.float32) + 0.5) * w - shift[seg, a]
-                for k in range(2):
-                    m |= (ca >= tlo[seg, a, k]) & (ca <= thi[seg, a, k])
-            idx = torch.nonzero(m).reshape(-1)
+            seg = torch.empty(g.num_voxels, dtype=torch.int32, device=dev)
+            flags = torch.empty(g.num_voxels, dtype=torch.int32, device=dev)
+            call('nksr_halo_band_flags', ptr(g.keys), ptr(g.ijk), g.num_voxels, ptr((klo >> (3 * d)).contiguous()), nc, ptr(shift), ptr(tlo), ptr(thi),
+                 float(w), ptr(seg), ptr(flags), stream())
+            idx = ops.compact(flags).long()
             sel.append(idx)
-            cnt.append(torch.bincount(seg[idx], minlength=nc))
+            cnt.append(torch.bincount(seg[idx].long(), minlength=nc))
         counts = torch.stack(cnt, 1).tolist()                                   # [nc][depth]   (one host read)
         keys = [svh.level(d).keys[sel[d]] for d in range(depth)]
         feats = [f._feat[d][sel[d]] for d in range(depth)]

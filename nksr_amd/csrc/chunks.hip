@@ -140,3 +140,42 @@ extern "C" int nksr_chunk_blend(int64_t n, const int32_t* offsets, const float* 
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
+
+// ---- halo selection of a batch of chunks (chunking.ChunkPart.pack_halos) ----------------------------------------------------------------
+// One thread per voxel of a level: its chunk = the last key range that starts at or before its key, its centre in the chunk's own frame,
+// inside one of the chunk's band intervals (two per axis, thresholds already widened by the level's support) or not.  The same
+// comparisons in the same fp32 arithmetic as chunking.pack_field's per-chunk masks (contraction is off in this file); before, ~65
+// torch launches per level.
+__global__ void __launch_bounds__(256) k_halo_band_flags(const int64_t* __restrict__ keys, const int32_t* __restrict__ ijk, int64_t n,
+                                                         const int64_t* __restrict__ klo, int nchunk, const float* __restrict__ shift,
+                                                         const float* __restrict__ tlo, const float* __restrict__ thi, float w,
+                                                         int32_t* __restrict__ seg_out, int32_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t k = keys[i];
+    int lo = 0, hi = nchunk;                                  // upper bound: the ranges that start at or before k
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (klo[mid] <= k) lo = mid + 1; else hi = mid;
+    }
+    const int seg = lo > 0 ? lo - 1 : 0;
+    bool in = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ca = ((float)ijk[i * 3 + a] + 0.5f) * w - shift[seg * 3 + a];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) in = in || (ca >= tlo[(seg * 3 + a) * 2 + q] && ca <= thi[(seg * 3 + a) * 2 + q]);
+    }
+    seg_out[i] = seg;
+    flags[i] = in ? 1 : 0;
+}
+
+extern "C" int nksr_halo_band_flags(const int64_t* keys, const int32_t* ijk, int64_t n, const int64_t* klo, int32_t nchunk, const float* shift,
+                                    const float* tlo, const float* thi, float w, int32_t* seg_out, int32_t* flags_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (nchunk < 1 || !keys || !ijk || !klo || !shift || !tlo || !thi || !seg_out || !flags_out) return nksr_set_error(NKSR_ERR_ARG, "halo_band_flags: NULL arrays / no chunks");
+    hipLaunchKernelGGL(k_halo_band_flags, dim3(nksr_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, keys, ijk, n, klo, (int)nchunk, shift, tlo, thi, w,
+                       seg_out, flags_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}
