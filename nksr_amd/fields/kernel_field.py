@@ -30,6 +30,7 @@ def pack_interpolator(interp):
 PC_RATIO = 40.0          # Chebyshev interval [lambda_max / PC_RATIO, lambda_max] of the coarse block (100 until late round 3: 11.16 -> 10.9
 #                          PCG iterations per chunk of the 64-chunk scene at the same step count; 10..20 are worse again, 200 much worse)
 SMALL_FIELD_UNKNOWNS = 1 << 16      # single fields up to this size take the coarse-level block at once, from level 1 (solve_fused)
+SMALL_FIELD_CHECK_EVERY = 6
 SMALL_FIELD_PC = {'first_level': 1, 'steps': 8, 'ratio': 40.0}
 PC_DROP_TOL = 0.005        # packed coarse block: off-diagonal entries below this fraction of the (unit) diagonal are left out
 _DETAIL = os.environ.get('NKSR_TIMING_DETAIL', '') == '1'
@@ -804,6 +805,10 @@ class KernelField(BaseField):
         # 18 iterations, the 10 000-point bunny scan 93 -> 53, the smoke sphere 94 -> 57: tools/small_pc_sweep.py).
         auto = cfg.get('coarse_precond') is None and segments is None
         small = auto and self._small_field()
+        if small:
+            # an iteration of such a field is 16 launches of a few microseconds: the 14 no-op iterations behind convergence at 18 of
+            # a 16-iteration round cost as much as 5 real ones -- the host looks every 6 (same iterates: convergence is per iteration on the device)
+            check_every = min(check_every, SMALL_FIELD_CHECK_EVERY)
         pc = self._coarse_precond(op, reg_weight, segments, override=SMALL_FIELD_PC if small else None) if (not auto or small or self.svh.depth >= 5) else None
         op['dense'] = None                      # (dense coarse rows nobody took over)
         td = _tick('coarse_precond', td)
