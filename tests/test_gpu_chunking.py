@@ -132,7 +132,7 @@ def test_simulated_two_ranks_equal_one_rank(scene):
     assert np.array_equal(fm, f1)                                                  # index-exact topology
 
 
-@pytest.mark.parametrize('adaptive_depth,mise_iter', [(2, 0), (2, 1), (2, 2), (3, 1), (1, 1)])
+@pytest.mark.parametrize('adaptive_depth,mise_iter', [(2, 0), (2, 1), (2, 2), (3, 1), (1, 1), ('carla', 1)])
 def test_simulated_two_ranks_mesh_the_adaptive_dual_graph_of_one_process(adaptive_depth, mise_iter):
     """``dual_graph='adaptive'`` on a field spread over ranks (adaptive_depth 2: leaves of two sizes): every simulated rank goes
     through the real halo step (pack_halos with the deeper bands of chunking.halo_inner -> unpack), meshes the hexahedra around
@@ -143,7 +143,12 @@ def test_simulated_two_ranks_mesh_the_adaptive_dual_graph_of_one_process(adaptiv
     from nksr_amd import chunking, configs, dist, meshing, utils
     dev = torch.device('cuda:0')
     xyz, nrm = utils.synth_terrain_patch(16000, seed=7, extent=(8.0, 4.0))
-    rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', adaptive_depth=adaptive_depth))
+    if adaptive_depth == 'carla':          # the preset with a UDF mask (NeuralField): the trim of a spread field asks every chunk's mask
+        rec = nksr_amd.Reconstructor(dev, config='carla')
+        adaptive_depth = int(rec.hparams.adaptive_depth)
+        assert adaptive_depth == 2
+    else:
+        rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', adaptive_depth=adaptive_depth))
     rec.dual_graph = 'adaptive'
     t = lambda a: torch.from_numpy(a).to(dev)
     args = (rec, t(xyz), t(nrm), None, 4.0 + 1e-3, 0.05, False, 2000, 1e-5, True, None)
