@@ -226,6 +226,8 @@ typedef struct {
     const int32_t* row_index;  /* [n] first row of every site (level-major layout; NULL = i * ncomp) */
     const int32_t* compact_cells; /* COMPACT rows of the matrix-free operator (nksr_fused_op_t.compact): its row_cells [L][level_stride] and */
     const int32_t* compact_nbr32; /* nbr32 [M][32]; NULL = dense rows.  val is then the compact array, one row per "site" (ncomp 1, no row_index) */
+    int64_t level_base;        /* level-major dense rows only: val STARTS at this level ([L - level_base, level_stride, 27]; the factor form of the
+                                * operator keeps dense rows of its coarse levels only) -- the assembly must then be asked for levels >= level_base */
 } nksr_siteset_t;
 
 /* Structure pass.  Per row: rowcount = structural upper entries (column voxel exists, B-spline supports

@@ -71,7 +71,7 @@ PC_MAX_STEPS = 16
 
 class SiteSetT(C.Structure):
     _fields_ = [('n', _i64), ('ncomp', _i32), ('weight', _f32), ('val', _vp), ('target', _vp),
-                ('start', _vp * MAX_DEPTH), ('end', _vp * MAX_DEPTH), ('level_stride', _i64), ('row_index', _vp), ('compact_cells', _vp), ('compact_nbr32', _vp)]
+                ('start', _vp * MAX_DEPTH), ('end', _vp * MAX_DEPTH), ('level_stride', _i64), ('row_index', _vp), ('compact_cells', _vp), ('compact_nbr32', _vp), ('level_base', _i64)]
 
 
 def _load():

@@ -75,7 +75,7 @@ __device__ __forceinline__ float asm_row_value(const nksr_siteset_t& S, int64_t 
     const int dd = col / 27, s = col - dd * 27;
     const int64_t site = S.ncomp == 1 ? q : q / 3;
     const int64_t row = (S.row_index ? (int64_t)S.row_index[site] : site * S.ncomp) + (q - site * S.ncomp);
-    return S.val[((int64_t)(d + dd) * S.level_stride + row) * 27 + s];
+    return S.val[((int64_t)(d + dd - S.level_base) * S.level_stride + row) * 27 + s];
 }
 
 // writes the accumulated tile(s) of cell c: block rows whose voxel exists, the right-hand-side column, the site count
@@ -182,9 +182,9 @@ __device__ __forceinline__ void asm_lm_pointers(const AsmArgs& A, int d, int r_l
         const int dd = col / 27, sl = col - dd * 27;
         P.on[n] = col < T || (col == T && S.target);
         P.mul[n] = (col == T && S.target) ? 1 : 27;
-        // (columns past T are never used but their loads are unconditional: they read level d -- the array may START at the first
-        // level that has cells, see KernelField.assemble: a base shifted below it must not be dereferenced)
-        P.p[n] = (col == T && S.target) ? S.target : S.val + (col < T ? (int64_t)(d + dd) * S.level_stride * 27 + sl : (int64_t)d * S.level_stride * 27);
+        // (columns past T are never used but their loads are unconditional: they read level d -- the array may START at level
+        // S.level_base, KernelField.assemble, and the launch's levels are >= it)
+        P.p[n] = (col == T && S.target) ? S.target : S.val + (col < T ? (int64_t)(d + dd - S.level_base) * S.level_stride * 27 + sl : (int64_t)(d - S.level_base) * S.level_stride * 27);
         if (S.compact_nbr32 && !(col == T && S.target)) {
             // COMPACT rows (csrc/fused.hip, k_fz_row_sizes): the rows r_lo .. r_hi of this cell lie in ONE cell of every coarser level too;
             // that cell's block holds, per row, the slots of its existing neighbours.  A column whose neighbour does not exist (or past
@@ -799,7 +799,11 @@ extern "C" int nksr_assemble(const nksr_hier_t* h, const nksr_siteset_t* sets, i
     for (int si = 0; si < nsets; ++si) {
         total_rows += sets[si].n * sets[si].ncomp;
         if (si > 0 && (sets[si].level_stride != 0) != lm) return nksr_set_error(NKSR_ERR_ARG, "site sets mix site-major and level-major rows");
+        if (sets[si].level_base < 0 || sets[si].level_base >= h->depth || (sets[si].level_base > 0 && (!sets[si].level_stride || sets[si].compact_nbr32)))
+            return nksr_set_error(NKSR_ERR_ARG, "site set: level_base needs dense level-major rows and a level of the hierarchy");
         lm = sets[si].level_stride != 0;
+        for (int d = 0; d < sets[si].level_base; ++d)
+            if (h->lv[d].n > 0) return nksr_set_error(NKSR_ERR_ARG, "site set: rows start at level %d but level %d of the hierarchy has cells", (int)sets[si].level_base, d);
     }
     for (int d = 0; d < h->depth; ++d) {
         const int n = h->lv[d].n;

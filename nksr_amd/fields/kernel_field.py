@@ -232,9 +232,9 @@ class KernelField(BaseField):
             S.n, S.ncomp, S.weight = fused_op['rows_total'], 1, 1.0
             if fused_op.get('row_format') == 'factors':
                 # the factor form holds no dense rows: those of the levels >= coarse_from were written out by the set-up sweep
-                # (or are expanded now); the array starts at level coarse_from, the assembly indexes levels absolutely
+                # (or are expanded now); the array starts at level coarse_from (nksr_siteset_t.level_base)
                 dense = self._dense_coarse_rows(fused_op, int(coarse_from))
-                S.val = dense.data_ptr() - int(coarse_from) * fused_op['rows_total'] * 27 * 4
+                S.val, S.level_base = ptr(dense), int(coarse_from)
                 keep.append(dense)
             else:
                 S.val = ptr(fused_op['rows_all'])

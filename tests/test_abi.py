@@ -26,7 +26,7 @@ def test_struct_layout_matches_header():
     from nksr_amd import _lib
     assert ctypes.sizeof(_lib.LevelT) == 80
     assert ctypes.sizeof(_lib.HierT) == 16 + 6 * 80
-    assert ctypes.sizeof(_lib.SiteSetT) == 32 + 2 * 6 * 8 + 16 + 16
+    assert ctypes.sizeof(_lib.SiteSetT) == 32 + 2 * 6 * 8 + 16 + 16 + 8
     assert ctypes.sizeof(_lib.FusedOpT) == 16 + 8 + 8 * 8 + 8 + 5 * 8 + 3 * 8 + 8 + 8 + 8 + 8
     assert ctypes.sizeof(_lib.CoarsePrecondT) == 16 + 8 + 14 * 8
     assert ctypes.sizeof(_lib.SegmentsT) == 8 + 3 * 8
