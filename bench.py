@@ -278,6 +278,8 @@ def main():
     ap.add_argument('--no-other-mode', action='store_true', help='skip the assembled-solve leg of the configs[2] sub-record')
     ap.add_argument('--no-small-inputs', action='store_true')
     ap.add_argument('--no-adaptive', action='store_true', help='skip the mesh_adaptive sub-records (the adaptive dual graph timed beside the lattice mesher, outside the timed region)')
+    ap.add_argument('--dual-graph', choices=['lattice', 'adaptive'], default='lattice', help="the mesher of the headline scene: the uniform lattice (default; the "
+                    "metric is quoted on it) or the adaptive dual graph (Reconstructor.dual_graph: deeper halos between ranks, cell-pair vertex names)")
     ap.add_argument('--no-live-pmc', action='store_true', help='do not collect roofline.traffic with rocprofv3 in this run (two counter passes over one extra step)')
     ap.add_argument('--cloud-steps', type=int, default=3)
     ap.add_argument('--dist-probe', action='store_true', help='launch check only: start the N ranks, run the handshake collectives over the '
@@ -378,6 +380,7 @@ def main():
     def run_terrain(steps, warmup, fused):
         rec = nksr_amd.Reconstructor(dev, hparams=configs.get_hparams('ks', tree_depth=5))
         rec.sync_timing = True
+        rec.dual_graph = args.dual_graph
         if args.chunk_batch_points > 0:
             rec.chunk_batch_points = args.chunk_batch_points
         xyz, nrm, scale, owner, bounds, n_scene, ntiles = terrain_setup(rec, dev, args.scene_points, rank, world)
@@ -407,6 +410,7 @@ def main():
                'pcg_iters_min_chunk': int(min([i['iters'] for i in infos])) if infos else 0,
                'jacobi_fallbacks': int(sum(int(getattr(p.field, 'solve_info', {}).get('jacobi_fallbacks', 0) or 0) for p in field.parts if p.solved)),
                'mesh_vertices': int(mesh.v.shape[0]), 'mesh_triangles': int(mesh.f.shape[0]),
+               'dual_graph': args.dual_graph,
                'parallelism': 'none' if world == 1 else 'chunks sharded over %d ranks (Morton-contiguous), sharded input, no collective in the solve, '
                                                         'one halo exchange, mesh gather + stitch on rank 0' % world}
         from nksr_amd.fields import kernel_field as _kf

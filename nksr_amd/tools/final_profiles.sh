@@ -27,4 +27,6 @@ NKSR_TAIL_GRAPH=adaptive timeout 600 python -m nksr_amd.tools.prof_rank_tail 8 3
 # the N = 2 launch path on this one GPU (gloo: two ranks share the device; a protocol run, not a scaling measurement)
 NKSR_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 1 --warmup 1 2> /dev/null | grep '^{' > gpurun_out/${tag}_bench_two_processes_one_gpu.json
 NKSR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 1 --warmup 1 2> /dev/null | grep '^{' > gpurun_out/${tag}_bench_eight_processes_one_gpu.json
+NKSR_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 1 --warmup 1 --dual-graph adaptive 2> /dev/null | grep '^{' > gpurun_out/${tag}_bench_two_processes_one_gpu_adaptive.json
+NKSR_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 8 --steps 1 --warmup 1 --dual-graph adaptive 2> /dev/null | grep '^{' > gpurun_out/${tag}_bench_eight_processes_one_gpu_adaptive.json
 ls -la gpurun_out | grep ${tag}_
