@@ -341,6 +341,22 @@ __global__ void k_gather_rows(const float* __restrict__ src, const int32_t* __re
     out[t] = v;
 }
 
+// the same for rows of 32 floats on 16-byte aligned arrays: eight lanes per row, 16 bytes each (the generic kernel spends a 64-bit
+// division per WORD: 4.6 ms per scene step at 1.9 TB/s)
+__global__ void __launch_bounds__(256) k_gather_rows32(const float4* __restrict__ src, const int32_t* __restrict__ idx, int64_t n,
+                                                       const float4* __restrict__ add, float4* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * 8) return;
+    const int j = idx[t >> 3];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j >= 0) v = src[(int64_t)j * 8 + (t & 7)];
+    if (add) {
+        const float4 a = add[t];
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    }
+    out[t] = v;
+}
+
 // out[i, o] = b[o] + sum_c W[o, c] in[i, c]   (Cin = 32, Cout <= 32)
 __global__ void k_linear(const float* __restrict__ in, int64_t n, const float* __restrict__ W, const float* __restrict__ b,
                          int Cout, float* __restrict__ out) {
@@ -403,6 +419,13 @@ extern "C" int nksr_pool_children(const float* child_feat, const int32_t* start,
 }
 extern "C" int nksr_gather_rows(const float* src, const int32_t* idx, int64_t n, int C, const float* add, float* out,
                                 void* stream) {
+    if (C == NN_C && !(((uintptr_t)src | (uintptr_t)add | (uintptr_t)out) & 15)) {
+        if (n <= 0) return NKSR_OK;
+        hipLaunchKernelGGL(k_gather_rows32, dim3(nksr_blocks(n * 8, 256)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src), idx, n,
+                           reinterpret_cast<const float4*>(add), reinterpret_cast<float4*>(out));
+        NKSR_CHECK_LAUNCH();
+        return NKSR_OK;
+    }
     LAUNCH1D(k_gather_rows, n * C, stream, src, idx, n, C, add, out);
     return NKSR_OK;
 }
