@@ -26,12 +26,15 @@ __global__ void __launch_bounds__(256) k_point_mlp(const float* __restrict__ xyz
                                                    const float* __restrict__ W2, const float* __restrict__ b2,
                                                    float* __restrict__ out) {
     __shared__ float sW1[NN_C * 6], sb1[NN_C], sW2[NN_C * NN_C], sb2[NN_C];
+    __shared__ float img[4][64 * 33];
     for (int i = threadIdx.x; i < NN_C * 6; i += blockDim.x) sW1[i] = W1[i];
     for (int i = threadIdx.x; i < NN_C * NN_C; i += blockDim.x) sW2[i] = W2[i];
     if (threadIdx.x < NN_C) { sb1[threadIdx.x] = b1[threadIdx.x]; sb2[threadIdx.x] = b2[threadIdx.x]; }
     __syncthreads();
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int64_t row0 = i - (threadIdx.x & 63);            // first row of the wavefront (a multiple of 64)
+    if (row0 >= n) return;                                  // (a whole wavefront past the end; a partial one keeps its lanes for the write-out)
+    if (i >= n) i = n - 1;                                  // (clamped: computes a row nobody stores)
     float in[6];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -48,11 +51,26 @@ __global__ void __launch_bounds__(256) k_point_mlp(const float* __restrict__ xyz
         for (int k = 0; k < 6; ++k) a = fmaf(sW1[c * 6 + k], in[k], a);
         h[c] = a > 0.f ? a : 0.f;
     }
+    // the 32 outputs of a lane go through a wave-private LDS image (stride 33 words: conflict-free) and leave as the wavefront's 64
+    // rows in one contiguous 8 KB run, 16 bytes per lane and instruction (a lane storing its own row word by word touched 64 lines per
+    // store instruction: 1.75 ms per scene step for 1.3 GB)
+    float* im = img[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
     for (int c = 0; c < NN_C; ++c) {
         float a = sb2[c];
 #pragma unroll
         for (int k = 0; k < NN_C; ++k) a = fmaf(sW2[c * NN_C + k], h[k], a);
-        out[i * NN_C + c] = a;
+        im[lane * 33 + c] = a;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int64_t left = n - row0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int p = j * 64 + lane, r = p >> 3, q = (p & 7) * 4;
+        if (r < left) {
+            const float4 v = make_float4(im[r * 33 + q], im[r * 33 + q + 1], im[r * 33 + q + 2], im[r * 33 + q + 3]);
+            *reinterpret_cast<float4*>(out + (row0 + r) * NN_C + q) = v;
+        }
     }
 }
 
@@ -386,6 +404,7 @@ __global__ void k_linear(const float* __restrict__ in, int64_t n, const float* _
 extern "C" int nksr_point_mlp(const float* xyz, const float* feat, int64_t n, float inv_w0, int C, const float* W1,
                               const float* b1, const float* W2, const float* b2, float* out, void* stream) {
     if (C != NN_C) return nksr_set_error(NKSR_ERR_ARG, "unet.f_maps must be %d", NN_C);
+    if ((uintptr_t)out & 15) return nksr_set_error(NKSR_ERR_ARG, "point_mlp: out must be 16-byte aligned (rows leave as 16-byte pieces)");
     LAUNCH1D(k_point_mlp, n, stream, xyz, feat, n, inv_w0, W1, b1, W2, b2, out);
     return NKSR_OK;
 }
