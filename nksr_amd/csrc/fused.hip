@@ -695,6 +695,15 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
         const float* p = part + (int64_t)(b0 + h) * 32 + s;
         float acc = 0.f;
         int b = h;
+        // (sixteen blocks requested per trip, added in the order of the four-block trips they replace: a cell of hundreds of blocks was a
+        // chain of as many dependent round trips / 4)
+        for (; b + 120 < n; b += 128, p += 4096) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = p[256 * q];
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) acc += (v[q] + v[q + 1]) + (v[q + 2] + v[q + 3]);
+        }
         for (; b + 24 < n; b += 32, p += 1024) acc += (p[0] + p[256]) + (p[512] + p[768]);
         for (; b < n; b += 8, p += 256) acc += p[0];
         partial[h][s] = acc;
@@ -725,15 +734,29 @@ __global__ void __launch_bounds__(256) k_fz_cellsum(FusedArgs A, const float* __
         acc[k] = n[k] > 0 ? part[(int64_t)b0[k] * 32 + s] : 0.f;
         a1[k] = n[k] > 1 ? part[(int64_t)(b0[k] + 1) * 32 + s] : 0.f;
     }
+    // the four cells' chains side by side (each cell's own order of additions as before: four blocks per trip, then one by one)
+    int nmax = 0;
 #pragma unroll
-    for (int k = 0; k < FZ_GI; ++k) {
-        acc[k] += a1[k];
-        const float* p = part + (int64_t)(b0[k] + 2) * 32 + s;
-        int b = 2;
-        for (; b + 4 <= n[k]; b += 4, p += 128) acc[k] += (p[0] + p[32]) + (p[64] + p[96]);
-        for (; b < n[k]; ++b, p += 32) acc[k] += p[0];
-        if (i0 + k < ncell && s < 27) ct[(int64_t)s * A.M + cell[k]] = acc[k];
+    for (int k = 0; k < FZ_GI; ++k) { acc[k] += a1[k]; nmax = n[k] > nmax ? n[k] : nmax; }
+    for (int b = 2; b < nmax; b += 4) {
+        float v[FZ_GI][4];
+#pragma unroll
+        for (int k = 0; k < FZ_GI; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[k][q] = b + q < n[k] ? part[(int64_t)(b0[k] + b + q) * 32 + s] : 0.f;
+#pragma unroll
+        for (int k = 0; k < FZ_GI; ++k) {
+            if (b + 4 <= n[k]) acc[k] += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (b + q < n[k]) acc[k] += v[k][q];
+            }
+        }
     }
+#pragma unroll
+    for (int k = 0; k < FZ_GI; ++k)
+        if (i0 + k < ncell && s < 27) ct[(int64_t)s * A.M + cell[k]] = acc[k];
 }
 
 // y_j = (MODE 0: reg x_j, 1: 0, 2: reg) + sum over the 27 neighbour cells c = nbrT[s'][j] of j:  ct[26 - s'][c]
