@@ -471,6 +471,11 @@ int nksr_chunk_blend(int64_t n, const int32_t* offsets, const float* pair_w, con
  * voxel i (keys ascending) belongs to chunk seg = the last of the ascending key ranges klo [nchunk] that starts at or before its key;
  * flag = 1 when its centre (ijk + 0.5) w - shift[seg] lies in one of the chunk's band intervals [tlo, thi] ([nchunk, 3, 2] each, an
  * unused interval = (+inf, -inf)) along some axis. */
+/* Seam candidates of a rank's mesh piece (the merge on rank 0, nksr_amd/dist.py): vertex i lies on the lattice edge (vertex vkey[i],
+ * axis[i]); flag = 1 when one of the four lattice cells around that edge belongs to another rank -- owner[chunk of the centre of the
+ * cell's base voxel] != rank, base voxel = floor(cell / cells_per_voxel), centre = (base + 0.5) w0, chunk as nksr_chunk_pair_counts. */
+int nksr_edge_seam_flags(const nksr_chunk_grid_t* grid, const int64_t* vkey, const int8_t* axis, int64_t n, int32_t cells_per_voxel, float w0,
+                         const int32_t* owner, int32_t rank, uint8_t* flags_out, void* stream);
 int nksr_halo_band_flags(const int64_t* keys, const int32_t* ijk, int64_t n, const int64_t* klo, int32_t nchunk, const float* shift,
                          const float* tlo, const float* thi, float w, int32_t* seg_out, int32_t* flags_out, void* stream);
 

@@ -692,6 +692,19 @@ class MultiChunkField(BaseField):
         w = self.svh.voxel_size
         return self.near_owned((ijk.to(torch.float32) + 0.5) * w, w)
 
+    def seam_flags(self, edge_vkey, edge_axis, cells_per_voxel):
+        """uint8 per mesh vertex of this rank's piece: 1 when another rank may emit the vertex too -- one of the four lattice cells
+        around its edge is not this rank's (csrc/chunks.hip k_edge_seam_flags: base_cell_mask's arithmetic).  Rank 0 then groups only
+        those (dist.merge_meshes)."""
+        n = int(edge_vkey.numel())
+        flags = torch.empty(n, dtype=torch.uint8, device=edge_vkey.device)
+        if n:
+            if getattr(self, '_owner_dev', None) is None:
+                self._owner_dev = torch.tensor(self.owner, dtype=torch.int32, device=edge_vkey.device)
+            call('nksr_edge_seam_flags', C.byref(self._cgrid), ptr(edge_vkey.contiguous()), ptr(edge_axis.to(torch.int8).contiguous()), n, int(cells_per_voxel),
+                 float(np.float32(self.svh.voxel_size)), ptr(self._owner_dev), int(self.rank), ptr(flags), stream())
+        return flags
+
     def owns_points(self, xyz):
         """Points (model units) inside a core this rank owns."""
         if self.world_size == 1:
@@ -745,7 +758,7 @@ class MultiChunkField(BaseField):
         if on_gpu:
             torch.cuda.current_stream().synchronize()
         t0 = time.perf_counter()
-        v, f = D.gather_meshes(res.v, res.f, res.edge_vkey, res.edge_axis)
+        v, f = D.gather_meshes(res.v, res.f, res.edge_vkey, res.edge_axis, seam=getattr(res, 'seam_flag', None))
         if on_gpu:
             torch.cuda.current_stream().synchronize()
         self.last_gather_s = time.perf_counter() - t0      # mesh gather (point-to-point to rank 0) + seam merge

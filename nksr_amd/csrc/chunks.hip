@@ -179,3 +179,44 @@ extern "C" int nksr_halo_band_flags(const int64_t* keys, const int32_t* ijk, int
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
+
+// ---- which mesh vertices of a rank's piece can ANOTHER rank emit too (the seam merge on rank 0 groups only those) --------------------------
+// A lattice-mesh vertex lies on the lattice edge (vertex g, axis a); the four lattice cells around that edge are the only ones whose
+// triangles use it, and a cell is meshed by the rank that owns the chunk holding the centre of its base voxel (chunking.base_cell_mask:
+// centre = (floor(cell / R) + 0.5) w0, chunk = floor((centre - origin) * (1 / chunk_size)) clamped -- the same fp32 operations here,
+// each rounded: contraction is off in this file).  flag = 1 when one of the four cells is not this rank's.
+__device__ __forceinline__ int floor_div_i(int x, int r) { return x >= 0 ? x / r : -((-x + r - 1) / r); }
+__global__ void __launch_bounds__(256) k_edge_seam_flags(nksr_chunk_grid_t G, const int64_t* __restrict__ vkey, const int8_t* __restrict__ axis,
+                                                         int64_t n, int R, float w0, const int32_t* __restrict__ owner, int rank,
+                                                         uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int g[3];
+    morton_decode_biased(vkey[i], NKSR_BIAS0, g[0], g[1], g[2]);
+    const int a = axis[i], b = (a + 1) % 3, c = (a + 2) % 3;
+    bool seam = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int cell[3] = {g[0], g[1], g[2]};
+        cell[b] -= q & 1;
+        cell[c] -= q >> 1;
+        int lin = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float centre = ((float)floor_div_i(cell[k], R) + 0.5f) * w0;
+            lin = lin * G.grid[k] + chunk_home(G, k, centre);
+        }
+        seam = seam || owner[lin] != rank;
+    }
+    flags[i] = seam ? 1 : 0;
+}
+
+extern "C" int nksr_edge_seam_flags(const nksr_chunk_grid_t* grid, const int64_t* vkey, const int8_t* axis, int64_t n, int32_t cells_per_voxel,
+                                    float w0, const int32_t* owner, int32_t rank, uint8_t* flags_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (!grid || !vkey || !axis || !owner || !flags_out || cells_per_voxel < 1) return nksr_set_error(NKSR_ERR_ARG, "edge_seam_flags: NULL arrays / cells_per_voxel < 1");
+    hipLaunchKernelGGL(k_edge_seam_flags, dim3(nksr_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, *grid, vkey, axis, n, (int)cells_per_voxel, w0, owner,
+                       (int)rank, flags_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}

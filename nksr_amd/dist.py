@@ -264,6 +264,8 @@ def merge_meshes(pieces):
     vertices ordered by (axis, vkey), faces in piece order; the representative of a merged vertex is its first
     occurrence.  On the GPU the grouping is a stable device radix sort of the lattice keys per axis
     (nksr_sort_pairs_u64_u32) + a flag scan; CPU tensors (the gloo tests) take the torch.unique route."""
+    if all(len(p) > 4 and p[4] is not None for p in pieces):
+        return _merge_flagged(pieces)
     v = torch.cat([p[0] for p in pieces])
     key = torch.cat([p[2] for p in pieces])
     ax = torch.cat([p[3] for p in pieces]).to(torch.int64)
@@ -299,16 +301,44 @@ def merge_meshes(pieces):
     return vv, new_index[f]
 
 
-def gather_meshes(v, f, vkey, axis, dst=0):
+def _merge_flagged(pieces):
+    """merge_meshes for pieces that say which of their vertices another piece may hold too (a fifth entry: uint8 flags,
+    chunking.MultiChunkField.seam_flags -- 0.3 % of the vertices of the bench scene): the unflagged vertices pass through in piece
+    order, the flagged ones are grouped by (axis, key) as in merge_meshes -- first occurrence the representative -- and follow them."""
+    v = torch.cat([p[0] for p in pieces])
+    flag = torch.cat([p[4].reshape(-1) for p in pieces]).to(torch.bool)
+    offs, faces = 0, []
+    for p in pieces:
+        faces.append(p[1] + offs)
+        offs += p[0].shape[0]
+    f = torch.cat(faces)
+    cand = torch.nonzero(flag).reshape(-1)
+    n_int = v.shape[0] - cand.numel()
+    new_index = torch.cumsum((~flag).to(torch.int64), 0) - 1            # (the entries of flagged vertices are overwritten below)
+    out = [v[~flag]]
+    if cand.numel():
+        key = torch.cat([p[2] for p in pieces])[cand]
+        ax = torch.cat([p[3] for p in pieces])[cand].to(torch.int64)
+        cv, ci = merge_meshes([(v[cand], torch.arange(cand.numel(), dtype=torch.int64, device=v.device).view(-1, 1).expand(-1, 3), key, ax)])
+        new_index[cand] = ci[:, 0] + n_int
+        out.append(cv)
+    return torch.cat(out), new_index[f]
+
+
+def gather_meshes(v, f, vkey, axis, dst=0, seam=None):
     """Gathers the per-rank mesh pieces on rank ``dst`` ONLY (point-to-point, after one size collective); ``dst`` merges
-    the seams and returns the full mesh, the other ranks keep their own piece."""
+    the seams and returns the full mesh, the other ranks keep their own piece.  ``seam`` (uint8 per vertex, or None on every rank):
+    the vertices another rank may hold too -- rank ``dst`` then groups only those."""
     rank, ws = world()
     if not active():
         return v, f
-    got = gather_tensors([v.reshape(-1).contiguous(), f.reshape(-1).contiguous(), vkey.contiguous(), axis.to(torch.int8).contiguous()], dst)
+    parts = [v.reshape(-1).contiguous(), f.reshape(-1).contiguous(), vkey.contiguous(), axis.to(torch.int8).contiguous()]
+    if seam is not None:
+        parts.append(seam.to(torch.uint8).contiguous())
+    got = gather_tensors(parts, dst)
     if rank != dst:
         return v, f
-    pieces = [(a.view(-1, 3), b.view(-1, 3), c, d) for a, b, c, d in got]
+    pieces = [(g[0].view(-1, 3), g[1].view(-1, 3), g[2], g[3]) + ((g[4],) if len(g) > 4 else ()) for g in got]
     return merge_meshes(pieces)
 
 

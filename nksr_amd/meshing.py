@@ -8,6 +8,8 @@ base dual cells -> (lattice vertices, f) -> MISE split of sign-changing cells ->
 table -> edge-keyed vertex dedup (radix sort + unique) -> mask trim -> world units.
 Host syncs happen only where a size (cells, vertices, triangles) must reach the host.
 """
+import os
+
 import torch
 
 from . import ops
@@ -66,6 +68,11 @@ def _extract(field, mise_iter, grid_upsample, max_points):
     if U < 1 or mise_iter < 0:
         raise RuntimeError('grid_upsample must be >= 1 and mise_iter >= 0')
     owned_only = hasattr(field, 'base_cell_mask') and getattr(field, 'world_size', 1) > 1
+    # a rank's piece says which of its vertices another rank may emit too (rank 0 groups only those); every rank decides alike --
+    # the gather's tensor count is part of the collective -- and an empty piece carries empty flags
+    use_seam = owned_only and dev.type == 'cuda' and hasattr(field, 'seam_flags') and os.environ.get('NKSR_SEAM_FLAGS', '1') != '0'
+    if use_seam:
+        empty.seam_flag = torch.zeros(0, dtype=torch.uint8, device=dev)
     # levels whose dual cells are meshed: the finest, and -- LayerField(dec_svh, adaptive_depth), models/nksr_net.py:132 -- the coarser
     # ones below adaptive_depth, which cover what the finest level leaves open (a structure head that stops at level 1, or input
     # sparser than the finest voxels): their extent at the SAME lattice resolution -- one uniform lattice over the adaptive
@@ -162,6 +169,8 @@ def _extract(field, mise_iter, grid_upsample, max_points):
     verts, faces, (edge_vkey, edge_axis) = _trim(field, verts, faces, (edge_vkey, edge_axis), masked=True)
     res = _result(field, verts, faces)
     res.edge_vkey, res.edge_axis, res.lattice_h = edge_vkey, edge_axis, h
+    if use_seam:
+        res.seam_flag = field.seam_flags(edge_vkey, edge_axis, U * (1 << mise_iter))       # which vertices rank 0 has to group
     return res
 
 

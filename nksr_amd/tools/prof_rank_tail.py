@@ -92,7 +92,9 @@ def main():
             return nm
         pieces = [(res.v, res.f, shifted(r)) for r in range(world)]
     else:
-        pieces = [(res.v, res.f, res.edge_vkey + r * 7919, res.edge_axis) for r in range(world)]
+        fl = getattr(res, 'seam_flag', None)      # (the pieces say which vertices another rank may hold too: rank 0 groups only those)
+        pieces = [(res.v, res.f, res.edge_vkey + r * 7919, res.edge_axis) + ((fl,) if fl is not None else ()) for r in range(world)]
+        print('seam candidates: %s of %d vertices per piece' % (int(fl.sum()) if fl is not None else 'all', res.v.shape[0]))
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()

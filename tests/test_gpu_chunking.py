@@ -105,7 +105,7 @@ def test_simulated_two_ranks_equal_one_rank(scene):
             assert ints.numel() <= chunking.pack_field(f)[0].numel() * (1.0 if scene == 'small' else 0.6)
             halo[c] = chunking.unpack_field(ints, flts, rec.hparams.voxel_size, rec.network.interpolators, dev)
             halo[c].solve_info = {}
-    pieces = []
+    pieces, flagged = [], []
     for r, mine in ((0, r0), (1, r1)):
         seen = {c: (mine.fields[c] if c in mine.fields else halo[c]) for c in allf}
         mf = r0.for_rank(r, 2, seen)          # r0 carries the 2-rank ownership table
@@ -113,7 +113,22 @@ def test_simulated_two_ranks_equal_one_rank(scene):
         p = meshing._extract(mf, 1, 1, -1)
         pieces.append((p.v, p.f, p.edge_vkey, p.edge_axis))
         assert p.f.shape[0] > 0
+        # the piece's seam candidates (csrc/chunks.hip k_edge_seam_flags): what _extract attaches = the field's flags for its vertices
+        assert torch.equal(p.seam_flag, mf.seam_flags(p.edge_vkey, p.edge_axis, 2)) and 0 < int(p.seam_flag.sum()) < 0.2 * p.v.shape[0]
+        flagged.append(p.seam_flag)
     v, f = dist.merge_meshes(pieces)
+    # every vertex both pieces hold is flagged in both; rank 0 grouping only the flagged ones gives the same mesh (another vertex order)
+    ids = [torch.stack([p[3].to(torch.int64), p[2]], 1) for p in pieces]
+    both = torch.cat(ids).unique(dim=0, return_counts=True)
+    shared = both[0][both[1] > 1]
+    assert shared.shape[0] > 100
+    for idp, fl in zip(ids, flagged):
+        u2, cnt = torch.cat([idp[fl.bool()], shared]).unique(dim=0, return_counts=True)
+        assert int((cnt > 1).sum()) == shared.shape[0]                    # all shared ids are among this piece's flagged ones
+    vf, ff = dist.merge_meshes([p + (fl,) for p, fl in zip(pieces, flagged)])
+    assert vf.shape == v.shape and ff.shape == f.shape
+    tri = lambda vv, fa: np.sort(np.ascontiguousarray(vv.cpu().numpy()[fa.cpu().numpy()].reshape(-1, 9)).view(np.dtype((np.void, 36))).ravel())
+    assert np.array_equal(tri(vf, ff), tri(v, f))                          # the same triangles, position for position
 
     class M:
         pass
