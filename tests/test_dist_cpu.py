@@ -74,6 +74,16 @@ def _worker(rank, world, port, q):
             assert (cnt == 2).sum() == 3          # two diagonals + the stitched seam edge
         else:
             assert mv.shape[0] == 4 and mf.shape[0] == 2   # non-destination ranks keep their piece
+        # --- the same gather with seam candidates: only the flagged vertices (the shared edge's two, + one that is nobody else's) are
+        # grouped on rank 0, the others pass through in piece order -- the same mesh in another vertex order
+        seam = torch.tensor([0, 1, 1, 0] if rank == 0 else [1, 0, 1, 1], dtype=torch.uint8)
+        sv, sf = D.gather_meshes(v, f, key, ax, seam=seam)
+        if rank == 0:
+            assert sv.shape[0] == 6 and sf.shape[0] == 4
+            tri = lambda vv, ff: sorted(tuple(vv[ff[i]].reshape(-1).tolist()) for i in range(ff.shape[0]))
+            assert tri(sv, sf) == tri(mv, mf)
+        else:
+            assert sv.shape[0] == 4 and sf.shape[0] == 2
         # --- the same two quads with five-word vertex names (the adaptive dual graph's pieces: dist.gather_named / merge_named)
         names = torch.stack([torch.ones(4, dtype=torch.int64), key, torch.zeros(4, dtype=torch.int64), torch.zeros(4, dtype=torch.int64), key + 100], 1)
         nv, nf, nn = D.gather_named(v, f, names)
