@@ -476,6 +476,10 @@ int nksr_chunk_blend(int64_t n, const int32_t* offsets, const float* pair_w, con
  * cell's base voxel] != rank, base voxel = floor(cell / cells_per_voxel), centre = (base + 0.5) w0, chunk as nksr_chunk_pair_counts. */
 int nksr_edge_seam_flags(const nksr_chunk_grid_t* grid, const int64_t* vkey, const int8_t* axis, int64_t n, int32_t cells_per_voxel, float w0,
                          const int32_t* owner, int32_t rank, uint8_t* flags_out, void* stream);
+/* Which points lie in a core this rank owns (reach = 0) or within `reach` of one along the split axes: flag = 1 when
+ * owner[chunk of (x + o)] == rank for an offset o in {-reach, 0, +reach} per split axis (the cells a rank meshes / evaluates). */
+int nksr_points_owner_flags(const nksr_chunk_grid_t* grid, const float* xyz, int64_t n, float reach, const int32_t* owner, int32_t rank,
+                            uint8_t* flags_out, void* stream);
 int nksr_halo_band_flags(const int64_t* keys, const int32_t* ijk, int64_t n, const int64_t* klo, int32_t nchunk, const float* shift,
                          const float* tlo, const float* thi, float w, int32_t* seg_out, int32_t* flags_out, void* stream);
 

@@ -181,6 +181,7 @@ _PROTOS = {
     'nksr_chunk_pair_fill': [_P(ChunkGridT), C.c_int, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_chunk_blend': [_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     'nksr_edge_seam_flags': [_P(ChunkGridT), _vp, _vp, _i64, _i32, _f32, _vp, _i32, _vp, _vp],
+    'nksr_points_owner_flags': [_P(ChunkGridT), _vp, _i64, _f32, _vp, _i32, _vp, _vp],
     'nksr_halo_band_flags': [_vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _f32, _vp, _vp, _vp],
     'nksr_knn_pca_normals': [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp],
     'nksr_nearest_index': [_vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _i64, C.c_int, _vp, _vp],
@@ -213,7 +214,7 @@ for _name, _args in _PROTOS.items():
     _fn.argtypes = _args
     _fn.restype = C.c_int
 
-EXPORTED = ['nksr_edge_seam_flags', 'nksr_halo_band_flags', 'nksr_conv3_wgrad_chunks', 'nksr_pcg_profile_samples', 'nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
+EXPORTED = ['nksr_points_owner_flags', 'nksr_edge_seam_flags', 'nksr_halo_band_flags', 'nksr_conv3_wgrad_chunks', 'nksr_pcg_profile_samples', 'nksr_last_error', 'nksr_version', 'nksr_pcg_workspace_bytes', 'nksr_spmv_workspace_bytes', 'nksr_assemble_workspace_bytes',
             'nksr_assemble_split_bytes',
             'nksr_fused_workspace_bytes', 'nksr_fused_item_entries', 'nksr_pcg_vector_workspace_bytes', 'nksr_pcg_vector_workspace_bytes_seg', 'nksr_pcg_profile_survey_bytes', 'nksr_bbox_work_floats'] + sorted(_PROTOS)
 

@@ -680,9 +680,7 @@ class MultiChunkField(BaseField):
     def base_cell_mask(self, ijk):
         if self.world_size == 1:
             return torch.ones(ijk.shape[0], dtype=torch.bool, device=ijk.device)
-        centers = (ijk.to(torch.float32) + 0.5) * self.svh.voxel_size
-        own = torch.tensor(self.owner, dtype=torch.long, device=ijk.device)
-        return own[self.chunk_of(centers)] == self.rank
+        return self.owns_points((ijk.to(torch.float32) + 0.5) * self.svh.voxel_size)
 
     def base_cell_halo_mask(self, ijk):
         """Owned cells plus one ring of neighbours: the MISE hanging-vertex rule needs to know whether
@@ -705,10 +703,23 @@ class MultiChunkField(BaseField):
                  float(np.float32(self.svh.voxel_size)), ptr(self._owner_dev), int(self.rank), ptr(flags), stream())
         return flags
 
+    def _owner_flags(self, xyz, reach):
+        """csrc/chunks.hip k_points_owner_flags: one launch instead of the ~100 torch launches of _near_owned_torch (same arithmetic)."""
+        xyz = xyz.to(torch.float32).contiguous()
+        n = xyz.shape[0]
+        flags = torch.empty(n, dtype=torch.uint8, device=xyz.device)
+        if n:
+            if getattr(self, '_owner_dev', None) is None:
+                self._owner_dev = torch.tensor(self.owner, dtype=torch.int32, device=xyz.device)
+            call('nksr_points_owner_flags', C.byref(self._cgrid), ptr(xyz), n, float(np.float32(reach)), ptr(self._owner_dev), int(self.rank), ptr(flags), stream())
+        return flags.bool()
+
     def owns_points(self, xyz):
         """Points (model units) inside a core this rank owns."""
         if self.world_size == 1:
             return torch.ones(xyz.shape[0], dtype=torch.bool, device=xyz.device)
+        if xyz.is_cuda:
+            return self._owner_flags(xyz, 0.0)
         own = torch.tensor(self.owner, dtype=torch.long, device=xyz.device)
         return own[self.chunk_of(xyz)] == self.rank
 
@@ -716,6 +727,12 @@ class MultiChunkField(BaseField):
         """Points whose box centre +- ``reach`` (along the split axes) touches a core this rank owns."""
         if self.world_size == 1:
             return torch.ones(centers.shape[0], dtype=torch.bool, device=centers.device)
+        if centers.is_cuda:
+            return self._owner_flags(centers, reach)
+        return self._near_owned_torch(centers, reach)
+
+    def _near_owned_torch(self, centers, reach):
+        """near_owned in torch operations (the specification of k_points_owner_flags; tests compare the two)."""
         dev = centers.device
         own = torch.tensor(self.owner, dtype=torch.long, device=dev)
         w = reach

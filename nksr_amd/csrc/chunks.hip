@@ -220,3 +220,36 @@ extern "C" int nksr_edge_seam_flags(const nksr_chunk_grid_t* grid, const int64_t
     NKSR_CHECK_LAUNCH();
     return NKSR_OK;
 }
+
+// ---- which points lie in (or within `reach` of) a core this rank owns (chunking.MultiChunkField.owns_points / near_owned) --------------------
+// flag = 1 when owner[chunk of (x + o)] == rank for some offset o in {-reach, 0, +reach}^(split axes); reach = 0: the chunk of x itself.
+// The arithmetic of chunk_of: (x + o) rounded, then floor(((x + o) - origin) * (1 / chunk_size)) clamped.  Before: ~100 torch launches per call.
+__global__ void __launch_bounds__(256) k_points_owner_flags(nksr_chunk_grid_t G, const float* __restrict__ xyz, int64_t n, float reach,
+                                                            const int32_t* __restrict__ owner, int rank, uint8_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int idx[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float x = xyz[i * 3 + a];
+        idx[a][1] = chunk_home(G, a, x);
+        const bool split = G.grid[a] > 1 && reach > 0.f;
+        idx[a][0] = split ? chunk_home(G, a, x + (-reach)) : idx[a][1];
+        idx[a][2] = split ? chunk_home(G, a, x + reach) : idx[a][1];
+    }
+    bool mine = false;
+    for (int q = 0; q < 27; ++q) {
+        const int kx = q / 9, ky = (q / 3) % 3, kz = q % 3;
+        mine = mine || owner[(idx[0][kx] * G.grid[1] + idx[1][ky]) * G.grid[2] + idx[2][kz]] == rank;
+    }
+    flags[i] = mine ? 1 : 0;
+}
+
+extern "C" int nksr_points_owner_flags(const nksr_chunk_grid_t* grid, const float* xyz, int64_t n, float reach, const int32_t* owner, int32_t rank,
+                                       uint8_t* flags_out, void* stream) {
+    if (n <= 0) return NKSR_OK;
+    if (!grid || !xyz || !owner || !flags_out || !(reach >= 0.f)) return nksr_set_error(NKSR_ERR_ARG, "points_owner_flags: NULL arrays / reach < 0");
+    hipLaunchKernelGGL(k_points_owner_flags, dim3(nksr_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, *grid, xyz, n, reach, owner, (int)rank, flags_out);
+    NKSR_CHECK_LAUNCH();
+    return NKSR_OK;
+}

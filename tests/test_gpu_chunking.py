@@ -214,6 +214,34 @@ def test_simulated_two_ranks_mesh_the_adaptive_dual_graph_of_one_process(adaptiv
             thin.extract_dual_mesh()
 
 
+def test_ownership_kernel_equals_its_torch_specification():
+    """csrc/chunks.hip k_points_owner_flags (the cells a rank meshes / evaluates: one launch) against the torch operations it replaces
+    (MultiChunkField._near_owned_torch / chunk_of), on random points, on points on and next to the chunk faces, for reach 0, one voxel
+    and the adaptive graph's zone."""
+    import nksr_amd
+    from nksr_amd import chunking
+    dev = torch.device('cuda:0')
+    xyz, nrm = _wide_scene()
+    rec = nksr_amd.Reconstructor(dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ext = float(xyz[:, 0].max() - xyz[:, 0].min())
+    for world in (2, 3):
+        mf = chunking.reconstruct_by_chunk(rec, t(xyz), t(nrm), None, ext / 3 + 1e-3, 0.05, False, 2000, 1e-5, True, None, sim=(1, world))
+        assert mf.world_size == world and mf.grid[0] == 3
+        g = torch.Generator().manual_seed(world)
+        lo, hi = torch.tensor(xyz.min(0)), torch.tensor(xyz.max(0))
+        pts = lo + (hi - lo) * torch.rand(200000, 3, generator=g) * 1.1 - 0.05 * (hi - lo)
+        faces = torch.tensor([mf.origin[0] + k * mf.chunk_size for k in range(4)], dtype=torch.float32)
+        near = pts[:4000].clone()
+        near[:, 0] = faces[torch.randint(0, 4, (4000,), generator=g)] + torch.tensor([0.0, 1e-7, -1e-7, 0.05, -0.05, 0.1, -0.1, 3e-6])[torch.randint(0, 8, (4000,), generator=g)]
+        pts = torch.cat([pts, near]).to(torch.float32).to(dev).contiguous()
+        own = torch.tensor(mf.owner, dtype=torch.long, device=dev)
+        assert torch.equal(mf.owns_points(pts), own[mf.chunk_of(pts)] == mf.rank)
+        for reach in (mf.svh.voxel_size, 3.5 * mf.svh.voxel_size, 0.37):
+            a, b = mf.near_owned(pts, reach), mf._near_owned_torch(pts, reach)
+            assert torch.equal(a, b) and 0 < int(a.sum()) < pts.shape[0]
+
+
 def test_batched_halo_pack_equals_the_per_chunk_pack_bit_for_bit():
     """ChunkPart.pack_halos (all chunks of a rank at once: one mask + one compaction per level) against pack_chunk(c, band) chunk by
     chunk -- the payloads of the halo exchange, integers and floats bit for bit; with and without the UDF mask features."""
